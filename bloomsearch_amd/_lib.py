@@ -1,0 +1,95 @@
+"""ctypes binding of libbloomgpu.so (include/bloomgpu.h).
+
+Fails loudly: if the shared library is missing, or a compute entry point is
+called without a gfx950 GPU, an exception is raised — there is no CPU fallback
+in the product path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "libbloomgpu.so")
+
+# status codes (bloomgpu.h)
+BSG_OK, BSG_E_INVALID, BSG_E_HIP, BSG_E_NOMEM, BSG_E_NOTFOUND, BSG_E_UNSUPPORTED, BSG_E_NODEVICE = 0, -1, -2, -3, -4, -5, -6
+KIND_FIELD, KIND_TOKEN, KIND_FIELD_TOKEN = 0, 1, 2
+OP_TERM, OP_AND, OP_OR, OP_TRUE, OP_FALSE = 0, 1, 2, 3, 4
+PROBE_ASYNC, PROBE_TIMED = 1, 2
+
+TERM_DTYPE = np.dtype([("h", "<u8", (4,)), ("kind", "<u4"), ("reserved", "<u4")])
+DESC_DTYPE = np.dtype([("word_off", "<u8"), ("m", "<u8"), ("k", "<u4"), ("reserved", "<u4")])
+
+
+class Timing(C.Structure):
+    _fields_ = [("n_probes", C.c_uint64), ("ms_terms_kernel", C.c_double), ("ms_eval_kernel", C.c_double),
+                ("stream_bytes", C.c_uint64)]
+
+
+class BloomGpuError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"libbloomgpu error {code}: {message}")
+        self.code = code
+
+
+def op(opcode: int, arg: int = 0) -> int:
+    return (opcode << 28) | (arg & 0x0FFFFFFF)
+
+
+# every symbol include/bloomgpu.h declares (tests assert the .so exports all of them)
+EXPORTS = [
+    "bsg_device_count", "bsg_open", "bsg_close", "bsg_last_error", "bsg_sync", "bsg_estimate_parameters",
+    "bsg_hash_entries", "bsg_build", "bsg_build_hashed", "bsg_arena_load", "bsg_arena_free",
+    "bsg_batch_create", "bsg_batch_free", "bsg_probe_batch", "bsg_probe", "bsg_timing_read",
+    "bsg_or_reduce", "bsg_or_words_dev", "bsg_or_reduce_dev",
+]
+
+_lib = None
+
+
+def load():
+    """Load libbloomgpu.so; raises ImportError if it has not been built (python -m bloomsearch_amd.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: build it with `python -m bloomsearch_amd.build` "
+                          "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int32
+    L.bsg_device_count.restype = i32
+    L.bsg_open.argtypes = [C.POINTER(i32), i32, C.POINTER(vp)]
+    L.bsg_close.argtypes = [vp]
+    L.bsg_last_error.argtypes = [vp]
+    L.bsg_last_error.restype = C.c_char_p
+    L.bsg_sync.argtypes = [vp]
+    L.bsg_estimate_parameters.argtypes = [u64, C.c_double, C.POINTER(u64), C.POINTER(u64)]
+    L.bsg_hash_entries.argtypes = [vp, vp, vp, u32, vp]
+    L.bsg_build.argtypes = [vp, vp, vp, u32, vp, vp, u32, vp, u64]
+    L.bsg_build_hashed.argtypes = [vp, vp, u32, vp, vp, u32, vp, u64]
+    L.bsg_arena_load.argtypes = [vp, vp, u64, vp, u32, C.POINTER(u64)]
+    L.bsg_arena_free.argtypes = [vp, u64]
+    L.bsg_batch_create.argtypes = [vp, vp, u32, vp, vp, u32, C.POINTER(u64)]
+    L.bsg_batch_free.argtypes = [vp, u64]
+    L.bsg_probe_batch.argtypes = [vp, u64, u64, u32, vp]
+    L.bsg_probe.argtypes = [vp, u64, vp, u32, vp, vp, u32, vp]
+    L.bsg_timing_read.argtypes = [vp, C.POINTER(Timing), i32]
+    L.bsg_or_reduce.argtypes = [vp, u64, u32, vp, u64]
+    L.bsg_or_words_dev.argtypes = [vp, vp, vp, u64, u32]
+    L.bsg_or_reduce_dev.argtypes = [vp, u64, u32, vp, u64]
+    for name in EXPORTS:
+        if name != "bsg_last_error":
+            getattr(L, name).restype = i32
+    _lib = L
+    return L
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data if a.size else None
+    return a

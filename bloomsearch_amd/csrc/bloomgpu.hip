@@ -1,0 +1,893 @@
+// bloomgpu.hip — C-ABI implementation of include/bloomgpu.h (gfx950 only).
+//
+// Host-side plumbing around the kernels in kernels.hip.h: contexts, per-device
+// streams, filter arenas (sharded round-robin over the context's devices),
+// compiled query batches, probe / build / OR-reduce entry points.
+// There is no CPU fallback anywhere in this file: without a GPU every compute
+// entry point fails with BSG_E_NODEVICE / BSG_E_HIP.
+#include "bloomgpu.h"
+#include "kernels.hip.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace {
+
+using bsg::DevDesc;
+
+thread_local std::string g_err;
+
+int32_t fail(int32_t code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            return fail(BSG_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                               \
+    } while (0)
+
+constexpr uint32_t kLdsCapWords = 8192;       // 64 KiB staged-filter cap (dynamic LDS without opt-in)
+constexpr uint64_t kAlignWords = 16;          // filters start on 128-byte boundaries in HBM
+constexpr uint32_t kBuildSliceEntries = 8192; // entries per workgroup for non-staged builds
+
+uint64_t barrett_magic(uint64_t m)
+{
+    if (m <= 1) return ~0ULL;
+    // floor(2^64 / m) without 128-bit division: (2^64 - 1) / m, +1 iff m divides 2^64 (m power of two)
+    uint64_t q = ~0ULL / m;
+    if ((m & (m - 1)) == 0) q += 1;
+    return q;
+}
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0;  // elements
+    hipError_t reserve(size_t n)
+    {
+        if (n <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), std::max<size_t>(n, 1) * sizeof(T));
+        if (e == hipSuccess) cap = n;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct EventTriple { hipEvent_t e0, e1, e2; uint64_t bytes; };
+
+struct Device {
+    int id = 0;
+    hipStream_t stream = nullptr;
+    std::mutex mu;                 // serialises enqueue + scratch reuse on this device
+    DevBuf<uint64_t> V;            // verdict scratch
+    DevBuf<uint64_t> out;          // survivors scratch
+    DevBuf<uint8_t> stage_a;       // build/hash staging
+    DevBuf<uint32_t> stage_off;
+    DevBuf<uint64_t> stage_h;
+    DevBuf<uint32_t> stage_fstart;
+    DevBuf<DevDesc> stage_desc;
+    DevBuf<bsg::BuildItem> stage_items;
+    DevBuf<uint64_t> stage_words;
+    std::vector<EventTriple> pending;
+    std::vector<EventTriple> free_events;
+};
+
+struct ArenaShard {
+    uint64_t *d_words = nullptr;
+    DevDesc *d_desc = nullptr;
+    uint32_t n_blocks = 0;          // local blocks
+    uint64_t n_words = 0;
+    uint64_t max_staged_words[3] = {0, 0, 0};
+    uint64_t sum_words[3] = {0, 0, 0};  // present filters, for stream-byte accounting
+    uint64_t fixed_m[3] = {0, 0, 0};    // common m if all present filters share geometry, else 0
+    uint32_t fixed_k[3] = {0, 0, 0};
+    bool geometry_uniform[3] = {true, true, true};
+};
+
+struct Arena {
+    uint32_t n_blocks = 0;
+    std::vector<ArenaShard> shards;  // one per device
+};
+
+struct BatchDev {
+    uint64_t *d_th = nullptr;
+    uint32_t *d_prog = nullptr;
+    uint32_t *d_chunk_off = nullptr;
+    uint32_t *d_chunk_len = nullptr;
+};
+
+struct Batch {
+    uint32_t n_queries = 0;
+    uint32_t Tp = 0, Wt = 0;
+    uint32_t n_kinds = 0;
+    uint32_t kind[3] = {0, 0, 0};
+    uint32_t term_begin[3] = {0, 0, 0};
+    uint32_t term_count[3] = {0, 0, 0};
+    uint32_t n_chunks = 0;
+    uint32_t max_depth = 1;
+    std::vector<BatchDev> dev;
+};
+
+}  // namespace
+
+struct bsg_ctx {
+    std::vector<std::unique_ptr<Device>> devs;
+    std::mutex mu;  // handle tables
+    std::map<uint64_t, std::shared_ptr<Arena>> arenas;
+    std::map<uint64_t, std::shared_ptr<Batch>> batches;
+    uint64_t next_id = 1;
+    bsg_timing timing{};
+};
+
+namespace {
+
+int32_t use_device(Device &d)
+{
+    HIP_TRY(hipSetDevice(d.id));
+    return BSG_OK;
+}
+
+void free_arena(bsg_ctx *ctx, Arena &a)
+{
+    for (size_t i = 0; i < a.shards.size(); ++i) {
+        (void)hipSetDevice(ctx->devs[i]->id);
+        if (a.shards[i].d_words) (void)hipFree(a.shards[i].d_words);
+        if (a.shards[i].d_desc) (void)hipFree(a.shards[i].d_desc);
+    }
+}
+
+void free_batch(bsg_ctx *ctx, Batch &b)
+{
+    for (size_t i = 0; i < b.dev.size(); ++i) {
+        (void)hipSetDevice(ctx->devs[i]->id);
+        if (b.dev[i].d_th) (void)hipFree(b.dev[i].d_th);
+        if (b.dev[i].d_prog) (void)hipFree(b.dev[i].d_prog);
+        if (b.dev[i].d_chunk_off) (void)hipFree(b.dev[i].d_chunk_off);
+        if (b.dev[i].d_chunk_len) (void)hipFree(b.dev[i].d_chunk_len);
+    }
+}
+
+int32_t drain_timing(bsg_ctx *ctx, Device &d)
+{
+    if (d.pending.empty()) return BSG_OK;
+    HIP_TRY(hipStreamSynchronize(d.stream));
+    for (auto &t : d.pending) {
+        float a = 0, b = 0;
+        HIP_TRY(hipEventElapsedTime(&a, t.e0, t.e1));
+        HIP_TRY(hipEventElapsedTime(&b, t.e1, t.e2));
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        ctx->timing.n_probes += 1;
+        ctx->timing.ms_terms_kernel += a;
+        ctx->timing.ms_eval_kernel += b;
+        ctx->timing.stream_bytes += t.bytes;
+        d.free_events.push_back(t);
+    }
+    d.pending.clear();
+    return BSG_OK;
+}
+
+// ---- program lowering: public n-ary postfix -> internal binary postfix ----
+struct Node {
+    uint32_t opc;   // BSG_OP_*
+    uint32_t arg;   // TERM: verdict position
+    std::vector<uint32_t> kids;
+};
+
+void emit_node(const std::vector<Node> &nodes, uint32_t id, std::vector<uint32_t> &out)
+{
+    const Node &n = nodes[id];
+    switch (n.opc) {
+    case BSG_OP_TERM: out.push_back((0u << 28) | n.arg); return;
+    case BSG_OP_TRUE: out.push_back(3u << 28); return;
+    case BSG_OP_FALSE: out.push_back(4u << 28); return;
+    default: break;
+    }
+    if (n.kids.empty()) {  // And() == true, Or() == false (query_exec.go:105-121)
+        out.push_back((n.opc == BSG_OP_AND ? 3u : 4u) << 28);
+        return;
+    }
+    emit_node(nodes, n.kids[0], out);
+    for (size_t c = 1; c < n.kids.size(); ++c) {
+        emit_node(nodes, n.kids[c], out);
+        out.push_back((n.opc == BSG_OP_AND ? 1u : 2u) << 28);
+    }
+}
+
+// Returns BSG_OK and the lowered program, or BSG_E_INVALID.
+int32_t lower_program(const uint32_t *ops, uint32_t n_ops, uint32_t n_terms, const std::vector<uint32_t> &term_pos,
+                      std::vector<uint32_t> &out, uint32_t &depth)
+{
+    out.clear();
+    depth = 1;
+    if (n_ops == 0) return BSG_OK;  // nil query: true
+    std::vector<Node> nodes;
+    std::vector<uint32_t> stack;
+    nodes.reserve(n_ops);
+    for (uint32_t j = 0; j < n_ops; ++j) {
+        const uint32_t opc = ops[j] >> 28, arg = ops[j] & 0x0FFFFFFFu;
+        Node n{opc, 0, {}};
+        switch (opc) {
+        case BSG_OP_TERM:
+            if (arg >= n_terms) return fail(BSG_E_INVALID, "program references term %u of %u", arg, n_terms);
+            n.arg = term_pos[arg];
+            break;
+        case BSG_OP_AND:
+        case BSG_OP_OR:
+            if (arg > stack.size()) return fail(BSG_E_INVALID, "program op %u pops %u of %zu", j, arg, stack.size());
+            n.kids.assign(stack.end() - arg, stack.end());
+            stack.resize(stack.size() - arg);
+            break;
+        case BSG_OP_TRUE:
+        case BSG_OP_FALSE:
+            break;
+        default:
+            return fail(BSG_E_INVALID, "unknown program opcode %u", opc);
+        }
+        nodes.push_back(std::move(n));
+        stack.push_back((uint32_t)nodes.size() - 1);
+    }
+    if (stack.size() != 1) return fail(BSG_E_INVALID, "program leaves %zu values on the stack", stack.size());
+    emit_node(nodes, stack[0], out);
+    uint32_t sp = 0;
+    for (uint32_t op : out) {
+        const uint32_t opc = op >> 28;
+        if (opc == 1u || opc == 2u) --sp; else ++sp;
+        depth = std::max(depth, sp);
+    }
+    return BSG_OK;
+}
+
+int32_t get_arena(bsg_ctx *ctx, uint64_t id, std::shared_ptr<Arena> &out)
+{
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    auto it = ctx->arenas.find(id);
+    if (it == ctx->arenas.end()) return fail(BSG_E_NOTFOUND, "unknown arena id %llu", (unsigned long long)id);
+    out = it->second;
+    return BSG_OK;
+}
+
+int32_t get_batch(bsg_ctx *ctx, uint64_t id, std::shared_ptr<Batch> &out)
+{
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    auto it = ctx->batches.find(id);
+    if (it == ctx->batches.end()) return fail(BSG_E_NOTFOUND, "unknown batch id %llu", (unsigned long long)id);
+    out = it->second;
+    return BSG_OK;
+}
+
+int32_t validate_descs(const bsg_filter_desc *desc, size_t n, uint64_t n_words)
+{
+    for (size_t i = 0; i < n; ++i) {
+        if (desc[i].m == 0) continue;
+        const uint64_t nw = (desc[i].m + 63) / 64;
+        if (desc[i].k == 0) return fail(BSG_E_INVALID, "descriptor %zu: k == 0", i);
+        if (desc[i].word_off > n_words || nw > n_words - desc[i].word_off)
+            return fail(BSG_E_INVALID, "descriptor %zu: words [%llu, +%llu) outside arena of %llu words", i,
+                        (unsigned long long)desc[i].word_off, (unsigned long long)nw, (unsigned long long)n_words);
+    }
+    return BSG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t bsg_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int32_t bsg_open(const int32_t *device_ids, int32_t n_devices, bsg_ctx **out_ctx)
+{
+    if (!out_ctx) return fail(BSG_E_INVALID, "out_ctx is null");
+    *out_ctx = nullptr;
+    if (n_devices < 1 || !device_ids) return fail(BSG_E_INVALID, "need at least one device id");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0)
+        return fail(BSG_E_NODEVICE, "no HIP device visible (libbloomgpu has no CPU fallback)");
+    auto ctx = std::make_unique<bsg_ctx>();
+    for (int32_t i = 0; i < n_devices; ++i) {
+        if (device_ids[i] < 0 || device_ids[i] >= count)
+            return fail(BSG_E_INVALID, "device id %d out of range [0,%d)", device_ids[i], count);
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, device_ids[i]));
+        if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+            return fail(BSG_E_NODEVICE, "device %d is %s; this library is built for gfx950 only", device_ids[i],
+                        prop.gcnArchName);
+        auto d = std::make_unique<Device>();
+        d->id = device_ids[i];
+        HIP_TRY(hipSetDevice(d->id));
+        HIP_TRY(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
+        ctx->devs.push_back(std::move(d));
+    }
+    *out_ctx = ctx.release();
+    return BSG_OK;
+}
+
+int32_t bsg_close(bsg_ctx *ctx)
+{
+    if (!ctx) return BSG_OK;
+    for (auto &kv : ctx->arenas) free_arena(ctx, *kv.second);
+    for (auto &kv : ctx->batches) free_batch(ctx, *kv.second);
+    for (auto &dp : ctx->devs) {
+        Device &d = *dp;
+        (void)hipSetDevice(d.id);
+        if (d.stream) (void)hipStreamSynchronize(d.stream);
+        for (auto &t : d.pending) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); (void)hipEventDestroy(t.e2); }
+        for (auto &t : d.free_events) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); (void)hipEventDestroy(t.e2); }
+        d.V.release(); d.out.release(); d.stage_a.release(); d.stage_off.release(); d.stage_h.release();
+        d.stage_fstart.release(); d.stage_desc.release(); d.stage_items.release(); d.stage_words.release();
+        if (d.stream) (void)hipStreamDestroy(d.stream);
+    }
+    delete ctx;
+    return BSG_OK;
+}
+
+const char *bsg_last_error(bsg_ctx *) { return g_err.c_str(); }
+
+int32_t bsg_sync(bsg_ctx *ctx)
+{
+    if (!ctx) return fail(BSG_E_INVALID, "ctx is null");
+    for (auto &dp : ctx->devs) {
+        std::lock_guard<std::mutex> lk(dp->mu);
+        if (int32_t rc = use_device(*dp)) return rc;
+        HIP_TRY(hipStreamSynchronize(dp->stream));
+    }
+    return BSG_OK;
+}
+
+int32_t bsg_estimate_parameters(uint64_t n, double p, uint64_t *m, uint64_t *k)
+{
+    if (!m || !k) return fail(BSG_E_INVALID, "null output");
+    if (n == 0 || !(p > 0.0 && p < 1.0)) return fail(BSG_E_INVALID, "need n >= 1 and 0 < p < 1");
+    // bloom/v3 EstimateParameters; New() clamps both to >= 1.
+    const double mm = std::ceil(-1.0 * (double)n * std::log(p) / std::pow(std::log(2.0), 2.0));
+    const double kk = std::ceil(std::log(2.0) * mm / (double)n);
+    *m = mm < 1.0 ? 1 : (uint64_t)mm;
+    *k = kk < 1.0 ? 1 : (uint64_t)kk;
+    return BSG_OK;
+}
+
+int32_t bsg_hash_entries(bsg_ctx *ctx, const uint8_t *bytes, const uint32_t *offsets, uint32_t n_entries,
+                         uint64_t *out_h)
+{
+    if (!ctx) return fail(BSG_E_INVALID, "ctx is null");
+    if (n_entries == 0) return BSG_OK;
+    if (!offsets || !out_h) return fail(BSG_E_INVALID, "null argument");
+    for (uint32_t e = 0; e < n_entries; ++e)
+        if (offsets[e + 1] < offsets[e]) return fail(BSG_E_INVALID, "offsets not monotone at %u", e);
+    const uint32_t n_bytes = offsets[n_entries];
+    if (n_bytes && !bytes) return fail(BSG_E_INVALID, "bytes is null");
+    Device &d = *ctx->devs[0];
+    std::lock_guard<std::mutex> lk(d.mu);
+    if (int32_t rc = use_device(d)) return rc;
+    HIP_TRY(d.stage_a.reserve((size_t)n_bytes + 16));
+    HIP_TRY(d.stage_off.reserve((size_t)n_entries + 1));
+    HIP_TRY(d.stage_h.reserve((size_t)n_entries * 4));
+    if (n_bytes) HIP_TRY(hipMemcpyAsync(d.stage_a.p, bytes, n_bytes, hipMemcpyHostToDevice, d.stream));
+    HIP_TRY(hipMemcpyAsync(d.stage_off.p, offsets, ((size_t)n_entries + 1) * 4, hipMemcpyHostToDevice, d.stream));
+    hipLaunchKernelGGL(bsg::k_hash_entries, dim3((n_entries + 255) / 256), dim3(256), 0, d.stream, d.stage_a.p,
+                       d.stage_off.p, n_entries, d.stage_h.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out_h, d.stage_h.p, (size_t)n_entries * 32, hipMemcpyDeviceToHost, d.stream));
+    HIP_TRY(hipStreamSynchronize(d.stream));
+    return BSG_OK;
+}
+
+static int32_t build_common(bsg_ctx *ctx, const uint8_t *bytes, const uint32_t *offsets, const uint64_t *h,
+                            uint32_t n_entries, const uint32_t *fstart, const bsg_filter_desc *desc,
+                            uint32_t n_filters, uint64_t *out_words, uint64_t n_words)
+{
+    if (!ctx) return fail(BSG_E_INVALID, "ctx is null");
+    if (n_filters == 0) return BSG_OK;
+    if (!fstart || !desc || !out_words) return fail(BSG_E_INVALID, "null argument");
+    if (int32_t rc = validate_descs(desc, n_filters, n_words)) return rc;
+    if (fstart[n_filters] != n_entries) return fail(BSG_E_INVALID, "filter_entry_start[n_filters] != n_entries");
+    for (uint32_t f = 0; f < n_filters; ++f)
+        if (fstart[f + 1] < fstart[f]) return fail(BSG_E_INVALID, "filter_entry_start not monotone at %u", f);
+    uint32_t n_bytes = 0;
+    if (!h) {
+        if (n_entries && !offsets) return fail(BSG_E_INVALID, "offsets is null");
+        for (uint32_t e = 0; e < n_entries; ++e)
+            if (offsets[e + 1] < offsets[e]) return fail(BSG_E_INVALID, "offsets not monotone at %u", e);
+        n_bytes = n_entries ? offsets[n_entries] : 0;
+        if (n_bytes && !bytes) return fail(BSG_E_INVALID, "bytes is null");
+    }
+    std::vector<DevDesc> dd(n_filters);
+    std::vector<bsg::BuildItem> items;
+    uint64_t max_staged = 0;
+    for (uint32_t f = 0; f < n_filters; ++f) {
+        dd[f] = DevDesc{desc[f].word_off, desc[f].m, barrett_magic(desc[f].m), desc[f].k, 0};
+        if (desc[f].m == 0) continue;
+        const uint64_t nw = (desc[f].m + 63) / 64;
+        if (nw <= kLdsCapWords) {
+            items.push_back({f, fstart[f], fstart[f + 1], 1u});
+            max_staged = std::max(max_staged, nw);
+        } else {
+            for (uint32_t e = fstart[f]; e < fstart[f + 1]; e += kBuildSliceEntries)
+                items.push_back({f, e, std::min(fstart[f + 1], e + kBuildSliceEntries), 0u});
+        }
+    }
+    Device &d = *ctx->devs[0];
+    std::lock_guard<std::mutex> lk(d.mu);
+    if (int32_t rc = use_device(d)) return rc;
+    HIP_TRY(d.stage_words.reserve(n_words));
+    HIP_TRY(hipMemsetAsync(d.stage_words.p, 0, n_words * 8, d.stream));
+    if (!items.empty()) {
+        HIP_TRY(d.stage_desc.reserve(n_filters));
+        HIP_TRY(d.stage_items.reserve(items.size()));
+        HIP_TRY(hipMemcpyAsync(d.stage_desc.p, dd.data(), dd.size() * sizeof(DevDesc), hipMemcpyHostToDevice, d.stream));
+        HIP_TRY(hipMemcpyAsync(d.stage_items.p, items.data(), items.size() * sizeof(bsg::BuildItem),
+                               hipMemcpyHostToDevice, d.stream));
+        bsg::BuildArgs a{};
+        if (h) {
+            HIP_TRY(d.stage_h.reserve((size_t)n_entries * 4));
+            if (n_entries) HIP_TRY(hipMemcpyAsync(d.stage_h.p, h, (size_t)n_entries * 32, hipMemcpyHostToDevice, d.stream));
+            a.h = d.stage_h.p;
+        } else {
+            HIP_TRY(d.stage_a.reserve((size_t)n_bytes + 16));
+            HIP_TRY(d.stage_off.reserve((size_t)n_entries + 1));
+            if (n_bytes) HIP_TRY(hipMemcpyAsync(d.stage_a.p, bytes, n_bytes, hipMemcpyHostToDevice, d.stream));
+            if (n_entries)
+                HIP_TRY(hipMemcpyAsync(d.stage_off.p, offsets, ((size_t)n_entries + 1) * 4, hipMemcpyHostToDevice, d.stream));
+            a.bytes = d.stage_a.p;
+            a.off = d.stage_off.p;
+        }
+        a.items = d.stage_items.p;
+        a.desc = d.stage_desc.p;
+        a.out = d.stage_words.p;
+        const size_t lds = std::max<uint64_t>(max_staged, 2) * 8;
+        hipLaunchKernelGGL(bsg::k_build, dim3((uint32_t)items.size()), dim3(bsg::kBuildThreads), lds, d.stream, a);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipMemcpyAsync(out_words, d.stage_words.p, n_words * 8, hipMemcpyDeviceToHost, d.stream));
+    HIP_TRY(hipStreamSynchronize(d.stream));
+    return BSG_OK;
+}
+
+int32_t bsg_build(bsg_ctx *ctx, const uint8_t *bytes, const uint32_t *offsets, uint32_t n_entries,
+                  const uint32_t *filter_entry_start, const bsg_filter_desc *desc, uint32_t n_filters,
+                  uint64_t *out_words, uint64_t n_words)
+{
+    return build_common(ctx, bytes, offsets, nullptr, n_entries, filter_entry_start, desc, n_filters, out_words, n_words);
+}
+
+int32_t bsg_build_hashed(bsg_ctx *ctx, const uint64_t *h, uint32_t n_entries, const uint32_t *filter_entry_start,
+                         const bsg_filter_desc *desc, uint32_t n_filters, uint64_t *out_words, uint64_t n_words)
+{
+    if (n_entries && !h) return fail(BSG_E_INVALID, "h is null");
+    static const uint64_t dummy = 0;
+    return build_common(ctx, nullptr, nullptr, h ? h : &dummy, n_entries, filter_entry_start, desc, n_filters,
+                        out_words, n_words);
+}
+
+int32_t bsg_arena_load(bsg_ctx *ctx, const uint64_t *words, uint64_t n_words, const bsg_filter_desc *desc,
+                       uint32_t n_blocks, uint64_t *out_arena_id)
+{
+    if (!ctx || !out_arena_id) return fail(BSG_E_INVALID, "null argument");
+    if (n_blocks && !desc) return fail(BSG_E_INVALID, "desc is null");
+    if (n_words && !words) return fail(BSG_E_INVALID, "words is null");
+    if (int32_t rc = validate_descs(desc, (size_t)n_blocks * 3, n_words)) return rc;
+    const uint32_t nd = (uint32_t)ctx->devs.size();
+    auto arena = std::make_shared<Arena>();
+    arena->n_blocks = n_blocks;
+    arena->shards.resize(nd);
+    for (uint32_t di = 0; di < nd; ++di) {
+        ArenaShard &s = arena->shards[di];
+        Device &d = *ctx->devs[di];
+        s.n_blocks = n_blocks > di ? (n_blocks - di + nd - 1) / nd : 0;
+        // re-lay the shard's filters on 128-byte boundaries
+        std::vector<DevDesc> dd((size_t)s.n_blocks * 3);
+        uint64_t cursor = 0;
+        for (uint32_t lb = 0; lb < s.n_blocks; ++lb) {
+            const uint32_t b = lb * nd + di;
+            for (uint32_t c = 0; c < 3; ++c) {
+                const bsg_filter_desc &f = desc[(size_t)b * 3 + c];
+                DevDesc &o = dd[(size_t)lb * 3 + c];
+                o = DevDesc{0, f.m, barrett_magic(f.m), f.k, 0};
+                if (f.m == 0) continue;
+                const uint64_t nw = (f.m + 63) / 64;
+                o.word_off = cursor;
+                cursor += (nw + kAlignWords - 1) / kAlignWords * kAlignWords;
+                s.sum_words[c] += nw;
+                if (nw <= kLdsCapWords) s.max_staged_words[c] = std::max(s.max_staged_words[c], nw);
+                if (s.fixed_m[c] == 0 && s.geometry_uniform[c]) { s.fixed_m[c] = f.m; s.fixed_k[c] = f.k; }
+                else if (s.fixed_m[c] != f.m || s.fixed_k[c] != f.k) s.geometry_uniform[c] = false;
+            }
+        }
+        s.n_words = cursor + kAlignWords;
+        // one repacked host image -> one H2D copy (the caller's pointers are not retained)
+        std::vector<uint64_t> image(s.n_words, 0);
+        for (uint32_t lb = 0; lb < s.n_blocks; ++lb) {
+            const uint32_t b = lb * nd + di;
+            for (uint32_t c = 0; c < 3; ++c) {
+                const bsg_filter_desc &f = desc[(size_t)b * 3 + c];
+                if (f.m == 0) continue;
+                memcpy(image.data() + dd[(size_t)lb * 3 + c].word_off, words + f.word_off, (f.m + 63) / 64 * 8);
+            }
+        }
+        std::lock_guard<std::mutex> lk(d.mu);
+        if (int32_t rc = use_device(d)) { free_arena(ctx, *arena); return rc; }
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&s.d_words), s.n_words * 8);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&s.d_desc), std::max<size_t>(dd.size(), 1) * sizeof(DevDesc));
+        if (e == hipSuccess && !dd.empty())
+            e = hipMemcpyAsync(s.d_desc, dd.data(), dd.size() * sizeof(DevDesc), hipMemcpyHostToDevice, d.stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(s.d_words, image.data(), s.n_words * 8, hipMemcpyHostToDevice, d.stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(d.stream);
+        if (e != hipSuccess) {
+            free_arena(ctx, *arena);
+            return fail(e == hipErrorOutOfMemory ? BSG_E_NOMEM : BSG_E_HIP, "arena upload failed: %s", hipGetErrorString(e));
+        }
+    }
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    const uint64_t id = ctx->next_id++;
+    ctx->arenas[id] = arena;
+    *out_arena_id = id;
+    return BSG_OK;
+}
+
+int32_t bsg_arena_free(bsg_ctx *ctx, uint64_t arena_id)
+{
+    if (!ctx) return fail(BSG_E_INVALID, "ctx is null");
+    std::shared_ptr<Arena> a;
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        auto it = ctx->arenas.find(arena_id);
+        if (it == ctx->arenas.end()) return fail(BSG_E_NOTFOUND, "unknown arena id %llu", (unsigned long long)arena_id);
+        a = it->second;
+        ctx->arenas.erase(it);
+    }
+    for (auto &dp : ctx->devs) {
+        std::lock_guard<std::mutex> lk(dp->mu);
+        (void)hipSetDevice(dp->id);
+        (void)hipStreamSynchronize(dp->stream);
+    }
+    free_arena(ctx, *a);
+    return BSG_OK;
+}
+
+int32_t bsg_batch_create(bsg_ctx *ctx, const bsg_term *terms, uint32_t n_terms, const uint32_t *prog_ops,
+                         const uint32_t *prog_off, uint32_t n_queries, uint64_t *out_batch_id)
+{
+    if (!ctx || !out_batch_id) return fail(BSG_E_INVALID, "null argument");
+    if (n_terms && !terms) return fail(BSG_E_INVALID, "terms is null");
+    if (n_queries && !prog_off) return fail(BSG_E_INVALID, "prog_off is null");
+    auto batch = std::make_shared<Batch>();
+    Batch &B = *batch;
+    B.n_queries = n_queries;
+    // group terms by kind; each kind's segment starts on a 64-term boundary
+    uint32_t count[3] = {0, 0, 0};
+    for (uint32_t t = 0; t < n_terms; ++t) {
+        if (terms[t].kind > 2) return fail(BSG_E_INVALID, "term %u has unknown kind %u", t, terms[t].kind);
+        count[terms[t].kind]++;
+    }
+    uint32_t begin_of_kind[3] = {0, 0, 0};
+    uint32_t cursor = 0;
+    for (uint32_t c = 0; c < 3; ++c) {
+        if (count[c] == 0) continue;
+        B.kind[B.n_kinds] = c;
+        B.term_begin[B.n_kinds] = cursor;
+        B.term_count[B.n_kinds] = count[c];
+        begin_of_kind[c] = cursor;
+        cursor += (count[c] + 63) / 64 * 64;
+        B.n_kinds++;
+    }
+    B.Tp = cursor;
+    B.Wt = cursor / 64;
+    std::vector<uint32_t> term_pos(n_terms);
+    std::vector<uint64_t> th((size_t)4 * std::max(B.Tp, 1u), 0);
+    uint32_t fill[3] = {0, 0, 0};
+    for (uint32_t t = 0; t < n_terms; ++t) {
+        const uint32_t c = terms[t].kind;
+        const uint32_t pos = begin_of_kind[c] + fill[c]++;
+        term_pos[t] = pos;
+        for (int j = 0; j < 4; ++j) th[(size_t)j * B.Tp + pos] = terms[t].h[j];
+    }
+    // lower programs, pack per 256-query chunk in lane-interleaved (coalesced) order
+    B.n_chunks = (n_queries + bsg::kEvalThreads - 1) / bsg::kEvalThreads;
+    std::vector<uint32_t> chunk_off(std::max(B.n_chunks, 1u), 0), chunk_len(std::max(B.n_chunks, 1u), 0);
+    std::vector<uint32_t> packed;
+    std::vector<std::vector<uint32_t>> lowered(bsg::kEvalThreads);
+    for (uint32_t c = 0; c < B.n_chunks; ++c) {
+        uint32_t maxlen = 0;
+        const uint32_t q0 = c * bsg::kEvalThreads;
+        const uint32_t nq = std::min<uint32_t>(bsg::kEvalThreads, n_queries - q0);
+        for (uint32_t i = 0; i < nq; ++i) {
+            const uint32_t q = q0 + i;
+            if (prog_off[q + 1] < prog_off[q]) return fail(BSG_E_INVALID, "prog_off not monotone at %u", q);
+            const uint32_t n_ops = prog_off[q + 1] - prog_off[q];
+            if (n_ops && !prog_ops) return fail(BSG_E_INVALID, "prog_ops is null");
+            uint32_t depth = 1;
+            if (int32_t rc = lower_program(prog_ops + prog_off[q], n_ops, n_terms, term_pos, lowered[i], depth)) return rc;
+            B.max_depth = std::max(B.max_depth, depth);
+            maxlen = std::max<uint32_t>(maxlen, (uint32_t)lowered[i].size());
+        }
+        chunk_off[c] = (uint32_t)packed.size();
+        chunk_len[c] = maxlen;
+        packed.resize(packed.size() + (size_t)maxlen * bsg::kEvalThreads, 7u << 28);
+        for (uint32_t i = 0; i < nq; ++i)
+            for (size_t j = 0; j < lowered[i].size(); ++j)
+                packed[chunk_off[c] + j * bsg::kEvalThreads + i] = lowered[i][j];
+    }
+    const size_t lds_need = ((size_t)B.Wt * 64 + (size_t)B.max_depth * bsg::kEvalThreads) * 8;
+    if (lds_need > 64 * 1024)
+        return fail(BSG_E_UNSUPPORTED, "batch needs %zu B of LDS (terms %u, depth %u); split the batch", lds_need, B.Tp, B.max_depth);
+    B.dev.resize(ctx->devs.size());
+    for (size_t di = 0; di < ctx->devs.size(); ++di) {
+        Device &d = *ctx->devs[di];
+        BatchDev &bd = B.dev[di];
+        std::lock_guard<std::mutex> lk(d.mu);
+        if (int32_t rc = use_device(d)) { free_batch(ctx, B); return rc; }
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&bd.d_th), th.size() * 8);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&bd.d_prog), std::max<size_t>(packed.size(), 1) * 4);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&bd.d_chunk_off), chunk_off.size() * 4);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&bd.d_chunk_len), chunk_len.size() * 4);
+        if (e == hipSuccess) e = hipMemcpyAsync(bd.d_th, th.data(), th.size() * 8, hipMemcpyHostToDevice, d.stream);
+        if (e == hipSuccess && !packed.empty())
+            e = hipMemcpyAsync(bd.d_prog, packed.data(), packed.size() * 4, hipMemcpyHostToDevice, d.stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(bd.d_chunk_off, chunk_off.data(), chunk_off.size() * 4, hipMemcpyHostToDevice, d.stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(bd.d_chunk_len, chunk_len.data(), chunk_len.size() * 4, hipMemcpyHostToDevice, d.stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(d.stream);
+        if (e != hipSuccess) {
+            free_batch(ctx, B);
+            return fail(e == hipErrorOutOfMemory ? BSG_E_NOMEM : BSG_E_HIP, "batch upload failed: %s", hipGetErrorString(e));
+        }
+    }
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    const uint64_t id = ctx->next_id++;
+    ctx->batches[id] = batch;
+    *out_batch_id = id;
+    return BSG_OK;
+}
+
+int32_t bsg_batch_free(bsg_ctx *ctx, uint64_t batch_id)
+{
+    if (!ctx) return fail(BSG_E_INVALID, "ctx is null");
+    std::shared_ptr<Batch> b;
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        auto it = ctx->batches.find(batch_id);
+        if (it == ctx->batches.end()) return fail(BSG_E_NOTFOUND, "unknown batch id %llu", (unsigned long long)batch_id);
+        b = it->second;
+        ctx->batches.erase(it);
+    }
+    for (auto &dp : ctx->devs) {
+        std::lock_guard<std::mutex> lk(dp->mu);
+        (void)hipSetDevice(dp->id);
+        (void)hipStreamSynchronize(dp->stream);
+    }
+    free_batch(ctx, *b);
+    return BSG_OK;
+}
+
+int32_t bsg_probe_batch(bsg_ctx *ctx, uint64_t arena_id, uint64_t batch_id, uint32_t flags, uint64_t *out_survivors)
+{
+    if (!ctx) return fail(BSG_E_INVALID, "ctx is null");
+    std::shared_ptr<Arena> arena;
+    std::shared_ptr<Batch> batch;
+    if (int32_t rc = get_arena(ctx, arena_id, arena)) return rc;
+    if (int32_t rc = get_batch(ctx, batch_id, batch)) return rc;
+    if ((flags & BSG_PROBE_ASYNC) && out_survivors)
+        return fail(BSG_E_INVALID, "BSG_PROBE_ASYNC cannot return survivors to the host");
+    const Batch &B = *batch;
+    const uint32_t nd = (uint32_t)ctx->devs.size();
+    const uint32_t Q = B.n_queries;
+    const uint64_t Gglobal = ((uint64_t)arena->n_blocks + 63) / 64;
+    if (Q == 0 || arena->n_blocks == 0) return BSG_OK;
+
+    std::vector<std::vector<uint64_t>> host_parts(nd > 1 && out_survivors ? nd : 0);
+    for (uint32_t di = 0; di < nd; ++di) {
+        Device &d = *ctx->devs[di];
+        const ArenaShard &s = arena->shards[di];
+        const BatchDev &bd = B.dev[di];
+        if (s.n_blocks == 0) continue;
+        std::lock_guard<std::mutex> lk(d.mu);
+        if (int32_t rc = use_device(d)) return rc;
+        const uint32_t G = (s.n_blocks + 63) / 64;
+        HIP_TRY(d.V.reserve((size_t)G * std::max(B.Wt, 1u) * 64));
+        HIP_TRY(d.out.reserve((size_t)Q * G));
+        EventTriple ev{};
+        const bool timed = flags & BSG_PROBE_TIMED;
+        if (timed) {
+            if (d.pending.size() >= 4096) if (int32_t rc = drain_timing(ctx, d)) return rc;
+            if (!d.free_events.empty()) { ev = d.free_events.back(); d.free_events.pop_back(); }
+            else {
+                HIP_TRY(hipEventCreate(&ev.e0)); HIP_TRY(hipEventCreate(&ev.e1)); HIP_TRY(hipEventCreate(&ev.e2));
+            }
+            ev.bytes = 0;
+            HIP_TRY(hipEventRecord(ev.e0, d.stream));
+        }
+        if (B.n_kinds > 0) {
+            bsg::ProbeArgs a{};
+            a.words = s.d_words; a.desc = s.d_desc; a.th = bd.d_th; a.V = d.V.p;
+            a.Tp = B.Tp; a.Wt = B.Wt; a.n_blocks = s.n_blocks; a.lds_cap_words = kLdsCapWords;
+            uint64_t lds_words = 2;
+            for (uint32_t y = 0; y < B.n_kinds; ++y) {
+                a.kind[y] = B.kind[y]; a.term_begin[y] = B.term_begin[y]; a.term_count[y] = B.term_count[y];
+                lds_words = std::max(lds_words, s.max_staged_words[B.kind[y]]);
+                ev.bytes += s.sum_words[B.kind[y]] * 8;
+            }
+            lds_words = (lds_words + 1) / 2 * 2;
+            hipLaunchKernelGGL(bsg::k_probe_terms, dim3(s.n_blocks, B.n_kinds), dim3(bsg::kProbeThreads),
+                               lds_words * 8, d.stream, a);
+            HIP_TRY(hipGetLastError());
+        }
+        if (timed) HIP_TRY(hipEventRecord(ev.e1, d.stream));
+        {
+            bsg::EvalArgs a{};
+            a.V = d.V.p; a.prog = bd.d_prog; a.chunk_off = bd.d_chunk_off; a.chunk_len = bd.d_chunk_len;
+            a.out = d.out.p; a.Wt = B.Wt; a.n_blocks = s.n_blocks; a.G = G; a.n_queries = Q;
+            const size_t lds = ((size_t)B.Wt * 64 + (size_t)B.max_depth * bsg::kEvalThreads) * 8;
+            hipLaunchKernelGGL(bsg::k_eval_programs, dim3(G, B.n_chunks), dim3(bsg::kEvalThreads), lds, d.stream, a);
+            HIP_TRY(hipGetLastError());
+        }
+        if (timed) { HIP_TRY(hipEventRecord(ev.e2, d.stream)); d.pending.push_back(ev); }
+        if (out_survivors) {
+            if (nd == 1) {
+                HIP_TRY(hipMemcpyAsync(out_survivors, d.out.p, (size_t)Q * G * 8, hipMemcpyDeviceToHost, d.stream));
+            } else {
+                host_parts[di].resize((size_t)Q * G);
+                HIP_TRY(hipMemcpyAsync(host_parts[di].data(), d.out.p, (size_t)Q * G * 8, hipMemcpyDeviceToHost, d.stream));
+            }
+        }
+    }
+    if (!(flags & BSG_PROBE_ASYNC)) {
+        for (uint32_t di = 0; di < nd; ++di) {
+            Device &d = *ctx->devs[di];
+            std::lock_guard<std::mutex> lk(d.mu);
+            if (int32_t rc = use_device(d)) return rc;
+            HIP_TRY(hipStreamSynchronize(d.stream));
+        }
+    }
+    if (out_survivors && nd > 1) {
+        // host-side gather: local block lb of device di is global block lb * nd + di
+        memset(out_survivors, 0, (size_t)Q * Gglobal * 8);
+        for (uint32_t di = 0; di < nd; ++di) {
+            const ArenaShard &s = arena->shards[di];
+            if (s.n_blocks == 0) continue;
+            const uint32_t G = (s.n_blocks + 63) / 64;
+            for (uint32_t q = 0; q < Q; ++q) {
+                const uint64_t *row = host_parts[di].data() + (size_t)q * G;
+                uint64_t *dst = out_survivors + (size_t)q * Gglobal;
+                for (uint32_t g = 0; g < G; ++g) {
+                    uint64_t w = row[g];
+                    while (w) {
+                        const uint32_t bit = (uint32_t)__builtin_ctzll(w);
+                        w &= w - 1;
+                        const uint64_t b = ((uint64_t)g * 64 + bit) * nd + di;
+                        dst[b >> 6] |= 1ULL << (b & 63);
+                    }
+                }
+            }
+        }
+    }
+    return BSG_OK;
+}
+
+int32_t bsg_probe(bsg_ctx *ctx, uint64_t arena_id, const bsg_term *terms, uint32_t n_terms, const uint32_t *prog_ops,
+                  const uint32_t *prog_off, uint32_t n_queries, uint64_t *out_survivors)
+{
+    if (n_queries && !out_survivors) return fail(BSG_E_INVALID, "out_survivors is null");
+    uint64_t bid = 0;
+    if (int32_t rc = bsg_batch_create(ctx, terms, n_terms, prog_ops, prog_off, n_queries, &bid)) return rc;
+    const int32_t rc = bsg_probe_batch(ctx, arena_id, bid, 0, out_survivors);
+    const std::string saved = g_err;
+    (void)bsg_batch_free(ctx, bid);
+    if (rc) g_err = saved;
+    return rc;
+}
+
+int32_t bsg_timing_read(bsg_ctx *ctx, bsg_timing *out, int32_t reset)
+{
+    if (!ctx || !out) return fail(BSG_E_INVALID, "null argument");
+    for (auto &dp : ctx->devs) {
+        std::lock_guard<std::mutex> lk(dp->mu);
+        if (int32_t rc = use_device(*dp)) return rc;
+        if (int32_t rc = drain_timing(ctx, *dp)) return rc;
+    }
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    *out = ctx->timing;
+    if (reset) ctx->timing = bsg_timing{};
+    return BSG_OK;
+}
+
+static int32_t or_reduce_shard(bsg_ctx *ctx, Arena &arena, uint32_t di, uint32_t kind, uint64_t n_words, uint64_t *d_out)
+{
+    Device &d = *ctx->devs[di];
+    ArenaShard &s = arena.shards[di];
+    if (!s.geometry_uniform[kind]) return fail(BSG_E_INVALID, "filters of kind %u do not share (m, k)", kind);
+    if (s.fixed_m[kind] != 0 && (s.fixed_m[kind] + 63) / 64 != n_words)
+        return fail(BSG_E_INVALID, "n_words %llu does not match m %llu", (unsigned long long)n_words,
+                    (unsigned long long)s.fixed_m[kind]);
+    const uint32_t grid = (uint32_t)std::min<uint64_t>((n_words + 255) / 256, 4096);
+    hipLaunchKernelGGL(bsg::k_or_reduce_blocks, dim3(std::max(grid, 1u)), dim3(256), 0, d.stream, s.d_words, s.d_desc,
+                       s.n_blocks, kind, n_words, d_out);
+    HIP_TRY(hipGetLastError());
+    return BSG_OK;
+}
+
+int32_t bsg_or_reduce_dev(bsg_ctx *ctx, uint64_t arena_id, uint32_t kind, void *d_out, uint64_t n_words)
+{
+    if (!ctx || !d_out) return fail(BSG_E_INVALID, "null argument");
+    if (kind > 2) return fail(BSG_E_INVALID, "unknown kind %u", kind);
+    if (ctx->devs.size() != 1) return fail(BSG_E_UNSUPPORTED, "bsg_or_reduce_dev needs a single-device context");
+    std::shared_ptr<Arena> arena;
+    if (int32_t rc = get_arena(ctx, arena_id, arena)) return rc;
+    Device &d = *ctx->devs[0];
+    std::lock_guard<std::mutex> lk(d.mu);
+    if (int32_t rc = use_device(d)) return rc;
+    if (int32_t rc = or_reduce_shard(ctx, *arena, 0, kind, n_words, static_cast<uint64_t *>(d_out))) return rc;
+    HIP_TRY(hipStreamSynchronize(d.stream));
+    return BSG_OK;
+}
+
+int32_t bsg_or_words_dev(bsg_ctx *ctx, void *d_dst, const void *d_src, uint64_t n_words, uint32_t n_src)
+{
+    if (!ctx || !d_dst || (n_src && !d_src)) return fail(BSG_E_INVALID, "null argument");
+    Device &d = *ctx->devs[0];
+    std::lock_guard<std::mutex> lk(d.mu);
+    if (int32_t rc = use_device(d)) return rc;
+    if (n_words && n_src) {
+        const uint32_t grid = (uint32_t)std::min<uint64_t>((n_words + 255) / 256, 4096);
+        hipLaunchKernelGGL(bsg::k_or_words, dim3(grid), dim3(256), 0, d.stream, static_cast<uint64_t *>(d_dst),
+                           static_cast<const uint64_t *>(d_src), n_words, n_src, 0);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipStreamSynchronize(d.stream));
+    return BSG_OK;
+}
+
+int32_t bsg_or_reduce(bsg_ctx *ctx, uint64_t arena_id, uint32_t kind, uint64_t *out_words, uint64_t n_words)
+{
+    if (!ctx || !out_words) return fail(BSG_E_INVALID, "null argument");
+    if (kind > 2) return fail(BSG_E_INVALID, "unknown kind %u", kind);
+    std::shared_ptr<Arena> arena;
+    if (int32_t rc = get_arena(ctx, arena_id, arena)) return rc;
+    const uint32_t nd = (uint32_t)ctx->devs.size();
+    // geometry must agree across shards too
+    uint64_t m = 0; uint32_t k = 0;
+    for (uint32_t di = 0; di < nd; ++di) {
+        const ArenaShard &s = arena->shards[di];
+        if (s.fixed_m[kind] == 0) continue;
+        if (m == 0) { m = s.fixed_m[kind]; k = s.fixed_k[kind]; }
+        else if (m != s.fixed_m[kind] || k != s.fixed_k[kind])
+            return fail(BSG_E_INVALID, "filters of kind %u do not share (m, k) across devices", kind);
+    }
+    std::vector<uint64_t> part(n_words);
+    memset(out_words, 0, n_words * 8);
+    for (uint32_t di = 0; di < nd; ++di) {
+        Device &d = *ctx->devs[di];
+        std::lock_guard<std::mutex> lk(d.mu);
+        if (int32_t rc = use_device(d)) return rc;
+        HIP_TRY(d.stage_words.reserve(n_words));
+        if (int32_t rc = or_reduce_shard(ctx, *arena, di, kind, n_words, d.stage_words.p)) return rc;
+        HIP_TRY(hipMemcpyAsync(part.data(), d.stage_words.p, n_words * 8, hipMemcpyDeviceToHost, d.stream));
+        HIP_TRY(hipStreamSynchronize(d.stream));
+        for (uint64_t i = 0; i < n_words; ++i) out_words[i] |= part[i];
+    }
+    return BSG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,149 @@
+"""Thin numpy-facing wrapper over the C-ABI (include/bloomgpu.h).
+
+Test / bench glue only: every method is one call into libbloomgpu.so; no
+arithmetic of the hot path is done in Python.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import DESC_DTYPE, TERM_DTYPE, BloomGpuError, Timing
+
+
+def pack_entries(entries):
+    """list[bytes|str] -> (u8 blob, u32 offsets[n+1]) in the layout bsg_hash_entries / bsg_build take."""
+    entries = [e.encode() if isinstance(e, str) else bytes(e) for e in entries]
+    off = np.zeros(len(entries) + 1, dtype=np.uint32)
+    if entries:
+        off[1:] = np.cumsum([len(e) for e in entries], dtype=np.uint64).astype(np.uint32)
+    blob = np.frombuffer(b"".join(entries), dtype=np.uint8).copy() if entries else np.zeros(0, dtype=np.uint8)
+    return blob, off
+
+
+def estimate_parameters(n: int, p: float):
+    """bloom/v3 EstimateParameters with New()'s clamps (host arithmetic, no GPU needed)."""
+    L = _lib.load()
+    m, k = C.c_uint64(), C.c_uint64()
+    rc = L.bsg_estimate_parameters(n, p, C.byref(m), C.byref(k))
+    if rc:
+        raise BloomGpuError(rc, L.bsg_last_error(None).decode())
+    return int(m.value), int(k.value)
+
+
+class Context:
+    """bsg_ctx: one or more gfx950 devices, per-device streams."""
+
+    def __init__(self, device_ids=(0,)):
+        self.L = _lib.load()
+        ids = (C.c_int32 * len(device_ids))(*device_ids)
+        h = C.c_void_p()
+        rc = self.L.bsg_open(ids, len(device_ids), C.byref(h))
+        if rc:
+            raise BloomGpuError(rc, self.L.bsg_last_error(None).decode())
+        self.h = h
+        self.n_devices = len(device_ids)
+
+    def _check(self, rc):
+        if rc:
+            raise BloomGpuError(rc, self.L.bsg_last_error(self.h).decode())
+
+    def close(self):
+        if self.h:
+            self.L.bsg_close(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def sync(self):
+        self._check(self.L.bsg_sync(self.h))
+
+    # ---- construct ----
+    def hash_entries(self, blob: np.ndarray, off: np.ndarray) -> np.ndarray:
+        n = len(off) - 1
+        out = np.zeros((n, 4), dtype=np.uint64)
+        self._check(self.L.bsg_hash_entries(self.h, _lib._ptr(blob), _lib._ptr(off), n, _lib._ptr(out)))
+        return out
+
+    def hash_strings(self, entries) -> np.ndarray:
+        return self.hash_entries(*pack_entries(entries))
+
+    def build(self, blob, off, filter_entry_start, desc, n_words: int) -> np.ndarray:
+        assert desc.dtype == DESC_DTYPE
+        out = np.empty(n_words, dtype=np.uint64)
+        fs = np.ascontiguousarray(filter_entry_start, dtype=np.uint32)
+        self._check(self.L.bsg_build(self.h, _lib._ptr(blob), _lib._ptr(off), len(off) - 1, _lib._ptr(fs),
+                                     _lib._ptr(desc), len(desc), _lib._ptr(out), n_words))
+        return out
+
+    def build_hashed(self, h, filter_entry_start, desc, n_words: int) -> np.ndarray:
+        assert desc.dtype == DESC_DTYPE
+        h = np.ascontiguousarray(h, dtype=np.uint64)
+        out = np.empty(n_words, dtype=np.uint64)
+        fs = np.ascontiguousarray(filter_entry_start, dtype=np.uint32)
+        self._check(self.L.bsg_build_hashed(self.h, _lib._ptr(h), len(h), _lib._ptr(fs), _lib._ptr(desc), len(desc),
+                                            _lib._ptr(out), n_words))
+        return out
+
+    # ---- probe ----
+    def arena_load(self, words: np.ndarray, desc: np.ndarray) -> int:
+        assert desc.dtype == DESC_DTYPE and len(desc) % 3 == 0
+        words = np.ascontiguousarray(words, dtype=np.uint64)
+        aid = C.c_uint64()
+        self._check(self.L.bsg_arena_load(self.h, _lib._ptr(words), len(words), _lib._ptr(desc), len(desc) // 3,
+                                          C.byref(aid)))
+        return int(aid.value)
+
+    def arena_free(self, arena_id: int):
+        self._check(self.L.bsg_arena_free(self.h, arena_id))
+
+    def batch_create(self, terms: np.ndarray, prog_ops, prog_off) -> int:
+        assert terms.dtype == TERM_DTYPE
+        ops = np.ascontiguousarray(prog_ops, dtype=np.uint32)
+        off = np.ascontiguousarray(prog_off, dtype=np.uint32)
+        bid = C.c_uint64()
+        self._check(self.L.bsg_batch_create(self.h, _lib._ptr(terms), len(terms), _lib._ptr(ops), _lib._ptr(off),
+                                            len(off) - 1, C.byref(bid)))
+        return int(bid.value)
+
+    def batch_free(self, batch_id: int):
+        self._check(self.L.bsg_batch_free(self.h, batch_id))
+
+    def probe_batch(self, arena_id: int, batch_id: int, n_queries: int, n_blocks: int, flags: int = 0,
+                    want_output: bool = True):
+        out = np.zeros((n_queries, (n_blocks + 63) // 64), dtype=np.uint64) if want_output else None
+        self._check(self.L.bsg_probe_batch(self.h, arena_id, batch_id, flags, _lib._ptr(out)))
+        return out
+
+    def probe(self, arena_id: int, n_blocks: int, terms: np.ndarray, prog_ops, prog_off) -> np.ndarray:
+        assert terms.dtype == TERM_DTYPE
+        ops = np.ascontiguousarray(prog_ops, dtype=np.uint32)
+        off = np.ascontiguousarray(prog_off, dtype=np.uint32)
+        nq = len(off) - 1
+        out = np.zeros((nq, (n_blocks + 63) // 64), dtype=np.uint64)
+        self._check(self.L.bsg_probe(self.h, arena_id, _lib._ptr(terms), len(terms), _lib._ptr(ops), _lib._ptr(off),
+                                     nq, _lib._ptr(out)))
+        return out
+
+    def timing_read(self, reset: bool = True) -> Timing:
+        t = Timing()
+        self._check(self.L.bsg_timing_read(self.h, C.byref(t), 1 if reset else 0))
+        return t
+
+    # ---- OR-reduce ----
+    def or_reduce(self, arena_id: int, kind: int, n_words: int) -> np.ndarray:
+        out = np.zeros(n_words, dtype=np.uint64)
+        self._check(self.L.bsg_or_reduce(self.h, arena_id, kind, _lib._ptr(out), n_words))
+        return out
+
+    def or_reduce_dev(self, arena_id: int, kind: int, d_out_ptr: int, n_words: int):
+        self._check(self.L.bsg_or_reduce_dev(self.h, arena_id, kind, C.c_void_p(d_out_ptr), n_words))
+
+    def or_words_dev(self, d_dst_ptr: int, d_src_ptr: int, n_words: int, n_src: int):
+        self._check(self.L.bsg_or_words_dev(self.h, C.c_void_p(d_dst_ptr), C.c_void_p(d_src_ptr), n_words, n_src))

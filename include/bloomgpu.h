@@ -1,0 +1,183 @@
+/*
+ * bloomgpu.h — C-ABI of libbloomgpu.so: bloomsearch's hierarchical bloom-filter
+ * construct + probe hot path on AMD MI355X (gfx950 / CDNA4).
+ *
+ * This is the drop-in boundary.  The reference (github.com/danthegoodman1/bloomsearch,
+ * pure Go) has no plugin seam at the bloom level, so the Go host binds these entry
+ * points with cgo at exactly the internal seams named beside each function
+ * (see INTEGRATION.md for the cgo stub).  Everything here is plain C99: int32
+ * status returns, opaque context, caller-owned pointers that are only read or
+ * written for the duration of the call (cgo rule: C never retains a Go pointer).
+ *
+ * Semantics replaced (reference file:line):
+ *   bsg_hash_entries / bsg_build ... buildSizedBloomFilter's AddString loop, ingest.go:139-145
+ *                                    (bloom/v3 v3.7.0 baseHashes + location + bitset.Set)
+ *   bsg_arena_load ................. the decoded result of blockFilterCursor.filtersFor /
+ *                                    parseFilterSection for every block, file_format.go:392-448,575
+ *   bsg_batch_create ............... the pruneBloomQuery tree, query_exec.go:220 / query.go:586-718,
+ *                                    with each distinct term hashed ONCE instead of per TestString
+ *   bsg_probe / bsg_probe_batch .... evaluateBlockFilters' per-block loop + evaluateBloomFilters /
+ *                                    evaluateBloomExpression / evaluateBloomCondition,
+ *                                    query_exec.go:572-615 and :75-159
+ *   bsg_or_reduce .................. north-star extension (fixed-geometry OR of block filters into a
+ *                                    file-level filter); the reference rebuilds instead, merge.go:447-453
+ *
+ * Threading: every entry point is re-entrant on one context (internal mutex
+ * around handle tables, per-call stream ordering); no thread-local "current
+ * device" is assumed.  No callbacks, no exceptions cross the boundary.
+ */
+#ifndef BLOOMGPU_H
+#define BLOOMGPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BSG_API __attribute__((visibility("default")))
+
+/* ---- status codes ---- */
+#define BSG_OK              0
+#define BSG_E_INVALID      -1  /* bad argument / malformed descriptor or program (rejected before any launch) */
+#define BSG_E_HIP          -2  /* HIP runtime error (message in bsg_last_error) */
+#define BSG_E_NOMEM        -3
+#define BSG_E_NOTFOUND     -4  /* unknown arena / batch id */
+#define BSG_E_UNSUPPORTED  -5
+#define BSG_E_NODEVICE     -6  /* no gfx950 device visible: the library never falls back to a CPU path */
+
+/* ---- filter kinds: which of a block's three filters a term tests
+ *      (BloomField / BloomToken / BloomFieldToken, query.go:480-484) ---- */
+#define BSG_KIND_FIELD        0u
+#define BSG_KIND_TOKEN        1u
+#define BSG_KIND_FIELD_TOKEN  2u
+
+/* ---- query program opcodes: op = (opcode << 28) | arg, postfix order ----
+ * TERM i : push TestString(term i) against the block's filter of term i's kind;
+ *          absent filter => true (fail-open, query_exec.go:137-151)
+ * AND n  : pop n, push conjunction   (n == 0 => true,  query_exec.go:115-121)
+ * OR  n  : pop n, push disjunction   (n == 0 => false, query_exec.go:105-114)
+ * TRUE   : nil expression / nil condition           (query_exec.go:84,97)
+ * FALSE  : unknown expression or condition type     (query_exec.go:122,156)
+ * A query with zero ops is a nil BloomQuery => true (query_exec.go:81-83). */
+#define BSG_OP_TERM   0u
+#define BSG_OP_AND    1u
+#define BSG_OP_OR     2u
+#define BSG_OP_TRUE   3u
+#define BSG_OP_FALSE  4u
+#define BSG_OP(opcode, arg) (((uint32_t)(opcode) << 28) | ((uint32_t)(arg) & 0x0FFFFFFFu))
+
+/* One distinct query term: the four bloom/v3 base hashes of the probed string
+ * (Field, Token, or Field+"::"+Token — tokenizer.go:509-511) and the filter kind. */
+typedef struct bsg_term {
+    uint64_t h[4];
+    uint32_t kind;
+    uint32_t reserved;
+} bsg_term;
+
+/* One filter inside a word arena.  Bit i of the filter is bit (i & 63) of
+ * words[word_off + (i >> 6)] (bitset v1.10.0 layout; native little-endian u64,
+ * i.e. the Go []uint64 as-is — the big-endian swap of WriteTo/ReadFrom is the
+ * wire format only).  m == 0 marks an absent (nil) filter. */
+typedef struct bsg_filter_desc {
+    uint64_t word_off;
+    uint64_t m;
+    uint32_t k;
+    uint32_t reserved;
+} bsg_filter_desc;
+
+/* Device-side timing of probes issued with BSG_PROBE_TIMED (HIP events on the
+ * library's own stream; accumulated until read). */
+typedef struct bsg_timing {
+    uint64_t n_probes;        /* probes accumulated                                  */
+    double   ms_terms_kernel; /* sum of probe_terms kernel durations (the HBM stream) */
+    double   ms_eval_kernel;  /* sum of eval_programs kernel durations               */
+    uint64_t stream_bytes;    /* sum over probes of bitset bytes streamed by probe_terms */
+} bsg_timing;
+
+#define BSG_PROBE_ASYNC  1u  /* enqueue only; caller later calls bsg_sync                    */
+#define BSG_PROBE_TIMED  2u  /* bracket the kernels with HIP events (see bsg_timing_read)    */
+
+typedef struct bsg_ctx bsg_ctx;
+
+/* ---- lifecycle (engine construct / Stop) ---- */
+BSG_API int32_t bsg_device_count(void);
+BSG_API int32_t bsg_open(const int32_t *device_ids, int32_t n_devices, bsg_ctx **out_ctx);
+BSG_API int32_t bsg_close(bsg_ctx *ctx);
+/* Message of the calling thread's most recent failure (valid until its next call). */
+BSG_API const char *bsg_last_error(bsg_ctx *ctx);
+BSG_API int32_t bsg_sync(bsg_ctx *ctx);
+
+/* ---- sizing: bloom/v3 EstimateParameters + New's clamps, as called by
+ * buildSizedBloomFilter with n = max(len(set), 1) (ingest.go:139-140).  Pure host
+ * arithmetic for non-Go hosts; a Go host keeps calling bloom.EstimateParameters so
+ * libm differences can never change (m, k). ---- */
+BSG_API int32_t bsg_estimate_parameters(uint64_t n, double false_positive_rate, uint64_t *m, uint64_t *k);
+
+/* ---- construct ---- */
+
+/* h[e] = bloom/v3 baseHashes(entry e): (murmur3_x64_128(d), murmur3_x64_128(d || 0x01)), seed 0.
+ * entry e = bytes[offsets[e] .. offsets[e+1]).  out_h: n_entries * 4 u64. */
+BSG_API int32_t bsg_hash_entries(bsg_ctx *ctx, const uint8_t *bytes, const uint32_t *offsets,
+                                 uint32_t n_entries, uint64_t *out_h);
+
+/* Build n_filters bitsets in one pass.  Entries are grouped by filter:
+ * filter f owns entries [filter_entry_start[f], filter_entry_start[f+1]).
+ * desc[f] gives (m, k) (computed by the caller, see above) and word_off into
+ * out_words, which the callee zero-fills and then populates: for every entry
+ * and i < k, bit (location(h, i) mod m) is set.  Result is a pure function of
+ * (entry set, m, k) — insertion order is irrelevant, exactly as for AddString. */
+BSG_API int32_t bsg_build(bsg_ctx *ctx, const uint8_t *bytes, const uint32_t *offsets, uint32_t n_entries,
+                          const uint32_t *filter_entry_start, const bsg_filter_desc *desc, uint32_t n_filters,
+                          uint64_t *out_words, uint64_t n_words);
+
+/* Same, from pre-computed base hashes (n_entries * 4 u64). */
+BSG_API int32_t bsg_build_hashed(bsg_ctx *ctx, const uint64_t *h, uint32_t n_entries,
+                                 const uint32_t *filter_entry_start, const bsg_filter_desc *desc,
+                                 uint32_t n_filters, uint64_t *out_words, uint64_t n_words);
+
+/* ---- probe ---- */
+
+/* Upload the filters of n_blocks blocks: desc[b*3 + kind].  Blocks are sharded
+ * round-robin over the context's devices (block b -> device b % n_devices). */
+BSG_API int32_t bsg_arena_load(bsg_ctx *ctx, const uint64_t *words, uint64_t n_words,
+                               const bsg_filter_desc *desc, uint32_t n_blocks, uint64_t *out_arena_id);
+BSG_API int32_t bsg_arena_free(bsg_ctx *ctx, uint64_t arena_id);
+
+/* Compile + upload a batch of queries: n_terms distinct terms and, per query q,
+ * the postfix program prog_ops[prog_off[q] .. prog_off[q+1]). */
+BSG_API int32_t bsg_batch_create(bsg_ctx *ctx, const bsg_term *terms, uint32_t n_terms,
+                                 const uint32_t *prog_ops, const uint32_t *prog_off, uint32_t n_queries,
+                                 uint64_t *out_batch_id);
+BSG_API int32_t bsg_batch_free(bsg_ctx *ctx, uint64_t batch_id);
+
+/* Evaluate every query of the batch against every block of the arena.
+ * out_survivors[q * ceil(n_blocks/64) + (b >> 6)] bit (b & 63) == 1  <=>  block b
+ * survives query q (evaluateBloomFilters returned true).  out_survivors may be
+ * NULL to leave the result on the device (benchmarks). */
+BSG_API int32_t bsg_probe_batch(bsg_ctx *ctx, uint64_t arena_id, uint64_t batch_id, uint32_t flags,
+                                uint64_t *out_survivors);
+
+/* One-shot convenience: batch_create + probe_batch + batch_free. */
+BSG_API int32_t bsg_probe(bsg_ctx *ctx, uint64_t arena_id, const bsg_term *terms, uint32_t n_terms,
+                          const uint32_t *prog_ops, const uint32_t *prog_off, uint32_t n_queries,
+                          uint64_t *out_survivors);
+
+BSG_API int32_t bsg_timing_read(bsg_ctx *ctx, bsg_timing *out, int32_t reset);
+
+/* ---- fixed-geometry OR-reduce (extension) ----
+ * All present filters of `kind` in the arena must share (m, k).  out_words
+ * (ceil(m/64) u64) receives their bitwise OR == build(union of entry sets, m, k). */
+BSG_API int32_t bsg_or_reduce(bsg_ctx *ctx, uint64_t arena_id, uint32_t kind, uint64_t *out_words, uint64_t n_words);
+
+/* Device-pointer helper for the one-process-per-GPU layer (torch.distributed all_gather of
+ * partial bitsets, then a local OR): d_dst[i] |= d_src[s*n_words + i] for s < n_src.
+ * Pointers are device pointers on the context's first device. */
+BSG_API int32_t bsg_or_words_dev(bsg_ctx *ctx, void *d_dst, const void *d_src, uint64_t n_words, uint32_t n_src);
+/* Per-device partial OR left on the device: writes n_words u64 at d_out. */
+BSG_API int32_t bsg_or_reduce_dev(bsg_ctx *ctx, uint64_t arena_id, uint32_t kind, void *d_out, uint64_t n_words);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BLOOMGPU_H */

@@ -1,0 +1,480 @@
+/*
+ * bloom_oracle.c — CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * A plain-C restatement of the bloom-filter arithmetic on bloomsearch's
+ * construct + probe hot path.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's `cpu_baseline` leg may load this; the shipped path
+ * (bloomsearch_amd/) never links, imports or calls it.
+ *
+ * PARITY STATUS: **parity unpinned at the bit level by the reference.**
+ * The reference (pure Go; no Go toolchain in this image) delegates the
+ * arithmetic to two un-vendored dependencies,
+ *     github.com/bits-and-blooms/bloom/v3  v3.7.0   (go.mod:6)
+ *     github.com/bits-and-blooms/bitset    v1.10.0  (go.mod:13)
+ * and its own tests hold no golden hash / bitset / serialized bytes.  This
+ * file therefore restates the *published* algorithm of those modules
+ * (assumptions B1..B5 of SURVEY.md §8c) and is pinned on what exists:
+ *   - MurmurHash3_x64_128 public vectors (external truth),
+ *   - the (n,p)->(m,k) values the reference's tests name
+ *     (bloom_tree_engine_test.go:368-376 -> (959,7); lifecycle test (2,0.02)),
+ *   - the hash-dependent outcomes W1..W4 harvested from the reference's tests
+ *     (bloom_tree_engine_test.go:368-400,1867-1901; file_format_test.go:100-165,
+ *      1028-1038),
+ *   - the reference's own call sites: ingest.go:127-145 (build),
+ *     query_exec.go:75-159 (evaluate), file_format.go:343-448 (section codec).
+ * tests/test_oracle_pins.py checks every one of those.
+ *
+ * Build: make -C oracle   (gcc -O2 -shared -fPIC -> oracle/libbloom_oracle.so)
+ */
+#include <stdint.h>
+#include <stddef.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <pthread.h>
+
+#define BO_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------ */
+/* MurmurHash3_x64_128 (Austin Appleby, public domain algorithm).       */
+/* bloom/v3 murmur.go implements exactly this with seed 0 (B2).         */
+/* ------------------------------------------------------------------ */
+static inline uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+
+static inline uint64_t fmix64(uint64_t k)
+{
+    k ^= k >> 33;
+    k *= 0xff51afd7ed558ccdULL;
+    k ^= k >> 33;
+    k *= 0xc4ceb9fe1a85ec53ULL;
+    k ^= k >> 33;
+    return k;
+}
+
+static inline uint64_t le64(const uint8_t *p)
+{
+    uint64_t v = 0;
+    for (int i = 7; i >= 0; --i) v = (v << 8) | p[i];
+    return v;
+}
+
+BO_API void bo_murmur3_x64_128(const uint8_t *data, uint64_t len, uint64_t seed, uint64_t out[2])
+{
+    const uint64_t c1 = 0x87c37b91114253d5ULL, c2 = 0x4cf5ad432745937fULL;
+    uint64_t h1 = seed, h2 = seed;
+    uint64_t nblocks = len / 16;
+    for (uint64_t i = 0; i < nblocks; ++i) {
+        uint64_t k1 = le64(data + 16 * i), k2 = le64(data + 16 * i + 8);
+        k1 *= c1; k1 = rotl64(k1, 31); k1 *= c2; h1 ^= k1;
+        h1 = rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729ULL;
+        k2 *= c2; k2 = rotl64(k2, 33); k2 *= c1; h2 ^= k2;
+        h2 = rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5ULL;
+    }
+    const uint8_t *tail = data + nblocks * 16;
+    uint64_t k1 = 0, k2 = 0;
+    unsigned t = (unsigned)(len & 15);
+    /* bytes 8..14 feed k2, bytes 0..7 feed k1 (little-endian lanes) */
+    for (unsigned i = t; i > 8; --i) k2 ^= (uint64_t)tail[i - 1] << (8 * (i - 9));
+    if (t > 8) { k2 *= c2; k2 = rotl64(k2, 33); k2 *= c1; h2 ^= k2; }
+    unsigned t1 = t > 8 ? 8 : t;
+    for (unsigned i = t1; i > 0; --i) k1 ^= (uint64_t)tail[i - 1] << (8 * (i - 1));
+    if (t > 0) { k1 *= c1; k1 = rotl64(k1, 31); k1 *= c2; h1 ^= k1; }
+    h1 ^= len; h2 ^= len;
+    h1 += h2; h2 += h1;
+    h1 = fmix64(h1); h2 = fmix64(h2);
+    h1 += h2; h2 += h1;
+    out[0] = h1; out[1] = h2;
+}
+
+/* B2: bloom/v3 baseHashes(data) = sum256(data):
+ *   (h0,h1) = murmur128(data), (h2,h3) = murmur128(data || 0x01), seed 0.
+ * The library computes the second pair without materialising the append and
+ * documents it as strictly equivalent; the oracle materialises it (obviously
+ * equivalent, and independent of the in-place formulation the GPU kernel uses).
+ * Call sites: ingest.go:142 (AddString), query_exec.go:141,147,154 (TestString). */
+BO_API void bo_base_hashes(const uint8_t *data, uint64_t len, uint64_t out[4])
+{
+    bo_murmur3_x64_128(data, len, 0, out);
+    uint8_t stackbuf[256];
+    uint8_t *buf = (len + 1 <= sizeof stackbuf) ? stackbuf : (uint8_t *)malloc(len + 1);
+    if (len) memcpy(buf, data, len);
+    buf[len] = 1;
+    bo_murmur3_x64_128(buf, len + 1, 0, out + 2);
+    if (buf != stackbuf) free(buf);
+}
+
+/* B3: bloom/v3 location(h, i) = h[i%2] + i*h[2 + (((i + (i%2)) % 4) / 2)]  (wrapping u64),
+ * then (*BloomFilter).location reduces it mod m. */
+BO_API uint64_t bo_location(const uint64_t h[4], uint64_t i)
+{
+    return h[i % 2] + i * h[2 + (((i + (i % 2)) % 4) / 2)];
+}
+
+/* B1: bloom/v3 EstimateParameters(n, p):
+ *   m = ceil(-1 * n * ln(p) / (ln 2)^2);  k = ceil(ln 2 * m / n)
+ * NewWithEstimates -> New(m,k) clamps each to >= 1.
+ * Call site: ingest.go:139-140 with n = max(len(entries), 1). */
+BO_API void bo_estimate_parameters(uint64_t n, double p, uint64_t *m, uint64_t *k)
+{
+    double mm = ceil(-1.0 * (double)n * log(p) / pow(log(2.0), 2.0));
+    double kk = ceil(log(2.0) * mm / (double)n);
+    uint64_t mi = (uint64_t)mm, ki = (uint64_t)kk;
+    *m = mi < 1 ? 1 : mi;
+    *k = ki < 1 ? 1 : ki;
+}
+
+/* ------------------------------------------------------------------ */
+/* Filter = (m, k, words[ceil(m/64)]); bit i <-> words[i>>6] bit (i&63)  */
+/* (bitset v1.10.0 layout, B5).                                         */
+/* ------------------------------------------------------------------ */
+BO_API uint64_t bo_words_for(uint64_t m) { return (m + 63) / 64; }
+
+/* B4 Add: set all k locations. */
+BO_API void bo_filter_add_hashes(uint64_t *words, uint64_t m, uint64_t k, const uint64_t h[4])
+{
+    for (uint64_t i = 0; i < k; ++i) {
+        uint64_t loc = bo_location(h, i) % m;
+        words[loc >> 6] |= 1ULL << (loc & 63);
+    }
+}
+
+BO_API void bo_filter_add(uint64_t *words, uint64_t m, uint64_t k, const uint8_t *data, uint64_t len)
+{
+    uint64_t h[4];
+    bo_base_hashes(data, len, h);
+    bo_filter_add_hashes(words, m, k, h);
+}
+
+/* B4 Test: all k locations set (early-out on first zero). */
+BO_API int bo_filter_test_hashes(const uint64_t *words, uint64_t m, uint64_t k, const uint64_t h[4])
+{
+    for (uint64_t i = 0; i < k; ++i) {
+        uint64_t loc = bo_location(h, i) % m;
+        if (!((words[loc >> 6] >> (loc & 63)) & 1)) return 0;
+    }
+    return 1;
+}
+
+BO_API int bo_filter_test(const uint64_t *words, uint64_t m, uint64_t k, const uint8_t *data, uint64_t len)
+{
+    uint64_t h[4];
+    bo_base_hashes(data, len, h);
+    return bo_filter_test_hashes(words, m, k, h);
+}
+
+/* buildSizedBloomFilter's insertion loop (ingest.go:139-145) over a packed
+ * entry list: entry e = bytes[off[e] .. off[e+1]).  words must be zeroed and
+ * sized bo_words_for(m).  Insertion order is irrelevant (OR is commutative). */
+BO_API void bo_build(uint64_t *words, uint64_t m, uint64_t k,
+                     const uint8_t *bytes, const uint32_t *off, uint64_t n_entries)
+{
+    for (uint64_t e = 0; e < n_entries; ++e)
+        bo_filter_add(words, m, k, bytes + off[e], off[e + 1] - off[e]);
+}
+
+/* ------------------------------------------------------------------ */
+/* Wire format.  B5: BloomFilter.WriteTo = u64 BE m, u64 BE k, then      */
+/* BitSet.WriteTo = u64 BE length(=m) + ceil(m/64) words, each u64 BE.   */
+/* Used by file_format.go:368 (WriteTo) / :419-420 (ReadFrom).           */
+/* ------------------------------------------------------------------ */
+static void put_be64(uint8_t *p, uint64_t v) { for (int i = 0; i < 8; ++i) p[i] = (uint8_t)(v >> (56 - 8 * i)); }
+static uint64_t get_be64(const uint8_t *p) { uint64_t v = 0; for (int i = 0; i < 8; ++i) v = (v << 8) | p[i]; return v; }
+static void put_le32(uint8_t *p, uint32_t v) { for (int i = 0; i < 4; ++i) p[i] = (uint8_t)(v >> (8 * i)); }
+static uint32_t get_le32(const uint8_t *p) { return (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24; }
+
+BO_API uint64_t bo_filter_serialized_size(uint64_t m) { return 24 + 8 * bo_words_for(m); }
+
+BO_API uint64_t bo_filter_serialize(const uint64_t *words, uint64_t m, uint64_t k, uint8_t *out)
+{
+    put_be64(out, m); put_be64(out + 8, k); put_be64(out + 16, m);
+    uint64_t nw = bo_words_for(m);
+    for (uint64_t i = 0; i < nw; ++i) put_be64(out + 24 + 8 * i, words[i]);
+    return 24 + 8 * nw;
+}
+
+/* Returns bytes consumed, or 0 on malformed input.  words_cap in words. */
+BO_API uint64_t bo_filter_deserialize(const uint8_t *in, uint64_t in_len, uint64_t *m, uint64_t *k,
+                                      uint64_t *words, uint64_t words_cap)
+{
+    if (in_len < 24) return 0;
+    uint64_t mm = get_be64(in), kk = get_be64(in + 8), blen = get_be64(in + 16);
+    uint64_t nw = bo_words_for(blen);
+    if (in_len < 24 + 8 * nw || nw > words_cap) return 0;
+    for (uint64_t i = 0; i < nw; ++i) words[i] = get_be64(in + 24 + 8 * i);
+    *m = mm; *k = kk;
+    return 24 + 8 * nw;
+}
+
+/* CRC32C (Castagnoli), reflected polynomial 0x82F63B78 — Go's
+ * crc32.MakeTable(crc32.Castagnoli) as used by file_format.go:378,403. */
+static uint32_t crc32c_table[256];
+static pthread_once_t crc_once = PTHREAD_ONCE_INIT;
+static void crc_init(void)
+{
+    for (uint32_t i = 0; i < 256; ++i) {
+        uint32_t c = i;
+        for (int j = 0; j < 8; ++j) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
+        crc32c_table[i] = c;
+    }
+}
+BO_API uint32_t bo_crc32c(const uint8_t *data, uint64_t len)
+{
+    pthread_once(&crc_once, crc_init);
+    uint32_t c = 0xFFFFFFFFu;
+    for (uint64_t i = 0; i < len; ++i) c = crc32c_table[(c ^ data[i]) & 0xFF] ^ (c >> 8);
+    return c ^ 0xFFFFFFFFu;
+}
+
+/* Filter section (file_format.go:334-384 encodeFilterSection):
+ *   [u8 flags: bit0 field, bit1 token, bit2 field-token]
+ *   per present filter, in field/token/fieldtoken order: [u32 LE length][filter bytes]
+ *   [u32 LE CRC32C of all preceding section bytes]
+ * present[c] selects the filter; words[c] may be NULL when absent. */
+BO_API uint64_t bo_section_size(const int present[3], const uint64_t m[3])
+{
+    uint64_t sz = 1 + 4;
+    for (int c = 0; c < 3; ++c) if (present[c]) sz += 4 + bo_filter_serialized_size(m[c]);
+    return sz;
+}
+
+BO_API uint64_t bo_encode_filter_section(const int present[3], const uint64_t *const words[3],
+                                         const uint64_t m[3], const uint64_t k[3], uint8_t *out)
+{
+    uint64_t pos = 0;
+    uint8_t flags = 0;
+    for (int c = 0; c < 3; ++c) if (present[c]) flags |= (uint8_t)(1u << c);
+    out[pos++] = flags;
+    for (int c = 0; c < 3; ++c) {
+        if (!present[c]) continue;
+        uint64_t n = bo_filter_serialize(words[c], m[c], k[c], out + pos + 4);
+        put_le32(out + pos, (uint32_t)n);
+        pos += 4 + n;
+    }
+    put_le32(out + pos, bo_crc32c(out, pos));
+    return pos + 4;
+}
+
+/* parseFilterSection (file_format.go:392-448).  Returns 0 ok; negative error:
+ *  -1 too small, -2 CRC mismatch (ErrInvalidHash), -3 unknown flag bits,
+ *  -4 truncated / length overrun, -5 filter decode failure, -6 trailing bytes.
+ * On success fills present/m/k and word_off[c] = byte offset of filter c's
+ * first BE word inside `section` (so callers can decode without copying). */
+BO_API int bo_parse_filter_section(const uint8_t *section, uint64_t len, int present[3],
+                                   uint64_t m[3], uint64_t k[3], uint64_t word_off[3])
+{
+    if (len < 5) return -1;
+    uint64_t plen = len - 4;
+    if (bo_crc32c(section, plen) != get_le32(section + plen)) return -2;
+    uint8_t flags = section[0];
+    if (flags & ~7u) return -3;
+    uint64_t pos = 1;
+    for (int c = 0; c < 3; ++c) {
+        present[c] = (flags >> c) & 1;
+        m[c] = k[c] = word_off[c] = 0;
+        if (!present[c]) continue;
+        if (plen - pos < 4) return -4;
+        uint64_t flen = get_le32(section + pos);
+        pos += 4;
+        if (flen > plen - pos) return -4;
+        if (flen < 24) return -5;
+        uint64_t mm = get_be64(section + pos), kk = get_be64(section + pos + 8), bl = get_be64(section + pos + 16);
+        if (24 + 8 * bo_words_for(bl) > flen) return -5;
+        m[c] = mm; k[c] = kk; word_off[c] = pos + 24;
+        pos += flen;
+    }
+    if (pos != plen) return -6;
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* Expression evaluation (query_exec.go:75-159).                        */
+/* A query is a postfix program over term indices (include/bloomgpu.h): */
+/*   op = (opcode << 28) | arg                                          */
+/*   0 TERM i : push TestString(term i) on the filter of term i's kind; */
+/*              nil filter => true (fail-open, query_exec.go:137-151)   */
+/*   1 AND n  : pop n, push all()  (n = 0 => true,  query_exec.go:115)  */
+/*   2 OR  n  : pop n, push any()  (n = 0 => false, query_exec.go:105)  */
+/*   3 TRUE   : nil expression / nil condition (query_exec.go:84,97)    */
+/*   4 FALSE  : unknown expression / condition type (:122, :156)        */
+/* An empty program is a nil query => true (query_exec.go:81-83).       */
+/* ------------------------------------------------------------------ */
+typedef struct { uint64_t h[4]; uint32_t kind; uint32_t reserved; } bo_term;
+typedef struct { uint64_t word_off; uint64_t m; uint32_t k; uint32_t reserved; } bo_filter_desc;
+
+static int eval_program(const uint32_t *ops, uint32_t n_ops, const uint8_t *term_verdict)
+{
+    if (n_ops == 0) return 1;
+    uint8_t stack[256];
+    int sp = 0;
+    for (uint32_t j = 0; j < n_ops; ++j) {
+        uint32_t opc = ops[j] >> 28, arg = ops[j] & 0x0FFFFFFFu;
+        switch (opc) {
+        case 0: stack[sp++] = term_verdict[arg]; break;
+        case 1: { int r = 1; for (uint32_t c = 0; c < arg; ++c) r &= stack[--sp]; stack[sp++] = (uint8_t)r; break; }
+        case 2: { int r = 0; for (uint32_t c = 0; c < arg; ++c) r |= stack[--sp]; stack[sp++] = (uint8_t)r; break; }
+        case 3: stack[sp++] = 1; break;
+        default: stack[sp++] = 0; break;
+        }
+    }
+    return stack[sp - 1];
+}
+
+/* Batched probe over an arena: for every query q and block b decide whether
+ * block b survives (evaluateBlockFilters' per-block verdict,
+ * query_exec.go:572-615).  desc[b*3 + kind]; m == 0 => filter absent.
+ * out: survivors[q][ceil(n_blocks/64)] little-endian bit b of word b>>6. */
+BO_API void bo_probe_batch(const uint64_t *arena_words, const bo_filter_desc *desc, uint32_t n_blocks,
+                           const bo_term *terms, uint32_t n_terms,
+                           const uint32_t *prog_ops, const uint32_t *prog_off, uint32_t n_queries,
+                           uint64_t *out)
+{
+    uint64_t wpq = ((uint64_t)n_blocks + 63) / 64;
+    memset(out, 0, (size_t)(wpq * n_queries * 8));
+    uint8_t *verdict = (uint8_t *)malloc(n_terms ? n_terms : 1);
+    for (uint32_t b = 0; b < n_blocks; ++b) {
+        for (uint32_t t = 0; t < n_terms; ++t) {
+            const bo_filter_desc *d = &desc[(uint64_t)b * 3 + terms[t].kind];
+            verdict[t] = d->m == 0 ? 1
+                       : (uint8_t)bo_filter_test_hashes(arena_words + d->word_off, d->m, d->k, terms[t].h);
+        }
+        for (uint32_t q = 0; q < n_queries; ++q)
+            if (eval_program(prog_ops + prog_off[q], prog_off[q + 1] - prog_off[q], verdict))
+                out[(uint64_t)q * wpq + (b >> 6)] |= 1ULL << (b & 63);
+    }
+    free(verdict);
+}
+
+/* ------------------------------------------------------------------ */
+/* CPU baseline ("port"): the probe the way the reference executes it — */
+/* per query, per block: parseFilterSection (CRC32C over the section +  */
+/* BE->native decode of all present filters into fresh words,           */
+/* file_format.go:392-448 via cursor.filtersFor, :575), then            */
+/* evaluateBloomFilters with short-circuit and a re-hash of every term  */
+/* string per TestString (query_exec.go:128-158).  Threads split the    */
+/* query range like MaxQueryConcurrency goroutines would.               */
+/* ------------------------------------------------------------------ */
+typedef struct {
+    const uint8_t *sections; const uint64_t *sec_off; uint32_t n_blocks;
+    const uint8_t *term_bytes; const uint32_t *term_off; const uint32_t *term_kind;
+    const uint32_t *prog_ops; const uint32_t *prog_off;
+    uint32_t q0, q1; uint64_t *out; uint64_t wpq; uint64_t max_words; int rc;
+} ref_job;
+
+static int eval_program_lazy(const uint32_t *ops, uint32_t n_ops, uint64_t *const fw[3], const int present[3],
+                             const uint64_t m[3], const uint64_t k[3],
+                             const uint8_t *term_bytes, const uint32_t *term_off, const uint32_t *term_kind)
+{
+    if (n_ops == 0) return 1;
+    uint8_t stack[256];
+    int sp = 0;
+    for (uint32_t j = 0; j < n_ops; ++j) {
+        uint32_t opc = ops[j] >> 28, arg = ops[j] & 0x0FFFFFFFu;
+        switch (opc) {
+        case 0: {
+            uint32_t c = term_kind[arg];
+            stack[sp++] = !present[c] ? 1
+                : (uint8_t)bo_filter_test(fw[c], m[c], k[c], term_bytes + term_off[arg], term_off[arg + 1] - term_off[arg]);
+            break; }
+        case 1: { int r = 1; for (uint32_t c = 0; c < arg; ++c) r &= stack[--sp]; stack[sp++] = (uint8_t)r; break; }
+        case 2: { int r = 0; for (uint32_t c = 0; c < arg; ++c) r |= stack[--sp]; stack[sp++] = (uint8_t)r; break; }
+        case 3: stack[sp++] = 1; break;
+        default: stack[sp++] = 0; break;
+        }
+    }
+    return stack[sp - 1];
+}
+
+static void *ref_worker(void *arg)
+{
+    ref_job *j = (ref_job *)arg;
+    uint64_t *fw[3];
+    for (int c = 0; c < 3; ++c) fw[c] = (uint64_t *)malloc((size_t)(j->max_words ? j->max_words : 1) * 8);
+    for (uint32_t q = j->q0; q < j->q1; ++q) {
+        for (uint32_t b = 0; b < j->n_blocks; ++b) {
+            const uint8_t *sec = j->sections + j->sec_off[b];
+            uint64_t slen = j->sec_off[b + 1] - j->sec_off[b];
+            int present[3]; uint64_t m[3], k[3], woff[3];
+            int rc = bo_parse_filter_section(sec, slen, present, m, k, woff);
+            if (rc) { j->rc = rc; continue; }
+            for (int c = 0; c < 3; ++c) {
+                if (!present[c]) continue;
+                uint64_t nw = bo_words_for(m[c]);
+                for (uint64_t w = 0; w < nw; ++w) fw[c][w] = get_be64(sec + woff[c] + 8 * w);
+            }
+            if (eval_program_lazy(j->prog_ops + j->prog_off[q], j->prog_off[q + 1] - j->prog_off[q],
+                                  fw, present, m, k, j->term_bytes, j->term_off, j->term_kind))
+                j->out[(uint64_t)q * j->wpq + (b >> 6)] |= 1ULL << (b & 63);
+        }
+    }
+    for (int c = 0; c < 3; ++c) free(fw[c]);
+    return NULL;
+}
+
+BO_API int bo_probe_reference_style(const uint8_t *sections, const uint64_t *sec_off, uint32_t n_blocks,
+                                    uint64_t max_words,
+                                    const uint8_t *term_bytes, const uint32_t *term_off, const uint32_t *term_kind,
+                                    const uint32_t *prog_ops, const uint32_t *prog_off, uint32_t n_queries,
+                                    uint32_t n_threads, uint64_t *out)
+{
+    uint64_t wpq = ((uint64_t)n_blocks + 63) / 64;
+    memset(out, 0, (size_t)(wpq * n_queries * 8));
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > 256) n_threads = 256;
+    pthread_t th[256]; ref_job jobs[256];
+    for (uint32_t t = 0; t < n_threads; ++t) {
+        ref_job *j = &jobs[t];
+        j->sections = sections; j->sec_off = sec_off; j->n_blocks = n_blocks;
+        j->term_bytes = term_bytes; j->term_off = term_off; j->term_kind = term_kind;
+        j->prog_ops = prog_ops; j->prog_off = prog_off;
+        j->q0 = (uint32_t)((uint64_t)n_queries * t / n_threads);
+        j->q1 = (uint32_t)((uint64_t)n_queries * (t + 1) / n_threads);
+        j->out = out; j->wpq = wpq; j->max_words = max_words; j->rc = 0;
+        pthread_create(&th[t], NULL, ref_worker, j);
+    }
+    int rc = 0;
+    for (uint32_t t = 0; t < n_threads; ++t) { pthread_join(th[t], NULL); if (jobs[t].rc) rc = jobs[t].rc; }
+    return rc;
+}
+
+/* CPU baseline for the build side: buildFilters over many filters
+ * (ingest.go:127-145), threads split the filter range. */
+typedef struct {
+    const uint8_t *bytes; const uint32_t *off; const uint32_t *fstart;
+    const bo_filter_desc *desc; uint64_t *words; uint32_t f0, f1;
+} build_job;
+
+static void *build_worker(void *arg)
+{
+    build_job *j = (build_job *)arg;
+    for (uint32_t f = j->f0; f < j->f1; ++f) {
+        const bo_filter_desc *d = &j->desc[f];
+        if (d->m == 0) continue;
+        uint64_t *w = j->words + d->word_off;
+        memset(w, 0, (size_t)bo_words_for(d->m) * 8);
+        for (uint32_t e = j->fstart[f]; e < j->fstart[f + 1]; ++e)
+            bo_filter_add(w, d->m, d->k, j->bytes + j->off[e], j->off[e + 1] - j->off[e]);
+    }
+    return NULL;
+}
+
+BO_API void bo_build_many(const uint8_t *bytes, const uint32_t *off, const uint32_t *filter_entry_start,
+                          const bo_filter_desc *desc, uint32_t n_filters, uint32_t n_threads, uint64_t *words)
+{
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > 256) n_threads = 256;
+    pthread_t th[256]; build_job jobs[256];
+    for (uint32_t t = 0; t < n_threads; ++t) {
+        build_job *j = &jobs[t];
+        j->bytes = bytes; j->off = off; j->fstart = filter_entry_start; j->desc = desc; j->words = words;
+        j->f0 = (uint32_t)((uint64_t)n_filters * t / n_threads);
+        j->f1 = (uint32_t)((uint64_t)n_filters * (t + 1) / n_threads);
+        pthread_create(&th[t], NULL, build_worker, j);
+    }
+    for (uint32_t t = 0; t < n_threads; ++t) pthread_join(th[t], NULL);
+}
+
+/* Fixed-geometry OR: OR_b build(S_b, m, k) == build(U S_b, m, k). */
+BO_API void bo_or_words(uint64_t *dst, const uint64_t *src, uint64_t n_words)
+{
+    for (uint64_t i = 0; i < n_words; ++i) dst[i] |= src[i];
+}

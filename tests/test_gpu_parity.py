@@ -1,0 +1,218 @@
+"""GPU parity tests proper: every result of the HIP path (through the C-ABI) is
+compared bit-for-bit with the CPU oracle on the same seeded inputs.  Integer /
+byte work => the bar is exact equality."""
+import numpy as np
+import pytest
+
+from bloomsearch_amd import query as Q
+from bloomsearch_amd._lib import DESC_DTYPE, TERM_DTYPE, BloomGpuError, BSG_E_INVALID, op, OP_AND, OP_TERM
+from bloomsearch_amd.arena import entry_sets_from_strings, plan_blocks
+from bloomsearch_amd.gpu import pack_entries
+from oracle import oracle as O
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def test_hash_entries_bit_exact(ctx):
+    rng = np.random.default_rng(11)
+    ents = [rng.integers(0, 256, size=n, dtype=np.uint8).tobytes() for n in list(range(0, 70)) * 3 + [255, 256, 257, 4095]]
+    ents += [b"user.name", b"user.name::alice", "日本語::héllo".encode(), b"", b"\x00", b"\x01"]
+    got = ctx.hash_strings(ents)
+    want = np.array([O.base_hashes(e) for e in ents], dtype=np.uint64)
+    assert np.array_equal(got, want)
+
+
+def test_hash_entries_large_batch(ctx):
+    rng = np.random.default_rng(12)
+    ents = [b"tok%d" % i for i in rng.integers(0, 1 << 40, size=50000)]
+    got = ctx.hash_strings(ents)
+    idx = rng.integers(0, len(ents), size=500)
+    for i in idx:
+        assert tuple(int(x) for x in got[i]) == O.base_hashes(ents[i])
+
+
+def test_build_bit_exact_small_medium_large_empty_absent(ctx):
+    rng = np.random.default_rng(13)
+    blocks = [
+        entry_sets_from_strings(["a", "b.c"], ["x%d" % i for i in range(300)], []),                # empty FT set => n=1, no bits
+        entry_sets_from_strings(["f%d" % i for i in range(9)], ["t%d" % i for i in range(20000)],   # ~35 KB (LDS staged)
+                                ["f::t%d" % i for i in range(20000)]),
+        entry_sets_from_strings(["only"], ["big%d" % i for i in range(60000)], ["k::v"]),            # > 64 KiB => global-atomic path
+        entry_sets_from_strings([], [], []),
+    ]
+    for fpr in (0.001, 0.01):
+        plan = plan_blocks(blocks, fpr, absent={(3, 1)})
+        got = ctx.build(plan.blob, plan.off, plan.fstart, plan.desc, plan.n_words)
+        want = H.oracle_words(plan)
+        assert np.array_equal(got, want)
+        # sizing rule: exact distinct counts (TestMeasuredFilterSizing, file_format_test.go:28-94)
+        assert plan.desc["m"][1 * 3 + 1] == O.estimate_parameters(20000, fpr)[0]
+        assert plan.desc["m"][0 * 3 + 2] == O.estimate_parameters(1, fpr)[0]
+        assert plan.desc["m"][3 * 3 + 1] == 0
+
+
+def test_build_hashed_equals_build(ctx):
+    blocks = [entry_sets_from_strings(["p"], ["w%d" % i for i in range(5000)], ["p::w%d" % i for i in range(5000)])]
+    plan = plan_blocks(blocks, 0.001)
+    a = ctx.build(plan.blob, plan.off, plan.fstart, plan.desc, plan.n_words)
+    h = ctx.hash_entries(plan.blob, plan.off)
+    b = ctx.build_hashed(h, plan.fstart, plan.desc, plan.n_words)
+    assert np.array_equal(a, b)
+    assert np.array_equal(a, H.oracle_words(plan))
+
+
+def test_build_order_invariance_and_no_false_negatives(ctx):
+    rng = np.random.default_rng(14)
+    toks = ["tok%d" % i for i in range(4000)]
+    p1 = plan_blocks([entry_sets_from_strings(["f"], toks, [])], 0.001)
+    p2 = plan_blocks([entry_sets_from_strings(["f"], [toks[i] for i in rng.permutation(len(toks))], [])], 0.001)
+    w1 = ctx.build(p1.blob, p1.off, p1.fstart, p1.desc, p1.n_words)
+    w2 = ctx.build(p2.blob, p2.off, p2.fstart, p2.desc, p2.n_words)
+    assert np.array_equal(w1, w2)
+    d = p1.desc[1]
+    f = O.Filter(int(d["m"]), int(d["k"]), w1[int(d["word_off"]): int(d["word_off"]) + O.words_for(int(d["m"]))])
+    assert all(f.test(t) for t in toks)
+
+
+@pytest.mark.parametrize("n_blocks,seed", [(1, 1), (63, 2), (64, 3), (65, 4), (130, 5), (257, 6)])
+def test_probe_random_arena_random_trees(ctx, n_blocks, seed):
+    rng = np.random.default_rng(100 + seed)
+    plan, blocks_str, vocab = H.make_random_arena(rng, n_blocks)
+    words = ctx.build(plan.blob, plan.off, plan.fstart, plan.desc, plan.n_words)
+    assert np.array_equal(words, H.oracle_words(plan))
+    exprs = [None] + [H.random_expression(rng, vocab, None) for _ in range(300)]
+    # make sure members are probed too: terms that really exist in some block
+    for b in rng.integers(0, n_blocks, size=40):
+        f, t, ft = blocks_str[b]
+        if t:
+            fld, tok = ft[rng.integers(0, len(ft))].split("::", 1)
+            exprs.append(Q.And(Q.Field(f[0]), Q.Token(t[rng.integers(0, len(t))]), Q.FieldToken(fld, tok)))
+    cb = Q.compile_queries(exprs)
+    ops, poff, _ = cb.arrays()
+    terms = H.gpu_terms(ctx, cb)
+    assert np.array_equal(terms["h"], H.oracle_terms(cb)["h"])
+    aid = ctx.arena_load(words, plan.desc)
+    try:
+        got = ctx.probe(aid, n_blocks, terms, ops, poff)
+    finally:
+        ctx.arena_free(aid)
+    want = O.probe_batch(words, plan.desc.view(O.DESC_DTYPE), terms.view(O.TERM_DTYPE), ops, poff)
+    assert np.array_equal(got, want)
+    assert want.any() and not want.all()
+
+
+def test_probe_nil_filters_fail_open_and_constants(ctx):
+    blocks = [entry_sets_from_strings(["a"], ["x"], ["a::x"]) for _ in range(5)]
+    plan = plan_blocks(blocks, 0.01, absent={(1, 0), (2, 1), (3, 2), (4, 0), (4, 1), (4, 2)})
+    words = ctx.build(plan.blob, plan.off, plan.fstart, plan.desc, plan.n_words)
+    exprs = [Q.Field("zzz"), Q.Token("zzz"), Q.FieldToken("q", "zzz"), Q.And(), Q.Or(), None,
+             Q.And(Q.Field("a"), Q.Token("x"), Q.FieldToken("a", "x")),
+             {"ExpressionType": "CONDITION", "Condition": None}, {"ExpressionType": "NOPE"}]
+    cb = Q.compile_queries(exprs)
+    ops, poff, _ = cb.arrays()
+    terms = H.gpu_terms(ctx, cb)
+    aid = ctx.arena_load(words, plan.desc)
+    got = ctx.probe(aid, 5, terms, ops, poff)
+    ctx.arena_free(aid)
+    want = O.probe_batch(words, plan.desc.view(O.DESC_DTYPE), terms.view(O.TERM_DTYPE), ops, poff)
+    assert np.array_equal(got, want)
+    bits = lambda q: [(int(got[q, 0]) >> b) & 1 for b in range(5)]
+    assert bits(0) == [0, 1, 0, 0, 1]      # nil field filter cannot disqualify (query_exec.go:137-140)
+    assert bits(1) == [0, 0, 1, 0, 1]
+    assert bits(2) == [0, 0, 0, 1, 1]
+    assert bits(3) == [1] * 5 and bits(4) == [0] * 5 and bits(5) == [1] * 5
+    assert bits(6) == [1] * 5 and bits(7) == [1] * 5 and bits(8) == [0] * 5
+
+
+def test_probe_oversize_filter_takes_gather_path(ctx):
+    big = ["big%d" % i for i in range(70000)]
+    blocks = [entry_sets_from_strings(["f"], big, ["f::" + t for t in big[:100]]),
+              entry_sets_from_strings(["f"], ["small"], ["f::small"])]
+    plan = plan_blocks(blocks, 0.001)
+    assert (int(plan.desc["m"][1]) + 63) // 64 > 8192
+    words = ctx.build(plan.blob, plan.off, plan.fstart, plan.desc, plan.n_words)
+    assert np.array_equal(words, H.oracle_words(plan))
+    exprs = [Q.Token(t) for t in big[:200]] + [Q.Token("nope%d" % i) for i in range(200)] + [Q.Token("small")]
+    cb = Q.compile_queries(exprs)
+    ops, poff, _ = cb.arrays()
+    terms = H.gpu_terms(ctx, cb)
+    aid = ctx.arena_load(words, plan.desc)
+    got = ctx.probe(aid, 2, terms, ops, poff)
+    ctx.arena_free(aid)
+    want = O.probe_batch(words, plan.desc.view(O.DESC_DTYPE), terms.view(O.TERM_DTYPE), ops, poff)
+    assert np.array_equal(got, want)
+    assert all(int(got[q, 0]) & 1 for q in range(200))
+
+
+def test_probe_resident_batch_reuse_and_timing(ctx):
+    from bloomsearch_amd._lib import PROBE_TIMED
+    rng = np.random.default_rng(21)
+    plan, blocks_str, vocab = H.make_random_arena(rng, 100, absent_frac=0.0)
+    words = ctx.build(plan.blob, plan.off, plan.fstart, plan.desc, plan.n_words)
+    cb = Q.compile_queries([H.random_expression(rng, vocab, None) for _ in range(700)])
+    ops, poff, _ = cb.arrays()
+    terms = H.gpu_terms(ctx, cb)
+    aid = ctx.arena_load(words, plan.desc)
+    bid = ctx.batch_create(terms, ops, poff)
+    want = O.probe_batch(words, plan.desc.view(O.DESC_DTYPE), terms.view(O.TERM_DTYPE), ops, poff)
+    ctx.timing_read(reset=True)
+    for _ in range(3):
+        got = ctx.probe_batch(aid, bid, cb.n_queries, 100, flags=PROBE_TIMED)
+        assert np.array_equal(got, want)
+    t = ctx.timing_read()
+    assert t.n_probes == 3 and t.ms_terms_kernel > 0 and t.ms_eval_kernel > 0 and t.stream_bytes > 0
+    ctx.batch_free(bid)
+    ctx.arena_free(aid)
+
+
+def test_malformed_inputs_rejected_before_launch(ctx):
+    desc = np.zeros(3, dtype=DESC_DTYPE)
+    desc[1] = (0, 6400, 3, 0)
+    with pytest.raises(BloomGpuError) as e:        # words outside the arena
+        ctx.arena_load(np.zeros(10, dtype=np.uint64), desc)
+    assert e.value.code == BSG_E_INVALID
+    aid = ctx.arena_load(np.zeros(100, dtype=np.uint64), desc)
+    terms = np.zeros(1, dtype=TERM_DTYPE)
+    with pytest.raises(BloomGpuError):             # TERM index out of range
+        ctx.probe(aid, 1, terms, [op(OP_TERM, 5)], [0, 1])
+    with pytest.raises(BloomGpuError):             # AND pops more than the stack holds
+        ctx.probe(aid, 1, terms, [op(OP_TERM, 0), op(OP_AND, 2)], [0, 2])
+    with pytest.raises(BloomGpuError):             # two values left on the stack
+        ctx.probe(aid, 1, terms, [op(OP_TERM, 0), op(OP_TERM, 0)], [0, 2])
+    terms["kind"] = 7
+    with pytest.raises(BloomGpuError):
+        ctx.probe(aid, 1, terms, [op(OP_TERM, 0)], [0, 1])
+    ctx.arena_free(aid)
+    with pytest.raises(BloomGpuError):
+        ctx.arena_free(aid)
+
+
+def test_or_reduce_fixed_geometry_equals_build_of_union(ctx):
+    # OR_b build(S_b, m, k) == build(U S_b, m, k) under one geometry
+    rng = np.random.default_rng(31)
+    universe = ["tok%d" % i for i in range(30000)]
+    m, k = O.estimate_parameters(len(universe), 0.001)
+    n_blocks = 37
+    parts = [[] for _ in range(n_blocks)]
+    for t in universe:
+        parts[rng.integers(0, n_blocks)].append(t)
+    nw = O.words_for(m)
+    stride = (nw + 1) // 2 * 2
+    desc = np.zeros(n_blocks * 3, dtype=DESC_DTYPE)
+    fstart = [0]
+    ents = []
+    for b in range(n_blocks):
+        fstart += [len(ents)]                                  # field: absent
+        desc[b * 3 + 1] = (b * stride, m, k, 0)
+        ents += parts[b]
+        fstart += [len(ents), len(ents)]                       # ft: absent
+    blob, off = pack_entries(ents)
+    words = ctx.build(blob, off, np.asarray(fstart, dtype=np.uint32), desc, n_blocks * stride)
+    aid = ctx.arena_load(words, desc)
+    got = ctx.or_reduce(aid, 1, nw)
+    ctx.arena_free(aid)
+    want = O.Filter(m, k)
+    for t in universe:
+        want.add(t)
+    assert np.array_equal(got, want.words)

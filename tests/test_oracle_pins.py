@@ -1,0 +1,184 @@
+"""Pins for the CPU oracle (oracle/bloom_oracle.c).
+
+The reference's tests hold NO golden filter bytes (parity
+unpinned), so the oracle is anchored on (a) public MurmurHash3_x64_128 vectors,
+(b) the (n,p)->(m,k) values the reference's tests name, (c) every
+hash-dependent outcome harvested from the reference's tests (W1..W4), and
+(d) structural identities of the wire format the reference's call sites imply.
+"""
+import struct
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+
+def test_murmur3_public_vectors():
+    # MurmurHash3_x64_128, seed 0 — public known answers (smhasher / widely published)
+    assert O.murmur3_x64_128(b"") == (0, 0)
+    assert O.murmur3_x64_128(b"hello") == (0xCBD8A7B341BD9B02, 0x5B1E906A48AE1D19)
+    assert O.murmur3_x64_128(b"The quick brown fox jumps over the lazy dog") == (0xE34BBC7BBC071B6C, 0x7A433CA9C49A9347)
+
+
+def test_base_hashes_are_murmur_of_d_and_d_plus_one():
+    # B2: (h0,h1) = murmur(d), (h2,h3) = murmur(d || 0x01); every tail length incl. the 15->16 boundary
+    rng = np.random.default_rng(1)
+    for n in list(range(0, 50)) + [63, 64, 65, 255, 256, 257, 1000]:
+        d = rng.integers(0, 256, size=n, dtype=np.uint8).tobytes()
+        h = O.base_hashes(d)
+        assert h[:2] == O.murmur3_x64_128(d)
+        assert h[2:] == O.murmur3_x64_128(d + b"\x01")
+
+
+def test_location_formula():
+    # B3: i=0:h0; 1:h1+h3; 2:h0+2h3; 3:h1+3h2; 4:h0+4h2; 5:h1+5h3; 6:h0+6h3; 7:h1+7h2 (wrapping)
+    h = (0xFFFFFFFFFFFFFFF0, 0x1111111111111111, 0x8000000000000001, 0x7FFFFFFFFFFFFFFF)
+    M = (1 << 64) - 1
+    expect = [h[0], h[1] + h[3], h[0] + 2 * h[3], h[1] + 3 * h[2], h[0] + 4 * h[2], h[1] + 5 * h[3],
+              h[0] + 6 * h[3], h[1] + 7 * h[2], h[0] + 8 * h[2], h[1] + 9 * h[3], h[0] + 10 * h[3]]
+    for i, e in enumerate(expect):
+        assert O.location(h, i) == e & M
+
+
+@pytest.mark.parametrize("n,p,mk", [
+    (100, 0.01, (959, 7)),        # bloom_tree_engine_test.go:368-376
+    (2, 0.01, (20, 7)),           # bloom_tree_engine_test.go:1867-1901 (2 field entries)
+    (1, 0.001, (15, 11)),         # empty set sized for one entry, ingest.go:135-140
+    (9, 0.001, (130, 11)),
+    (101, 0.001, (1453, 10)),
+    (20000, 0.001, (287552, 10)),
+    (50000, 0.01, (479253, 7)),   # file_format_test.go:100-165
+])
+def test_estimate_parameters(n, p, mk):
+    assert O.estimate_parameters(n, p) == mk
+
+
+def test_W1_evaluate_bloom_filters_fixture():
+    # bloom_tree_engine_test.go:368-400: "nonexistent.field" must miss, members must hit
+    f = O.Filter.with_estimates(100, 0.01)
+    f.add("user.name"); f.add("user.age")
+    assert f.test("user.name") and f.test("user.age")
+    assert not f.test("nonexistent.field")
+    t = O.Filter.with_estimates(100, 0.01)
+    t.add("alice"); t.add("30")
+    assert t.test("alice") and t.test("30")
+    ft = O.Filter.with_estimates(100, 0.01)
+    ft.add("user.name::alice"); ft.add("user.age::30")
+    assert ft.test("user.name::alice")
+
+
+def test_W2_file_level_field_prune():
+    # bloom_tree_engine_test.go:1867-1901: file with fields {id, service} is pruned for Field("message")
+    f = O.build_sized(["id", "service"], 0.01)
+    assert (f.m, f.k) == (20, 7)
+    assert not f.test("message")
+
+
+def test_W3_merge_rebuild_absent_tokens():
+    # file_format_test.go:1028-1038: after merge, at least one of zzzabsent0..4 misses
+    f = O.build_sized(["a%d" % i for i in range(20)] + ["b%d" % i for i in range(200)], 0.001)
+    assert not all(f.test("zzzabsent%d" % i) for i in range(5))
+
+
+def test_W4_false_positive_budget():
+    # file_format_test.go:100-165: 50 000 tokens at fpr 0.01, <= 3x budget over 10 000 absent probes
+    f = O.build_sized(["tok%d" % i for i in range(50000)], 0.01)
+    assert (f.m, f.k) == (479253, 7)
+    assert all(f.test("tok%d" % i) for i in range(0, 50000, 7))          # no false negatives
+    fp = sum(f.test("absent%d" % i) for i in range(10000))
+    assert fp <= 300
+    assert fp == 99   # the restatement's exact count; flips if any hash detail changes
+
+
+def test_bitset_layout_and_wire_format():
+    # B5: bit i <-> words[i>>6] bit (i&63); WriteTo = BE m, BE k, BE len(=m), BE words
+    f = O.Filter(130, 3)
+    f.words[0] = 1 | (1 << 63)
+    f.words[2] = 2
+    raw = f.serialize()
+    assert len(raw) == 24 + 8 * 3
+    assert struct.unpack(">QQQ", raw[:24]) == (130, 3, 130)
+    assert struct.unpack(">QQQ", raw[24:]) == (1 | (1 << 63), 0, 2)
+    g = O.Filter.deserialize(raw)
+    assert (g.m, g.k) == (130, 3) and np.array_equal(g.words, f.words)
+
+
+def test_crc32c_known_answer():
+    assert O.crc32c(b"123456789") == 0xE3069283   # CRC-32C (Castagnoli) check value
+    assert O.crc32c(b"") == 0
+
+
+def test_filter_section_codec_roundtrip_and_errors():
+    f = O.build_sized(["user.name", "user.age"], 0.01)
+    t = O.build_sized(["alice", "30"], 0.01)
+    for filters in ([f, t, None], [None, None, None], [f, None, t], [f, t, f]):
+        sec = O.encode_filter_section(filters)
+        flags = sum(1 << c for c in range(3) if filters[c] is not None)
+        assert sec[0] == flags
+        # size identity: 1 + sum(4 + 24 + 8*ceil(m/64)) + 4
+        assert len(sec) == 1 + sum(4 + 24 + 8 * O.words_for(x.m) for x in filters if x is not None) + 4
+        assert struct.unpack("<I", sec[-4:])[0] == O.crc32c(sec[:-4])
+        back = O.parse_filter_section(sec)
+        for a, b in zip(filters, back):
+            assert (a is None) == (b is None)
+            if a is not None:
+                assert (a.m, a.k) == (b.m, b.k) and np.array_equal(a.words, b.words)
+    sec = bytearray(O.encode_filter_section([f, t, None]))
+    sec[10] ^= 0x40
+    with pytest.raises(ValueError) as e:           # ErrInvalidHash (file_format.go:403-405)
+        O.parse_filter_section(bytes(sec))
+    assert e.value.args[0] == -2
+    with pytest.raises(ValueError) as e:           # too small (file_format.go:393-395)
+        O.parse_filter_section(b"\x00\x00")
+    assert e.value.args[0] == -1
+    bad = bytes([0x08]) + b""
+    bad = bad + struct.pack("<I", O.crc32c(bad))
+    with pytest.raises(ValueError) as e:           # unrecognized flags (file_format.go:408-410)
+        O.parse_filter_section(bad)
+    assert e.value.args[0] == -3
+
+
+def test_build_is_order_invariant_and_union_identity():
+    rng = np.random.default_rng(5)
+    ents = ["e%d" % i for i in range(500)]
+    a = O.Filter(4099, 5); b = O.Filter(4099, 5)
+    for e in ents: a.add(e)
+    for i in rng.permutation(len(ents)): b.add(ents[i])
+    assert np.array_equal(a.words, b.words)
+    # fixed geometry: OR of per-shard builds == build of the union
+    parts = [O.Filter(4099, 5) for _ in range(4)]
+    for i, e in enumerate(ents): parts[i % 4].add(e)
+    acc = np.zeros_like(a.words)
+    for p in parts: acc |= p.words
+    assert np.array_equal(acc, a.words)
+
+
+def test_probe_batch_matches_per_filter_tests():
+    # the batched oracle agrees with the scalar Filter.test path on the TestEvaluateBloomFilters fixture
+    from bloomsearch_amd import query as Q
+    from tests.helpers import oracle_terms
+    f = O.build_sized(["user.name", "user.age"], 0.01)
+    t = O.build_sized(["alice", "30"], 0.01)
+    ft = O.build_sized(["user.name::alice", "user.age::30"], 0.01)
+    # NewWithEstimates(100, 0.01) in the reference fixture; sizes differ here but semantics are the same
+    words = np.concatenate([f.words, t.words, ft.words])
+    desc = np.zeros(3, dtype=O.DESC_DTYPE)
+    off = 0
+    for c, x in enumerate((f, t, ft)):
+        desc[c] = (off, x.m, x.k, 0)
+        off += len(x.words)
+    cases = [
+        (None, True),
+        (Q.Field("user.name"), True),
+        (Q.Token("alice"), True),
+        (Q.FieldToken("user.name", "alice"), True),
+        (Q.Or(Q.Field("nonexistent.field"), Q.Field("user.name")), True),
+        (Q.Or(), False),
+        (Q.And(), True),
+    ]
+    cb = Q.compile_queries([c[0] for c in cases])
+    ops, poff, _ = cb.arrays()
+    out = O.probe_batch(words, desc, oracle_terms(cb).view(O.TERM_DTYPE), ops, poff)
+    for q, (_, want) in enumerate(cases):
+        assert bool(out[q, 0] & 1) == want
