@@ -730,8 +730,11 @@ int32_t bsg_probe_batch(bsg_ctx *ctx, uint64_t arena_id, uint64_t batch_id, uint
                 ev.bytes += s.sum_words[B.kind[y]] * 8;
             }
             lds_words = (lds_words + 1) / 2 * 2;
+            uint32_t max_tw = 0;
+            for (uint32_t y = 0; y < B.n_kinds; ++y) max_tw = std::max(max_tw, (B.term_count[y] + 63) / 64);
+            const size_t head = ((size_t)max_tw * 8 + 4 + 15) & ~(size_t)15;
             hipLaunchKernelGGL(bsg::k_probe_terms, dim3(s.n_blocks, B.n_kinds), dim3(bsg::kProbeThreads),
-                               lds_words * 8, d.stream, a);
+                               head + lds_words * 8, d.stream, a);
             HIP_TRY(hipGetLastError());
         }
         if (timed) HIP_TRY(hipEventRecord(ev.e1, d.stream));

@@ -16,7 +16,7 @@ namespace bsg {
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kWave = 64;
-constexpr int kProbeThreads = 256;
+constexpr int kProbeThreads = 512;
 constexpr int kEvalThreads = 256;
 constexpr int kBuildThreads = 256;
 
@@ -171,6 +171,127 @@ struct ProbeArgs {
     uint32_t term_count[3];       // real terms of that kind
 };
 
+// x mod m for m < 2^31: the remainder candidate x - q*m lies in [0, 2m) so only
+// its low 32 bits are needed.
+__device__ __forceinline__ uint32_t mod_m32(uint64_t x, uint32_t m, uint64_t magic)
+{
+    const uint64_t q = __umul64hi(x, magic);
+    uint32_t r = (uint32_t)x - (uint32_t)q * m;
+    if (r >= m) r -= m;
+    return r;
+}
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+typedef __attribute__((address_space(3))) uint64_t lds_u64;
+
+template <bool M32, typename BITS32>
+__device__ __forceinline__ bool test_location(BITS32 bits, const DevDesc &d, uint64_t x)
+{
+    if (M32) {
+        const uint32_t loc = mod_m32(x, (uint32_t)d.m, d.magic);
+        return (bits[loc >> 5] >> (loc & 31)) & 1u;
+    } else {
+        const uint64_t loc = mod_m(x, d.m, d.magic);
+        return (bits[loc >> 5] >> ((uint32_t)loc & 31)) & 1u;
+    }
+}
+
+// Mode A (few terms): every wave-task is one (location index i, 64-term word w) pair, so all
+// k locations of all terms are tested concurrently — one probe per lane, no serial early-out
+// chain.  Pass masks are AND-ed into the LDS verdict words.
+template <bool M32, typename BITS32>
+__device__ __forceinline__ void probe_parallel_k(const ProbeArgs &a, const DevDesc &d, BITS32 bits, uint32_t t0,
+                                                 uint32_t n_real, uint32_t n_tw, lds_u64 *vw, uint32_t wave, uint32_t lane)
+{
+    constexpr uint32_t n_waves = kProbeThreads / kWave;
+    const uint32_t n_tasks = n_tw * d.k;
+    for (uint32_t task = wave; task < n_tasks; task += n_waves) {
+        const uint32_t i = task / n_tw, w = task - i * n_tw;
+        const uint32_t idx = w * 64 + lane;
+        const uint32_t t = t0 + idx;
+        const uint32_t r = i & 3u;
+        const uint64_t ha = a.th[(uint64_t)(i & 1u) * a.Tp + t];
+        const uint64_t hb = a.th[(uint64_t)((r == 1u || r == 2u) ? 3u : 2u) * a.Tp + t];
+        bool pass = true;
+        if (idx < n_real) pass = test_location<M32>(bits, d, ha + (uint64_t)i * hb);
+        const uint64_t mask = __ballot(pass);
+        if (lane == 0 && mask != ~0ULL) __hip_atomic_fetch_and(&vw[w], mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+}
+
+// Mode B (many terms): persistent lanes.  A lane keeps one term in registers and tests one
+// location per iteration; the moment a term is rejected (or accepted after k hits) the lane draws
+// the next term index from a workgroup-wide LDS ticket (one ds_add per wave per iteration, ranks by
+// mbcnt), so all 64 lanes stay busy and the expected work is ~2 probes per absent term instead of
+// the wave-wide maximum.  Lanes refilling in the same iteration get consecutive tickets, so their
+// hash loads stay coalesced.
+template <bool M32, typename BITS32>
+__device__ __forceinline__ void probe_persistent(const ProbeArgs &a, const DevDesc &d, BITS32 bits, uint32_t t0,
+                                                 uint32_t n_real, lds_u32 *vbits, lds_u32 *ticket, uint32_t lane)
+{
+    uint64_t h0 = 0, h1 = 0, h2 = 0, h3 = 0;
+    uint32_t idx = 0, i = 0;
+    bool busy = false, exhausted = false;
+    for (;;) {
+        const bool need = !busy && !exhausted;
+        const uint64_t need_mask = __ballot(need);
+        if (need_mask) {
+            uint32_t base = 0;
+            if (lane == (uint32_t)__builtin_ctzll(need_mask))
+                base = __hip_atomic_fetch_add(ticket, (uint32_t)__builtin_popcountll(need_mask), __ATOMIC_RELAXED,
+                                              __HIP_MEMORY_SCOPE_WORKGROUP);
+            base = __shfl(base, __builtin_ctzll(need_mask), kWave);
+            if (need) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need_mask >> 32),
+                                                                __builtin_amdgcn_mbcnt_lo((uint32_t)need_mask, 0u));
+                idx = base + rank;
+                if (idx < n_real) {
+                    const uint32_t t = t0 + idx;
+                    h0 = a.th[t]; h1 = a.th[(uint64_t)a.Tp + t];
+                    h2 = a.th[2ull * a.Tp + t]; h3 = a.th[3ull * a.Tp + t];
+                    i = 0; busy = true;
+                } else {
+                    exhausted = true;
+                }
+            }
+        }
+        if (__ballot(busy) == 0) break;
+        if (busy) {
+            const bool hit = test_location<M32>(bits, d, location(h0, h1, h2, h3, i));
+            if (!hit) {
+                busy = false;
+            } else if (++i == d.k) {
+                __hip_atomic_fetch_or(&vbits[idx >> 5], 1u << (idx & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                busy = false;
+            }
+        }
+    }
+}
+
+constexpr uint32_t kParallelKMaxWords = 8;  // term words (x64 terms) up to which mode A is used
+
+template <bool M32, typename BITS32>
+__device__ __forceinline__ void probe_block(const ProbeArgs &a, const DevDesc &d, BITS32 bits, uint32_t t0,
+                                            uint32_t n_real, uint32_t n_tw, lds_u64 *vw, lds_u32 *ticket,
+                                            uint64_t *vout, uint32_t tid)
+{
+    const uint32_t lane = tid & (kWave - 1), wave = tid / kWave;
+    const bool par = n_tw <= kParallelKMaxWords;
+    // verdict words start as "all real terms pass" (mode A ANDs failures in) or zero (mode B ORs hits in)
+    for (uint32_t w = tid; w < n_tw; w += kProbeThreads) {
+        const uint32_t rem = n_real - w * 64;
+        vw[w] = par ? (rem >= 64 ? ~0ULL : ((1ULL << rem) - 1)) : 0ULL;
+    }
+    if (tid == 0) *ticket = 0;
+    __syncthreads();
+    if (par) probe_parallel_k<M32>(a, d, bits, t0, n_real, n_tw, vw, wave, lane);
+    else     probe_persistent<M32>(a, d, bits, t0, n_real, (lds_u32 *)vw, ticket, lane);
+    __syncthreads();
+    for (uint32_t w = tid; w < n_tw; w += kProbeThreads) vout[(uint64_t)w * 64] = vw[w];
+}
+
 __global__ __launch_bounds__(kProbeThreads) void k_probe_terms(const ProbeArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
@@ -191,36 +312,32 @@ __global__ __launch_bounds__(kProbeThreads) void k_probe_terms(const ProbeArgs a
         for (uint32_t w = tid; w < n_tw; w += kProbeThreads) vout[(uint64_t)w * 64] = ~0ULL;
         return;
     }
-    const uint64_t nw = (d.m + 63) >> 6;
-    const bool staged = nw <= a.lds_cap_words;
-    const uint64_t *src = a.words + d.word_off;
-    const uint32_t *bits;
-    if (staged) {
-        const uint32_t n16 = (uint32_t)((nw + 1) >> 1);  // 16-byte units (arena pads filters to even words)
-        const u32x4 *s4 = reinterpret_cast<const u32x4 *>(src);
-        u32x4 *d4 = reinterpret_cast<u32x4 *>(lds64);
-        for (uint32_t i = tid; i < n16; i += kProbeThreads) d4[i] = s4[i];
-        __syncthreads();
-        bits = reinterpret_cast<const uint32_t *>(lds64);
-    } else {
-        bits = reinterpret_cast<const uint32_t *>(src);
-    }
+    // LDS carve: [verdict words | ticket | pad to 16 B][bitset image]
+    lds_u64 *vw = (lds_u64 *)lds64;
+    lds_u32 *ticket = (lds_u32 *)(vw + n_tw);
+    const uint32_t head_bytes = (n_tw * 8 + 4 + 15) & ~15u;
+    char *image = reinterpret_cast<char *>(lds64) + head_bytes;
 
-    for (uint32_t w = wave; w < n_tw; w += n_waves) {
-        const uint32_t t = t0 + w * 64 + lane;
-        bool alive = (w * 64 + lane) < n_real;
-        const uint64_t h0 = a.th[t], h1 = a.th[(uint64_t)a.Tp + t];
-        const uint64_t h2 = a.th[2ull * a.Tp + t], h3 = a.th[3ull * a.Tp + t];
-        for (uint32_t i = 0; i < d.k; ++i) {
-            if (__ballot(alive) == 0) break;
-            if (alive) {
-                const uint64_t loc = mod_m(location(h0, h1, h2, h3, i), d.m, d.magic);
-                const uint32_t word = bits[loc >> 5];
-                alive = (word >> (loc & 31)) & 1u;
-            }
+    const uint64_t nw = (d.m + 63) >> 6;
+    const uint64_t *src = a.words + d.word_off;
+    if (nw <= a.lds_cap_words) {
+        // HBM -> LDS by LDS-DMA: every wave issues all of its 1 KiB pieces back to back
+        // (64 lanes x 16 B, no VGPR round trip), one wait for the whole filter.
+        const uint32_t nbytes = (uint32_t)(((nw + 1) >> 1) << 4);
+        const char *g = reinterpret_cast<const char *>(src);
+        for (uint32_t c = wave * 1024u; c < nbytes; c += n_waves * 1024u) {
+            const uint32_t boff = c + lane * 16u;
+            if (boff < nbytes)
+                __builtin_amdgcn_global_load_lds((glb_void *)(g + boff), (lds_void *)(image + c), 16, 0, 0);
         }
-        const uint64_t verdict = __ballot(alive);
-        if (lane == 0) vout[(uint64_t)w * 64] = verdict;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const lds_u32 *lbits = (const lds_u32 *)image;
+        if (d.m < (1ull << 31)) probe_block<true>(a, d, lbits, t0, n_real, n_tw, vw, ticket, vout, tid);
+        else                    probe_block<false>(a, d, lbits, t0, n_real, n_tw, vw, ticket, vout, tid);
+    } else {
+        const uint32_t *gbits = reinterpret_cast<const uint32_t *>(src);
+        if (d.m < (1ull << 31)) probe_block<true>(a, d, gbits, t0, n_real, n_tw, vw, ticket, vout, tid);
+        else                    probe_block<false>(a, d, gbits, t0, n_real, n_tw, vw, ticket, vout, tid);
     }
 }
 

@@ -66,10 +66,8 @@ def _fmt_uints(values: np.ndarray, prefix: bytes = b""):
     values = np.asarray(values, dtype=np.uint64)
     blobs, lens = [], []
     nd = np.ones(len(values), dtype=np.int64)
-    p = np.uint64(10)
-    for _ in range(19):
-        nd += values >= p
-        p = p * np.uint64(10)
+    for e in range(1, 20):
+        nd += values >= np.uint64(10 ** e)
     P = len(prefix)
     pre = np.frombuffer(prefix, dtype=np.uint8)
     for d in np.unique(nd):
