@@ -7,6 +7,7 @@
 // entry point fails with BSG_E_NODEVICE / BSG_E_HIP.
 #include "bloomgpu.h"
 #include "kernels.hip.h"
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cmath>
@@ -73,7 +74,9 @@ struct DevBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
-struct EventTriple { hipEvent_t e0, e1, e2; uint64_t bytes; };
+// start/stop timestamps of the two dispatches themselves (hipExtLaunchKernel), i.e. the same
+// begin/end a rocprofv3 kernel trace reports — not events bracketing the launches.
+struct EventTriple { hipEvent_t k1s, k1e, k2s, k2e; uint64_t bytes; };
 
 struct Device {
     int id = 0;
@@ -114,6 +117,8 @@ struct BatchDev {
     uint32_t *d_prog = nullptr;
     uint32_t *d_chunk_off = nullptr;
     uint32_t *d_chunk_len = nullptr;
+    uint32_t *d_cw_off = nullptr;
+    uint32_t *d_cw = nullptr;
 };
 
 struct Batch {
@@ -125,6 +130,7 @@ struct Batch {
     uint32_t term_count[3] = {0, 0, 0};
     uint32_t n_chunks = 0;
     uint32_t max_depth = 1;
+    uint32_t max_cw = 1;            // most verdict words any 256-query chunk references
     std::vector<BatchDev> dev;
 };
 
@@ -164,6 +170,8 @@ void free_batch(bsg_ctx *ctx, Batch &b)
         if (b.dev[i].d_prog) (void)hipFree(b.dev[i].d_prog);
         if (b.dev[i].d_chunk_off) (void)hipFree(b.dev[i].d_chunk_off);
         if (b.dev[i].d_chunk_len) (void)hipFree(b.dev[i].d_chunk_len);
+        if (b.dev[i].d_cw_off) (void)hipFree(b.dev[i].d_cw_off);
+        if (b.dev[i].d_cw) (void)hipFree(b.dev[i].d_cw);
     }
 }
 
@@ -173,8 +181,8 @@ int32_t drain_timing(bsg_ctx *ctx, Device &d)
     HIP_TRY(hipStreamSynchronize(d.stream));
     for (auto &t : d.pending) {
         float a = 0, b = 0;
-        HIP_TRY(hipEventElapsedTime(&a, t.e0, t.e1));
-        HIP_TRY(hipEventElapsedTime(&b, t.e1, t.e2));
+        HIP_TRY(hipEventElapsedTime(&a, t.k1s, t.k1e));
+        HIP_TRY(hipEventElapsedTime(&b, t.k2s, t.k2e));
         std::lock_guard<std::mutex> lk(ctx->mu);
         ctx->timing.n_probes += 1;
         ctx->timing.ms_terms_kernel += a;
@@ -335,8 +343,11 @@ int32_t bsg_close(bsg_ctx *ctx)
         Device &d = *dp;
         (void)hipSetDevice(d.id);
         if (d.stream) (void)hipStreamSynchronize(d.stream);
-        for (auto &t : d.pending) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); (void)hipEventDestroy(t.e2); }
-        for (auto &t : d.free_events) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); (void)hipEventDestroy(t.e2); }
+        for (auto *v : {&d.pending, &d.free_events})
+            for (auto &t : *v) {
+                (void)hipEventDestroy(t.k1s); (void)hipEventDestroy(t.k1e);
+                (void)hipEventDestroy(t.k2s); (void)hipEventDestroy(t.k2e);
+            }
         d.V.release(); d.out.release(); d.stage_a.release(); d.stage_off.release(); d.stage_h.release();
         d.stage_fstart.release(); d.stage_desc.release(); d.stage_items.release(); d.stage_words.release();
         if (d.stream) (void)hipStreamDestroy(d.stream);
@@ -609,6 +620,7 @@ int32_t bsg_batch_create(bsg_ctx *ctx, const bsg_term *terms, uint32_t n_terms, 
     B.n_chunks = (n_queries + bsg::kEvalThreads - 1) / bsg::kEvalThreads;
     std::vector<uint32_t> chunk_off(std::max(B.n_chunks, 1u), 0), chunk_len(std::max(B.n_chunks, 1u), 0);
     std::vector<uint32_t> packed;
+    std::vector<uint32_t> cw_off((size_t)B.n_chunks + 1, 0), cw;
     std::vector<std::vector<uint32_t>> lowered(bsg::kEvalThreads);
     for (uint32_t c = 0; c < B.n_chunks; ++c) {
         uint32_t maxlen = 0;
@@ -624,16 +636,43 @@ int32_t bsg_batch_create(bsg_ctx *ctx, const bsg_term *terms, uint32_t n_terms, 
             B.max_depth = std::max(B.max_depth, depth);
             maxlen = std::max<uint32_t>(maxlen, (uint32_t)lowered[i].size());
         }
+        // verdict words this chunk references -> slots; TERM args become slot * 64 + bit
+        std::vector<uint32_t> words;
+        for (uint32_t i = 0; i < nq; ++i)
+            for (uint32_t op : lowered[i])
+                if ((op >> 28) == 0u) words.push_back((op & 0x0FFFFFFFu) >> 6);
+        std::sort(words.begin(), words.end());
+        words.erase(std::unique(words.begin(), words.end()), words.end());
+        cw_off[c] = (uint32_t)cw.size();
+        cw.insert(cw.end(), words.begin(), words.end());
+        B.max_cw = std::max<uint32_t>(B.max_cw, (uint32_t)words.size());
         chunk_off[c] = (uint32_t)packed.size();
         chunk_len[c] = maxlen;
         packed.resize(packed.size() + (size_t)maxlen * bsg::kEvalThreads, 7u << 28);
         for (uint32_t i = 0; i < nq; ++i)
-            for (size_t j = 0; j < lowered[i].size(); ++j)
-                packed[chunk_off[c] + j * bsg::kEvalThreads + i] = lowered[i][j];
+            for (size_t j = 0; j < lowered[i].size(); ++j) {
+                uint32_t op = lowered[i][j];
+                if ((op >> 28) == 0u) {
+                    const uint32_t pos = op & 0x0FFFFFFFu;
+                    const uint32_t slot = (uint32_t)(std::lower_bound(words.begin(), words.end(), pos >> 6) - words.begin());
+                    op = slot * 64 + (pos & 63);
+                }
+                packed[chunk_off[c] + j * bsg::kEvalThreads + i] = op;
+            }
     }
-    const size_t lds_need = ((size_t)B.Wt * 64 + (size_t)B.max_depth * bsg::kEvalThreads) * 8;
+    cw_off[B.n_chunks] = (uint32_t)cw.size();
+    const size_t lds_need = ((size_t)B.max_cw * 64 + (size_t)B.max_depth * bsg::kEvalThreads) * 8;
     if (lds_need > 64 * 1024)
-        return fail(BSG_E_UNSUPPORTED, "batch needs %zu B of LDS (terms %u, depth %u); split the batch", lds_need, B.Tp, B.max_depth);
+        return fail(BSG_E_UNSUPPORTED, "a 256-query chunk needs %zu B of LDS (%u verdict words, stack depth %u)", lds_need,
+                    B.max_cw, B.max_depth);
+    {
+        // k_probe_terms keeps per-kind verdict words + wave queues in LDS beside the bitset image
+        uint32_t max_tw = 0;
+        for (uint32_t y = 0; y < B.n_kinds; ++y) max_tw = std::max(max_tw, (B.term_count[y] + 63) / 64);
+        if (bsg::probe_lds_head_bytes(max_tw) > 48 * 1024)
+            return fail(BSG_E_UNSUPPORTED, "%u distinct terms of one kind exceed what one probe launch holds; split the batch",
+                        max_tw * 64);
+    }
     B.dev.resize(ctx->devs.size());
     for (size_t di = 0; di < ctx->devs.size(); ++di) {
         Device &d = *ctx->devs[di];
@@ -644,6 +683,10 @@ int32_t bsg_batch_create(bsg_ctx *ctx, const bsg_term *terms, uint32_t n_terms, 
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&bd.d_prog), std::max<size_t>(packed.size(), 1) * 4);
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&bd.d_chunk_off), chunk_off.size() * 4);
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&bd.d_chunk_len), chunk_len.size() * 4);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&bd.d_cw_off), cw_off.size() * 4);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&bd.d_cw), std::max<size_t>(cw.size(), 1) * 4);
+        if (e == hipSuccess) e = hipMemcpyAsync(bd.d_cw_off, cw_off.data(), cw_off.size() * 4, hipMemcpyHostToDevice, d.stream);
+        if (e == hipSuccess && !cw.empty()) e = hipMemcpyAsync(bd.d_cw, cw.data(), cw.size() * 4, hipMemcpyHostToDevice, d.stream);
         if (e == hipSuccess) e = hipMemcpyAsync(bd.d_th, th.data(), th.size() * 8, hipMemcpyHostToDevice, d.stream);
         if (e == hipSuccess && !packed.empty())
             e = hipMemcpyAsync(bd.d_prog, packed.data(), packed.size() * 4, hipMemcpyHostToDevice, d.stream);
@@ -714,39 +757,46 @@ int32_t bsg_probe_batch(bsg_ctx *ctx, uint64_t arena_id, uint64_t batch_id, uint
             if (d.pending.size() >= 4096) if (int32_t rc = drain_timing(ctx, d)) return rc;
             if (!d.free_events.empty()) { ev = d.free_events.back(); d.free_events.pop_back(); }
             else {
-                HIP_TRY(hipEventCreate(&ev.e0)); HIP_TRY(hipEventCreate(&ev.e1)); HIP_TRY(hipEventCreate(&ev.e2));
+                HIP_TRY(hipEventCreate(&ev.k1s)); HIP_TRY(hipEventCreate(&ev.k1e));
+                HIP_TRY(hipEventCreate(&ev.k2s)); HIP_TRY(hipEventCreate(&ev.k2e));
             }
             ev.bytes = 0;
-            HIP_TRY(hipEventRecord(ev.e0, d.stream));
         }
         if (B.n_kinds > 0) {
             bsg::ProbeArgs a{};
             a.words = s.d_words; a.desc = s.d_desc; a.th = bd.d_th; a.V = d.V.p;
             a.Tp = B.Tp; a.Wt = B.Wt; a.n_blocks = s.n_blocks; a.lds_cap_words = kLdsCapWords;
+            uint32_t max_tw = 0;
+            for (uint32_t y = 0; y < B.n_kinds; ++y) max_tw = std::max(max_tw, (B.term_count[y] + 63) / 64);
+            const size_t head = bsg::probe_lds_head_bytes(max_tw);
+            // staged-filter cap for this launch: what is left of 64 KiB of dynamic LDS after the head
+            const uint64_t cap_words = head + 32 < 65536 ? (65536 - head) / 16 * 2 : 0;
+            a.lds_cap_words = (uint32_t)std::min<uint64_t>(kLdsCapWords, cap_words);
             uint64_t lds_words = 2;
             for (uint32_t y = 0; y < B.n_kinds; ++y) {
                 a.kind[y] = B.kind[y]; a.term_begin[y] = B.term_begin[y]; a.term_count[y] = B.term_count[y];
-                lds_words = std::max(lds_words, s.max_staged_words[B.kind[y]]);
+                lds_words = std::max(lds_words, std::min<uint64_t>(s.max_staged_words[B.kind[y]], a.lds_cap_words));
                 ev.bytes += s.sum_words[B.kind[y]] * 8;
             }
             lds_words = (lds_words + 1) / 2 * 2;
-            uint32_t max_tw = 0;
-            for (uint32_t y = 0; y < B.n_kinds; ++y) max_tw = std::max(max_tw, (B.term_count[y] + 63) / 64);
-            const size_t head = ((size_t)max_tw * 8 + 4 + 15) & ~(size_t)15;
-            hipLaunchKernelGGL(bsg::k_probe_terms, dim3(s.n_blocks, B.n_kinds), dim3(bsg::kProbeThreads),
-                               head + lds_words * 8, d.stream, a);
+            hipExtLaunchKernelGGL(bsg::k_probe_terms, dim3(s.n_blocks, B.n_kinds), dim3(bsg::kProbeThreads),
+                                  (uint32_t)(head + lds_words * 8), d.stream, timed ? ev.k1s : nullptr,
+                                  timed ? ev.k1e : nullptr, 0, a);
             HIP_TRY(hipGetLastError());
         }
-        if (timed) HIP_TRY(hipEventRecord(ev.e1, d.stream));
         {
             bsg::EvalArgs a{};
             a.V = d.V.p; a.prog = bd.d_prog; a.chunk_off = bd.d_chunk_off; a.chunk_len = bd.d_chunk_len;
             a.out = d.out.p; a.Wt = B.Wt; a.n_blocks = s.n_blocks; a.G = G; a.n_queries = Q;
-            const size_t lds = ((size_t)B.Wt * 64 + (size_t)B.max_depth * bsg::kEvalThreads) * 8;
-            hipLaunchKernelGGL(bsg::k_eval_programs, dim3(G, B.n_chunks), dim3(bsg::kEvalThreads), lds, d.stream, a);
+            a.cw_off = bd.d_cw_off; a.cw = bd.d_cw; a.max_cw = B.max_cw;
+            const size_t lds = ((size_t)B.max_cw * 64 + (size_t)B.max_depth * bsg::kEvalThreads) * 8;
+            hipExtLaunchKernelGGL(bsg::k_eval_programs, dim3(G, B.n_chunks), dim3(bsg::kEvalThreads), (uint32_t)lds,
+                                  d.stream, timed ? ev.k2s : nullptr, timed ? ev.k2e : nullptr, 0, a);
             HIP_TRY(hipGetLastError());
         }
-        if (timed) { HIP_TRY(hipEventRecord(ev.e2, d.stream)); d.pending.push_back(ev); }
+        if (timed) {
+            if (B.n_kinds > 0) d.pending.push_back(ev); else d.free_events.push_back(ev);
+        }
         if (out_survivors) {
             if (nd == 1) {
                 HIP_TRY(hipMemcpyAsync(out_survivors, d.out.p, (size_t)Q * G * 8, hipMemcpyDeviceToHost, d.stream));
@@ -786,6 +836,14 @@ int32_t bsg_probe_batch(bsg_ctx *ctx, uint64_t arena_id, uint64_t batch_id, uint
             }
         }
     }
+    return BSG_OK;
+}
+
+int32_t bsg_probe_many(bsg_ctx *ctx, const uint64_t *arena_ids, uint32_t n_arenas, uint64_t batch_id, uint32_t flags)
+{
+    if (!ctx || (n_arenas && !arena_ids)) return fail(BSG_E_INVALID, "null argument");
+    for (uint32_t i = 0; i < n_arenas; ++i)
+        if (int32_t rc = bsg_probe_batch(ctx, arena_ids[i], batch_id, flags | BSG_PROBE_ASYNC, nullptr)) return rc;
     return BSG_OK;
 }
 

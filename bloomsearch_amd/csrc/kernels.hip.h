@@ -185,111 +185,214 @@ typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 typedef __attribute__((address_space(3))) uint64_t lds_u64;
+typedef __attribute__((address_space(3))) uint16_t lds_u16;
 
-template <bool M32, typename BITS32>
-__device__ __forceinline__ bool test_location(BITS32 bits, const DevDesc &d, uint64_t x)
+// location index -> bit position in the filter
+template <bool M32>
+__device__ __forceinline__ uint64_t locate(const DevDesc &d, uint64_t x)
 {
-    if (M32) {
-        const uint32_t loc = mod_m32(x, (uint32_t)d.m, d.magic);
-        return (bits[loc >> 5] >> (loc & 31)) & 1u;
-    } else {
-        const uint64_t loc = mod_m(x, d.m, d.magic);
-        return (bits[loc >> 5] >> ((uint32_t)loc & 31)) & 1u;
-    }
+    if (M32) return mod_m32(x, (uint32_t)d.m, d.magic);
+    return mod_m(x, d.m, d.magic);
 }
+template <typename BITS32>
+__device__ __forceinline__ bool test_bit(BITS32 bits, uint64_t loc)
+{
+    return (bits[loc >> 5] >> ((uint32_t)loc & 31u)) & 1u;
+}
+// hashes feeding location(h, i) for a wave-uniform i: (h[i%2], h[2 + (((i + i%2) % 4) / 2)])
+__device__ __forceinline__ uint32_t ha_row(uint32_t i) { return i & 1u; }
+__device__ __forceinline__ uint32_t hb_row(uint32_t i) { const uint32_t r = i & 3u; return (r == 1u || r == 2u) ? 3u : 2u; }
 
-// Mode A (few terms): every wave-task is one (location index i, 64-term word w) pair, so all
+constexpr uint32_t kProbeWaves = kProbeThreads / kWave;
+constexpr uint32_t kParallelKMaxWords = 2;  // term words (x64 terms) up to which mode A is used
+
+// Mode A (<= 128 terms): every wave-task is one (location index i, 64-term word w) pair, so all
 // k locations of all terms are tested concurrently — one probe per lane, no serial early-out
-// chain.  Pass masks are AND-ed into the LDS verdict words.
-template <bool M32, typename BITS32>
-__device__ __forceinline__ void probe_parallel_k(const ProbeArgs &a, const DevDesc &d, BITS32 bits, uint32_t t0,
-                                                 uint32_t n_real, uint32_t n_tw, lds_u64 *vw, uint32_t wave, uint32_t lane)
+// chain.  The hash loads and the modulo of a wave's first task are issued BEFORE the workgroup
+// waits for the bitset DMA; only the LDS bit test sits behind the barrier.
+struct ParTask { uint64_t loc; uint32_t w; bool real; };
+
+template <bool M32>
+__device__ __forceinline__ ParTask par_task_prepare(const ProbeArgs &a, const DevDesc &d, uint32_t t0, uint32_t n_real,
+                                                    uint32_t n_tw, uint32_t task, uint32_t lane)
 {
-    constexpr uint32_t n_waves = kProbeThreads / kWave;
-    const uint32_t n_tasks = n_tw * d.k;
-    for (uint32_t task = wave; task < n_tasks; task += n_waves) {
-        const uint32_t i = task / n_tw, w = task - i * n_tw;
-        const uint32_t idx = w * 64 + lane;
-        const uint32_t t = t0 + idx;
-        const uint32_t r = i & 3u;
-        const uint64_t ha = a.th[(uint64_t)(i & 1u) * a.Tp + t];
-        const uint64_t hb = a.th[(uint64_t)((r == 1u || r == 2u) ? 3u : 2u) * a.Tp + t];
-        bool pass = true;
-        if (idx < n_real) pass = test_location<M32>(bits, d, ha + (uint64_t)i * hb);
-        const uint64_t mask = __ballot(pass);
-        if (lane == 0 && mask != ~0ULL) __hip_atomic_fetch_and(&vw[w], mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
+    const uint32_t i = task / n_tw, w = task - i * n_tw;
+    const uint32_t idx = w * 64 + lane;
+    const uint32_t t = t0 + idx;
+    const uint64_t ha = a.th[(uint64_t)ha_row(i) * a.Tp + t];
+    const uint64_t hb = a.th[(uint64_t)hb_row(i) * a.Tp + t];
+    ParTask p;
+    p.loc = locate<M32>(d, ha + (uint64_t)i * hb);
+    p.w = w;
+    p.real = idx < n_real;
+    return p;
 }
 
-// Mode B (many terms): persistent lanes.  A lane keeps one term in registers and tests one
-// location per iteration; the moment a term is rejected (or accepted after k hits) the lane draws
-// the next term index from a workgroup-wide LDS ticket (one ds_add per wave per iteration, ranks by
-// mbcnt), so all 64 lanes stay busy and the expected work is ~2 probes per absent term instead of
-// the wave-wide maximum.  Lanes refilling in the same iteration get consecutive tickets, so their
-// hash loads stay coalesced.
-template <bool M32, typename BITS32>
-__device__ __forceinline__ void probe_persistent(const ProbeArgs &a, const DevDesc &d, BITS32 bits, uint32_t t0,
-                                                 uint32_t n_real, lds_u32 *vbits, lds_u32 *ticket, uint32_t lane)
+template <typename BITS32>
+__device__ __forceinline__ void par_task_finish(const ParTask &p, BITS32 bits, lds_u64 *vw, uint32_t lane)
 {
-    uint64_t h0 = 0, h1 = 0, h2 = 0, h3 = 0;
-    uint32_t idx = 0, i = 0;
-    bool busy = false, exhausted = false;
-    for (;;) {
-        const bool need = !busy && !exhausted;
-        const uint64_t need_mask = __ballot(need);
-        if (need_mask) {
-            uint32_t base = 0;
-            if (lane == (uint32_t)__builtin_ctzll(need_mask))
-                base = __hip_atomic_fetch_add(ticket, (uint32_t)__builtin_popcountll(need_mask), __ATOMIC_RELAXED,
-                                              __HIP_MEMORY_SCOPE_WORKGROUP);
-            base = __shfl(base, __builtin_ctzll(need_mask), kWave);
-            if (need) {
-                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need_mask >> 32),
-                                                                __builtin_amdgcn_mbcnt_lo((uint32_t)need_mask, 0u));
-                idx = base + rank;
-                if (idx < n_real) {
-                    const uint32_t t = t0 + idx;
-                    h0 = a.th[t]; h1 = a.th[(uint64_t)a.Tp + t];
-                    h2 = a.th[2ull * a.Tp + t]; h3 = a.th[3ull * a.Tp + t];
-                    i = 0; busy = true;
-                } else {
-                    exhausted = true;
+    const bool pass = !p.real || test_bit(bits, p.loc);
+    const uint64_t mask = __ballot(pass);
+    if (lane == 0 && mask != ~0ULL) __hip_atomic_fetch_and(&vw[p.w], mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// Mode C (many terms).  Each wave owns a contiguous range of term words and runs
+//   round 0 : location 0 of every term (8 B/term, coalesced), survivors compacted into the wave's
+//             private LDS queue (ballot + mbcnt; no atomics, no barriers);
+//   round 1 : location 1 of the survivors (gathered hashes), compacted in place;
+//   tail    : the remaining ~1/4 of the terms keep all four hashes in registers and run locations
+//             2..k-1 with a wave-level early-out (no further table loads).
+// Loads are issued kGroup chunks at a time so a wave pays one L2 round trip per stage, not per
+// 64-term chunk.  Absent terms die geometrically: ~2 probes per absent term.
+constexpr uint32_t kGroup = 4;
+
+template <bool M32, typename BITS32>
+__device__ __forceinline__ void probe_rounds(const ProbeArgs &a, const DevDesc &d, BITS32 bits, uint32_t t0,
+                                             uint32_t n_real, uint32_t n_tw, lds_u16 *queues, lds_u32 *vbits,
+                                             uint32_t wave, uint32_t lane, const uint64_t (&loc_first)[kGroup])
+{
+    const uint32_t wpw = (n_tw + kProbeWaves - 1) / kProbeWaves;
+    const uint32_t w0 = wave * wpw;
+    if (w0 >= n_tw) return;
+    const uint32_t w1 = min(n_tw, w0 + wpw);
+    lds_u16 *q = queues + (uint32_t)w0 * 64;
+    const uint32_t base = w0 * 64;
+    const uint64_t *th = a.th + t0 + base;   // this wave's slice of hash row 0
+    uint32_t qn = 0;
+
+    auto compact = [&](bool hit, uint32_t value, uint32_t &count) {
+        const uint64_t mask = __ballot(hit);
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+        if (hit) q[count + rank] = (uint16_t)value;
+        count += (uint32_t)__builtin_popcountll(mask);
+    };
+
+    // ---- round 0 ----
+    for (uint32_t w = w0; w < w1; w += kGroup) {
+        uint64_t loc[kGroup];
+        if (w == w0) {
+#pragma unroll
+            for (uint32_t u = 0; u < kGroup; ++u) loc[u] = loc_first[u];   // computed before the DMA wait
+        } else {
+            uint64_t h[kGroup];
+#pragma unroll
+            for (uint32_t u = 0; u < kGroup; ++u) h[u] = (w + u < w1) ? th[(w + u - w0) * 64 + lane] : 0;
+#pragma unroll
+            for (uint32_t u = 0; u < kGroup; ++u) loc[u] = locate<M32>(d, h[u]);
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < kGroup; ++u) {
+            if (w + u < w1) {   // wave-uniform
+                const uint32_t li = (w + u - w0) * 64 + lane;
+                compact(base + li < n_real && test_bit(bits, loc[u]), li, qn);
+            }
+        }
+    }
+    if (d.k == 1) goto publish;
+    // ---- round 1 (location 1 = h1 + h3) ----
+    {
+        const uint64_t *r1 = th + (uint64_t)a.Tp, *r3 = th + 3ull * a.Tp;
+        uint32_t out = 0;
+        for (uint32_t j = 0; j < qn; j += 64 * kGroup) {
+            uint32_t li[kGroup];
+            uint64_t x[kGroup];
+#pragma unroll
+            for (uint32_t u = 0; u < kGroup; ++u) li[u] = (j + u * 64 + lane < qn) ? (uint32_t)q[j + u * 64 + lane] : 0u;
+#pragma unroll
+            for (uint32_t u = 0; u < kGroup; ++u) x[u] = (j + u * 64 < qn) ? r1[li[u]] + r3[li[u]] : 0;
+#pragma unroll
+            for (uint32_t u = 0; u < kGroup; ++u) {
+                if (j + u * 64 < qn) {   // wave-uniform
+                    const bool valid = j + u * 64 + lane < qn;
+                    compact(valid && test_bit(bits, locate<M32>(d, x[u])), li[u], out);   // out <= j: in place is safe
                 }
             }
         }
-        if (__ballot(busy) == 0) break;
-        if (busy) {
-            const bool hit = test_location<M32>(bits, d, location(h0, h1, h2, h3, i));
-            if (!hit) {
-                busy = false;
-            } else if (++i == d.k) {
-                __hip_atomic_fetch_or(&vbits[idx >> 5], 1u << (idx & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                busy = false;
+        qn = out;
+    }
+    // ---- tail: locations 2..k-1 from registers ----
+    if (d.k > 2) {
+        const uint64_t *r1 = th + (uint64_t)a.Tp, *r2 = th + 2ull * a.Tp, *r3 = th + 3ull * a.Tp;
+        for (uint32_t j = 0; j < qn; j += 128) {
+            const bool two = j + 64 < qn;
+            bool aliveA = j + lane < qn, aliveB = two && (j + 64 + lane < qn);
+            const uint32_t liA = aliveA ? (uint32_t)q[j + lane] : 0u, liB = aliveB ? (uint32_t)q[j + 64 + lane] : 0u;
+            const uint64_t a0 = th[liA], a1 = r1[liA], a2 = r2[liA], a3 = r3[liA];
+            uint64_t b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+            if (two) { b0 = th[liB]; b1 = r1[liB]; b2 = r2[liB]; b3 = r3[liB]; }
+            for (uint32_t i = 2; i < d.k; ++i) {
+                if ((__ballot(aliveA) | __ballot(aliveB)) == 0) break;
+                if (aliveA) aliveA = test_bit(bits, locate<M32>(d, location(a0, a1, a2, a3, i)));
+                if (aliveB) aliveB = test_bit(bits, locate<M32>(d, location(b0, b1, b2, b3, i)));
             }
+            if (aliveA) __hip_atomic_fetch_or(&vbits[(base + liA) >> 5], 1u << ((base + liA) & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (aliveB) __hip_atomic_fetch_or(&vbits[(base + liB) >> 5], 1u << ((base + liB) & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
+        return;
+    }
+publish:
+    for (uint32_t j = lane; j < qn; j += 64) {
+        const uint32_t idx = base + q[j];
+        __hip_atomic_fetch_or(&vbits[idx >> 5], 1u << (idx & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
 }
 
-constexpr uint32_t kParallelKMaxWords = 8;  // term words (x64 terms) up to which mode A is used
-
-template <bool M32, typename BITS32>
-__device__ __forceinline__ void probe_block(const ProbeArgs &a, const DevDesc &d, BITS32 bits, uint32_t t0,
-                                            uint32_t n_real, uint32_t n_tw, lds_u64 *vw, lds_u32 *ticket,
+template <bool M32, bool STAGED>
+__device__ __forceinline__ void probe_block(const ProbeArgs &a, const DevDesc &d, const uint64_t *src, char *image,
+                                            uint32_t t0, uint32_t n_real, uint32_t n_tw, lds_u64 *vw, lds_u16 *queues,
                                             uint64_t *vout, uint32_t tid)
 {
     const uint32_t lane = tid & (kWave - 1), wave = tid / kWave;
     const bool par = n_tw <= kParallelKMaxWords;
-    // verdict words start as "all real terms pass" (mode A ANDs failures in) or zero (mode B ORs hits in)
+    const uint32_t n_tasks = n_tw * d.k;
+    // ---- work that does not need the bitset: runs while the DMA is in flight ----
     for (uint32_t w = tid; w < n_tw; w += kProbeThreads) {
         const uint32_t rem = n_real - w * 64;
-        vw[w] = par ? (rem >= 64 ? ~0ULL : ((1ULL << rem) - 1)) : 0ULL;
+        vw[w] = par ? (rem >= 64 ? ~0ULL : ((1ULL << rem) - 1)) : 0ULL;   // A: AND failures in; C: OR hits in
     }
-    if (tid == 0) *ticket = 0;
+    ParTask first{};
+    uint64_t loc_first[kGroup] = {};
+    if (par) {
+        if (wave < n_tasks) first = par_task_prepare<M32>(a, d, t0, n_real, n_tw, wave, lane);
+    } else {
+        const uint32_t wpw = (n_tw + kProbeWaves - 1) / kProbeWaves;
+        const uint32_t w0 = wave * wpw, w1 = min(n_tw, w0 + wpw);
+        uint64_t h[kGroup];
+#pragma unroll
+        for (uint32_t u = 0; u < kGroup; ++u) h[u] = (w0 + u < w1) ? a.th[t0 + (w0 + u) * 64 + lane] : 0;
+#pragma unroll
+        for (uint32_t u = 0; u < kGroup; ++u) loc_first[u] = locate<M32>(d, h[u]);
+    }
+    if (STAGED) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (par) probe_parallel_k<M32>(a, d, bits, t0, n_real, n_tw, vw, wave, lane);
-    else     probe_persistent<M32>(a, d, bits, t0, n_real, (lds_u32 *)vw, ticket, lane);
+    // ---- bit tests ----
+    if (STAGED) {
+        const lds_u32 *bits = (const lds_u32 *)image;
+        if (par) {
+            if (wave < n_tasks) par_task_finish(first, bits, vw, lane);
+            for (uint32_t task = wave + kProbeWaves; task < n_tasks; task += kProbeWaves)
+                par_task_finish(par_task_prepare<M32>(a, d, t0, n_real, n_tw, task, lane), bits, vw, lane);
+        } else {
+            probe_rounds<M32>(a, d, bits, t0, n_real, n_tw, queues, (lds_u32 *)vw, wave, lane, loc_first);
+        }
+    } else {
+        const uint32_t *bits = reinterpret_cast<const uint32_t *>(src);
+        if (par) {
+            if (wave < n_tasks) par_task_finish(first, bits, vw, lane);
+            for (uint32_t task = wave + kProbeWaves; task < n_tasks; task += kProbeWaves)
+                par_task_finish(par_task_prepare<M32>(a, d, t0, n_real, n_tw, task, lane), bits, vw, lane);
+        } else {
+            probe_rounds<M32>(a, d, bits, t0, n_real, n_tw, queues, (lds_u32 *)vw, wave, lane, loc_first);
+        }
+    }
     __syncthreads();
     for (uint32_t w = tid; w < n_tw; w += kProbeThreads) vout[(uint64_t)w * 64] = vw[w];
+}
+
+// LDS carve of k_probe_terms: [verdict words n_tw x 8 B][wave queues n_tw x 64 x 2 B][pad to 16 B][bitset image]
+__host__ __device__ inline uint32_t probe_lds_head_bytes(uint32_t n_tw)
+{
+    return (n_tw * 8u + n_tw * 128u + 15u) & ~15u;
 }
 
 __global__ __launch_bounds__(kProbeThreads) void k_probe_terms(const ProbeArgs a)
@@ -300,7 +403,6 @@ __global__ __launch_bounds__(kProbeThreads) void k_probe_terms(const ProbeArgs a
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & (kWave - 1);
     const uint32_t wave = tid / kWave;
-    constexpr uint32_t n_waves = kProbeThreads / kWave;
 
     const DevDesc d = a.desc[(uint64_t)b * 3 + a.kind[y]];
     const uint32_t t0 = a.term_begin[y];
@@ -312,53 +414,53 @@ __global__ __launch_bounds__(kProbeThreads) void k_probe_terms(const ProbeArgs a
         for (uint32_t w = tid; w < n_tw; w += kProbeThreads) vout[(uint64_t)w * 64] = ~0ULL;
         return;
     }
-    // LDS carve: [verdict words | ticket | pad to 16 B][bitset image]
     lds_u64 *vw = (lds_u64 *)lds64;
-    lds_u32 *ticket = (lds_u32 *)(vw + n_tw);
-    const uint32_t head_bytes = (n_tw * 8 + 4 + 15) & ~15u;
-    char *image = reinterpret_cast<char *>(lds64) + head_bytes;
+    lds_u16 *queues = (lds_u16 *)(vw + n_tw);
+    char *image = reinterpret_cast<char *>(lds64) + probe_lds_head_bytes(n_tw);
 
     const uint64_t nw = (d.m + 63) >> 6;
     const uint64_t *src = a.words + d.word_off;
+    const bool m32 = d.m < (1ull << 31);
     if (nw <= a.lds_cap_words) {
         // HBM -> LDS by LDS-DMA: every wave issues all of its 1 KiB pieces back to back
-        // (64 lanes x 16 B, no VGPR round trip), one wait for the whole filter.
+        // (64 lanes x 16 B, no VGPR round trip); the single wait sits in probe_block.
         const uint32_t nbytes = (uint32_t)(((nw + 1) >> 1) << 4);
         const char *g = reinterpret_cast<const char *>(src);
-        for (uint32_t c = wave * 1024u; c < nbytes; c += n_waves * 1024u) {
+        for (uint32_t c = wave * 1024u; c < nbytes; c += kProbeWaves * 1024u) {
             const uint32_t boff = c + lane * 16u;
             if (boff < nbytes)
                 __builtin_amdgcn_global_load_lds((glb_void *)(g + boff), (lds_void *)(image + c), 16, 0, 0);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const lds_u32 *lbits = (const lds_u32 *)image;
-        if (d.m < (1ull << 31)) probe_block<true>(a, d, lbits, t0, n_real, n_tw, vw, ticket, vout, tid);
-        else                    probe_block<false>(a, d, lbits, t0, n_real, n_tw, vw, ticket, vout, tid);
+        if (m32) probe_block<true, true>(a, d, src, image, t0, n_real, n_tw, vw, queues, vout, tid);
+        else     probe_block<false, true>(a, d, src, image, t0, n_real, n_tw, vw, queues, vout, tid);
     } else {
-        const uint32_t *gbits = reinterpret_cast<const uint32_t *>(src);
-        if (d.m < (1ull << 31)) probe_block<true>(a, d, gbits, t0, n_real, n_tw, vw, ticket, vout, tid);
-        else                    probe_block<false>(a, d, gbits, t0, n_real, n_tw, vw, ticket, vout, tid);
+        if (m32) probe_block<true, false>(a, d, src, image, t0, n_real, n_tw, vw, queues, vout, tid);
+        else     probe_block<false, false>(a, d, src, image, t0, n_real, n_tw, vw, queues, vout, tid);
     }
 }
 
 // ---------------------------------------------------------------------------
 // K2  eval_programs: workgroup = (group of 64 blocks, chunk of 256 queries).
-// Prologue: transpose the group's verdict words so VT[term] is a 64-block mask.
+// Prologue: transpose the verdict words this chunk's programs reference (host-built
+// per-chunk word list) so VT[slot * 64 + bit] is a 64-block mask of one term.
 // Body: every lane runs its query's binary postfix program on u64 masks, i.e.
 // 64 blocks per bitwise op; result is the survivors word out[q * G + g].
 // Internal ops (lowered on the host from the public n-ary form):
-//   0 TERM pos | 1 AND2 | 2 OR2 | 3 TRUE | 4 FALSE | 7 NOP
+//   0 TERM (slot * 64 + bit) | 1 AND2 | 2 OR2 | 3 TRUE | 4 FALSE | 7 NOP
 // ---------------------------------------------------------------------------
 struct EvalArgs {
     const uint64_t *V;
-    const uint32_t *prog;       // chunk c: prog[chunk_off[c] + j * 256 + lane]
+    const uint32_t *prog;        // chunk c: prog[chunk_off[c] + j * 256 + lane]
     const uint32_t *chunk_off;
     const uint32_t *chunk_len;
-    uint64_t *out;              // [n_queries][G]
+    const uint32_t *cw_off;      // chunk c needs verdict words cw[cw_off[c] .. cw_off[c+1])
+    const uint32_t *cw;
+    uint64_t *out;               // [n_queries][G]
     uint32_t Wt;
     uint32_t n_blocks;
     uint32_t G;
     uint32_t n_queries;
+    uint32_t max_cw;             // max words of any chunk (LDS carve)
 };
 
 __global__ __launch_bounds__(kEvalThreads) void k_eval_programs(const EvalArgs a)
@@ -372,24 +474,31 @@ __global__ __launch_bounds__(kEvalThreads) void k_eval_programs(const EvalArgs a
     constexpr uint32_t n_waves = kEvalThreads / kWave;
 
     uint64_t *VT = lds64;
-    uint64_t *stk = lds64 + (uint64_t)a.Wt * 64 + tid;  // per-lane stack, stride kEvalThreads
+    uint64_t *stk = lds64 + (uint64_t)a.max_cw * 64 + tid;  // per-lane stack, stride kEvalThreads
+
+    const uint32_t len = a.chunk_len[c];
+    const uint32_t *P = a.prog + a.chunk_off[c] + tid;
+    // the program words do not depend on the verdicts: fetch them while V is in flight
+    constexpr uint32_t kPre = 8;
+    uint32_t pre[kPre];
+#pragma unroll
+    for (uint32_t j = 0; j < kPre; ++j) pre[j] = j < len ? P[(uint64_t)j * kEvalThreads] : (7u << 28);
 
     const bool row_valid = (g * 64 + (uint32_t)lane) < a.n_blocks;
-    for (uint32_t w = wave; w < a.Wt; w += n_waves) {
+    const uint32_t cw0 = a.cw_off[c], ncw = a.cw_off[c + 1] - cw0;
+    for (uint32_t s = wave; s < ncw; s += n_waves) {
+        const uint32_t w = a.cw[cw0 + s];
         uint64_t x = row_valid ? a.V[((uint64_t)g * a.Wt + w) * 64 + lane] : 0ULL;
-        VT[w * 64 + lane] = wave_transpose64(x, lane);
+        VT[s * 64 + lane] = wave_transpose64(x, lane);
     }
     __syncthreads();
 
     const uint32_t q = c * kEvalThreads + tid;
-    const uint32_t len = a.chunk_len[c];
-    const uint32_t *P = a.prog + a.chunk_off[c] + tid;
     uint64_t top = ~0ULL;  // empty program == nil query == true
     uint32_t sp = 0;       // number of values on the stack (top kept in a register)
-    for (uint32_t j = 0; j < len; ++j) {
-        const uint32_t op = P[(uint64_t)j * kEvalThreads];
+    auto step = [&](uint32_t op) {
         const uint32_t opc = op >> 28;
-        if (opc == 7u) continue;
+        if (opc == 7u) return;
         if (opc == 1u || opc == 2u) {
             --sp;
             const uint64_t under = stk[(uint64_t)(sp - 1) * kEvalThreads];
@@ -399,7 +508,10 @@ __global__ __launch_bounds__(kEvalThreads) void k_eval_programs(const EvalArgs a
             ++sp;
             top = (opc == 0u) ? VT[op & 0x0FFFFFFFu] : (opc == 3u ? ~0ULL : 0ULL);
         }
-    }
+    };
+#pragma unroll
+    for (uint32_t j = 0; j < kPre; ++j) if (j < len) step(pre[j]);
+    for (uint32_t j = kPre; j < len; ++j) step(P[(uint64_t)j * kEvalThreads]);
     const uint32_t nvalid = a.n_blocks - g * 64;
     const uint64_t valid = nvalid >= 64 ? ~0ULL : ((1ULL << nvalid) - 1);
     if (q < a.n_queries) a.out[(uint64_t)q * a.G + g] = top & valid;

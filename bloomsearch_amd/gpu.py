@@ -121,6 +121,10 @@ class Context:
         self._check(self.L.bsg_probe_batch(self.h, arena_id, batch_id, flags, _lib._ptr(out)))
         return out
 
+    def probe_many(self, arena_ids, batch_id: int, flags: int = 0):
+        ids = np.ascontiguousarray(arena_ids, dtype=np.uint64)
+        self._check(self.L.bsg_probe_many(self.h, _lib._ptr(ids), len(ids), batch_id, flags))
+
     def probe(self, arena_id: int, n_blocks: int, terms: np.ndarray, prog_ops, prog_off) -> np.ndarray:
         assert terms.dtype == TERM_DTYPE
         ops = np.ascontiguousarray(prog_ops, dtype=np.uint32)

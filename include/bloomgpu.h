@@ -158,6 +158,12 @@ BSG_API int32_t bsg_batch_free(bsg_ctx *ctx, uint64_t batch_id);
 BSG_API int32_t bsg_probe_batch(bsg_ctx *ctx, uint64_t arena_id, uint64_t batch_id, uint32_t flags,
                                 uint64_t *out_survivors);
 
+/* Enqueue one probe of the same batch against each of n_arenas arenas (e.g. the candidate
+ * files of one query stage) without returning to the caller in between; results stay on the
+ * device.  Equivalent to n_arenas bsg_probe_batch(..., flags | BSG_PROBE_ASYNC, NULL) calls. */
+BSG_API int32_t bsg_probe_many(bsg_ctx *ctx, const uint64_t *arena_ids, uint32_t n_arenas, uint64_t batch_id,
+                               uint32_t flags);
+
 /* One-shot convenience: batch_create + probe_batch + batch_free. */
 BSG_API int32_t bsg_probe(bsg_ctx *ctx, uint64_t arena_id, const bsg_term *terms, uint32_t n_terms,
                           const uint32_t *prog_ops, const uint32_t *prog_off, uint32_t n_queries,
