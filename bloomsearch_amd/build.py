@@ -33,7 +33,7 @@ def sources():
 
 def _deps():
     return sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "host", "*.h*")) + \
-        glob.glob(os.path.join(INCLUDE, "*.h"))
+        glob.glob(os.path.join(CSRC, "host", "*.inc")) + glob.glob(os.path.join(INCLUDE, "*.h"))
 
 
 def needs_build() -> bool:
@@ -48,7 +48,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return LIB
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
            "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
-           "-I", INCLUDE, "-I", CSRC, "-o", LIB + ".tmp"] + sources() + ["-lpthread"]
+           "-I", INCLUDE, "-I", CSRC, "-I", os.path.join(CSRC, "host"), "-o", LIB + ".tmp"] + sources() + ["-lpthread"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

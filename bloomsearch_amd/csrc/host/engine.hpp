@@ -1,0 +1,376 @@
+// engine.hpp — host-side mirror of the reference's BloomSearchEngine surface for THIS path only:
+//   IngestRows  (ingest.go:170, processIngestRequest :330-531: partitioning, whole-batch validation,
+//                indexRow into per-partition bloomEntrySets, flush triggers)
+//   Flush       (ingest.go:197; handleFlush flush.go:138-282: per partition buffer buildFilters ->
+//                encodeFilterSection; unionInto(fileEntries); file-level buildFilters; counts stamped)
+//   Query       (query_exec.go:201-444: file stage over file-level filters, evaluateBlockFilters per
+//                candidate block with BloomFilterSkipped stats, final matchRowBytes scan)
+//   Merge       (merge.go:440-817 rebuild semantics: re-index every row, right-size, never OR)
+// The bloom arithmetic runs on the GPU through the C-ABI (bsg_build / bsg_arena_load / bsg_probe);
+// there is no CPU bloom path here.  Storage, compression, durability, goroutines and the
+// DataStore / MetaStore plugins are out of scope: "files" are kept in memory with the reference's
+// filter-section bytes (section_codec.hpp) so the wire layout is exercised end to end.
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <string>
+#include <string_view>
+#include <vector>
+
+#include "bloomgpu.h"
+#include "entry_sets.hpp"
+#include "expression.hpp"
+#include "section_codec.hpp"
+
+namespace bsh {
+
+enum EngineError : int32_t {
+    kEngineOk = 0,
+    kErrInvalidConfig = -101,   // ErrInvalidConfig (engine.go:16-34)
+    kErrEngineStopped = -102,   // ErrEngineStopped
+    kErrInvalidRow = -103,      // a row of the batch is not a JSON object: whole batch rejected (ingest.go:378-397)
+    kErrInvalidQuery = -104,
+    kErrGpu = -105,             // a bsg_* call failed (message carries bsg_last_error)
+    kErrInvalidHash = -106,     // ErrInvalidHash: filter section CRC mismatch
+};
+
+struct EngineConfig {           // BloomSearchEngineConfig (engine.go:82-147), the knobs on this path
+    uint64_t max_row_group_rows = 10000;
+    uint64_t max_row_group_bytes = 10ull * 1024 * 1024;
+    uint64_t max_buffered_rows = 1000;
+    uint64_t max_buffered_bytes = 1ull * 1024 * 1024;
+    double bloom_false_positive_rate = 0.001;
+    std::string partition_field;  // PartitionFunc stand-in: top-level key whose text is the partition id ("" = none)
+};
+
+struct DataBlock {
+    std::string partition_id;
+    std::vector<std::string> rows;
+    uint64_t row_bytes = 0;              // uncompressed row bytes incl. the 4-byte length prefixes
+    uint64_t block_offset = 0;           // RowDataOffset within the (virtual) file
+    BloomEntryCounts counts;             // DataBlockMetadata.BloomEntryCounts (file_format.go:753-757)
+    double fpr = 0;
+    std::vector<uint8_t> filter_section; // encodeFilterSection bytes
+};
+
+struct DataFile {
+    uint64_t file_id = 0;
+    std::vector<DataBlock> blocks;
+    BloomEntryCounts counts;
+    std::vector<uint8_t> filter_section; // file-level filters
+};
+
+struct BlockStats {                      // query_exec.go:63-72
+    uint64_t file_id = 0, block_offset = 0;
+    int64_t rows_processed = 0, bytes_processed = 0, total_rows = 0, total_bytes = 0;
+    bool bloom_filter_skipped = false;
+};
+
+struct QueryResult {
+    std::vector<std::string> rows;
+    std::vector<BlockStats> block_stats;
+    uint64_t files_considered = 0, files_bloom_skipped = 0;
+};
+
+class BloomSearchEngine {
+public:
+    BloomSearchEngine(const EngineConfig &cfg, bsg_ctx *ctx) : cfg_(cfg), ctx_(ctx) {}
+    ~BloomSearchEngine() { drop_arenas(); }
+
+    static int32_t validate(const EngineConfig &c, std::string &err)
+    {
+        if (c.max_row_group_rows == 0 || c.max_row_group_bytes == 0) { err = "MaxRowGroupRows / MaxRowGroupBytes must be positive"; return kErrInvalidConfig; }
+        if (!(c.bloom_false_positive_rate > 0.0 && c.bloom_false_positive_rate < 1.0)) { err = "BloomFalsePositiveRate must be in (0, 1)"; return kErrInvalidConfig; }
+        return kEngineOk;
+    }
+
+    const std::string &last_error() const { return err_; }
+    const std::vector<DataFile> &files() const { return files_; }
+
+    void stop() { stopped_ = true; }
+
+    // rows: one marshaled JSON object per element.  Whole batch is validated before any buffer
+    // is touched (ingest.go:378-397).
+    int32_t ingest_rows(const std::vector<std::string_view> &rows)
+    {
+        if (stopped_) return fail(kErrEngineStopped, "engine stopped");
+        if (rows.empty()) return kEngineOk;  // ingest.go:356-359
+        std::vector<std::string> pids(rows.size());
+        for (size_t i = 0; i < rows.size(); ++i) {
+            JNode dom;
+            if (!parse_dom(rows[i], dom) || dom.type != JType::Object) return fail(kErrInvalidRow, "row " + std::to_string(i) + " is not a JSON object");
+            if (!cfg_.partition_field.empty()) {
+                const JNode *v = dom.get(cfg_.partition_field);
+                if (v && (v->type == JType::String || v->type == JType::Number)) pids[i] = v->text;
+                else if (v && v->type == JType::True) pids[i] = "true";
+                else if (v && v->type == JType::False) pids[i] = "false";
+            }
+        }
+        bool should_flush = false;
+        for (size_t i = 0; i < rows.size(); ++i) {
+            PartitionBuffer &pb = buffers_[pids[i]];
+            pb.entries.index_row(rows[i]);          // HOT: walk + tokenize + dedup (ingest.go:450)
+            pb.rows.emplace_back(rows[i]);
+            pb.bytes += rows[i].size() + 4;
+            buffered_rows_ += 1;
+            buffered_bytes_ += rows[i].size() + 4;
+            if (pb.rows.size() >= cfg_.max_row_group_rows || pb.bytes >= cfg_.max_row_group_bytes) should_flush = true;
+        }
+        if (buffered_rows_ >= cfg_.max_buffered_rows || buffered_bytes_ >= cfg_.max_buffered_bytes) should_flush = true;
+        return should_flush ? flush() : kEngineOk;
+    }
+
+    // handleFlush: one file, one data block per partition buffer, all filters built in ONE bsg_build call.
+    int32_t flush()
+    {
+        if (buffers_.empty()) return kEngineOk;
+        DataFile file;
+        file.file_id = next_file_id_++;
+        BloomEntrySets file_entries;
+        std::vector<const BloomEntrySets *> sets;
+        for (auto &kv : buffers_) {
+            DataBlock blk;
+            blk.partition_id = kv.first;
+            blk.rows = std::move(kv.second.rows);
+            blk.row_bytes = kv.second.bytes;
+            blk.counts = kv.second.entries.counts();
+            blk.fpr = cfg_.bloom_false_positive_rate;
+            kv.second.entries.union_into(file_entries);   // flush.go:221
+            file.blocks.push_back(std::move(blk));
+        }
+        for (auto &kv : buffers_) sets.push_back(&kv.second.entries);
+        sets.push_back(&file_entries);                    // file-level filters sized for the union (flush.go:253)
+        std::vector<std::vector<uint8_t>> sections;
+        if (int32_t rc = build_sections(sets, sections)) return rc;
+        uint64_t off = 0;
+        for (size_t b = 0; b < file.blocks.size(); ++b) {
+            file.blocks[b].filter_section = std::move(sections[b]);
+            file.blocks[b].block_offset = off;
+            off += file.blocks[b].row_bytes;
+        }
+        file.counts = file_entries.counts();
+        file.filter_section = std::move(sections.back());
+        files_.push_back(std::move(file));
+        buffers_.clear();
+        buffered_rows_ = buffered_bytes_ = 0;
+        drop_arenas();
+        return kEngineOk;
+    }
+
+    // Merge (merge.go rebuild semantics): every source row is re-walked into fresh block + file
+    // entry sets and filters are rebuilt right-sized; blocks of one partition are merged while they
+    // fit MaxRowGroupRows / MaxRowGroupBytes.
+    int32_t merge()
+    {
+        if (files_.size() < 2) return kEngineOk;
+        std::map<std::string, std::vector<DataBlock *>> by_partition;
+        for (auto &f : files_) for (auto &b : f.blocks) by_partition[b.partition_id].push_back(&b);
+        DataFile out;
+        out.file_id = next_file_id_++;
+        std::vector<std::unique_ptr<BloomEntrySets>> block_sets;
+        BloomEntrySets file_entries;
+        for (auto &kv : by_partition) {
+            DataBlock cur;
+            auto start_block = [&]() { cur = DataBlock{}; cur.partition_id = kv.first; cur.fpr = cfg_.bloom_false_positive_rate; block_sets.push_back(std::make_unique<BloomEntrySets>()); };
+            auto finish_block = [&]() {
+                cur.counts = block_sets.back()->counts();
+                block_sets.back()->union_into(file_entries);
+                out.blocks.push_back(std::move(cur));
+            };
+            start_block();
+            for (DataBlock *src : kv.second) {
+                if (!cur.rows.empty() && (cur.rows.size() + src->rows.size() > cfg_.max_row_group_rows ||
+                                          cur.row_bytes + src->row_bytes > cfg_.max_row_group_bytes)) { finish_block(); start_block(); }
+                for (auto &r : src->rows) {
+                    block_sets.back()->index_row(r);      // merge.go:746
+                    cur.row_bytes += r.size() + 4;
+                    cur.rows.push_back(std::move(r));
+                }
+            }
+            finish_block();
+        }
+        std::vector<const BloomEntrySets *> sets;
+        for (auto &s : block_sets) sets.push_back(s.get());
+        sets.push_back(&file_entries);
+        std::vector<std::vector<uint8_t>> sections;
+        if (int32_t rc = build_sections(sets, sections)) return rc;
+        uint64_t off = 0;
+        for (size_t b = 0; b < out.blocks.size(); ++b) {
+            out.blocks[b].filter_section = std::move(sections[b]);
+            out.blocks[b].block_offset = off;
+            off += out.blocks[b].row_bytes;
+        }
+        out.counts = file_entries.counts();
+        out.filter_section = std::move(sections.back());
+        files_.clear();
+        files_.push_back(std::move(out));
+        drop_arenas();
+        return kEngineOk;
+    }
+
+    // Query: nil expression => no bloom conditions => no filter reads, every block scanned (query_exec.go:503-508).
+    int32_t query(const BloomExpression *expr, QueryResult &out)
+    {
+        out = QueryResult{};
+        std::vector<uint8_t> file_ok(files_.size(), 1);
+        std::vector<std::vector<uint8_t>> block_ok(files_.size());
+        for (size_t f = 0; f < files_.size(); ++f) block_ok[f].assign(files_[f].blocks.size(), 1);
+        if (expr && !files_.empty()) {
+            if (int32_t rc = ensure_arenas()) return rc;
+            QueryBatch qb;
+            qb.add_query(expr);
+            std::vector<bsg_term> terms;
+            if (int32_t rc = hash_terms(qb, terms)) return rc;
+            std::vector<uint64_t> fs((files_.size() + 63) / 64), bs((total_blocks_ + 63) / 64);
+            if (bsg_probe(ctx_, files_arena_, terms.data(), (uint32_t)terms.size(), qb.prog_ops.data(), qb.prog_off.data(), 1, fs.data()))
+                return fail(kErrGpu, bsg_last_error(ctx_));
+            if (bsg_probe(ctx_, blocks_arena_, terms.data(), (uint32_t)terms.size(), qb.prog_ops.data(), qb.prog_off.data(), 1, bs.data()))
+                return fail(kErrGpu, bsg_last_error(ctx_));
+            size_t g = 0;
+            for (size_t f = 0; f < files_.size(); ++f) {
+                file_ok[f] = (fs[f >> 6] >> (f & 63)) & 1;
+                for (size_t b = 0; b < files_[f].blocks.size(); ++b, ++g) block_ok[f][b] = (bs[g >> 6] >> (g & 63)) & 1;
+            }
+        }
+        RowMatcher matcher(expr);
+        for (size_t f = 0; f < files_.size(); ++f) {
+            out.files_considered++;
+            if (!file_ok[f]) { out.files_bloom_skipped++; continue; }   // file stage prune: no BlockStats for its blocks
+            for (size_t b = 0; b < files_[f].blocks.size(); ++b) {
+                const DataBlock &blk = files_[f].blocks[b];
+                BlockStats st;
+                st.file_id = files_[f].file_id; st.block_offset = blk.block_offset;
+                st.total_rows = (int64_t)blk.rows.size();
+                st.total_bytes = (int64_t)(blk.row_bytes + blk.filter_section.size());
+                if (!block_ok[f][b]) {                                    // query_exec.go:607-614
+                    st.bloom_filter_skipped = true;
+                    out.block_stats.push_back(st);
+                    continue;
+                }
+                for (const std::string &row : blk.rows) {
+                    st.rows_processed++;
+                    st.bytes_processed += (int64_t)row.size() + 4;
+                    if (matcher.match(row)) out.rows.push_back(row);
+                }
+                out.block_stats.push_back(st);
+            }
+        }
+        return kEngineOk;
+    }
+
+private:
+    struct PartitionBuffer {
+        BloomEntrySets entries;
+        std::vector<std::string> rows;
+        uint64_t bytes = 0;
+    };
+
+    EngineConfig cfg_;
+    bsg_ctx *ctx_;
+    std::map<std::string, PartitionBuffer> buffers_;
+    uint64_t buffered_rows_ = 0, buffered_bytes_ = 0;
+    std::vector<DataFile> files_;
+    uint64_t next_file_id_ = 1;
+    bool stopped_ = false;
+    std::string err_;
+    uint64_t files_arena_ = 0, blocks_arena_ = 0, total_blocks_ = 0;
+    bool arenas_valid_ = false;
+
+    int32_t fail(int32_t code, std::string msg) { err_ = std::move(msg); return code; }
+
+    void drop_arenas()
+    {
+        if (arenas_valid_) { bsg_arena_free(ctx_, files_arena_); bsg_arena_free(ctx_, blocks_arena_); }
+        arenas_valid_ = false;
+    }
+
+    // buildFilters for many entry-set triples at once: sizes via EstimateParameters(max(n,1), fpr),
+    // one bsg_build, then encodeFilterSection per triple.
+    int32_t build_sections(const std::vector<const BloomEntrySets *> &sets, std::vector<std::vector<uint8_t>> &sections)
+    {
+        std::vector<uint8_t> bytes;
+        std::vector<uint32_t> offsets{0}, fstart{0};
+        std::vector<bsg_filter_desc> desc(sets.size() * 3);
+        uint64_t cursor = 0;
+        for (size_t s = 0; s < sets.size(); ++s)
+            for (uint32_t c = 0; c < 3; ++c) {
+                const auto &set = sets[s]->set_of(c);
+                uint64_t m = 0, k = 0;
+                if (bsg_estimate_parameters(std::max<uint64_t>(set.size(), 1), cfg_.bloom_false_positive_rate, &m, &k))
+                    return fail(kErrGpu, bsg_last_error(ctx_));
+                desc[s * 3 + c] = bsg_filter_desc{cursor, m, (uint32_t)k, 0};
+                cursor += ((m + 63) / 64 + 1) / 2 * 2;
+                pack_entries(set, bytes, offsets);
+                fstart.push_back((uint32_t)offsets.size() - 1);
+            }
+        std::vector<uint64_t> words(std::max<uint64_t>(cursor, 2));
+        if (bsg_build(ctx_, bytes.data(), offsets.data(), (uint32_t)offsets.size() - 1, fstart.data(), desc.data(),
+                      (uint32_t)desc.size(), words.data(), words.size()))
+            return fail(kErrGpu, bsg_last_error(ctx_));
+        sections.resize(sets.size());
+        for (size_t s = 0; s < sets.size(); ++s) {
+            FilterView fv[3];
+            for (uint32_t c = 0; c < 3; ++c) fv[c] = FilterView{words.data() + desc[s * 3 + c].word_off, desc[s * 3 + c].m, desc[s * 3 + c].k};
+            sections[s] = encode_filter_section(fv);
+        }
+        return kEngineOk;
+    }
+
+    // Decode every stored section (parseFilterSection incl. CRC) into one word arena and upload it.
+    int32_t load_arena(const std::vector<const std::vector<uint8_t> *> &sections, uint64_t &arena_id)
+    {
+        std::vector<uint64_t> words;
+        std::vector<bsg_filter_desc> desc(sections.size() * 3);
+        for (size_t s = 0; s < sections.size(); ++s) {
+            ParsedFilter pf[3];
+            const int32_t rc = parse_filter_section(sections[s]->data(), sections[s]->size(), pf);
+            if (rc == kSectionBadHash) return fail(kErrInvalidHash, "filter section CRC32C mismatch");
+            if (rc) return fail(kErrInvalidHash, "malformed filter section (" + std::to_string(rc) + ")");
+            for (uint32_t c = 0; c < 3; ++c) {
+                if (!pf[c].present) { desc[s * 3 + c] = bsg_filter_desc{0, 0, 0, 0}; continue; }
+                desc[s * 3 + c] = bsg_filter_desc{words.size(), pf[c].m, (uint32_t)pf[c].k, 0};
+                words.insert(words.end(), pf[c].words.begin(), pf[c].words.end());
+                if (words.size() & 1) words.push_back(0);
+            }
+        }
+        if (words.empty()) words.push_back(0);
+        if (bsg_arena_load(ctx_, words.data(), words.size(), desc.data(), (uint32_t)sections.size(), &arena_id))
+            return fail(kErrGpu, bsg_last_error(ctx_));
+        return kEngineOk;
+    }
+
+    int32_t ensure_arenas()
+    {
+        if (arenas_valid_) return kEngineOk;
+        std::vector<const std::vector<uint8_t> *> fsec, bsec;
+        for (auto &f : files_) { fsec.push_back(&f.filter_section); for (auto &b : f.blocks) bsec.push_back(&b.filter_section); }
+        total_blocks_ = bsec.size();
+        if (int32_t rc = load_arena(fsec, files_arena_)) return rc;
+        if (int32_t rc = load_arena(bsec, blocks_arena_)) { bsg_arena_free(ctx_, files_arena_); return rc; }
+        arenas_valid_ = true;
+        return kEngineOk;
+    }
+
+    // Each distinct term is hashed once per query, on the device (bsg_hash_entries).
+    int32_t hash_terms(const QueryBatch &qb, std::vector<bsg_term> &terms)
+    {
+        std::vector<uint8_t> bytes;
+        std::vector<uint32_t> offsets{0};
+        for (auto &s : qb.term_strings) { bytes.insert(bytes.end(), s.begin(), s.end()); offsets.push_back((uint32_t)bytes.size()); }
+        std::vector<uint64_t> h(qb.term_strings.size() * 4);
+        if (!qb.term_strings.empty() &&
+            bsg_hash_entries(ctx_, bytes.data(), offsets.data(), (uint32_t)qb.term_strings.size(), h.data()))
+            return fail(kErrGpu, bsg_last_error(ctx_));
+        terms.resize(qb.term_strings.size());
+        for (size_t i = 0; i < terms.size(); ++i) {
+            for (int j = 0; j < 4; ++j) terms[i].h[j] = h[i * 4 + j];
+            terms[i].kind = qb.term_kinds[i];
+            terms[i].reserved = 0;
+        }
+        return kEngineOk;
+    }
+};
+
+}  // namespace bsh

@@ -1,0 +1,243 @@
+// expression.hpp — the bloom query algebra of the reference and its two consumers:
+//   * BloomExpression / BloomCondition with Field / Token / FieldToken / And / Or and the
+//     same-type flattening of flattenExpressions (query.go:478-610); AndBloomQueries (:709-718);
+//     JSON in the exact shape of the reference's exported structs.
+//   * QueryBatch: lowering of a batch of trees to the C-ABI form (bloomgpu.h): distinct terms and
+//     one postfix program per query, case by case after evaluateBloomExpression /
+//     evaluateBloomCondition (query_exec.go:89-159).
+//   * RowMatcher: the final exact test on a row (compiledRowMatcher semantics,
+//     row_matcher.go:204-626, for bloom conditions): single walk, FieldToken compares
+//     (path, token) PAIRS — not the joined key (row_matcher.go:296-301, :587).
+#pragma once
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <string>
+#include <string_view>
+#include <unordered_map>
+#include <vector>
+
+#include "bloomgpu.h"
+#include "json.hpp"
+#include "text.hpp"
+#include "walker.hpp"
+
+namespace bsh {
+
+enum class CondType : uint8_t { Field, Token, FieldToken, Unknown };
+enum class ExprType : uint8_t { Condition, And, Or, Unknown };
+
+struct BloomCondition {
+    CondType type = CondType::Unknown;
+    std::string field, token;
+};
+
+struct BloomExpression {
+    ExprType type = ExprType::Unknown;
+    bool has_condition = false;   // Condition != nil
+    BloomCondition condition;
+    std::vector<BloomExpression> children;
+};
+
+inline BloomExpression Field(std::string field)
+{
+    BloomExpression e; e.type = ExprType::Condition; e.has_condition = true;
+    e.condition.type = CondType::Field; e.condition.field = std::move(field);
+    return e;
+}
+inline BloomExpression Token(std::string token)
+{
+    BloomExpression e; e.type = ExprType::Condition; e.has_condition = true;
+    e.condition.type = CondType::Token; e.condition.token = std::move(token);
+    return e;
+}
+inline BloomExpression FieldToken(std::string field, std::string token)
+{
+    BloomExpression e; e.type = ExprType::Condition; e.has_condition = true;
+    e.condition.type = CondType::FieldToken; e.condition.field = std::move(field); e.condition.token = std::move(token);
+    return e;
+}
+inline std::vector<BloomExpression> flatten_expressions(std::vector<BloomExpression> in, ExprType t)
+{
+    std::vector<BloomExpression> out;  // query.go:600-610
+    for (auto &e : in) {
+        if (e.type == t && !e.has_condition) for (auto &c : e.children) out.push_back(std::move(c));
+        else out.push_back(std::move(e));
+    }
+    return out;
+}
+inline BloomExpression And(std::vector<BloomExpression> kids)
+{
+    BloomExpression e; e.type = ExprType::And; e.children = flatten_expressions(std::move(kids), ExprType::And);
+    return e;
+}
+inline BloomExpression Or(std::vector<BloomExpression> kids)
+{
+    BloomExpression e; e.type = ExprType::Or; e.children = flatten_expressions(std::move(kids), ExprType::Or);
+    return e;
+}
+
+// makeFieldTokenKey (tokenizer.go:509-511)
+inline std::string make_field_token_key(std::string_view field, std::string_view token)
+{
+    std::string k(field);
+    k.append("::");
+    k.append(token);
+    return k;
+}
+
+// ---- JSON (the reference's exported struct shape) ----
+// {"ExpressionType":"AND|OR|CONDITION","Condition":{"Type":"FIELD|TOKEN|FIELD_TOKEN","Field":..,"Token":..},"Children":[..]}
+inline bool expression_from_json(const JNode &n, BloomExpression &out)
+{
+    if (n.type != JType::Object) return false;
+    const JNode *t = n.get("ExpressionType");
+    const std::string ts = (t && t->type == JType::String) ? t->text : "";
+    out.type = ts == "CONDITION" ? ExprType::Condition : ts == "AND" ? ExprType::And : ts == "OR" ? ExprType::Or : ExprType::Unknown;
+    const JNode *c = n.get("Condition");
+    out.has_condition = c && c->type == JType::Object;
+    if (out.has_condition) {
+        const JNode *ct = c->get("Type"), *f = c->get("Field"), *tk = c->get("Token");
+        const std::string cts = (ct && ct->type == JType::String) ? ct->text : "";
+        out.condition.type = cts == "FIELD" ? CondType::Field : cts == "TOKEN" ? CondType::Token
+                           : cts == "FIELD_TOKEN" ? CondType::FieldToken : CondType::Unknown;
+        out.condition.field = (f && f->type == JType::String) ? f->text : "";
+        out.condition.token = (tk && tk->type == JType::String) ? tk->text : "";
+    }
+    const JNode *kids = n.get("Children");
+    if (kids && kids->type == JType::Array) {
+        out.children.resize(kids->items.size());
+        for (size_t i = 0; i < kids->items.size(); ++i)
+            if (kids->items[i].type == JType::Null) { out.children[i].type = ExprType::Condition; out.children[i].has_condition = false; }
+            else if (!expression_from_json(kids->items[i], out.children[i])) return false;
+    }
+    return true;
+}
+
+// ---- lowering to the C-ABI ----
+class QueryBatch {
+public:
+    std::vector<std::string> term_strings;
+    std::vector<uint32_t> term_kinds;
+    std::vector<uint32_t> prog_ops;
+    std::vector<uint32_t> prog_off{0};
+
+    // expression == nullptr: nil BloomQuery / nil Expression => zero ops => true (query_exec.go:81-83)
+    void add_query(const BloomExpression *expression)
+    {
+        if (expression) emit(*expression);
+        prog_off.push_back((uint32_t)prog_ops.size());
+    }
+    uint32_t n_queries() const { return (uint32_t)prog_off.size() - 1; }
+
+private:
+    std::map<std::pair<uint32_t, std::string>, uint32_t> index_;
+
+    uint32_t term(uint32_t kind, std::string s)
+    {
+        auto key = std::make_pair(kind, std::move(s));
+        auto it = index_.find(key);
+        if (it != index_.end()) return it->second;
+        const uint32_t i = (uint32_t)term_strings.size();
+        term_strings.push_back(key.second);
+        term_kinds.push_back(kind);
+        index_.emplace(std::move(key), i);
+        return i;
+    }
+
+    void emit(const BloomExpression &e)
+    {
+        switch (e.type) {
+        case ExprType::Condition:
+            if (!e.has_condition) { prog_ops.push_back(BSG_OP(BSG_OP_TRUE, 0)); return; }  // query_exec.go:101-104
+            switch (e.condition.type) {
+            case CondType::Field: prog_ops.push_back(BSG_OP(BSG_OP_TERM, term(BSG_KIND_FIELD, e.condition.field))); return;
+            case CondType::Token: prog_ops.push_back(BSG_OP(BSG_OP_TERM, term(BSG_KIND_TOKEN, e.condition.token))); return;
+            case CondType::FieldToken:
+                prog_ops.push_back(BSG_OP(BSG_OP_TERM, term(BSG_KIND_FIELD_TOKEN, make_field_token_key(e.condition.field, e.condition.token))));
+                return;
+            default: prog_ops.push_back(BSG_OP(BSG_OP_FALSE, 0)); return;  // :155-156
+            }
+        case ExprType::And:
+        case ExprType::Or:
+            for (auto &c : e.children) emit(c);
+            prog_ops.push_back(BSG_OP(e.type == ExprType::And ? BSG_OP_AND : BSG_OP_OR, (uint32_t)e.children.size()));
+            return;
+        default:
+            prog_ops.push_back(BSG_OP(BSG_OP_FALSE, 0));  // :122-123
+        }
+    }
+};
+
+// ---- final exact row test ----
+class RowMatcher {
+public:
+    explicit RowMatcher(const BloomExpression *expression)
+    {
+        if (expression) { root_ = *expression; has_root_ = true; collect(root_); }
+    }
+
+    // matchRowBytes (row_matcher.go:486-573, bloom conditions): one walk, monotone satisfaction flags,
+    // tree evaluated after the walk (the reference's early exit changes cost, not verdicts).
+    bool match(std::string_view row)
+    {
+        if (!has_root_) return true;
+        sat_.assign(conds_.size(), 0);
+        walker_.walk(row, [&](const Emission &e) {
+            for (size_t i = 0; i < conds_.size(); ++i)
+                if (!sat_[i] && conds_[i]->type == CondType::Field && e.path == conds_[i]->field) sat_[i] = 1;
+            if (!e.is_leaf || !e.has_text || !wants_tokens_) return true;
+            for_each_word(e.text, [&](std::string_view word) {
+                fold_.clear();
+                append_folded_word(fold_, word);
+                for (size_t i = 0; i < conds_.size(); ++i) {
+                    if (sat_[i]) continue;
+                    const BloomCondition &c = *conds_[i];
+                    if (c.type == CondType::Token) { if (fold_ == c.token) sat_[i] = 1; }               // targets never normalised
+                    else if (c.type == CondType::FieldToken) { if (e.path == c.field && fold_ == c.token) sat_[i] = 1; }
+                }
+                return true;
+            });
+            return true;
+        });
+        size_t next = 0;
+        return eval(root_, next);
+    }
+
+private:
+    BloomExpression root_;
+    bool has_root_ = false, wants_tokens_ = false;
+    std::vector<const BloomCondition *> conds_;  // pre-order, matching eval()'s traversal
+    std::vector<uint8_t> sat_;
+    PathWalker walker_;
+    std::string fold_;
+
+    void collect(const BloomExpression &e)
+    {
+        if (e.type == ExprType::Condition) {
+            if (e.has_condition && e.condition.type != CondType::Unknown) {
+                conds_.push_back(&e.condition);
+                if (e.condition.type != CondType::Field) wants_tokens_ = true;
+            }
+            return;
+        }
+        if (e.type == ExprType::And || e.type == ExprType::Or) for (auto &c : e.children) collect(c);
+    }
+
+    // evalMatcherNode (row_matcher.go:257-290): nil condition => true, empty Or => false,
+    // empty And => true, unknown expression/condition => false.
+    bool eval(const BloomExpression &e, size_t &next) const
+    {
+        switch (e.type) {
+        case ExprType::Condition:
+            if (!e.has_condition) return true;
+            if (e.condition.type == CondType::Unknown) return false;
+            return sat_[next++] != 0;
+        case ExprType::And: { bool r = true; for (auto &c : e.children) r = eval(c, next) && r; return r; }
+        case ExprType::Or: { bool r = false; for (auto &c : e.children) r = eval(c, next) || r; return r; }
+        default: return false;
+        }
+    }
+};
+
+}  // namespace bsh

@@ -1,0 +1,225 @@
+"""End-to-end tests of the engine mirror (IngestRows / Flush / Query / Merge) on the GPU, written to
+read like the reference's own engine tests: same rows, same queries, same expected outcomes.
+Bloom arithmetic runs in the HIP kernels (bsg_build / bsg_probe); the oracle is only the checker.
+
+Scenarios after: query_cursor_test.go:442-524 (TestBlockStatsAccuracy), file_format_test.go:28-94
+(TestMeasuredFilterSizing), :940-1055 (TestMergeRebuildsFilters), no_false_negatives_test.go:103-321 and
+:467-611 (TestPropertyNoFalseNegatives), bloom_tree_engine_test.go:1867-1901 (file-level prune).
+"""
+import numpy as np
+import pytest
+
+from bloomsearch_amd import host as Hst, query as Q
+from oracle import oracle as O
+from oracle import walker_oracle as W
+from tests.test_host_tables import KEYS, _random_value, go_marshal
+
+pytestmark = pytest.mark.gpu
+
+
+def new_engine(ctx, **cfg):
+    return Hst.Engine(ctx, **cfg)
+
+
+def ingest_and_flush(engine, rows):
+    engine.ingest_rows([go_marshal(r) for r in rows])
+    engine.flush()
+
+
+def result_ids(res):
+    return {r["id"] for r in res["rows"]}
+
+
+def test_block_stats_accuracy(ctx):
+    e = new_engine(ctx, PartitionField="partition", BloomFalsePositiveRate=1e-6)
+    ingest_and_flush(e, [
+        {"id": 1.0, "partition": "a", "message": "alphaonly"},
+        {"id": 2.0, "partition": "a", "message": "alphaonly"},
+        {"id": 3.0, "partition": "b", "message": "betaonly"},
+        {"id": 4.0, "partition": "b", "message": "betaonly"},
+        {"id": 5.0, "partition": "b", "message": "betaonly"},
+    ])
+    res = e.query(Q.Token("alphaonly"))
+    assert len(res["rows"]) == 2
+    stats = res["stats"]["BlockStats"]
+    assert len(stats) == 2
+    skipped = [b for b in stats if b["BloomFilterSkipped"]]
+    scanned = [b for b in stats if not b["BloomFilterSkipped"]]
+    assert len(skipped) == 1 and len(scanned) == 1
+    assert skipped[0]["RowsProcessed"] == 0 and skipped[0]["BytesProcessed"] == 0
+    assert skipped[0]["TotalRows"] == 3 and skipped[0]["TotalBytes"] > 0
+    assert scanned[0]["RowsProcessed"] == 2 == scanned[0]["TotalRows"] and scanned[0]["BytesProcessed"] > 0
+
+
+def test_measured_filter_sizing(ctx):
+    e = new_engine(ctx)
+    ingest_and_flush(e, [{"id": "row%d" % i, "color": "red"} for i in range(100)])
+    d = e.describe()
+    assert len(d["files"]) == 1 and len(d["files"][0]["blocks"]) == 1
+    want = {"Fields": 2, "Tokens": 101, "FieldTokens": 101}
+    f = d["files"][0]
+    assert f["BloomEntryCounts"] == want and f["blocks"][0]["BloomEntryCounts"] == want
+    for filt in (f["filters"], f["blocks"][0]["filters"]):
+        for got, n in zip(filt, (2, 101, 101)):
+            m, k = O.estimate_parameters(n, 0.001)      # == bloom.NewWithEstimates(count, fpr).Cap()/K()
+            assert (got["m"], got["k"]) == (m, k)
+    assert f["blocks"][0]["filters"][0]["m"] != O.estimate_parameters(100, 0.001)[0]   # not row-count sized
+    # size identity of the stored section: 1 + sum(4 + 24 + 8*ceil(m/64)) + 4
+    assert f["blocks"][0]["BloomFilterSize"] == 1 + sum(4 + 24 + 8 * O.words_for(x["m"]) for x in f["blocks"][0]["filters"]) + 4
+
+
+def test_engine_filter_bytes_equal_oracle_build(ctx):
+    """The wire bytes the engine stores == encodeFilterSection of oracle-built filters over the same rows."""
+    rows = [go_marshal({"id": i, "msg": "hello world %d" % (i % 7), "user": {"name": "U%d" % (i % 13)}}) for i in range(500)]
+    e = new_engine(ctx, MaxBufferedRows=100000)
+    e.ingest_rows(rows)
+    e.flush()
+    sets = (set(), set(), set())
+    for r in rows:
+        W.index_row(r, sets)
+    want = O.encode_filter_section([O.build_sized(sorted(s), 0.001) for s in sets])
+    assert e.section_bytes(0, 0) == want
+    assert e.section_bytes(0, -1) == want        # single block: file-level union == block sets
+
+
+def test_no_false_negative_regressions(ctx):
+    e = new_engine(ctx)
+    ingest_and_flush(e, [{"id": 1, "user_id": 1234567}, {"id": 2, "big": 9007199254740993}])
+    assert result_ids(e.query(Q.FieldToken("user_id", "1234567"))) == {1}
+    assert result_ids(e.query(Q.FieldToken("big", "9007199254740993"))) == {2}
+    assert result_ids(e.query(Q.Token("1234567"))) == {1}
+
+    e = new_engine(ctx)
+    ingest_and_flush(e, [{"id": 1, "a.b": "hello"}, {"id": 2, "a": {"b": "world"}}, {"id": 3, "user.name": "x"}, {"id": 4, ".a": "xyz"}])
+    assert result_ids(e.query(Q.Field("a.b"))) == {1, 2}
+    assert result_ids(e.query(Q.FieldToken("a.b", "hello"))) == {1}
+    assert result_ids(e.query(Q.FieldToken("a.b", "world"))) == {2}
+    assert result_ids(e.query(Q.Field("a"))) == {1, 2}
+    assert result_ids(e.query(Q.Field("user"))) == {3}      # the FieldRegex("user", ...) bloom guard's Field term
+
+    e = new_engine(ctx)
+    ingest_and_flush(e, [{"id": 1, "ab": "x"}, {"id": 2, "a*": 1}, {"id": 3, "back\\slash": "v", "q?x": "y"}])
+    assert result_ids(e.query(Q.Field("a*"))) == {2}
+    assert result_ids(e.query(Q.FieldToken("a*", "1"))) == {2}
+    assert result_ids(e.query(Q.Field("back\\slash"))) == {3}
+    assert result_ids(e.query(Q.FieldToken("q?x", "y"))) == {3}
+
+    e = new_engine(ctx)
+    ingest_and_flush(e, [{"id": 1, "user": {"name": "x"}}, {"id": 2, "other": "y"}])
+    assert result_ids(e.query(Q.Field("user"))) == {1}
+
+    e = new_engine(ctx)
+    ingest_and_flush(e, [{"id": 1, "p": {"x": 7, "y": "hi"}}, {"id": 2, "ts": "2020-01-02T03:04:05Z"}, {"id": 3, "data": "aGk="}, {"id": 4, "n": None}])
+    assert result_ids(e.query(Q.FieldToken("p.x", "7"))) == {1}
+    assert result_ids(e.query(Q.FieldToken("p.y", "hi"))) == {1}
+    assert result_ids(e.query(Q.FieldToken("ts", "2020-01-02t03:04:05z"))) == {2}
+    assert result_ids(e.query(Q.FieldToken("data", "agk="))) == {3}
+    assert result_ids(e.query(Q.Field("n"))) == {4}
+    assert result_ids(e.query(Q.FieldToken("n", "null"))) == set()
+
+
+def test_file_level_prune_produces_no_block_stats(ctx):
+    # bloom_tree_engine_test.go:1867-1901: file 1 has fields {id, service}; Field("message") prunes it at FILE level
+    e = new_engine(ctx, BloomFalsePositiveRate=0.01)
+    ingest_and_flush(e, [{"id": 1, "service": "auth"}])
+    ingest_and_flush(e, [{"id": 2, "service": "auth", "message": "boom"}])
+    res = e.query(Q.Field("message"))
+    assert result_ids(res) == {2}
+    assert len(res["stats"]["BlockStats"]) == 1
+    assert res["stats"]["FilesConsidered"] == 2 and res["stats"]["FilesBloomSkipped"] == 1
+    # nil query: no bloom conditions => nothing read, everything scanned (query_exec.go:503-508)
+    res = e.query(None)
+    assert result_ids(res) == {1, 2} and not any(b["BloomFilterSkipped"] for b in res["stats"]["BlockStats"])
+
+
+def test_property_no_false_negatives(ctx):
+    rng = np.random.default_rng(7)
+    rows = []
+    for i in range(100):
+        obj = {KEYS[rng.integers(0, len(KEYS))]: _random_value(rng, 0) for _ in range(rng.integers(1, 6))}
+        obj["id"] = i
+        rows.append(obj)
+    e = new_engine(ctx, PartitionField="id", MaxBufferedRows=100000)    # one block per row: pruning really bites
+    ingest_and_flush(e, rows)
+    checked = 0
+    for obj in rows[::3]:
+        raw = go_marshal(obj)
+        fields, tokens, fts = W.index_row(raw)
+        for q in [Q.Field(f) for f in sorted(fields)[:4]] + [Q.Token(t) for t in sorted(tokens)[:4]] + \
+                 [Q.FieldToken(*ft.split("::", 1)) for ft in sorted(fts)[:4] if ft.count("::") == 1]:
+            res = e.query(q)
+            assert obj["id"] in result_ids(res), (q, raw)
+            for r in res["rows"]:                       # and nothing that does not match comes back
+                assert W.matches_bloom_expression(go_marshal(r), q)
+            checked += 1
+    assert checked > 100
+
+
+def test_surviving_block_sets_match_oracle(ctx):
+    """BloomFilterSkipped per block == oracle probe over the engine's own stored filter bytes."""
+    rows = [{"id": i, "partition": "p%d" % (i % 9), "msg": "w%d shared" % (i % 23), "k%d" % (i % 5): i} for i in range(300)]
+    e = new_engine(ctx, PartitionField="partition", MaxBufferedRows=100000)
+    ingest_and_flush(e, rows)
+    n_blocks = len(e.describe()["files"][0]["blocks"])
+    filters = [O.parse_filter_section(e.section_bytes(0, b)) for b in range(n_blocks)]
+    for q in (Q.Token("w3"), Q.And(Q.Field("k2"), Q.Token("shared")), Q.Or(Q.FieldToken("msg", "w22"), Q.Field("k4")), Q.Token("zzz")):
+        res = e.query(q)
+        got = [not b["BloomFilterSkipped"] for b in res["stats"]["BlockStats"]]
+
+        def ev(x, fl):
+            et = x["ExpressionType"]
+            if et == "CONDITION":
+                kind, s = Q.term_of(x["Condition"])
+                return fl[kind].test(s)
+            vals = [ev(c, fl) for c in x["Children"]]
+            return all(vals) if et == "AND" else any(vals)
+        want = [ev(q, fl) for fl in filters]
+        if sum(want) == 0 and res["stats"]["FilesBloomSkipped"] == 1:
+            assert got == []
+        else:
+            assert got == want
+
+
+def test_merge_rebuilds_right_sized_filters(ctx):
+    # file_format_test.go:940-1055: merged file's filters are rebuilt for the UNION's distinct counts (never OR-ed)
+    e = new_engine(ctx)
+    ingest_and_flush(e, [{"id": "a%d" % i, "kind": "x"} for i in range(20)])
+    ingest_and_flush(e, [{"id": "b%d" % i, "kind": "x"} for i in range(200)])
+    assert len(e.describe()["files"]) == 2
+    e.merge()
+    d = e.describe()
+    assert len(d["files"]) == 1 and len(d["files"][0]["blocks"]) == 1
+    want = {"Fields": 2, "Tokens": 221, "FieldTokens": 221}
+    assert d["files"][0]["BloomEntryCounts"] == want and d["files"][0]["blocks"][0]["BloomEntryCounts"] == want
+    assert d["files"][0]["filters"][1]["m"] == O.estimate_parameters(221, 0.001)[0]
+    assert len(e.query(Q.Token("a7"))["rows"]) == 1 and len(e.query(Q.Token("b150"))["rows"]) == 1
+    assert len(e.query(Q.Token("zzzabsent0"))["rows"]) == 0
+
+
+def test_engine_errors(ctx):
+    with pytest.raises(Hst.HostError) as ei:
+        new_engine(ctx, BloomFalsePositiveRate=1.5)
+    assert ei.value.code == -101                      # ErrInvalidConfig
+    e = new_engine(ctx)
+    with pytest.raises(Hst.HostError) as ei:          # whole batch rejected, nothing buffered (ingest.go:378-397)
+        e.ingest_rows([b'{"id":1}', b'[1,2]'])
+    assert ei.value.code == -103
+    e.flush()
+    assert e.describe()["files"] == []
+    e.stop()
+    with pytest.raises(Hst.HostError) as ei:
+        e.ingest_rows([b'{"id":1}'])
+    assert ei.value.code == -102                      # ErrEngineStopped
+    assert e.query(None)["rows"] == []                # queries still served after Stop
+
+
+def test_flush_triggers(ctx):
+    e = new_engine(ctx, MaxRowGroupRows=10, MaxBufferedRows=1000)
+    e.ingest_rows([go_marshal({"id": i}) for i in range(9)])
+    assert e.describe()["files"] == []
+    e.ingest_rows([go_marshal({"id": 9})])           # partition hit MaxRowGroupRows => flush (ingest.go:497-503)
+    assert len(e.describe()["files"]) == 1
+    e = new_engine(ctx, MaxBufferedRows=5, PartitionField="id")
+    e.ingest_rows([go_marshal({"id": i}) for i in range(5)])     # buffer hit MaxBufferedRows (ingest.go:512-516)
+    d = e.describe()
+    assert len(d["files"]) == 1 and len(d["files"][0]["blocks"]) == 5
