@@ -125,6 +125,8 @@ def main():
     ap.add_argument("--fpr", type=float, default=0.001)
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU baseline work (0 = skip)")
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--scaled", type=int, default=16,
+                    help="also time C2': the arena replicated this many times inside one launch (0/1 = skip)")
     ap.add_argument("--timed-every", type=int, default=4,
                     help="timestamp the kernels of every Nth step inside the timed region (0 = never)")
     args = ap.parse_args()
@@ -195,13 +197,11 @@ def main():
         torch.cuda.synchronize()
 
     # steps are enqueued through bsg_probe_many, 32 per C call (one step = one arena probe), so the
-    # Python/ctypes call overhead is not what is being measured; every kernel is individually
-    # timestamped (BSG_PROBE_TIMED: the dispatches' own start/stop, as a rocprofv3 kernel trace sees them)
-    order = lambda n: [arenas[i % R] for i in range(n)]
-    te = args.timed_every
-
-    def run_steps(n):
-        ids = order(n)
+    # Python/ctypes call overhead is not what is being measured.  Every te-th step's kernels are
+    # individually timestamped inside the timed region (BSG_PROBE_TIMED: the dispatches' own start/stop
+    # timestamps, i.e. what a rocprofv3 kernel trace reports for them).
+    def run_steps(ids, te):
+        n = len(ids)
         if te == 1:
             for i in range(0, n, 32):
                 ctx.probe_many(ids[i: i + 32], bid, _lib.PROBE_ASYNC | _lib.PROBE_TIMED)
@@ -215,22 +215,45 @@ def main():
                 else:
                     ctx.probe_many(chunk, bid, _lib.PROBE_ASYNC)
 
-    run_steps(args.warmup)
-    ctx.sync()
-    ctx.timing_read(reset=True)
+    def measure(arena_list, steps, warmup, te):
+        run_steps([arena_list[i % len(arena_list)] for i in range(warmup)], te)
+        ctx.sync()
+        ctx.timing_read(reset=True)
+        sync_all()
+        t0 = time.perf_counter()
+        run_steps([arena_list[i % len(arena_list)] for i in range(steps)], te)
+        ctx.sync()
+        sync_all()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, ctx.timing_read()
 
-    sync_all()
-    t0 = time.perf_counter()
-    run_steps(args.steps)
-    ctx.sync()
-    sync_all()
-    elapsed = time.perf_counter() - t0
+    elapsed, tm = measure(arenas, args.steps, args.warmup, args.timed_every)
 
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    tm = ctx.timing_read()
+    # ---- C2' (SURVEY 8d): the same arena replicated x S inside ONE launch so steady-state streaming
+    # bandwidth is visible next to the launch-latency-bound 35 MB case (N=1 only) ----
+    scaled = None
+    if args.scaled > 1 and world == 1:
+        for a in arenas[1:]:
+            ctx.arena_free(a)
+        arenas = arenas[:1]
+        S = args.scaled
+        t0 = time.time()
+        big = ctx.arena_load(words, np.tile(plan.desc, S))       # S address-distinct copies of every filter
+        log("scaled arena: %d blocks (%.2f GB of FT bitsets per launch) loaded in %.1fs" % (B * S, ft_bytes * S / 1e9, time.time() - t0))
+        s_steps = max(4, min(args.steps, 20))
+        s_elapsed, s_tm = measure([big], s_steps, 2, 1)
+        s_bytes = s_tm.stream_bytes / max(s_tm.n_probes, 1) + 33 * len(terms)
+        s_ms = s_tm.ms_terms_kernel / max(s_tm.n_probes, 1)
+        scaled = {"blocks": B * S, "steps": s_steps, "ms_per_step": s_elapsed / s_steps * 1e3,
+                  "value": NQ * B * S * 3 * s_steps / s_elapsed, "kernel_ms": s_ms,
+                  "eval_kernel_ms": s_tm.ms_eval_kernel / max(s_tm.n_probes, 1),
+                  "algorithmic_bytes_per_launch": s_bytes, "achieved": s_bytes / (s_ms * 1e-3) / 1e9,
+                  "frac": s_bytes / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+        ctx.arena_free(big)
 
     terms_per_query = 3
     probes_per_step = NQ * B * terms_per_query * world
@@ -257,6 +280,9 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": k1_ms,
                          "eval_kernel_ms": k2_ms},
         }
+        if scaled:
+            out["roofline_scaled"] = dict(scaled, bound="hbm", kernel="k_probe_terms", peak=HBM_PEAK_GBPS, unit="GB/s",
+                                          note="C2' of SURVEY 8d: same filters replicated x%d at distinct addresses, one launch" % args.scaled)
         if args.cpu_budget > 0 and world == 1:
             base, cpu_out, nq = cpu_baseline(words, plan.desc, cb, ops, poff, B, args.cpu_budget, log)
             if not args.no_check and not np.array_equal(cpu_out, got[:nq]):

@@ -425,7 +425,11 @@ static void *ref_worker(void *arg)
             for (int c = 0; c < 3; ++c) {
                 if (!present[c]) continue;
                 uint64_t nw = bo_words_for(m[c]);
-                for (uint64_t w = 0; w < nw; ++w) fw[c][w] = get_be64(sec + woff[c] + 8 * w);
+                for (uint64_t w = 0; w < nw; ++w) {   /* binary.BigEndian.Uint64 per word: one bswap load */
+                    uint64_t v;
+                    memcpy(&v, sec + woff[c] + 8 * w, 8);
+                    fw[c][w] = __builtin_bswap64(v);
+                }
             }
             if (eval_program_lazy(j->prog_ops + j->prog_off[q], j->prog_off[q + 1] - j->prog_off[q],
                                   fw, present, m, k, j->term_bytes, j->term_off, j->term_kind))
