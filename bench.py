@@ -120,7 +120,8 @@ def main():
     ap.add_argument("--blocks", type=int, default=1000, help="blocks per GPU")
     ap.add_argument("--rows-per-block", type=int, default=10000)
     ap.add_argument("--queries", type=int, default=4096)
-    ap.add_argument("--workload", default="needle", choices=["needle", "lowcard"])
+    ap.add_argument("--workload", default="c2", choices=["c2", "needle"],
+                    help="c2: SURVEY 8d C2 And(FT(level), FT(service), FT(nested.region)); needle: third term is FT(user_id) (~4k distinct terms)")
     ap.add_argument("--replicas", type=int, default=0, help="address-distinct arena replicas (0 = auto)")
     ap.add_argument("--fpr", type=float, default=0.001)
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU baseline work (0 = skip)")
