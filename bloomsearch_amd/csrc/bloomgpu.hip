@@ -93,6 +93,8 @@ struct Device {
     DevBuf<uint64_t> stage_words;
     std::vector<EventTriple> pending;
     std::vector<EventTriple> free_events;
+    hipEvent_t kb0 = nullptr, kb1 = nullptr;  // start/stop timestamps of the last k_build / k_hash_entries dispatch
+    float last_build_ms = 0.f, last_hash_ms = 0.f;
 };
 
 struct ArenaShard {
@@ -343,6 +345,7 @@ int32_t bsg_close(bsg_ctx *ctx)
         Device &d = *dp;
         (void)hipSetDevice(d.id);
         if (d.stream) (void)hipStreamSynchronize(d.stream);
+        if (d.kb0) { (void)hipEventDestroy(d.kb0); (void)hipEventDestroy(d.kb1); }
         for (auto *v : {&d.pending, &d.free_events})
             for (auto &t : *v) {
                 (void)hipEventDestroy(t.k1s); (void)hipEventDestroy(t.k1e);
@@ -394,16 +397,18 @@ int32_t bsg_hash_entries(bsg_ctx *ctx, const uint8_t *bytes, const uint32_t *off
     Device &d = *ctx->devs[0];
     std::lock_guard<std::mutex> lk(d.mu);
     if (int32_t rc = use_device(d)) return rc;
-    HIP_TRY(d.stage_a.reserve((size_t)n_bytes + 16));
+    HIP_TRY(d.stage_a.reserve((size_t)n_bytes + 64));
     HIP_TRY(d.stage_off.reserve((size_t)n_entries + 1));
     HIP_TRY(d.stage_h.reserve((size_t)n_entries * 4));
     if (n_bytes) HIP_TRY(hipMemcpyAsync(d.stage_a.p, bytes, n_bytes, hipMemcpyHostToDevice, d.stream));
     HIP_TRY(hipMemcpyAsync(d.stage_off.p, offsets, ((size_t)n_entries + 1) * 4, hipMemcpyHostToDevice, d.stream));
-    hipLaunchKernelGGL(bsg::k_hash_entries, dim3((n_entries + 255) / 256), dim3(256), 0, d.stream, d.stage_a.p,
-                       d.stage_off.p, n_entries, d.stage_h.p);
+    if (!d.kb0) { HIP_TRY(hipEventCreate(&d.kb0)); HIP_TRY(hipEventCreate(&d.kb1)); }
+    hipExtLaunchKernelGGL(bsg::k_hash_entries, dim3((n_entries + 255) / 256), dim3(256), 0, d.stream, d.kb0, d.kb1, 0,
+                          (const uint8_t *)d.stage_a.p, (const uint32_t *)d.stage_off.p, n_entries, d.stage_h.p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out_h, d.stage_h.p, (size_t)n_entries * 32, hipMemcpyDeviceToHost, d.stream));
     HIP_TRY(hipStreamSynchronize(d.stream));
+    HIP_TRY(hipEventElapsedTime(&d.last_hash_ms, d.kb0, d.kb1));
     return BSG_OK;
 }
 
@@ -446,6 +451,7 @@ static int32_t build_common(bsg_ctx *ctx, const uint8_t *bytes, const uint32_t *
     if (int32_t rc = use_device(d)) return rc;
     HIP_TRY(d.stage_words.reserve(n_words));
     HIP_TRY(hipMemsetAsync(d.stage_words.p, 0, n_words * 8, d.stream));
+    bool launched = false;
     if (!items.empty()) {
         HIP_TRY(d.stage_desc.reserve(n_filters));
         HIP_TRY(d.stage_items.reserve(items.size()));
@@ -458,7 +464,7 @@ static int32_t build_common(bsg_ctx *ctx, const uint8_t *bytes, const uint32_t *
             if (n_entries) HIP_TRY(hipMemcpyAsync(d.stage_h.p, h, (size_t)n_entries * 32, hipMemcpyHostToDevice, d.stream));
             a.h = d.stage_h.p;
         } else {
-            HIP_TRY(d.stage_a.reserve((size_t)n_bytes + 16));
+            HIP_TRY(d.stage_a.reserve((size_t)n_bytes + 64));
             HIP_TRY(d.stage_off.reserve((size_t)n_entries + 1));
             if (n_bytes) HIP_TRY(hipMemcpyAsync(d.stage_a.p, bytes, n_bytes, hipMemcpyHostToDevice, d.stream));
             if (n_entries)
@@ -470,11 +476,16 @@ static int32_t build_common(bsg_ctx *ctx, const uint8_t *bytes, const uint32_t *
         a.desc = d.stage_desc.p;
         a.out = d.stage_words.p;
         const size_t lds = std::max<uint64_t>(max_staged, 2) * 8;
-        hipLaunchKernelGGL(bsg::k_build, dim3((uint32_t)items.size()), dim3(bsg::kBuildThreads), lds, d.stream, a);
+        if (!d.kb0) { HIP_TRY(hipEventCreate(&d.kb0)); HIP_TRY(hipEventCreate(&d.kb1)); }
+        hipExtLaunchKernelGGL(bsg::k_build, dim3((uint32_t)items.size()), dim3(bsg::kBuildThreads), (uint32_t)lds, d.stream,
+                              d.kb0, d.kb1, 0, a);
         HIP_TRY(hipGetLastError());
+        launched = true;
     }
     HIP_TRY(hipMemcpyAsync(out_words, d.stage_words.p, n_words * 8, hipMemcpyDeviceToHost, d.stream));
     HIP_TRY(hipStreamSynchronize(d.stream));
+    d.last_build_ms = 0.f;
+    if (launched) HIP_TRY(hipEventElapsedTime(&d.last_build_ms, d.kb0, d.kb1));
     return BSG_OK;
 }
 
@@ -858,6 +869,16 @@ int32_t bsg_probe(bsg_ctx *ctx, uint64_t arena_id, const bsg_term *terms, uint32
     (void)bsg_batch_free(ctx, bid);
     if (rc) g_err = saved;
     return rc;
+}
+
+int32_t bsg_last_kernel_ms(bsg_ctx *ctx, float *build_ms, float *hash_ms)
+{
+    if (!ctx) return fail(BSG_E_INVALID, "ctx is null");
+    Device &d = *ctx->devs[0];
+    std::lock_guard<std::mutex> lk(d.mu);
+    if (build_ms) *build_ms = d.last_build_ms;
+    if (hash_ms) *hash_ms = d.last_hash_ms;
+    return BSG_OK;
 }
 
 int32_t bsg_timing_read(bsg_ctx *ctx, bsg_timing *out, int32_t reset)

@@ -18,7 +18,8 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kWave = 64;
 constexpr int kProbeThreads = 512;
 constexpr int kEvalThreads = 256;
-constexpr int kBuildThreads = 256;
+constexpr int kBuildThreads = 512;
+
 
 // Device-side filter descriptor: the public (word_off, m, k) plus the Barrett
 // reciprocal magic = floor(2^64 / m) (m == 1 -> 2^64 - 1) so that
@@ -105,6 +106,80 @@ __device__ __forceinline__ void base_hashes(BytePtr p, uint32_t len, uint64_t h[
         uint64_t b1 = h1, b2 = h2;
         if (t == 15) {
             bmix(b1, b2, k1, k2);          // the padded tail is a whole 16-byte block
+        } else {
+            if (t + 1 > 8) mix_k2(b2, k2);
+            mix_k1(b1, k1);
+        }
+        murmur_finalize(b1, b2, (uint64_t)len + 1, h[2], h[3]);
+    }
+}
+
+// Word-wise variant for entries packed in a blob with >= 16 readable bytes after the last entry
+// (the library's staging buffers guarantee it): two unaligned 8-byte loads per 16 bytes instead of
+// byte loads; bytes past the entry's end are masked off.
+__device__ __forceinline__ uint64_t load_u64_unaligned(const uint8_t *p)
+{
+    uint64_t v;
+    __builtin_memcpy(&v, p, 8);
+    return v;
+}
+
+__device__ __forceinline__ void base_hashes_words(const uint8_t *p, uint32_t len, uint64_t h[4])
+{
+    uint64_t h1 = 0, h2 = 0;
+    const uint32_t nb = len >> 4;
+    for (uint32_t i = 0; i < nb; ++i) bmix(h1, h2, load_u64_unaligned(p + 16 * i), load_u64_unaligned(p + 16 * i + 8));
+    const uint32_t t = len & 15u;
+    uint64_t k1 = load_u64_unaligned(p + 16 * nb), k2 = load_u64_unaligned(p + 16 * nb + 8);
+    if (t < 8) { k1 = t ? (k1 & (~0ULL >> (64 - 8 * t))) : 0; k2 = 0; }
+    else       { k2 = t > 8 ? (k2 & (~0ULL >> (64 - 8 * (t - 8)))) : 0; }
+    {
+        uint64_t a1 = h1, a2 = h2;
+        if (t > 8) mix_k2(a2, k2);
+        if (t > 0) mix_k1(a1, k1);
+        murmur_finalize(a1, a2, len, h[0], h[1]);
+    }
+    {
+        if (t < 8) k1 |= 1ULL << (8 * t);
+        else       k2 |= 1ULL << (8 * (t - 8));
+        uint64_t b1 = h1, b2 = h2;
+        if (t == 15) {
+            bmix(b1, b2, k1, k2);
+        } else {
+            if (t + 1 > 8) mix_k2(b2, k2);
+            mix_k1(b1, k1);
+        }
+        murmur_finalize(b1, b2, (uint64_t)len + 1, h[2], h[3]);
+    }
+}
+
+// Same as base_hashes_words with the entry's first 32 bytes already in registers (w[0..3], loaded
+// early so several entries' loads are in flight together); longer entries load the rest on demand.
+__device__ __forceinline__ void base_hashes_pre32(const uint8_t *p, uint32_t len, const uint64_t w[4], uint64_t h[4])
+{
+    uint64_t h1 = 0, h2 = 0;
+    const uint32_t nb = len >> 4;
+    if (nb >= 1) bmix(h1, h2, w[0], w[1]);
+    for (uint32_t i = 1; i < nb; ++i) bmix(h1, h2, load_u64_unaligned(p + 16 * i), load_u64_unaligned(p + 16 * i + 8));
+    const uint32_t t = len & 15u;
+    uint64_t k1, k2;
+    if (nb == 0) { k1 = w[0]; k2 = w[1]; }
+    else if (nb == 1) { k1 = w[2]; k2 = w[3]; }
+    else { k1 = load_u64_unaligned(p + 16 * nb); k2 = load_u64_unaligned(p + 16 * nb + 8); }
+    if (t < 8) { k1 = t ? (k1 & (~0ULL >> (64 - 8 * t))) : 0; k2 = 0; }
+    else       { k2 = t > 8 ? (k2 & (~0ULL >> (64 - 8 * (t - 8)))) : 0; }
+    {
+        uint64_t a1 = h1, a2 = h2;
+        if (t > 8) mix_k2(a2, k2);
+        if (t > 0) mix_k1(a1, k1);
+        murmur_finalize(a1, a2, len, h[0], h[1]);
+    }
+    {
+        if (t < 8) k1 |= 1ULL << (8 * t);
+        else       k2 |= 1ULL << (8 * (t - 8));
+        uint64_t b1 = h1, b2 = h2;
+        if (t == 15) {
+            bmix(b1, b2, k1, k2);
         } else {
             if (t + 1 > 8) mix_k2(b2, k2);
             mix_k1(b1, k1);
@@ -526,7 +601,7 @@ __global__ __launch_bounds__(256) void k_hash_entries(const uint8_t *bytes, cons
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n) return;
     uint64_t h[4];
-    base_hashes(bytes + off[e], off[e + 1] - off[e], h);
+    base_hashes_words(bytes + off[e], off[e + 1] - off[e], h);
     ulonglong2 *o = reinterpret_cast<ulonglong2 *>(out + (uint64_t)e * 4);
     o[0] = make_ulonglong2(h[0], h[1]);
     o[1] = make_ulonglong2(h[2], h[3]);
@@ -553,6 +628,48 @@ struct BuildArgs {
     uint64_t *out;
 };
 
+// Sets the k bits of one entry.  Locations use running sums i*h2, i*h3 (64-bit adds) instead of a
+// 64-bit multiply per location.
+template <bool M32, typename BITS32>
+__device__ __forceinline__ void set_entry_bits(BITS32 bits, const DevDesc &d, const uint64_t h[4])
+{
+    uint64_t s2 = 0, s3 = 0;
+    for (uint32_t i = 0; i < d.k; ++i) {
+        const uint32_t r = i & 3u;
+        const uint64_t x = ((i & 1u) ? h[1] : h[0]) + ((r == 1u || r == 2u) ? s3 : s2);
+        s2 += h[2]; s3 += h[3];
+        const uint64_t loc = locate<M32>(d, x);
+#ifdef BSG_LAB_NO_ATOMICS      // lab only: keep the location live without touching the bitset
+        asm volatile("" ::"v"((uint32_t)loc));
+#else
+        __hip_atomic_fetch_or(&bits[loc >> 5], 1u << ((uint32_t)loc & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+    }
+}
+
+template <bool M32, typename BITS32>
+__device__ __forceinline__ void build_entries(const BuildArgs &a, const BuildItem &it, const DevDesc &d, BITS32 bits, uint32_t tid)
+{
+    if (a.h) {
+        for (uint32_t e = it.e_begin + tid; e < it.e_end; e += kBuildThreads) {
+            const ulonglong2 *hp = reinterpret_cast<const ulonglong2 *>(a.h + (uint64_t)e * 4);
+            const ulonglong2 x = hp[0], y = hp[1];
+            const uint64_t h[4] = {x.x, x.y, y.x, y.y};
+            set_entry_bits<M32>(bits, d, h);
+        }
+        return;
+    }
+    // One entry per lane per trip.  Measured on gfx950 (tools/build_lab.hip): preloading 32 bytes of 2-4
+    // entries per lane is slower on real (10-23 byte) entries — the extra unaligned 8-byte loads cost more
+    // than the overlap buys; k_build is bound by 64-bit integer multiplies (murmur + Barrett), not by loads.
+    for (uint32_t e = it.e_begin + tid; e < it.e_end; e += kBuildThreads) {
+        const uint32_t o0 = a.off[e], o1 = a.off[e + 1];
+        uint64_t h[4];
+        base_hashes_words(a.bytes + o0, o1 - o0, h);
+        set_entry_bits<M32>(bits, d, h);
+    }
+}
+
 __global__ __launch_bounds__(kBuildThreads) void k_build(const BuildArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
@@ -561,32 +678,20 @@ __global__ __launch_bounds__(kBuildThreads) void k_build(const BuildArgs a)
     const uint32_t tid = threadIdx.x;
     if (d.m == 0) return;
     const uint64_t nw = (d.m + 63) >> 6;
-    uint32_t *bits;
+    const bool m32 = d.m < (1ull << 31);
     if (it.staged) {
         for (uint32_t i = tid; i < nw; i += kBuildThreads) lds64[i] = 0;
         __syncthreads();
-        bits = reinterpret_cast<uint32_t *>(lds64);
-    } else {
-        bits = reinterpret_cast<uint32_t *>(a.out + d.word_off);
-    }
-    for (uint32_t e = it.e_begin + tid; e < it.e_end; e += kBuildThreads) {
-        uint64_t h[4];
-        if (a.h) {
-            const ulonglong2 *hp = reinterpret_cast<const ulonglong2 *>(a.h + (uint64_t)e * 4);
-            const ulonglong2 x = hp[0], y = hp[1];
-            h[0] = x.x; h[1] = x.y; h[2] = y.x; h[3] = y.y;
-        } else {
-            base_hashes(a.bytes + a.off[e], a.off[e + 1] - a.off[e], h);
-        }
-        for (uint32_t i = 0; i < d.k; ++i) {
-            const uint64_t loc = mod_m(location(h[0], h[1], h[2], h[3], i), d.m, d.magic);
-            atomicOr(&bits[loc >> 5], 1u << (loc & 31));
-        }
-    }
-    if (it.staged) {
+        lds_u32 *bits = (lds_u32 *)lds64;
+        if (m32) build_entries<true>(a, it, d, bits, tid);
+        else     build_entries<false>(a, it, d, bits, tid);
         __syncthreads();
         uint64_t *dst = a.out + d.word_off;
         for (uint32_t i = tid; i < nw; i += kBuildThreads) dst[i] = lds64[i];
+    } else {
+        uint32_t *bits = reinterpret_cast<uint32_t *>(a.out + d.word_off);
+        if (m32) build_entries<true>(a, it, d, bits, tid);
+        else     build_entries<false>(a, it, d, bits, tid);
     }
 }
 

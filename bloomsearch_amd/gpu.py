@@ -140,6 +140,11 @@ class Context:
         self._check(self.L.bsg_timing_read(self.h, C.byref(t), 1 if reset else 0))
         return t
 
+    def last_kernel_ms(self):
+        b, h = C.c_float(), C.c_float()
+        self._check(self.L.bsg_last_kernel_ms(self.h, C.byref(b), C.byref(h)))
+        return float(b.value), float(h.value)
+
     # ---- OR-reduce ----
     def or_reduce(self, arena_id: int, kind: int, n_words: int) -> np.ndarray:
         out = np.zeros(n_words, dtype=np.uint64)

@@ -170,6 +170,9 @@ BSG_API int32_t bsg_probe(bsg_ctx *ctx, uint64_t arena_id, const bsg_term *terms
                           uint64_t *out_survivors);
 
 BSG_API int32_t bsg_timing_read(bsg_ctx *ctx, bsg_timing *out, int32_t reset);
+/* Device time (the dispatch's own start/stop timestamps) of the most recent k_build / k_hash_entries
+ * launch made through bsg_build* / bsg_hash_entries on the context's first device. */
+BSG_API int32_t bsg_last_kernel_ms(bsg_ctx *ctx, float *build_ms, float *hash_ms);
 
 /* ---- fixed-geometry OR-reduce (extension) ----
  * All present filters of `kind` in the arena must share (m, k).  out_words

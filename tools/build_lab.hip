@@ -1,0 +1,41 @@
+// build_lab: time k_build variants on synthetic entries.  ./build_lab N_FILTERS ENTRIES_PER_FILTER ENTRY_LEN
+#include "../bloomsearch_amd/csrc/kernels.hip.h"
+#include <hip/hip_ext.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <random>
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+using namespace bsg;
+int main(int argc, char **argv)
+{
+    const uint32_t F = argc > 1 ? atoi(argv[1]) : 600, E = argc > 2 ? atoi(argv[2]) : 19600, L = argc > 3 ? atoi(argv[3]) : 13, K = argc > 4 ? atoi(argv[4]) : 10;
+    const uint64_t n = (uint64_t)F * E;
+    std::mt19937_64 rng(1);
+    std::vector<uint8_t> bytes(n * L + 64);
+    for (auto &b : bytes) b = (uint8_t)rng();
+    std::vector<uint32_t> off(n + 1);
+    for (uint64_t i = 0; i <= n; ++i) off[i] = (uint32_t)(i * L);
+    const uint64_t m = 281629, nw = (m + 63) / 64, stride = (nw + 15) / 16 * 16;
+    std::vector<DevDesc> desc(F);
+    std::vector<BuildItem> items(F);
+    for (uint32_t f = 0; f < F; ++f) { desc[f] = DevDesc{stride * f, m, ~0ULL / m, K, 0}; items[f] = BuildItem{f, f * E, (f + 1) * E, 1}; }
+    uint8_t *db; uint32_t *doff; DevDesc *dd; BuildItem *di; uint64_t *dout;
+    CHECK(hipMalloc(&db, bytes.size())); CHECK(hipMemcpy(db, bytes.data(), bytes.size(), hipMemcpyHostToDevice));
+    CHECK(hipMalloc(&doff, off.size() * 4)); CHECK(hipMemcpy(doff, off.data(), off.size() * 4, hipMemcpyHostToDevice));
+    CHECK(hipMalloc(&dd, F * sizeof(DevDesc))); CHECK(hipMemcpy(dd, desc.data(), F * sizeof(DevDesc), hipMemcpyHostToDevice));
+    CHECK(hipMalloc(&di, F * sizeof(BuildItem))); CHECK(hipMemcpy(di, items.data(), F * sizeof(BuildItem), hipMemcpyHostToDevice));
+    CHECK(hipMalloc(&dout, stride * F * 8));
+    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    BuildArgs a{db, doff, nullptr, di, dd, dout};
+    float best = 1e9, tot = 0;
+    for (int it = 0; it < 6; ++it) {
+        hipExtLaunchKernelGGL(k_build, dim3(F), dim3(kBuildThreads), (uint32_t)(nw * 8), 0, e0, e1, 0, a);
+        CHECK(hipEventSynchronize(e1));
+        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+        if (it) { tot += ms; best = ms < best ? ms : best; }
+    }
+    printf("F=%u E=%u L=%u K=%u threads=%d: avg %.1f us  best %.1f us  (%.2f ns/entry, %.0f GB/s entry bytes+offsets)\n", F, E, L, K, kBuildThreads,
+           tot / 5 * 1e3, best * 1e3, tot / 5 * 1e6 / n, (double)n * (L + 4) / (tot / 5 * 1e-3) / 1e9);
+    return 0;
+}

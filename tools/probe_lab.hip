@@ -34,6 +34,34 @@ __global__ __launch_bounds__(256) void k_read_only(const u32x4 *p, uint64_t n16,
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * 256) acc ^= p[i];
     if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345) out[0] = 1;
 }
+
+// variant: no descriptor load — address from blockIdx * stride, size from args (quantifies the dependent-load cost)
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_stream_nodesc(const uint64_t *words, uint64_t stride, uint32_t nw, uint64_t *out)
+{
+    extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t nbytes = (uint32_t)(((nw + 1) >> 1) << 4);
+    const char *g = reinterpret_cast<const char *>(words + stride * blockIdx.x);
+    char *image = reinterpret_cast<char *>(lds64);
+    for (uint32_t c = wave * 1024u; c < nbytes; c += (THREADS / 64) * 1024u) {
+        const uint32_t boff = c + lane * 16u;
+        if (boff < nbytes) __builtin_amdgcn_global_load_lds((glb_void *)(g + boff), (lds_void *)(image + c), 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) out[blockIdx.x] = lds64[nw - 1];
+}
+// variant: plain register loads (no LDS), one workgroup per filter
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_stream_regs(const uint64_t *words, uint64_t stride, uint32_t nw, uint64_t *out)
+{
+    const u32x4 *p = reinterpret_cast<const u32x4 *>(words + stride * blockIdx.x);
+    const uint32_t n16 = (nw + 1) >> 1;
+    u32x4 acc = {0, 0, 0, 0};
+    for (uint32_t i = threadIdx.x; i < n16; i += THREADS) acc ^= p[i];
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345) out[blockIdx.x] = 1;
+}
 __global__ void k_empty(uint64_t *out) { if (threadIdx.x == 9999) out[0] = 1; }
 
 int main(int argc, char **argv)
@@ -84,6 +112,11 @@ int main(int argc, char **argv)
     timeit("read_only grid=2048", [&](int r, hipEvent_t a0, hipEvent_t a1) { hipExtLaunchKernelGGL(k_read_only, dim3(2048), dim3(256), 0, st, a0, a1, 0, (const u32x4 *)dw[r], (uint64_t)(stride * B / 2), (uint32_t *)dout); });
     timeit("read_only grid=8192", [&](int r, hipEvent_t a0, hipEvent_t a1) { hipExtLaunchKernelGGL(k_read_only, dim3(8192), dim3(256), 0, st, a0, a1, 0, (const u32x4 *)dw[r], (uint64_t)(stride * B / 2), (uint32_t *)dout); });
     timeit("stream_only (LDS-DMA)", [&](int r, hipEvent_t a0, hipEvent_t a1) { hipExtLaunchKernelGGL(k_stream_only, dim3(B), dim3(512), lds, st, a0, a1, 0, (const uint64_t *)dw[r], (const DevDesc *)dd, dout); });
+    timeit("stream nodesc 512", [&](int r, hipEvent_t a0, hipEvent_t a1) { hipExtLaunchKernelGGL(k_stream_nodesc<512>, dim3(B), dim3(512), lds, st, a0, a1, 0, (const uint64_t *)dw[r], stride, nw, dout); });
+    timeit("stream nodesc 256", [&](int r, hipEvent_t a0, hipEvent_t a1) { hipExtLaunchKernelGGL(k_stream_nodesc<256>, dim3(B), dim3(256), lds, st, a0, a1, 0, (const uint64_t *)dw[r], stride, nw, dout); });
+    timeit("stream nodesc 1024", [&](int r, hipEvent_t a0, hipEvent_t a1) { hipExtLaunchKernelGGL(k_stream_nodesc<1024>, dim3(B), dim3(1024), lds, st, a0, a1, 0, (const uint64_t *)dw[r], stride, nw, dout); });
+    timeit("stream regs 512", [&](int r, hipEvent_t a0, hipEvent_t a1) { hipExtLaunchKernelGGL(k_stream_regs<512>, dim3(B), dim3(512), 0, st, a0, a1, 0, (const uint64_t *)dw[r], stride, nw, dout); });
+    timeit("stream regs 256", [&](int r, hipEvent_t a0, hipEvent_t a1) { hipExtLaunchKernelGGL(k_stream_regs<256>, dim3(B), dim3(256), 0, st, a0, a1, 0, (const uint64_t *)dw[r], stride, nw, dout); });
     timeit("k_probe_terms", [&](int r, hipEvent_t a0, hipEvent_t a1) { a.words = dw[r]; hipExtLaunchKernelGGL(k_probe_terms, dim3(B, 1), dim3(kProbeThreads), lds, st, a0, a1, 0, a); });
     return 0;
 }
