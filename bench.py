@@ -206,19 +206,10 @@ def main():
     # individually timestamped inside the timed region (BSG_PROBE_TIMED: the dispatches' own start/stop
     # timestamps, i.e. what a rocprofv3 kernel trace reports for them).
     def run_steps(ids, te):
-        n = len(ids)
-        if te == 1:
-            for i in range(0, n, 32):
-                ctx.probe_many(ids[i: i + 32], bid, _lib.PROBE_ASYNC | _lib.PROBE_TIMED)
-        else:
-            for i in range(0, n, 32):
-                chunk = ids[i: i + 32]
-                if te > 1:   # first step of each group of te is timestamped
-                    for j in range(0, len(chunk), te):
-                        ctx.probe_many(chunk[j: j + 1], bid, _lib.PROBE_ASYNC | _lib.PROBE_TIMED)
-                        ctx.probe_many(chunk[j + 1: j + te], bid, _lib.PROBE_ASYNC)
-                else:
-                    ctx.probe_many(chunk, bid, _lib.PROBE_ASYNC)
+        ctx.set_timed_stride(max(te, 1))
+        flags = _lib.PROBE_ASYNC | (_lib.PROBE_TIMED if te > 0 else 0)
+        for i in range(0, len(ids), 64):
+            ctx.probe_many(ids[i: i + 64], bid, flags)
 
     def measure(arena_list, steps, warmup, te):
         run_steps([arena_list[i % len(arena_list)] for i in range(warmup)], te)
@@ -227,6 +218,7 @@ def main():
         sync_all()
         t0 = time.perf_counter()
         run_steps([arena_list[i % len(arena_list)] for i in range(steps)], te)
+        t_enq = time.perf_counter() - t0
         ctx.sync()
         sync_all()
         dt = time.perf_counter() - t0
@@ -234,6 +226,7 @@ def main():
             t = torch.tensor([dt], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
+        log("%d steps: host enqueue %.2f us/step, wall %.2f us/step" % (steps, t_enq / steps * 1e6, dt / steps * 1e6))
         return dt, ctx.timing_read()
 
     elapsed, tm = measure(arenas, args.steps, args.warmup, args.timed_every)

@@ -43,7 +43,7 @@ def op(opcode: int, arg: int = 0) -> int:
 EXPORTS = [
     "bsg_device_count", "bsg_open", "bsg_close", "bsg_last_error", "bsg_sync", "bsg_estimate_parameters",
     "bsg_hash_entries", "bsg_build", "bsg_build_hashed", "bsg_arena_load", "bsg_arena_free",
-    "bsg_batch_create", "bsg_batch_free", "bsg_probe_batch", "bsg_probe_many", "bsg_probe", "bsg_timing_read", "bsg_last_kernel_ms",
+    "bsg_batch_create", "bsg_batch_free", "bsg_probe_batch", "bsg_probe_many", "bsg_probe", "bsg_timing_read", "bsg_set_timed_stride", "bsg_last_kernel_ms",
     "bsg_or_reduce", "bsg_or_words_dev", "bsg_or_reduce_dev",
 ]
 
@@ -75,9 +75,10 @@ def load():
     L.bsg_batch_create.argtypes = [vp, vp, u32, vp, vp, u32, C.POINTER(u64)]
     L.bsg_batch_free.argtypes = [vp, u64]
     L.bsg_probe_batch.argtypes = [vp, u64, u64, u32, vp]
-    L.bsg_probe_many.argtypes = [vp, vp, u32, u64, u32]
+    L.bsg_probe_many.argtypes = [vp, vp, u32, u64, u32, vp]
     L.bsg_probe.argtypes = [vp, u64, vp, u32, vp, vp, u32, vp]
     L.bsg_timing_read.argtypes = [vp, C.POINTER(Timing), i32]
+    L.bsg_set_timed_stride.argtypes = [vp, u32]
     L.bsg_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.bsg_or_reduce.argtypes = [vp, u64, u32, vp, u64]
     L.bsg_or_words_dev.argtypes = [vp, vp, vp, u64, u32]

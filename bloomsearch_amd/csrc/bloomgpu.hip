@@ -82,8 +82,8 @@ struct Device {
     int id = 0;
     hipStream_t stream = nullptr;
     std::mutex mu;                 // serialises enqueue + scratch reuse on this device
-    DevBuf<uint64_t> V;            // verdict scratch
-    DevBuf<uint64_t> out;          // survivors scratch
+    DevBuf<uint64_t> V[2];         // verdict scratch (two slots: bsg_probe_many software-pipelines launches)
+    DevBuf<uint64_t> out[2];       // survivors scratch
     DevBuf<uint8_t> stage_a;       // build/hash staging
     DevBuf<uint32_t> stage_off;
     DevBuf<uint64_t> stage_h;
@@ -145,6 +145,8 @@ struct bsg_ctx {
     std::map<uint64_t, std::shared_ptr<Batch>> batches;
     uint64_t next_id = 1;
     bsg_timing timing{};
+    uint32_t timed_stride = 1;   // with BSG_PROBE_TIMED, timestamp every timed_stride-th probe
+    uint64_t timed_counter = 0;
 };
 
 namespace {
@@ -330,6 +332,7 @@ int32_t bsg_open(const int32_t *device_ids, int32_t n_devices, bsg_ctx **out_ctx
         d->id = device_ids[i];
         HIP_TRY(hipSetDevice(d->id));
         HIP_TRY(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
+
         ctx->devs.push_back(std::move(d));
     }
     *out_ctx = ctx.release();
@@ -351,7 +354,7 @@ int32_t bsg_close(bsg_ctx *ctx)
                 (void)hipEventDestroy(t.k1s); (void)hipEventDestroy(t.k1e);
                 (void)hipEventDestroy(t.k2s); (void)hipEventDestroy(t.k2e);
             }
-        d.V.release(); d.out.release(); d.stage_a.release(); d.stage_off.release(); d.stage_h.release();
+        d.V[0].release(); d.V[1].release(); d.out[0].release(); d.out[1].release(); d.stage_a.release(); d.stage_off.release(); d.stage_h.release();
         d.stage_fstart.release(); d.stage_desc.release(); d.stage_items.release(); d.stage_words.release();
         if (d.stream) (void)hipStreamDestroy(d.stream);
     }
@@ -736,7 +739,79 @@ int32_t bsg_batch_free(bsg_ctx *ctx, uint64_t batch_id)
     return BSG_OK;
 }
 
-int32_t bsg_probe_batch(bsg_ctx *ctx, uint64_t arena_id, uint64_t batch_id, uint32_t flags, uint64_t *out_survivors)
+}  // extern "C"
+
+namespace {
+
+int32_t take_events(bsg_ctx *ctx, Device &d, EventTriple &ev)
+{
+    if (d.pending.size() >= 4096) if (int32_t rc = drain_timing(ctx, d)) return rc;
+    if (!d.free_events.empty()) { ev = d.free_events.back(); d.free_events.pop_back(); }
+    else {
+        HIP_TRY(hipEventCreate(&ev.k1s)); HIP_TRY(hipEventCreate(&ev.k1e));
+        HIP_TRY(hipEventCreate(&ev.k2s)); HIP_TRY(hipEventCreate(&ev.k2e));
+    }
+    ev.bytes = 0;
+    return BSG_OK;
+}
+
+// K1: stream every referenced bitset once, one verdict word per (block, 64 terms) into V[slot].
+int32_t enqueue_terms(Device &d, const ArenaShard &s, const BatchDev &bd, const Batch &B, uint32_t slot, EventTriple *ev)
+{
+    const uint32_t G = (s.n_blocks + 63) / 64;
+    HIP_TRY(d.V[slot].reserve((size_t)G * std::max(B.Wt, 1u) * 64));
+    if (B.n_kinds == 0) return BSG_OK;
+    bsg::ProbeArgs a{};
+    a.words = s.d_words; a.desc = s.d_desc; a.th = bd.d_th; a.V = d.V[slot].p;
+    a.Tp = B.Tp; a.Wt = B.Wt; a.n_blocks = s.n_blocks;
+    uint32_t max_tw = 0;
+    for (uint32_t y = 0; y < B.n_kinds; ++y) max_tw = std::max(max_tw, (B.term_count[y] + 63) / 64);
+    const size_t head = bsg::probe_lds_head_bytes(max_tw);
+    // staged-filter cap for this launch: what is left of 64 KiB of dynamic LDS after the head
+    const uint64_t cap_words = head + 32 < 65536 ? (65536 - head) / 16 * 2 : 0;
+    a.lds_cap_words = (uint32_t)std::min<uint64_t>(kLdsCapWords, cap_words);
+    uint64_t lds_words = 2;
+    for (uint32_t y = 0; y < B.n_kinds; ++y) {
+        a.kind[y] = B.kind[y]; a.term_begin[y] = B.term_begin[y]; a.term_count[y] = B.term_count[y];
+        lds_words = std::max(lds_words, std::min<uint64_t>(s.max_staged_words[B.kind[y]], a.lds_cap_words));
+        if (ev) ev->bytes += s.sum_words[B.kind[y]] * 8;
+    }
+    lds_words = (lds_words + 1) / 2 * 2;
+    hipExtLaunchKernelGGL(bsg::k_probe_terms, dim3(s.n_blocks, B.n_kinds), dim3(bsg::kProbeThreads),
+                          (uint32_t)(head + lds_words * 8), d.stream, ev ? ev->k1s : nullptr, ev ? ev->k1e : nullptr, 0, a);
+    HIP_TRY(hipGetLastError());
+    return BSG_OK;
+}
+
+// K2: programs over V[slot] -> out[slot].  any_order: the dispatch carries no barrier bit against the
+// packet before it (hipExtAnyOrderLaunch); bsg_probe_many uses it to let K2(i) start beside K1(i+1).
+int32_t enqueue_eval(Device &d, const ArenaShard &s, const BatchDev &bd, const Batch &B, uint32_t slot, EventTriple *ev,
+                     bool any_order)
+{
+    const uint32_t G = (s.n_blocks + 63) / 64;
+    HIP_TRY(d.out[slot].reserve((size_t)B.n_queries * G));
+    bsg::EvalArgs a{};
+    a.V = d.V[slot].p; a.prog = bd.d_prog; a.chunk_off = bd.d_chunk_off; a.chunk_len = bd.d_chunk_len;
+    a.out = d.out[slot].p; a.Wt = B.Wt; a.n_blocks = s.n_blocks; a.G = G; a.n_queries = B.n_queries;
+    a.cw_off = bd.d_cw_off; a.cw = bd.d_cw; a.max_cw = B.max_cw;
+    const size_t lds = ((size_t)B.max_cw * 64 + (size_t)B.max_depth * bsg::kEvalThreads) * 8;
+    hipExtLaunchKernelGGL(bsg::k_eval_programs, dim3(G, B.n_chunks), dim3(bsg::kEvalThreads), (uint32_t)lds, d.stream,
+                          ev ? ev->k2s : nullptr, ev ? ev->k2e : nullptr, any_order ? hipExtAnyOrderLaunch : 0, a);
+    HIP_TRY(hipGetLastError());
+    return BSG_OK;
+}
+
+}  // namespace
+
+extern "C" int32_t bsg_set_timed_stride(bsg_ctx *ctx, uint32_t stride)
+{
+    if (!ctx) return fail(BSG_E_INVALID, "ctx is null");
+    ctx->timed_stride = stride ? stride : 1;
+    ctx->timed_counter = 0;
+    return BSG_OK;
+}
+
+extern "C" int32_t bsg_probe_batch(bsg_ctx *ctx, uint64_t arena_id, uint64_t batch_id, uint32_t flags, uint64_t *out_survivors)
 {
     if (!ctx) return fail(BSG_E_INVALID, "ctx is null");
     std::shared_ptr<Arena> arena;
@@ -750,6 +825,7 @@ int32_t bsg_probe_batch(bsg_ctx *ctx, uint64_t arena_id, uint64_t batch_id, uint
     const uint32_t Q = B.n_queries;
     const uint64_t Gglobal = ((uint64_t)arena->n_blocks + 63) / 64;
     if (Q == 0 || arena->n_blocks == 0) return BSG_OK;
+    const bool timed = flags & BSG_PROBE_TIMED;
 
     std::vector<std::vector<uint64_t>> host_parts(nd > 1 && out_survivors ? nd : 0);
     for (uint32_t di = 0; di < nd; ++di) {
@@ -760,60 +836,19 @@ int32_t bsg_probe_batch(bsg_ctx *ctx, uint64_t arena_id, uint64_t batch_id, uint
         std::lock_guard<std::mutex> lk(d.mu);
         if (int32_t rc = use_device(d)) return rc;
         const uint32_t G = (s.n_blocks + 63) / 64;
-        HIP_TRY(d.V.reserve((size_t)G * std::max(B.Wt, 1u) * 64));
-        HIP_TRY(d.out.reserve((size_t)Q * G));
         EventTriple ev{};
-        const bool timed = flags & BSG_PROBE_TIMED;
-        if (timed) {
-            if (d.pending.size() >= 4096) if (int32_t rc = drain_timing(ctx, d)) return rc;
-            if (!d.free_events.empty()) { ev = d.free_events.back(); d.free_events.pop_back(); }
-            else {
-                HIP_TRY(hipEventCreate(&ev.k1s)); HIP_TRY(hipEventCreate(&ev.k1e));
-                HIP_TRY(hipEventCreate(&ev.k2s)); HIP_TRY(hipEventCreate(&ev.k2e));
-            }
-            ev.bytes = 0;
-        }
-        if (B.n_kinds > 0) {
-            bsg::ProbeArgs a{};
-            a.words = s.d_words; a.desc = s.d_desc; a.th = bd.d_th; a.V = d.V.p;
-            a.Tp = B.Tp; a.Wt = B.Wt; a.n_blocks = s.n_blocks; a.lds_cap_words = kLdsCapWords;
-            uint32_t max_tw = 0;
-            for (uint32_t y = 0; y < B.n_kinds; ++y) max_tw = std::max(max_tw, (B.term_count[y] + 63) / 64);
-            const size_t head = bsg::probe_lds_head_bytes(max_tw);
-            // staged-filter cap for this launch: what is left of 64 KiB of dynamic LDS after the head
-            const uint64_t cap_words = head + 32 < 65536 ? (65536 - head) / 16 * 2 : 0;
-            a.lds_cap_words = (uint32_t)std::min<uint64_t>(kLdsCapWords, cap_words);
-            uint64_t lds_words = 2;
-            for (uint32_t y = 0; y < B.n_kinds; ++y) {
-                a.kind[y] = B.kind[y]; a.term_begin[y] = B.term_begin[y]; a.term_count[y] = B.term_count[y];
-                lds_words = std::max(lds_words, std::min<uint64_t>(s.max_staged_words[B.kind[y]], a.lds_cap_words));
-                ev.bytes += s.sum_words[B.kind[y]] * 8;
-            }
-            lds_words = (lds_words + 1) / 2 * 2;
-            hipExtLaunchKernelGGL(bsg::k_probe_terms, dim3(s.n_blocks, B.n_kinds), dim3(bsg::kProbeThreads),
-                                  (uint32_t)(head + lds_words * 8), d.stream, timed ? ev.k1s : nullptr,
-                                  timed ? ev.k1e : nullptr, 0, a);
-            HIP_TRY(hipGetLastError());
-        }
-        {
-            bsg::EvalArgs a{};
-            a.V = d.V.p; a.prog = bd.d_prog; a.chunk_off = bd.d_chunk_off; a.chunk_len = bd.d_chunk_len;
-            a.out = d.out.p; a.Wt = B.Wt; a.n_blocks = s.n_blocks; a.G = G; a.n_queries = Q;
-            a.cw_off = bd.d_cw_off; a.cw = bd.d_cw; a.max_cw = B.max_cw;
-            const size_t lds = ((size_t)B.max_cw * 64 + (size_t)B.max_depth * bsg::kEvalThreads) * 8;
-            hipExtLaunchKernelGGL(bsg::k_eval_programs, dim3(G, B.n_chunks), dim3(bsg::kEvalThreads), (uint32_t)lds,
-                                  d.stream, timed ? ev.k2s : nullptr, timed ? ev.k2e : nullptr, 0, a);
-            HIP_TRY(hipGetLastError());
-        }
+        if (timed) if (int32_t rc = take_events(ctx, d, ev)) return rc;
+        if (int32_t rc = enqueue_terms(d, s, bd, B, 0, timed ? &ev : nullptr)) return rc;
+        if (int32_t rc = enqueue_eval(d, s, bd, B, 0, timed ? &ev : nullptr, false)) return rc;
         if (timed) {
             if (B.n_kinds > 0) d.pending.push_back(ev); else d.free_events.push_back(ev);
         }
         if (out_survivors) {
             if (nd == 1) {
-                HIP_TRY(hipMemcpyAsync(out_survivors, d.out.p, (size_t)Q * G * 8, hipMemcpyDeviceToHost, d.stream));
+                HIP_TRY(hipMemcpyAsync(out_survivors, d.out[0].p, (size_t)Q * G * 8, hipMemcpyDeviceToHost, d.stream));
             } else {
                 host_parts[di].resize((size_t)Q * G);
-                HIP_TRY(hipMemcpyAsync(host_parts[di].data(), d.out.p, (size_t)Q * G * 8, hipMemcpyDeviceToHost, d.stream));
+                HIP_TRY(hipMemcpyAsync(host_parts[di].data(), d.out[0].p, (size_t)Q * G * 8, hipMemcpyDeviceToHost, d.stream));
             }
         }
     }
@@ -850,13 +885,64 @@ int32_t bsg_probe_batch(bsg_ctx *ctx, uint64_t arena_id, uint64_t batch_id, uint
     return BSG_OK;
 }
 
-int32_t bsg_probe_many(bsg_ctx *ctx, const uint64_t *arena_ids, uint32_t n_arenas, uint64_t batch_id, uint32_t flags)
+// Software-pipelined enqueue on one in-order stream; per device the queue holds
+//   K1(0) | K1(1) K2(0)* | K1(2) K2(1)* | ... | K2(n-1)
+// where * dispatches carry no barrier bit (hipExtAnyOrderLaunch): K2(i) only needs K1(i), which the
+// in-order K1(i+1) ahead of it has already waited for, so the packet processor may start it beside
+// K1(i+1).  V/out are double-buffered by step parity; K1(i+2) is in-order, i.e. behind K2(i).
+// (A two-stream variant with cross-stream events was measured slower: each hipEventRecord /
+// hipStreamWaitEvent costs the host 3-4 us, more than the overlap buys at this kernel size.)
+extern "C" int32_t bsg_probe_many(bsg_ctx *ctx, const uint64_t *arena_ids, uint32_t n_arenas, uint64_t batch_id, uint32_t flags,
+                                  uint64_t *out_survivors)
 {
     if (!ctx || (n_arenas && !arena_ids)) return fail(BSG_E_INVALID, "null argument");
-    for (uint32_t i = 0; i < n_arenas; ++i)
-        if (int32_t rc = bsg_probe_batch(ctx, arena_ids[i], batch_id, flags | BSG_PROBE_ASYNC, nullptr)) return rc;
+    if (out_survivors && ctx->devs.size() != 1)
+        return fail(BSG_E_UNSUPPORTED, "bsg_probe_many returns survivors only on single-device contexts");
+    std::shared_ptr<Batch> batch;
+    if (int32_t rc = get_batch(ctx, batch_id, batch)) return rc;
+    const Batch &B = *batch;
+    std::vector<std::shared_ptr<Arena>> arenas(n_arenas);
+    for (uint32_t i = 0; i < n_arenas; ++i) if (int32_t rc = get_arena(ctx, arena_ids[i], arenas[i])) return rc;
+    if (B.n_queries == 0 || n_arenas == 0) return BSG_OK;
+    const bool timed = flags & BSG_PROBE_TIMED;
+    for (uint32_t di = 0; di < ctx->devs.size(); ++di) {
+        Device &d = *ctx->devs[di];
+        const BatchDev &bd = B.dev[di];
+        std::lock_guard<std::mutex> lk(d.mu);
+        if (int32_t rc = use_device(d)) return rc;
+        std::vector<EventTriple> evs(n_arenas);
+        std::vector<uint8_t> tflag(n_arenas, 0);
+        std::vector<uint64_t> out_off(n_arenas + 1, 0);   // arena i's survivors start at out_survivors + out_off[i]
+        for (uint32_t i = 0; i < n_arenas; ++i)
+            out_off[i + 1] = out_off[i] + (uint64_t)B.n_queries * (((uint64_t)arenas[i]->n_blocks + 63) / 64);
+        const ArenaShard *prev = nullptr;
+        uint32_t prev_i = 0, prev_slot = 0, n_done = 0;
+        auto finish = [&](const ArenaShard &ps, uint32_t pi, uint32_t slot, bool any_order) -> int32_t {
+            if (int32_t rc = enqueue_eval(d, ps, bd, B, slot, tflag[pi] ? &evs[pi] : nullptr, any_order)) return rc;
+            if (tflag[pi]) { if (B.n_kinds > 0) d.pending.push_back(evs[pi]); else d.free_events.push_back(evs[pi]); }
+            if (out_survivors)
+                HIP_TRY(hipMemcpyAsync(out_survivors + out_off[pi], d.out[slot].p, (out_off[pi + 1] - out_off[pi]) * 8,
+                                       hipMemcpyDeviceToHost, d.stream));
+            return BSG_OK;
+        };
+        for (uint32_t i = 0; i < n_arenas; ++i) {
+            const ArenaShard &s = arenas[i]->shards[di];
+            if (s.n_blocks == 0) continue;
+            const uint32_t slot = n_done & 1;
+            tflag[i] = timed && (ctx->timed_stride <= 1 || (ctx->timed_counter++ % ctx->timed_stride) == 0);
+            if (tflag[i]) if (int32_t rc = take_events(ctx, d, evs[i])) return rc;
+            if (int32_t rc = enqueue_terms(d, s, bd, B, slot, tflag[i] ? &evs[i] : nullptr)) return rc;
+            if (prev) if (int32_t rc = finish(*prev, prev_i, prev_slot, true)) return rc;
+            prev = &s; prev_i = i; prev_slot = slot;
+            ++n_done;
+        }
+        if (prev) if (int32_t rc = finish(*prev, prev_i, prev_slot, false)) return rc;
+        if (out_survivors) HIP_TRY(hipStreamSynchronize(d.stream));
+    }
     return BSG_OK;
 }
+
+extern "C" {
 
 int32_t bsg_probe(bsg_ctx *ctx, uint64_t arena_id, const bsg_term *terms, uint32_t n_terms, const uint32_t *prog_ops,
                   const uint32_t *prog_off, uint32_t n_queries, uint64_t *out_survivors)

@@ -121,9 +121,20 @@ class Context:
         self._check(self.L.bsg_probe_batch(self.h, arena_id, batch_id, flags, _lib._ptr(out)))
         return out
 
-    def probe_many(self, arena_ids, batch_id: int, flags: int = 0):
+    def probe_many(self, arena_ids, batch_id: int, flags: int = 0, n_queries: int = 0, n_blocks=None):
+        """n_blocks (list, one per arena) given => synchronous, returns a list of survivor arrays."""
         ids = np.ascontiguousarray(arena_ids, dtype=np.uint64)
-        self._check(self.L.bsg_probe_many(self.h, _lib._ptr(ids), len(ids), batch_id, flags))
+        if n_blocks is None:
+            self._check(self.L.bsg_probe_many(self.h, _lib._ptr(ids), len(ids), batch_id, flags, None))
+            return None
+        sizes = [n_queries * ((nb + 63) // 64) for nb in n_blocks]
+        out = np.zeros(max(sum(sizes), 1), dtype=np.uint64)
+        self._check(self.L.bsg_probe_many(self.h, _lib._ptr(ids), len(ids), batch_id, flags, _lib._ptr(out)))
+        res, o = [], 0
+        for sz, nb in zip(sizes, n_blocks):
+            res.append(out[o: o + sz].reshape(n_queries, (nb + 63) // 64))
+            o += sz
+        return res
 
     def probe(self, arena_id: int, n_blocks: int, terms: np.ndarray, prog_ops, prog_off) -> np.ndarray:
         assert terms.dtype == TERM_DTYPE
@@ -139,6 +150,9 @@ class Context:
         t = Timing()
         self._check(self.L.bsg_timing_read(self.h, C.byref(t), 1 if reset else 0))
         return t
+
+    def set_timed_stride(self, stride: int):
+        self._check(self.L.bsg_set_timed_stride(self.h, stride))
 
     def last_kernel_ms(self):
         b, h = C.c_float(), C.c_float()

@@ -158,11 +158,14 @@ BSG_API int32_t bsg_batch_free(bsg_ctx *ctx, uint64_t batch_id);
 BSG_API int32_t bsg_probe_batch(bsg_ctx *ctx, uint64_t arena_id, uint64_t batch_id, uint32_t flags,
                                 uint64_t *out_survivors);
 
-/* Enqueue one probe of the same batch against each of n_arenas arenas (e.g. the candidate
- * files of one query stage) without returning to the caller in between; results stay on the
- * device.  Equivalent to n_arenas bsg_probe_batch(..., flags | BSG_PROBE_ASYNC, NULL) calls. */
+/* Probe the same batch against each of n_arenas arenas (e.g. the candidate files of one query
+ * stage) in one call.  Launches are software-pipelined: the program-evaluation kernel of arena i
+ * runs beside the bitset-streaming kernel of arena i+1.  out_survivors == NULL: enqueue only
+ * (results stay on the device; pair with bsg_sync).  Otherwise the call is synchronous and arena
+ * i's survivors ([n_queries][ceil(n_blocks_i / 64)] u64) are written back to back in arena order
+ * (single-device contexts). */
 BSG_API int32_t bsg_probe_many(bsg_ctx *ctx, const uint64_t *arena_ids, uint32_t n_arenas, uint64_t batch_id,
-                               uint32_t flags);
+                               uint32_t flags, uint64_t *out_survivors);
 
 /* One-shot convenience: batch_create + probe_batch + batch_free. */
 BSG_API int32_t bsg_probe(bsg_ctx *ctx, uint64_t arena_id, const bsg_term *terms, uint32_t n_terms,
@@ -170,6 +173,8 @@ BSG_API int32_t bsg_probe(bsg_ctx *ctx, uint64_t arena_id, const bsg_term *terms
                           uint64_t *out_survivors);
 
 BSG_API int32_t bsg_timing_read(bsg_ctx *ctx, bsg_timing *out, int32_t reset);
+/* With BSG_PROBE_TIMED, bsg_probe_many timestamps only every stride-th probe (default 1 = all). */
+BSG_API int32_t bsg_set_timed_stride(bsg_ctx *ctx, uint32_t stride);
 /* Device time (the dispatch's own start/stop timestamps) of the most recent k_build / k_hash_entries
  * launch made through bsg_build* / bsg_hash_entries on the context's first device. */
 BSG_API int32_t bsg_last_kernel_ms(bsg_ctx *ctx, float *build_ms, float *hash_ms);

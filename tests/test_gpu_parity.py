@@ -216,3 +216,33 @@ def test_or_reduce_fixed_geometry_equals_build_of_union(ctx):
     for t in universe:
         want.add(t)
     assert np.array_equal(got, want.words)
+
+
+def test_probe_many_pipelined_equals_individual_probes(ctx):
+    """bsg_probe_many software-pipelines K2(i) beside K1(i+1) on double-buffered scratch: results must be
+    those of one-at-a-time probes, for arenas of different shapes and odd/even counts."""
+    rng = np.random.default_rng(77)
+    arenas, wants, nbs = [], [], []
+    vocab = None
+    plans = []
+    for n_blocks in (70, 3, 129, 64, 200):
+        plan, blocks_str, vocab = H.make_random_arena(rng, n_blocks, absent_frac=0.02)
+        plans.append((plan, ctx.build(plan.blob, plan.off, plan.fstart, plan.desc, plan.n_words)))
+    cb = Q.compile_queries([None] + [H.random_expression(rng, vocab, None) for _ in range(600)])
+    ops, poff, _ = cb.arrays()
+    terms = H.gpu_terms(ctx, cb)
+    bid = ctx.batch_create(terms, ops, poff)
+    for plan, words in plans:
+        arenas.append(ctx.arena_load(words, plan.desc))
+        nbs.append(plan.n_blocks)
+        wants.append(O.probe_batch(words, plan.desc.view(O.DESC_DTYPE), terms.view(O.TERM_DTYPE), ops, poff))
+    for ids in ([0, 1, 2, 3, 4], [4, 4, 0], [2], [1, 3, 1, 3, 1, 3, 0]):
+        got = ctx.probe_many([arenas[i] for i in ids], bid, n_queries=cb.n_queries, n_blocks=[nbs[i] for i in ids])
+        for g, i in zip(got, ids):
+            assert np.array_equal(g, wants[i]), ids
+    # async form + a following synchronous probe still sees consistent scratch
+    ctx.probe_many([arenas[i] for i in (0, 1, 2, 3)], bid)
+    assert np.array_equal(ctx.probe_batch(arenas[4], bid, cb.n_queries, nbs[4]), wants[4])
+    for a in arenas:
+        ctx.arena_free(a)
+    ctx.batch_free(bid)
