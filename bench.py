@@ -128,7 +128,7 @@ def main():
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--scaled", type=int, default=16,
                     help="also time C2': the arena replicated this many times inside one launch (0/1 = skip)")
-    ap.add_argument("--timed-every", type=int, default=4,
+    ap.add_argument("--timed-every", type=int, default=8,
                     help="timestamp the kernels of every Nth step inside the timed region (0 = never)")
     args = ap.parse_args()
 

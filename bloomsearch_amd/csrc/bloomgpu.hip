@@ -76,7 +76,7 @@ struct DevBuf {
 
 // start/stop timestamps of the two dispatches themselves (hipExtLaunchKernel), i.e. the same
 // begin/end a rocprofv3 kernel trace reports — not events bracketing the launches.
-struct EventTriple { hipEvent_t k1s, k1e, k2s, k2e; uint64_t bytes; };
+struct EventTriple { hipEvent_t k1s, k1e, k2s, k2e; uint64_t bytes; bool has_k2; };
 
 struct Device {
     int id = 0;
@@ -186,7 +186,7 @@ int32_t drain_timing(bsg_ctx *ctx, Device &d)
     for (auto &t : d.pending) {
         float a = 0, b = 0;
         HIP_TRY(hipEventElapsedTime(&a, t.k1s, t.k1e));
-        HIP_TRY(hipEventElapsedTime(&b, t.k2s, t.k2e));
+        if (t.has_k2) HIP_TRY(hipEventElapsedTime(&b, t.k2s, t.k2e));   // fused launches carry K2 inside K1's dispatch
         std::lock_guard<std::mutex> lk(ctx->mu);
         ctx->timing.n_probes += 1;
         ctx->timing.ms_terms_kernel += a;
@@ -752,16 +752,17 @@ int32_t take_events(bsg_ctx *ctx, Device &d, EventTriple &ev)
         HIP_TRY(hipEventCreate(&ev.k2s)); HIP_TRY(hipEventCreate(&ev.k2e));
     }
     ev.bytes = 0;
+    ev.has_k2 = false;
     return BSG_OK;
 }
 
-// K1: stream every referenced bitset once, one verdict word per (block, 64 terms) into V[slot].
-int32_t enqueue_terms(Device &d, const ArenaShard &s, const BatchDev &bd, const Batch &B, uint32_t slot, EventTriple *ev)
+// K1 arguments: stream every referenced bitset once, one verdict word per (block, 64 terms) into V[slot].
+int32_t make_probe_args(Device &d, const ArenaShard &s, const BatchDev &bd, const Batch &B, uint32_t slot, EventTriple *ev,
+                        bsg::ProbeArgs &a, uint32_t &lds_bytes)
 {
     const uint32_t G = (s.n_blocks + 63) / 64;
     HIP_TRY(d.V[slot].reserve((size_t)G * std::max(B.Wt, 1u) * 64));
-    if (B.n_kinds == 0) return BSG_OK;
-    bsg::ProbeArgs a{};
+    a = bsg::ProbeArgs{};
     a.words = s.d_words; a.desc = s.d_desc; a.th = bd.d_th; a.V = d.V[slot].p;
     a.Tp = B.Tp; a.Wt = B.Wt; a.n_blocks = s.n_blocks;
     uint32_t max_tw = 0;
@@ -777,26 +778,62 @@ int32_t enqueue_terms(Device &d, const ArenaShard &s, const BatchDev &bd, const 
         if (ev) ev->bytes += s.sum_words[B.kind[y]] * 8;
     }
     lds_words = (lds_words + 1) / 2 * 2;
-    hipExtLaunchKernelGGL(bsg::k_probe_terms, dim3(s.n_blocks, B.n_kinds), dim3(bsg::kProbeThreads),
-                          (uint32_t)(head + lds_words * 8), d.stream, ev ? ev->k1s : nullptr, ev ? ev->k1e : nullptr, 0, a);
+    lds_bytes = (uint32_t)(head + lds_words * 8);
+    return BSG_OK;
+}
+
+int32_t make_eval_args(Device &d, const ArenaShard &s, const BatchDev &bd, const Batch &B, uint32_t slot, bsg::EvalArgs &a)
+{
+    const uint32_t G = (s.n_blocks + 63) / 64;
+    HIP_TRY(d.out[slot].reserve((size_t)B.n_queries * G));
+    a = bsg::EvalArgs{};
+    a.V = d.V[slot].p; a.prog = bd.d_prog; a.chunk_off = bd.d_chunk_off; a.chunk_len = bd.d_chunk_len;
+    a.out = d.out[slot].p; a.Wt = B.Wt; a.n_blocks = s.n_blocks; a.G = G; a.n_queries = B.n_queries;
+    a.cw_off = bd.d_cw_off; a.cw = bd.d_cw; a.max_cw = B.max_cw;
+    return BSG_OK;
+}
+
+int32_t enqueue_terms(Device &d, const ArenaShard &s, const BatchDev &bd, const Batch &B, uint32_t slot, EventTriple *ev)
+{
+    bsg::ProbeArgs a;
+    uint32_t lds = 0;
+    if (int32_t rc = make_probe_args(d, s, bd, B, slot, ev, a, lds)) return rc;
+    if (B.n_kinds == 0) return BSG_OK;
+    hipExtLaunchKernelGGL(bsg::k_probe_terms, dim3(s.n_blocks, B.n_kinds), dim3(bsg::kProbeThreads), lds, d.stream,
+                          ev ? ev->k1s : nullptr, ev ? ev->k1e : nullptr, 0, a);
     HIP_TRY(hipGetLastError());
     return BSG_OK;
 }
 
-// K2: programs over V[slot] -> out[slot].  any_order: the dispatch carries no barrier bit against the
-// packet before it (hipExtAnyOrderLaunch); bsg_probe_many uses it to let K2(i) start beside K1(i+1).
-int32_t enqueue_eval(Device &d, const ArenaShard &s, const BatchDev &bd, const Batch &B, uint32_t slot, EventTriple *ev,
-                     bool any_order)
+// K2: programs over V[slot] -> out[slot].
+int32_t enqueue_eval(Device &d, const ArenaShard &s, const BatchDev &bd, const Batch &B, uint32_t slot, EventTriple *ev)
 {
-    const uint32_t G = (s.n_blocks + 63) / 64;
-    HIP_TRY(d.out[slot].reserve((size_t)B.n_queries * G));
-    bsg::EvalArgs a{};
-    a.V = d.V[slot].p; a.prog = bd.d_prog; a.chunk_off = bd.d_chunk_off; a.chunk_len = bd.d_chunk_len;
-    a.out = d.out[slot].p; a.Wt = B.Wt; a.n_blocks = s.n_blocks; a.G = G; a.n_queries = B.n_queries;
-    a.cw_off = bd.d_cw_off; a.cw = bd.d_cw; a.max_cw = B.max_cw;
-    const size_t lds = ((size_t)B.max_cw * 64 + (size_t)B.max_depth * bsg::kEvalThreads) * 8;
-    hipExtLaunchKernelGGL(bsg::k_eval_programs, dim3(G, B.n_chunks), dim3(bsg::kEvalThreads), (uint32_t)lds, d.stream,
-                          ev ? ev->k2s : nullptr, ev ? ev->k2e : nullptr, any_order ? hipExtAnyOrderLaunch : 0, a);
+    bsg::EvalArgs a;
+    if (int32_t rc = make_eval_args(d, s, bd, B, slot, a)) return rc;
+    hipExtLaunchKernelGGL(bsg::k_eval_programs, dim3(a.G, B.n_chunks), dim3(bsg::kEvalThreads),
+                          bsg::eval_lds_bytes(B.max_cw, B.max_depth), d.stream, ev ? ev->k2s : nullptr,
+                          ev ? ev->k2e : nullptr, 0, a);
+    HIP_TRY(hipGetLastError());
+    if (ev) ev->has_k2 = true;
+    return BSG_OK;
+}
+
+// One launch: K1 of the current arena (slot) + K2 of the previous arena (pslot).  See k_probe_fused.
+int32_t enqueue_fused(Device &d, const ArenaShard &s, uint32_t slot, const ArenaShard &ps, uint32_t pslot, const BatchDev &bd,
+                      const Batch &B, EventTriple *ev)
+{
+    bsg::FusedArgs f{};
+    uint32_t lds = 0;
+    if (int32_t rc = make_probe_args(d, s, bd, B, slot, ev, f.p, lds)) return rc;
+    if (int32_t rc = make_eval_args(d, ps, bd, B, pslot, f.e)) return rc;
+    f.n_probe_x = s.n_blocks;
+    f.n_probe = s.n_blocks * B.n_kinds;
+    f.eval_pairs = (B.n_chunks + 1) / 2;
+    f.eval_lds_half = bsg::eval_lds_bytes(B.max_cw, B.max_depth);
+    lds = std::max(lds, 2 * f.eval_lds_half);
+    const uint32_t grid = f.n_probe + f.e.G * f.eval_pairs;
+    hipExtLaunchKernelGGL(bsg::k_probe_fused, dim3(grid), dim3(bsg::kProbeThreads), lds, d.stream, ev ? ev->k1s : nullptr,
+                          ev ? ev->k1e : nullptr, 0, f);
     HIP_TRY(hipGetLastError());
     return BSG_OK;
 }
@@ -839,7 +876,7 @@ extern "C" int32_t bsg_probe_batch(bsg_ctx *ctx, uint64_t arena_id, uint64_t bat
         EventTriple ev{};
         if (timed) if (int32_t rc = take_events(ctx, d, ev)) return rc;
         if (int32_t rc = enqueue_terms(d, s, bd, B, 0, timed ? &ev : nullptr)) return rc;
-        if (int32_t rc = enqueue_eval(d, s, bd, B, 0, timed ? &ev : nullptr, false)) return rc;
+        if (int32_t rc = enqueue_eval(d, s, bd, B, 0, timed ? &ev : nullptr)) return rc;
         if (timed) {
             if (B.n_kinds > 0) d.pending.push_back(ev); else d.free_events.push_back(ev);
         }
@@ -885,13 +922,13 @@ extern "C" int32_t bsg_probe_batch(bsg_ctx *ctx, uint64_t arena_id, uint64_t bat
     return BSG_OK;
 }
 
-// Software-pipelined enqueue on one in-order stream; per device the queue holds
-//   K1(0) | K1(1) K2(0)* | K1(2) K2(1)* | ... | K2(n-1)
-// where * dispatches carry no barrier bit (hipExtAnyOrderLaunch): K2(i) only needs K1(i), which the
-// in-order K1(i+1) ahead of it has already waited for, so the packet processor may start it beside
-// K1(i+1).  V/out are double-buffered by step parity; K1(i+2) is in-order, i.e. behind K2(i).
-// (A two-stream variant with cross-stream events was measured slower: each hipEventRecord /
-// hipStreamWaitEvent costs the host 3-4 us, more than the overlap buys at this kernel size.)
+// Software-pipelined enqueue on one in-order stream; per device the launches are
+//   K1(0) | F(1) = K1(1) + K2(0) | F(2) = K1(2) + K2(1) | ... | K2(n-1)
+// F = k_probe_fused: the program evaluation of arena i-1 rides in the tail of the grid that streams
+// arena i's bitsets, so a step costs one dispatch ramp instead of two.  V/out are double-buffered by
+// step parity (K1(i) writes slot i&1 while K2(i-1) reads slot (i-1)&1).
+// (Measured alternatives on MI355X: a second stream with cross-stream events is slower — every
+// hipEventRecord / hipStreamWaitEvent costs the host 3-4 us; hipExtAnyOrderLaunch on K2 gave no overlap.)
 extern "C" int32_t bsg_probe_many(bsg_ctx *ctx, const uint64_t *arena_ids, uint32_t n_arenas, uint64_t batch_id, uint32_t flags,
                                   uint64_t *out_survivors)
 {
@@ -905,6 +942,7 @@ extern "C" int32_t bsg_probe_many(bsg_ctx *ctx, const uint64_t *arena_ids, uint3
     for (uint32_t i = 0; i < n_arenas; ++i) if (int32_t rc = get_arena(ctx, arena_ids[i], arenas[i])) return rc;
     if (B.n_queries == 0 || n_arenas == 0) return BSG_OK;
     const bool timed = flags & BSG_PROBE_TIMED;
+    const bool fuse = B.n_kinds > 0 && 2 * bsg::eval_lds_bytes(B.max_cw, B.max_depth) <= 64 * 1024;
     for (uint32_t di = 0; di < ctx->devs.size(); ++di) {
         Device &d = *ctx->devs[di];
         const BatchDev &bd = B.dev[di];
@@ -917,8 +955,7 @@ extern "C" int32_t bsg_probe_many(bsg_ctx *ctx, const uint64_t *arena_ids, uint3
             out_off[i + 1] = out_off[i] + (uint64_t)B.n_queries * (((uint64_t)arenas[i]->n_blocks + 63) / 64);
         const ArenaShard *prev = nullptr;
         uint32_t prev_i = 0, prev_slot = 0, n_done = 0;
-        auto finish = [&](const ArenaShard &ps, uint32_t pi, uint32_t slot, bool any_order) -> int32_t {
-            if (int32_t rc = enqueue_eval(d, ps, bd, B, slot, tflag[pi] ? &evs[pi] : nullptr, any_order)) return rc;
+        auto after_eval = [&](uint32_t pi, uint32_t slot) -> int32_t {   // bookkeeping once K2(pi) is enqueued
             if (tflag[pi]) { if (B.n_kinds > 0) d.pending.push_back(evs[pi]); else d.free_events.push_back(evs[pi]); }
             if (out_survivors)
                 HIP_TRY(hipMemcpyAsync(out_survivors + out_off[pi], d.out[slot].p, (out_off[pi + 1] - out_off[pi]) * 8,
@@ -931,12 +968,28 @@ extern "C" int32_t bsg_probe_many(bsg_ctx *ctx, const uint64_t *arena_ids, uint3
             const uint32_t slot = n_done & 1;
             tflag[i] = timed && (ctx->timed_stride <= 1 || (ctx->timed_counter++ % ctx->timed_stride) == 0);
             if (tflag[i]) if (int32_t rc = take_events(ctx, d, evs[i])) return rc;
-            if (int32_t rc = enqueue_terms(d, s, bd, B, slot, tflag[i] ? &evs[i] : nullptr)) return rc;
-            if (prev) if (int32_t rc = finish(*prev, prev_i, prev_slot, true)) return rc;
+            EventTriple *ev = tflag[i] ? &evs[i] : nullptr;
+            // timestamped probes are never fused: each of their two kernels keeps its own dispatch, so its own
+            // start/stop timestamps (what bsg_timing_read and a rocprofv3 kernel trace report) stay observable
+            if (prev && fuse && !tflag[i] && !tflag[prev_i]) {
+                if (int32_t rc = enqueue_fused(d, s, slot, *prev, prev_slot, bd, B, ev)) return rc;
+                if (int32_t rc = after_eval(prev_i, prev_slot)) return rc;
+            } else {
+                if (prev) {
+                    if (int32_t rc = enqueue_eval(d, *prev, bd, B, prev_slot, tflag[prev_i] ? &evs[prev_i] : nullptr)) return rc;
+                    if (int32_t rc = after_eval(prev_i, prev_slot)) return rc;
+                }
+                // (Draining the queue before a timestamped probe was tried and rejected: after even a short idle gap
+                // the next streaming kernel measures 12-14 us instead of 8-9.5 us — the GPU leaves its busy state.)
+                if (int32_t rc = enqueue_terms(d, s, bd, B, slot, ev)) return rc;
+            }
             prev = &s; prev_i = i; prev_slot = slot;
             ++n_done;
         }
-        if (prev) if (int32_t rc = finish(*prev, prev_i, prev_slot, false)) return rc;
+        if (prev) {
+            if (int32_t rc = enqueue_eval(d, *prev, bd, B, prev_slot, tflag[prev_i] ? &evs[prev_i] : nullptr)) return rc;
+            if (int32_t rc = after_eval(prev_i, prev_slot)) return rc;
+        }
         if (out_survivors) HIP_TRY(hipStreamSynchronize(d.stream));
     }
     return BSG_OK;

@@ -470,11 +470,8 @@ __host__ __device__ inline uint32_t probe_lds_head_bytes(uint32_t n_tw)
     return (n_tw * 8u + n_tw * 128u + 15u) & ~15u;
 }
 
-__global__ __launch_bounds__(kProbeThreads) void k_probe_terms(const ProbeArgs a)
+__device__ __forceinline__ void probe_role(const ProbeArgs &a, uint32_t b, uint32_t y, uint64_t *lds64)
 {
-    extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
-    const uint32_t b = blockIdx.x;
-    const uint32_t y = blockIdx.y;
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & (kWave - 1);
     const uint32_t wave = tid / kWave;
@@ -514,6 +511,12 @@ __global__ __launch_bounds__(kProbeThreads) void k_probe_terms(const ProbeArgs a
     }
 }
 
+__global__ __launch_bounds__(kProbeThreads) void k_probe_terms(const ProbeArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
+    probe_role(a, blockIdx.x, blockIdx.y, lds64);
+}
+
 // ---------------------------------------------------------------------------
 // K2  eval_programs: workgroup = (group of 64 blocks, chunk of 256 queries).
 // Prologue: transpose the verdict words this chunk's programs reference (host-built
@@ -538,37 +541,43 @@ struct EvalArgs {
     uint32_t max_cw;             // max words of any chunk (LDS carve)
 };
 
-__global__ __launch_bounds__(kEvalThreads) void k_eval_programs(const EvalArgs a)
+// LDS bytes one 256-query half needs: transposed verdict words + per-lane stack
+__host__ __device__ inline uint32_t eval_lds_bytes(uint32_t max_cw, uint32_t max_depth)
 {
-    extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
-    const uint32_t g = blockIdx.x;
-    const uint32_t c = blockIdx.y;
-    const uint32_t tid = threadIdx.x;
-    const int lane = tid & (kWave - 1);
-    const uint32_t wave = tid / kWave;
+    return (max_cw * 64u + max_depth * (uint32_t)kEvalThreads) * 8u;
+}
+
+// Evaluates chunk c (256 queries) against block group g with the 256 threads htid = 0..255 of one
+// "half" (a whole k_eval_programs workgroup, or half of a fused workgroup).  `active` = false halves
+// only take part in the barrier.
+__device__ __forceinline__ void eval_role(const EvalArgs &a, uint32_t g, uint32_t c, uint32_t htid, uint64_t *lds, bool active)
+{
+    const int lane = htid & (kWave - 1);
+    const uint32_t wave = htid / kWave;
     constexpr uint32_t n_waves = kEvalThreads / kWave;
-
-    uint64_t *VT = lds64;
-    uint64_t *stk = lds64 + (uint64_t)a.max_cw * 64 + tid;  // per-lane stack, stride kEvalThreads
-
-    const uint32_t len = a.chunk_len[c];
-    const uint32_t *P = a.prog + a.chunk_off[c] + tid;
-    // the program words do not depend on the verdicts: fetch them while V is in flight
+    uint64_t *VT = lds;
+    uint64_t *stk = lds + (uint64_t)a.max_cw * 64 + htid;  // per-lane stack, stride kEvalThreads
     constexpr uint32_t kPre = 8;
     uint32_t pre[kPre];
+    uint32_t len = 0;
+    const uint32_t *P = a.prog;
+    if (active) {
+        len = a.chunk_len[c];
+        P = a.prog + a.chunk_off[c] + htid;
+        // the program words do not depend on the verdicts: fetch them while V is in flight
 #pragma unroll
-    for (uint32_t j = 0; j < kPre; ++j) pre[j] = j < len ? P[(uint64_t)j * kEvalThreads] : (7u << 28);
-
-    const bool row_valid = (g * 64 + (uint32_t)lane) < a.n_blocks;
-    const uint32_t cw0 = a.cw_off[c], ncw = a.cw_off[c + 1] - cw0;
-    for (uint32_t s = wave; s < ncw; s += n_waves) {
-        const uint32_t w = a.cw[cw0 + s];
-        uint64_t x = row_valid ? a.V[((uint64_t)g * a.Wt + w) * 64 + lane] : 0ULL;
-        VT[s * 64 + lane] = wave_transpose64(x, lane);
+        for (uint32_t j = 0; j < kPre; ++j) pre[j] = j < len ? P[(uint64_t)j * kEvalThreads] : (7u << 28);
+        const bool row_valid = (g * 64 + (uint32_t)lane) < a.n_blocks;
+        const uint32_t cw0 = a.cw_off[c], ncw = a.cw_off[c + 1] - cw0;
+        for (uint32_t s = wave; s < ncw; s += n_waves) {
+            const uint32_t w = a.cw[cw0 + s];
+            uint64_t x = row_valid ? a.V[((uint64_t)g * a.Wt + w) * 64 + lane] : 0ULL;
+            VT[s * 64 + lane] = wave_transpose64(x, lane);
+        }
     }
     __syncthreads();
-
-    const uint32_t q = c * kEvalThreads + tid;
+    if (!active) return;
+    const uint32_t q = c * kEvalThreads + htid;
     uint64_t top = ~0ULL;  // empty program == nil query == true
     uint32_t sp = 0;       // number of values on the stack (top kept in a register)
     auto step = [&](uint32_t op) {
@@ -590,6 +599,46 @@ __global__ __launch_bounds__(kEvalThreads) void k_eval_programs(const EvalArgs a
     const uint32_t nvalid = a.n_blocks - g * 64;
     const uint64_t valid = nvalid >= 64 ? ~0ULL : ((1ULL << nvalid) - 1);
     if (q < a.n_queries) a.out[(uint64_t)q * a.G + g] = top & valid;
+}
+
+__global__ __launch_bounds__(kEvalThreads) void k_eval_programs(const EvalArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
+    eval_role(a, blockIdx.x, blockIdx.y, threadIdx.x, lds64, true);
+}
+
+// ---------------------------------------------------------------------------
+// K1+K2 fused launch used by bsg_probe_many: workgroups [0, n_probe) stream arena i's bitsets
+// (probe role, exactly k_probe_terms), workgroups [n_probe, n_probe + n_eval) evaluate the programs
+// of arena i-1 from the verdicts the previous launch left in the other scratch slot (eval role: two
+// 256-query chunks per 512-thread workgroup).  The eval workgroups sit at the FRONT of the grid: their
+// ~4 us chain of dependent latencies (program words, verdict words, transposes, LDS stack) runs while the
+// probe workgroups keep HBM saturated, instead of costing a second kernel between two streaming kernels.
+// ---------------------------------------------------------------------------
+struct FusedArgs {
+    ProbeArgs p;
+    EvalArgs e;
+    uint32_t n_probe_x;      // probe role: blocks of arena i (grid x of k_probe_terms)
+    uint32_t n_probe;        // = n_probe_x * number of referenced kinds
+    uint32_t eval_pairs;     // ceil(n_chunks / 2) of the eval role
+    uint32_t eval_lds_half;  // bytes of LDS per 256-query half
+};
+
+__global__ __launch_bounds__(kProbeThreads) void k_probe_fused(const FusedArgs f)
+{
+    extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
+    const uint32_t id = blockIdx.x;
+    const uint32_t n_eval = f.e.G * f.eval_pairs;
+    if (id >= n_eval) {
+        const uint32_t j = id - n_eval;
+        probe_role(f.p, j % f.n_probe_x, j / f.n_probe_x, lds64);
+    } else {
+        const uint32_t g = id / f.eval_pairs, pair = id - g * f.eval_pairs;
+        const uint32_t half = threadIdx.x >> 8, htid = threadIdx.x & 255u;
+        const uint32_t c = pair * 2 + half;
+        const uint32_t n_chunks = (f.e.n_queries + kEvalThreads - 1) / kEvalThreads;
+        eval_role(f.e, g, c, htid, lds64 + (uint64_t)half * (f.eval_lds_half / 8), c < n_chunks);
+    }
 }
 
 // ---------------------------------------------------------------------------

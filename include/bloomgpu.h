@@ -159,8 +159,9 @@ BSG_API int32_t bsg_probe_batch(bsg_ctx *ctx, uint64_t arena_id, uint64_t batch_
                                 uint64_t *out_survivors);
 
 /* Probe the same batch against each of n_arenas arenas (e.g. the candidate files of one query
- * stage) in one call.  Launches are software-pipelined: the program-evaluation kernel of arena i
- * runs beside the bitset-streaming kernel of arena i+1.  out_survivors == NULL: enqueue only
+ * stage) in one call.  Launches are software-pipelined: the program evaluation of arena i rides inside
+ * the launch that streams arena i+1's bitsets (k_probe_fused); probes selected for timestamping
+ * (BSG_PROBE_TIMED, bsg_set_timed_stride) run as two separate launches instead.  out_survivors == NULL: enqueue only
  * (results stay on the device; pair with bsg_sync).  Otherwise the call is synchronous and arena
  * i's survivors ([n_queries][ceil(n_blocks_i / 64)] u64) are written back to back in arena order
  * (single-device contexts). */
