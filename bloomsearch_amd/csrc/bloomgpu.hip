@@ -45,7 +45,8 @@ int32_t fail(int32_t code, const char *fmt, ...)
                         __FILE__, __LINE__);                                               \
     } while (0)
 
-constexpr uint32_t kLdsCapWords = 8192;       // 64 KiB staged-filter cap (dynamic LDS without opt-in)
+constexpr uint32_t kLdsBudget = 144 * 1024;   // dynamic LDS a workgroup may request (of 160 KiB per CU; opt-in above 64 KiB)
+constexpr uint32_t kLdsCapWords = kLdsBudget / 8;  // staged-filter cap before the per-launch head is taken off
 constexpr uint64_t kAlignWords = 16;          // filters start on 128-byte boundaries in HBM
 constexpr uint32_t kBuildSliceEntries = 8192; // entries per workgroup for non-staged builds
 
@@ -332,6 +333,10 @@ int32_t bsg_open(const int32_t *device_ids, int32_t n_devices, bsg_ctx **out_ctx
         d->id = device_ids[i];
         HIP_TRY(hipSetDevice(d->id));
         HIP_TRY(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
+        // more than 64 KiB of dynamic LDS per workgroup is opt-in per kernel
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(bsg::k_probe_terms), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(bsg::k_probe_fused), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(bsg::k_build), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
 
         ctx->devs.push_back(std::move(d));
     }
@@ -768,8 +773,8 @@ int32_t make_probe_args(Device &d, const ArenaShard &s, const BatchDev &bd, cons
     uint32_t max_tw = 0;
     for (uint32_t y = 0; y < B.n_kinds; ++y) max_tw = std::max(max_tw, (B.term_count[y] + 63) / 64);
     const size_t head = bsg::probe_lds_head_bytes(max_tw);
-    // staged-filter cap for this launch: what is left of 64 KiB of dynamic LDS after the head
-    const uint64_t cap_words = head + 32 < 65536 ? (65536 - head) / 16 * 2 : 0;
+    // staged-filter cap for this launch: what is left of the LDS budget after the head
+    const uint64_t cap_words = head + 32 < kLdsBudget ? (kLdsBudget - head) / 16 * 2 : 0;
     a.lds_cap_words = (uint32_t)std::min<uint64_t>(kLdsCapWords, cap_words);
     uint64_t lds_words = 2;
     for (uint32_t y = 0; y < B.n_kinds; ++y) {

@@ -38,18 +38,20 @@ def test_build_bit_exact_small_medium_large_empty_absent(ctx):
         entry_sets_from_strings(["a", "b.c"], ["x%d" % i for i in range(300)], []),                # empty FT set => n=1, no bits
         entry_sets_from_strings(["f%d" % i for i in range(9)], ["t%d" % i for i in range(20000)],   # ~35 KB (LDS staged)
                                 ["f::t%d" % i for i in range(20000)]),
-        entry_sets_from_strings(["only"], ["big%d" % i for i in range(60000)], ["k::v"]),            # > 64 KiB => global-atomic path
+        entry_sets_from_strings(["only"], ["big%d" % i for i in range(60000)], ["k::v"]),            # 105 KiB: still LDS-staged (opt-in LDS)
+        entry_sets_from_strings(["only"], ["huge%d" % i for i in range(160000)], ["k::v"]),          # > 144 KiB budget at both fprs => global-atomic path
         entry_sets_from_strings([], [], []),
     ]
     for fpr in (0.001, 0.01):
-        plan = plan_blocks(blocks, fpr, absent={(3, 1)})
+        plan = plan_blocks(blocks, fpr, absent={(4, 1)})
         got = ctx.build(plan.blob, plan.off, plan.fstart, plan.desc, plan.n_words)
         want = H.oracle_words(plan)
         assert np.array_equal(got, want)
         # sizing rule: exact distinct counts (TestMeasuredFilterSizing, file_format_test.go:28-94)
         assert plan.desc["m"][1 * 3 + 1] == O.estimate_parameters(20000, fpr)[0]
         assert plan.desc["m"][0 * 3 + 2] == O.estimate_parameters(1, fpr)[0]
-        assert plan.desc["m"][3 * 3 + 1] == 0
+        assert plan.desc["m"][4 * 3 + 1] == 0
+        assert (int(plan.desc["m"][3 * 3 + 1]) + 63) // 64 * 8 > 144 * 1024
 
 
 def test_build_hashed_equals_build(ctx):
@@ -126,11 +128,11 @@ def test_probe_nil_filters_fail_open_and_constants(ctx):
 
 
 def test_probe_oversize_filter_takes_gather_path(ctx):
-    big = ["big%d" % i for i in range(70000)]
+    big = ["big%d" % i for i in range(110000)]
     blocks = [entry_sets_from_strings(["f"], big, ["f::" + t for t in big[:100]]),
               entry_sets_from_strings(["f"], ["small"], ["f::small"])]
     plan = plan_blocks(blocks, 0.001)
-    assert (int(plan.desc["m"][1]) + 63) // 64 > 8192
+    assert (int(plan.desc["m"][1]) + 63) // 64 * 8 > 144 * 1024
     words = ctx.build(plan.blob, plan.off, plan.fstart, plan.desc, plan.n_words)
     assert np.array_equal(words, H.oracle_words(plan))
     exprs = [Q.Token(t) for t in big[:200]] + [Q.Token("nope%d" % i) for i in range(200)] + [Q.Token("small")]
@@ -246,3 +248,42 @@ def test_probe_many_pipelined_equals_individual_probes(ctx):
     for a in arenas:
         ctx.arena_free(a)
     ctx.batch_free(bid)
+
+
+def test_large_block_filter_is_lds_staged_and_bit_exact(ctx):
+    """A 10 MiB-row-group-sized block (70k distinct tokens => 123 KiB bitset) fits the opt-in LDS budget."""
+    toks = ["tok%d" % i for i in range(70000)]
+    plan = plan_blocks([entry_sets_from_strings(["f"], toks, ["f::x"]) for _ in range(3)], 0.001)
+    nbytes = (int(plan.desc["m"][1]) + 63) // 64 * 8
+    assert 64 * 1024 < nbytes < 144 * 1024
+    words = ctx.build(plan.blob, plan.off, plan.fstart, plan.desc, plan.n_words)
+    assert np.array_equal(words, H.oracle_words(plan))
+    exprs = [Q.Token(t) for t in toks[:300]] + [Q.Token("nope%d" % i) for i in range(300)]
+    cb = Q.compile_queries(exprs)
+    ops, poff, _ = cb.arrays()
+    terms = H.gpu_terms(ctx, cb)
+    aid = ctx.arena_load(words, plan.desc)
+    got = ctx.probe(aid, 3, terms, ops, poff)
+    ctx.arena_free(aid)
+    assert np.array_equal(got, O.probe_batch(words, plan.desc.view(O.DESC_DTYPE), terms.view(O.TERM_DTYPE), ops, poff))
+
+
+def test_multi_device_context_shards_round_robin_and_gathers():
+    """A context over several devices shards blocks b -> device b % n and gathers survivor bitsets on the host.
+    The GPU box has one GPU, so the same device is listed twice/thrice: the sharding, per-shard launches and the
+    host-side interleave are exactly the N-GPU code path."""
+    from bloomsearch_amd.gpu import Context
+    rng = np.random.default_rng(55)
+    for devs, n_blocks in (((0, 0), 131), ((0, 0, 0), 64), ((0, 0), 1)):
+        plan, blocks_str, vocab = H.make_random_arena(rng, n_blocks, absent_frac=0.03)
+        with Context(devs) as mctx:
+            words = mctx.build(plan.blob, plan.off, plan.fstart, plan.desc, plan.n_words)
+            cb = Q.compile_queries([None] + [H.random_expression(rng, vocab, None) for _ in range(300)])
+            ops, poff, _ = cb.arrays()
+            terms = H.gpu_terms(mctx, cb)
+            aid = mctx.arena_load(words, plan.desc)
+            got = mctx.probe(aid, n_blocks, terms, ops, poff)
+            want = O.probe_batch(words, plan.desc.view(O.DESC_DTYPE), terms.view(O.TERM_DTYPE), ops, poff)
+            assert np.array_equal(got, want)
+            # fixed-geometry OR-reduce across the shards of a multi-device context
+            mctx.arena_free(aid)
