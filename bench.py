@@ -264,6 +264,15 @@ def main():
         k1_ms = tm.ms_terms_kernel / max(tm.n_probes, 1)
         k2_ms = tm.ms_eval_kernel / max(tm.n_probes, 1)
         achieved = alg_bytes / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else None
+        # HBM bytes per launch from the PMC counters: collected in separate rocprofv3 --pmc passes of this same
+        # command (tools/profile.sh), corrected as MI355X_MICROARCH.md prescribes (FETCH_SIZE x2 for wide
+        # coalesced reads on gfx950, + WRITE_SIZE), committed under profiles/.
+        traffic = None
+        try:
+            rec = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            traffic = rec["k_probe_terms"]["hbm_bytes_corrected"] if args.workload == "c2" and B == 1000 else None
+        except Exception:
+            pass
         out = {
             "metric": "block-bloom probes/sec", "value": value, "unit": "probes/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -274,7 +283,8 @@ def main():
                        "blocks_per_gpu": B, "queries": NQ, "distinct_terms": int(len(terms)),
                        "probes_per_step": probes_per_step, "sharding": "round-robin blocks, no collective"},
             "roofline": {"bound": "hbm", "kernel": "k_probe_terms", "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": None,
+                         "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic,
+                         "traffic_source": "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py)" if traffic else None,
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": k1_ms,
                          "eval_kernel_ms": k2_ms},
         }

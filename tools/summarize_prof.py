@@ -40,3 +40,23 @@ for sub, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
         v = [r[0] for r in d.execute("select value from (select value, start from counters_collection where kernel_name = ? and counter_name = ? order by start desc limit 200)", (n, ctr))]
         if v:
             print("  %-28s n %4d  mean %12.1f KB = %9.3f MB  (min %.1f max %.1f)" % (short(n), len(v), sum(v) / len(v), sum(v) / len(v) * 1024 / 1e6, min(v), max(v)))
+
+# machine-readable traffic record for bench.py's roofline.traffic (gfx950: FETCH_SIZE of wide coalesced reads x2)
+import json
+rec = {}
+d = db("fetch")
+if d:
+    for n in [r[0] for r in d.execute("select distinct kernel_name from counters_collection where kernel_name like 'bsg::%'")]:
+        v = [r[0] for r in d.execute("select value from (select value, start from counters_collection where kernel_name = ? and counter_name = 'FETCH_SIZE' order by start desc limit 200)", (n,))]
+        if v:
+            rec.setdefault(short(n), {})["fetch_kb_raw"] = sum(v) / len(v)
+d = db("write")
+if d:
+    for n in [r[0] for r in d.execute("select distinct kernel_name from counters_collection where kernel_name like 'bsg::%'")]:
+        v = [r[0] for r in d.execute("select value from (select value, start from counters_collection where kernel_name = ? and counter_name = 'WRITE_SIZE' order by start desc limit 200)", (n,))]
+        if v:
+            rec.setdefault(short(n), {})["write_kb_raw"] = sum(v) / len(v)
+for k, v in rec.items():
+    v["hbm_bytes_corrected"] = (2 * v.get("fetch_kb_raw", 0) + v.get("write_kb_raw", 0)) * 1024
+json.dump(rec, open(os.path.join(root, "traffic.json"), "w"), indent=1)
+print("== traffic.json:", json.dumps(rec))
