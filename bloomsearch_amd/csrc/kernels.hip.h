@@ -314,12 +314,16 @@ __device__ __forceinline__ void par_task_finish(const ParTask &p, BITS32 bits, l
 // Mode C (many terms).  Each wave owns a contiguous range of term words and runs
 //   round 0 : location 0 of every term (8 B/term, coalesced), survivors compacted into the wave's
 //             private LDS queue (ballot + mbcnt; no atomics, no barriers);
-//   round 1 : location 1 of the survivors (gathered hashes), compacted in place;
-//   tail    : the remaining ~1/4 of the terms keep all four hashes in registers and run locations
-//             2..k-1 with a wave-level early-out (no further table loads).
+//   rounds 1..kCompactRounds : one location per round for the survivors (two gathered hash rows),
+//             compacted in place;
+//   tail    : what is left keeps all four hashes in registers and runs the remaining locations with a
+//             wave-level early-out (no further table loads).
 // Loads are issued kGroup chunks at a time so a wave pays one L2 round trip per stage, not per
 // 64-term chunk.  Absent terms die geometrically: ~2 probes per absent term.
 constexpr uint32_t kGroup = 4;
+constexpr uint32_t kCompactRounds = 1;   // locations 1..kCompactRounds run as compaction rounds, the rest from registers
+// (measured on MI355X: 1 and 3 rounds tie at ~4k terms — the extra gathers cost what the saved VALU buys — and 1 is
+// faster at 256-1024 terms; the many-term mode is bound by L2 gather latency, VALU is ~40% busy)
 
 template <bool M32, typename BITS32>
 __device__ __forceinline__ void probe_rounds(const ProbeArgs &a, const DevDesc &d, BITS32 bits, uint32_t t0,
@@ -363,49 +367,52 @@ __device__ __forceinline__ void probe_rounds(const ProbeArgs &a, const DevDesc &
             }
         }
     }
-    if (d.k == 1) goto publish;
-    // ---- round 1 (location 1 = h1 + h3) ----
+    // ---- rounds 1..kCompactRounds: one location per round, survivors compacted in place ----
     {
-        const uint64_t *r1 = th + (uint64_t)a.Tp, *r3 = th + 3ull * a.Tp;
-        uint32_t out = 0;
-        for (uint32_t j = 0; j < qn; j += 64 * kGroup) {
-            uint32_t li[kGroup];
-            uint64_t x[kGroup];
+        uint32_t i = 1;
+        for (; i < d.k && i <= kCompactRounds && qn != 0; ++i) {
+            const uint64_t *ra = th + (uint64_t)ha_row(i) * a.Tp, *rb = th + (uint64_t)hb_row(i) * a.Tp;
+            uint32_t out = 0;
+            for (uint32_t j = 0; j < qn; j += 64 * kGroup) {
+                uint32_t li[kGroup];
+                uint64_t x[kGroup];
 #pragma unroll
-            for (uint32_t u = 0; u < kGroup; ++u) li[u] = (j + u * 64 + lane < qn) ? (uint32_t)q[j + u * 64 + lane] : 0u;
+                for (uint32_t u = 0; u < kGroup; ++u) li[u] = (j + u * 64 + lane < qn) ? (uint32_t)q[j + u * 64 + lane] : 0u;
 #pragma unroll
-            for (uint32_t u = 0; u < kGroup; ++u) x[u] = (j + u * 64 < qn) ? r1[li[u]] + r3[li[u]] : 0;
+                for (uint32_t u = 0; u < kGroup; ++u) x[u] = (j + u * 64 < qn) ? ra[li[u]] + (uint64_t)i * rb[li[u]] : 0;
 #pragma unroll
-            for (uint32_t u = 0; u < kGroup; ++u) {
-                if (j + u * 64 < qn) {   // wave-uniform
-                    const bool valid = j + u * 64 + lane < qn;
-                    compact(valid && test_bit(bits, locate<M32>(d, x[u])), li[u], out);   // out <= j: in place is safe
+                for (uint32_t u = 0; u < kGroup; ++u) {
+                    if (j + u * 64 < qn) {   // wave-uniform
+                        const bool valid = j + u * 64 + lane < qn;
+                        compact(valid && test_bit(bits, locate<M32>(d, x[u])), li[u], out);   // out <= j: in place is safe
+                    }
                 }
             }
+            qn = out;
         }
-        qn = out;
-    }
-    // ---- tail: locations 2..k-1 from registers ----
-    if (d.k > 2) {
-        const uint64_t *r1 = th + (uint64_t)a.Tp, *r2 = th + 2ull * a.Tp, *r3 = th + 3ull * a.Tp;
-        for (uint32_t j = 0; j < qn; j += 128) {
-            const bool two = j + 64 < qn;
-            bool aliveA = j + lane < qn, aliveB = two && (j + 64 + lane < qn);
-            const uint32_t liA = aliveA ? (uint32_t)q[j + lane] : 0u, liB = aliveB ? (uint32_t)q[j + 64 + lane] : 0u;
-            const uint64_t a0 = th[liA], a1 = r1[liA], a2 = r2[liA], a3 = r3[liA];
-            uint64_t b0 = 0, b1 = 0, b2 = 0, b3 = 0;
-            if (two) { b0 = th[liB]; b1 = r1[liB]; b2 = r2[liB]; b3 = r3[liB]; }
-            for (uint32_t i = 2; i < d.k; ++i) {
-                if ((__ballot(aliveA) | __ballot(aliveB)) == 0) break;
-                if (aliveA) aliveA = test_bit(bits, locate<M32>(d, location(a0, a1, a2, a3, i)));
-                if (aliveB) aliveB = test_bit(bits, locate<M32>(d, location(b0, b1, b2, b3, i)));
+        // ---- tail: remaining locations from registers, two chunks interleaved, wave-level early-out ----
+        if (i < d.k && qn != 0) {
+            const uint64_t *r1 = th + (uint64_t)a.Tp, *r2 = th + 2ull * a.Tp, *r3 = th + 3ull * a.Tp;
+            const uint32_t i0 = i;
+            for (uint32_t j = 0; j < qn; j += 128) {
+                const bool two = j + 64 < qn;
+                bool aliveA = j + lane < qn, aliveB = two && (j + 64 + lane < qn);
+                const uint32_t liA = aliveA ? (uint32_t)q[j + lane] : 0u, liB = aliveB ? (uint32_t)q[j + 64 + lane] : 0u;
+                const uint64_t a0 = th[liA], a1 = r1[liA], a2 = r2[liA], a3 = r3[liA];
+                uint64_t b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+                if (two) { b0 = th[liB]; b1 = r1[liB]; b2 = r2[liB]; b3 = r3[liB]; }
+                for (uint32_t ii = i0; ii < d.k; ++ii) {
+                    if ((__ballot(aliveA) | __ballot(aliveB)) == 0) break;
+                    if (aliveA) aliveA = test_bit(bits, locate<M32>(d, location(a0, a1, a2, a3, ii)));
+                    if (aliveB) aliveB = test_bit(bits, locate<M32>(d, location(b0, b1, b2, b3, ii)));
+                }
+                if (aliveA) __hip_atomic_fetch_or(&vbits[(base + liA) >> 5], 1u << ((base + liA) & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (aliveB) __hip_atomic_fetch_or(&vbits[(base + liB) >> 5], 1u << ((base + liB) & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
-            if (aliveA) __hip_atomic_fetch_or(&vbits[(base + liA) >> 5], 1u << ((base + liA) & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (aliveB) __hip_atomic_fetch_or(&vbits[(base + liB) >> 5], 1u << ((base + liB) & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            return;
         }
-        return;
     }
-publish:
+    // every location passed during the compaction rounds (k <= kCompactRounds + 1): the queue holds the accepted terms
     for (uint32_t j = lane; j < qn; j += 64) {
         const uint32_t idx = base + q[j];
         __hip_atomic_fetch_or(&vbits[idx >> 5], 1u << (idx & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
