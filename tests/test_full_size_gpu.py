@@ -1,0 +1,112 @@
+"""BASELINE configs[1] at FULL size on the GPU (10 M rows / 1 000 blocks, Q = 4 096 three-term AND queries),
+checked through size-independent properties plus an oracle check on a bounded sample:
+  * bitsets: oracle rebuild of a sample of blocks is bit-identical; the XOR checksum over ALL words is stable
+    across two independent GPU builds (build is a pure function of the entry sets);
+  * no false negatives: a query whose three terms are all really present in block b survives in b;
+  * monotonicity: survivors(And(a,b,c)) == survivors(a) & survivors(b) & survivors(c), Or likewise (bitwise);
+  * idempotence: probing the same batch twice (and through the pipelined bsg_probe_many) gives identical bits;
+  * a sample of queries is compared bit-for-bit with the oracle over all 1 000 blocks.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from bloomsearch_amd import query as Q, synth
+from bloomsearch_amd._lib import TERM_DTYPE
+from bloomsearch_amd.arena import plan_blocks
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+B, ROWS, NQ = 1000, 10000, 4096
+
+
+def _gen(b):
+    return synth.block_entry_sets(b * ROWS, ROWS)
+
+
+@pytest.fixture(scope="module")
+def c2(ctx):
+    import multiprocessing as mp
+    with mp.get_context("fork").Pool(min(32, os.cpu_count() or 1)) as pool:
+        blocks = pool.map(_gen, range(B), chunksize=8)
+    plan = plan_blocks(blocks, 0.001)
+    words = ctx.build(plan.blob, plan.off, plan.fstart, plan.desc, plan.n_words)
+    return plan, words
+
+
+def test_full_size_bitsets(ctx, c2):
+    plan, words = c2
+    again = ctx.build(plan.blob, plan.off, plan.fstart, plan.desc, plan.n_words)
+    assert np.bitwise_xor.reduce(words) == np.bitwise_xor.reduce(again) and np.array_equal(words, again)
+    # sizing: exact distinct counts => EstimateParameters(count, 0.001) for every filter
+    for b in (0, 499, 999):
+        for c in range(3):
+            assert (int(plan.desc["m"][b * 3 + c]), int(plan.desc["k"][b * 3 + c])) == O.estimate_parameters(max(int(plan.counts[b, c]), 1), 0.001)
+    # oracle rebuild of a bounded sample of filters, bit for bit
+    for f in (0, 1, 2, 3 * 500 + 1, 3 * 999 + 2):
+        d = plan.desc[f]
+        e0, e1 = int(plan.fstart[f]), int(plan.fstart[f + 1])
+        filt = O.Filter(int(d["m"]), int(d["k"]))
+        raw = plan.blob.tobytes()
+        for e in range(e0, e1):
+            filt.add(raw[int(plan.off[e]): int(plan.off[e + 1])])
+        nw = O.words_for(int(d["m"]))
+        assert np.array_equal(filt.words, words[int(d["word_off"]): int(d["word_off"]) + nw])
+
+
+def test_full_size_probe_properties(ctx, c2):
+    plan, words = c2
+    rng = np.random.default_rng(2)
+    d = synth.draws(0, B * ROWS)
+    # queries built from real rows: row r of block b has (level, service, region) => the AND must survive in block b
+    rows = rng.integers(0, B * ROWS, size=NQ // 2)
+    exprs, must = [], []
+    for r in rows:
+        lv, sv, rg = synth.LEVELS[d["level"][r]], synth.SERVICES[d["service"][r]], "region-%d" % d["region"][r]
+        uid = str(int(d["user_id"][r]))
+        exprs.append(Q.And(Q.FieldToken("level", lv), Q.FieldToken("service", sv), Q.FieldToken("user_id", uid)))
+        must.append(int(r) // ROWS)
+    for _ in range(NQ - len(exprs)):
+        exprs.append(Q.And(Q.FieldToken("level", synth.LEVELS[rng.integers(0, 4)]), Q.FieldToken("service", "absent-%d" % rng.integers(0, 9)),
+                           Q.FieldToken("nested.region", "region-%d" % rng.integers(0, 12))))
+    cb = Q.compile_queries(exprs)
+    ops, poff, kinds = cb.arrays()
+    terms = np.zeros(len(cb.term_strings), dtype=TERM_DTYPE)
+    terms["h"] = ctx.hash_strings(cb.term_strings)
+    terms["kind"] = kinds
+    aid = ctx.arena_load(words, plan.desc)
+    bid = ctx.batch_create(terms, ops, poff)
+    got = ctx.probe_batch(aid, bid, NQ, B)
+    # no false negatives
+    for q, b in enumerate(must):
+        assert (int(got[q, b >> 6]) >> (b & 63)) & 1, (q, b)
+    # idempotence, also through the fused/pipelined path
+    assert np.array_equal(got, ctx.probe_batch(aid, bid, NQ, B))
+    many = ctx.probe_many([aid, aid, aid], bid, n_queries=NQ, n_blocks=[B, B, B])
+    assert all(np.array_equal(m, got) for m in many)
+    # monotonicity: And == bitwise AND of its single-term probes
+    singles = Q.compile_queries([Q.FieldToken("level", "error"), Q.FieldToken("service", "payment"), Q.FieldToken("user_id", "4242"),
+                                 Q.And(Q.FieldToken("level", "error"), Q.FieldToken("service", "payment"), Q.FieldToken("user_id", "4242")),
+                                 Q.Or(Q.FieldToken("level", "error"), Q.FieldToken("service", "payment"), Q.FieldToken("user_id", "4242"))])
+    sops, spoff, skinds = singles.arrays()
+    sterms = np.zeros(len(singles.term_strings), dtype=TERM_DTYPE)
+    sterms["h"] = ctx.hash_strings(singles.term_strings)
+    sterms["kind"] = skinds
+    s = ctx.probe(aid, B, sterms, sops, spoff)
+    assert np.array_equal(s[3], s[0] & s[1] & s[2]) and np.array_equal(s[4], s[0] | s[1] | s[2])
+    # bounded oracle sample: 48 queries over all 1 000 blocks, bit for bit
+    idx = np.concatenate([np.arange(24), np.arange(NQ - 24, NQ)])
+    sub = Q.compile_queries([exprs[i] for i in idx])
+    o2, p2, k2 = sub.arrays()
+    t2 = np.zeros(len(sub.term_strings), dtype=O.TERM_DTYPE)
+    for i, sname in enumerate(sub.term_strings):
+        t2["h"][i] = O.base_hashes(sname)
+        t2["kind"][i] = k2[i]
+    want = O.probe_batch(words, plan.desc.view(O.DESC_DTYPE), t2, o2, p2)
+    assert np.array_equal(got[idx], want)
+    # the last block group is partial (1000 = 15 * 64 + 40): no bits beyond block 999
+    assert not (got[:, -1] >> np.uint64(40)).any()
+    ctx.batch_free(bid)
+    ctx.arena_free(aid)
