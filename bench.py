@@ -126,7 +126,7 @@ def main():
     ap.add_argument("--fpr", type=float, default=0.001)
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU baseline work (0 = skip)")
     ap.add_argument("--no-check", action="store_true")
-    ap.add_argument("--scaled", type=int, default=16,
+    ap.add_argument("--scaled", type=int, default=64,
                     help="also time C2': the arena replicated this many times inside one launch (0/1 = skip)")
     ap.add_argument("--timed-every", type=int, default=8,
                     help="timestamp the kernels of every Nth step inside the timed region (0 = never)")

@@ -798,6 +798,10 @@ int32_t make_eval_args(Device &d, const ArenaShard &s, const BatchDev &bd, const
     return BSG_OK;
 }
 
+// Small arenas keep one block group per eval workgroup (latency); large ones tile kEvalGroupTile groups so a
+// query's survivor words leave as one 32-byte store instead of four strided 8-byte stores.
+uint32_t eval_tile_for(uint32_t G) { return G >= 64 ? bsg::kEvalGroupTile : 1u; }
+
 int32_t enqueue_terms(Device &d, const ArenaShard &s, const BatchDev &bd, const Batch &B, uint32_t slot, EventTriple *ev)
 {
     bsg::ProbeArgs a;
@@ -815,9 +819,10 @@ int32_t enqueue_eval(Device &d, const ArenaShard &s, const BatchDev &bd, const B
 {
     bsg::EvalArgs a;
     if (int32_t rc = make_eval_args(d, s, bd, B, slot, a)) return rc;
-    hipExtLaunchKernelGGL(bsg::k_eval_programs, dim3(a.G, B.n_chunks), dim3(bsg::kEvalThreads),
+    const uint32_t tile = eval_tile_for(a.G);
+    hipExtLaunchKernelGGL(bsg::k_eval_programs, dim3((a.G + tile - 1) / tile, B.n_chunks), dim3(bsg::kEvalThreads),
                           bsg::eval_lds_bytes(B.max_cw, B.max_depth), d.stream, ev ? ev->k2s : nullptr,
-                          ev ? ev->k2e : nullptr, 0, a);
+                          ev ? ev->k2e : nullptr, 0, a, tile);
     HIP_TRY(hipGetLastError());
     if (ev) ev->has_k2 = true;
     return BSG_OK;
@@ -836,7 +841,8 @@ int32_t enqueue_fused(Device &d, const ArenaShard &s, uint32_t slot, const Arena
     f.eval_pairs = (B.n_chunks + 1) / 2;
     f.eval_lds_half = bsg::eval_lds_bytes(B.max_cw, B.max_depth);
     lds = std::max(lds, 2 * f.eval_lds_half);
-    const uint32_t grid = f.n_probe + f.e.G * f.eval_pairs;
+    f.eval_tile = eval_tile_for(f.e.G);
+    const uint32_t grid = f.n_probe + (f.e.G + f.eval_tile - 1) / f.eval_tile * f.eval_pairs;
     hipExtLaunchKernelGGL(bsg::k_probe_fused, dim3(grid), dim3(bsg::kProbeThreads), lds, d.stream, ev ? ev->k1s : nullptr,
                           ev ? ev->k1e : nullptr, 0, f);
     HIP_TRY(hipGetLastError());

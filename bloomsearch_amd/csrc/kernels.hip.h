@@ -560,10 +560,14 @@ __host__ __device__ inline uint32_t eval_lds_bytes(uint32_t max_cw, uint32_t max
     return (max_cw * 64u + max_depth * (uint32_t)kEvalThreads) * 8u;
 }
 
-// Evaluates chunk c (256 queries) against block group g with the 256 threads htid = 0..255 of one
-// "half" (a whole k_eval_programs workgroup, or half of a fused workgroup).  `active` = false halves
-// only take part in the barrier.
-__device__ __forceinline__ void eval_role(const EvalArgs &a, uint32_t g, uint32_t c, uint32_t htid, uint64_t *lds, bool active)
+constexpr uint32_t kEvalGroupTile = 4;   // block groups one eval "half" handles back to back (=> 32-byte stores per lane)
+
+// Evaluates chunk c (256 queries) against block groups [g0, g0 + gt) with the 256 threads htid = 0..255
+// of one "half" (a whole k_eval_programs workgroup, or half of a fused workgroup).  The program words
+// are fetched once and reused for every group; the gt survivor words of a query are stored together.
+// `active` = false halves only take part in the barriers.
+__device__ __forceinline__ void eval_role(const EvalArgs &a, uint32_t g0, uint32_t gt, uint32_t c, uint32_t htid, uint64_t *lds,
+                                          bool active)
 {
     const int lane = htid & (kWave - 1);
     const uint32_t wave = htid / kWave;
@@ -572,7 +576,7 @@ __device__ __forceinline__ void eval_role(const EvalArgs &a, uint32_t g, uint32_
     uint64_t *stk = lds + (uint64_t)a.max_cw * 64 + htid;  // per-lane stack, stride kEvalThreads
     constexpr uint32_t kPre = 8;
     uint32_t pre[kPre];
-    uint32_t len = 0;
+    uint32_t len = 0, cw0 = 0, ncw = 0;
     const uint32_t *P = a.prog;
     if (active) {
         len = a.chunk_len[c];
@@ -580,44 +584,62 @@ __device__ __forceinline__ void eval_role(const EvalArgs &a, uint32_t g, uint32_
         // the program words do not depend on the verdicts: fetch them while V is in flight
 #pragma unroll
         for (uint32_t j = 0; j < kPre; ++j) pre[j] = j < len ? P[(uint64_t)j * kEvalThreads] : (7u << 28);
-        const bool row_valid = (g * 64 + (uint32_t)lane) < a.n_blocks;
-        const uint32_t cw0 = a.cw_off[c], ncw = a.cw_off[c + 1] - cw0;
-        for (uint32_t s = wave; s < ncw; s += n_waves) {
-            const uint32_t w = a.cw[cw0 + s];
-            uint64_t x = row_valid ? a.V[((uint64_t)g * a.Wt + w) * 64 + lane] : 0ULL;
-            VT[s * 64 + lane] = wave_transpose64(x, lane);
+        cw0 = a.cw_off[c];
+        ncw = a.cw_off[c + 1] - cw0;
+    }
+    const uint32_t q = c * kEvalThreads + htid;
+    uint64_t res[kEvalGroupTile];
+#pragma unroll
+    for (uint32_t t = 0; t < kEvalGroupTile; ++t) {
+        if (t < gt) {   // workgroup-uniform
+            const uint32_t g = g0 + t;
+            if (t > 0) __syncthreads();   // everyone is done reading VT of the previous group
+            if (active) {
+                const bool row_valid = (g * 64 + (uint32_t)lane) < a.n_blocks;
+                for (uint32_t s = wave; s < ncw; s += n_waves) {
+                    const uint32_t w = a.cw[cw0 + s];
+                    uint64_t x = row_valid ? a.V[((uint64_t)g * a.Wt + w) * 64 + lane] : 0ULL;
+                    VT[s * 64 + lane] = wave_transpose64(x, lane);
+                }
+            }
+            __syncthreads();
+            uint64_t top = ~0ULL;  // empty program == nil query == true
+            if (active) {
+                uint32_t sp = 0;   // number of values on the stack (top kept in a register)
+                auto step = [&](uint32_t op) {
+                    const uint32_t opc = op >> 28;
+                    if (opc == 7u) return;
+                    if (opc == 1u || opc == 2u) {
+                        --sp;
+                        const uint64_t under = stk[(uint64_t)(sp - 1) * kEvalThreads];
+                        top = (opc == 1u) ? (under & top) : (under | top);
+                    } else {
+                        if (sp > 0) stk[(uint64_t)(sp - 1) * kEvalThreads] = top;
+                        ++sp;
+                        top = (opc == 0u) ? VT[op & 0x0FFFFFFFu] : (opc == 3u ? ~0ULL : 0ULL);
+                    }
+                };
+#pragma unroll
+                for (uint32_t j = 0; j < kPre; ++j) if (j < len) step(pre[j]);
+                for (uint32_t j = kPre; j < len; ++j) step(P[(uint64_t)j * kEvalThreads]);
+            }
+            const uint32_t nvalid = a.n_blocks - g * 64;
+            res[t] = top & (nvalid >= 64 ? ~0ULL : ((1ULL << nvalid) - 1));
         }
     }
-    __syncthreads();
-    if (!active) return;
-    const uint32_t q = c * kEvalThreads + htid;
-    uint64_t top = ~0ULL;  // empty program == nil query == true
-    uint32_t sp = 0;       // number of values on the stack (top kept in a register)
-    auto step = [&](uint32_t op) {
-        const uint32_t opc = op >> 28;
-        if (opc == 7u) return;
-        if (opc == 1u || opc == 2u) {
-            --sp;
-            const uint64_t under = stk[(uint64_t)(sp - 1) * kEvalThreads];
-            top = (opc == 1u) ? (under & top) : (under | top);
-        } else {
-            if (sp > 0) stk[(uint64_t)(sp - 1) * kEvalThreads] = top;
-            ++sp;
-            top = (opc == 0u) ? VT[op & 0x0FFFFFFFu] : (opc == 3u ? ~0ULL : 0ULL);
-        }
-    };
+    if (active && q < a.n_queries) {
+        uint64_t *dst = a.out + (uint64_t)q * a.G + g0;
 #pragma unroll
-    for (uint32_t j = 0; j < kPre; ++j) if (j < len) step(pre[j]);
-    for (uint32_t j = kPre; j < len; ++j) step(P[(uint64_t)j * kEvalThreads]);
-    const uint32_t nvalid = a.n_blocks - g * 64;
-    const uint64_t valid = nvalid >= 64 ? ~0ULL : ((1ULL << nvalid) - 1);
-    if (q < a.n_queries) a.out[(uint64_t)q * a.G + g] = top & valid;
+        for (uint32_t t = 0; t < kEvalGroupTile; ++t) if (t < gt) dst[t] = res[t];
+    }
 }
 
-__global__ __launch_bounds__(kEvalThreads) void k_eval_programs(const EvalArgs a)
+// grid = (ceil(G / tile), n_chunks); tile (1 or kEvalGroupTile) is chosen by the host
+__global__ __launch_bounds__(kEvalThreads) void k_eval_programs(const EvalArgs a, const uint32_t tile)
 {
     extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
-    eval_role(a, blockIdx.x, blockIdx.y, threadIdx.x, lds64, true);
+    const uint32_t g0 = blockIdx.x * tile;
+    eval_role(a, g0, min(tile, a.G - g0), blockIdx.y, threadIdx.x, lds64, true);
 }
 
 // ---------------------------------------------------------------------------
@@ -635,22 +657,25 @@ struct FusedArgs {
     uint32_t n_probe;        // = n_probe_x * number of referenced kinds
     uint32_t eval_pairs;     // ceil(n_chunks / 2) of the eval role
     uint32_t eval_lds_half;  // bytes of LDS per 256-query half
+    uint32_t eval_tile;      // block groups per eval half (1 or kEvalGroupTile)
 };
 
 __global__ __launch_bounds__(kProbeThreads) void k_probe_fused(const FusedArgs f)
 {
     extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
     const uint32_t id = blockIdx.x;
-    const uint32_t n_eval = f.e.G * f.eval_pairs;
+    const uint32_t g_tiles = (f.e.G + f.eval_tile - 1) / f.eval_tile;
+    const uint32_t n_eval = g_tiles * f.eval_pairs;
     if (id >= n_eval) {
         const uint32_t j = id - n_eval;
         probe_role(f.p, j % f.n_probe_x, j / f.n_probe_x, lds64);
     } else {
-        const uint32_t g = id / f.eval_pairs, pair = id - g * f.eval_pairs;
+        const uint32_t gtile = id / f.eval_pairs, pair = id - gtile * f.eval_pairs;
         const uint32_t half = threadIdx.x >> 8, htid = threadIdx.x & 255u;
         const uint32_t c = pair * 2 + half;
         const uint32_t n_chunks = (f.e.n_queries + kEvalThreads - 1) / kEvalThreads;
-        eval_role(f.e, g, c, htid, lds64 + (uint64_t)half * (f.eval_lds_half / 8), c < n_chunks);
+        const uint32_t g0 = gtile * f.eval_tile;
+        eval_role(f.e, g0, min(f.eval_tile, f.e.G - g0), c, htid, lds64 + (uint64_t)half * (f.eval_lds_half / 8), c < n_chunks);
     }
 }
 

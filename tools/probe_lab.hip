@@ -117,6 +117,22 @@ int main(int argc, char **argv)
     timeit("stream nodesc 1024", [&](int r, hipEvent_t a0, hipEvent_t a1) { hipExtLaunchKernelGGL(k_stream_nodesc<1024>, dim3(B), dim3(1024), lds, st, a0, a1, 0, (const uint64_t *)dw[r], stride, nw, dout); });
     timeit("stream regs 512", [&](int r, hipEvent_t a0, hipEvent_t a1) { hipExtLaunchKernelGGL(k_stream_regs<512>, dim3(B), dim3(512), 0, st, a0, a1, 0, (const uint64_t *)dw[r], stride, nw, dout); });
     timeit("stream regs 256", [&](int r, hipEvent_t a0, hipEvent_t a1) { hipExtLaunchKernelGGL(k_stream_regs<256>, dim3(B), dim3(256), 0, st, a0, a1, 0, (const uint64_t *)dw[r], stride, nw, dout); });
+    {   // per-arena dispatch time of k_probe_terms: is the spread address dependent?
+        std::vector<double> per(R, 0); std::vector<int> cnt(R, 0);
+        for (uint32_t i = 0; i < iters * 2; ++i) {
+            const int r = i % R; a.words = dw[r];
+            hipExtLaunchKernelGGL(k_probe_terms, dim3(B, 1), dim3(kProbeThreads), lds, st, e0, e1, 0, a);
+            CHECK(hipEventSynchronize(e1)); float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); per[r] += ms; cnt[r]++;
+        }
+        printf("per-arena avg us:"); for (uint32_t r = 0; r < R; ++r) printf(" %.2f", per[r] / cnt[r] * 1e3); printf("\n");
+        // same arena every time (cache resident) for comparison
+        double tot = 0; a.words = dw[0];
+        for (uint32_t i = 0; i < iters; ++i) {
+            hipExtLaunchKernelGGL(k_probe_terms, dim3(B, 1), dim3(kProbeThreads), lds, st, e0, e1, 0, a);
+            CHECK(hipEventSynchronize(e1)); float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); tot += ms;
+        }
+        printf("same arena (MALL-resident) avg %.2f us\n", tot / iters * 1e3);
+    }
     timeit("k_probe_terms", [&](int r, hipEvent_t a0, hipEvent_t a1) { a.words = dw[r]; hipExtLaunchKernelGGL(k_probe_terms, dim3(B, 1), dim3(kProbeThreads), lds, st, a0, a1, 0, a); });
     return 0;
 }
