@@ -42,7 +42,7 @@ def op(opcode: int, arg: int = 0) -> int:
 # every symbol include/bloomgpu.h declares (tests assert the .so exports all of them)
 EXPORTS = [
     "bsg_device_count", "bsg_open", "bsg_close", "bsg_last_error", "bsg_sync", "bsg_estimate_parameters",
-    "bsg_hash_entries", "bsg_build", "bsg_build_hashed", "bsg_arena_load", "bsg_arena_free",
+    "bsg_hash_entries", "bsg_build", "bsg_build_hashed", "bsg_arena_load", "bsg_arena_load_sections", "bsg_arena_free",
     "bsg_batch_create", "bsg_batch_free", "bsg_probe_batch", "bsg_probe_many", "bsg_probe", "bsg_timing_read", "bsg_set_timed_stride", "bsg_last_kernel_ms",
     "bsg_or_reduce", "bsg_or_words_dev", "bsg_or_reduce_dev",
 ]
@@ -71,6 +71,7 @@ def load():
     L.bsg_build.argtypes = [vp, vp, vp, u32, vp, vp, u32, vp, u64]
     L.bsg_build_hashed.argtypes = [vp, vp, u32, vp, vp, u32, vp, u64]
     L.bsg_arena_load.argtypes = [vp, vp, u64, vp, u32, C.POINTER(u64)]
+    L.bsg_arena_load_sections.argtypes = [vp, vp, u64, vp, u32, vp, C.POINTER(u64)]
     L.bsg_arena_free.argtypes = [vp, u64]
     L.bsg_batch_create.argtypes = [vp, vp, u32, vp, vp, u32, C.POINTER(u64)]
     L.bsg_batch_free.argtypes = [vp, u64]

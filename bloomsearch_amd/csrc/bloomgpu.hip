@@ -94,6 +94,7 @@ struct Device {
     DevBuf<uint64_t> stage_words;
     std::vector<EventTriple> pending;
     std::vector<EventTriple> free_events;
+    bsg::CrcConsts *d_crc = nullptr;          // CRC32C slice-by-8 tables + x^(2^i) mod P (k_decode_sections)
     hipEvent_t kb0 = nullptr, kb1 = nullptr;  // start/stop timestamps of the last k_build / k_hash_entries dispatch
     float last_build_ms = 0.f, last_hash_ms = 0.f;
 };
@@ -354,6 +355,7 @@ int32_t bsg_close(bsg_ctx *ctx)
         (void)hipSetDevice(d.id);
         if (d.stream) (void)hipStreamSynchronize(d.stream);
         if (d.kb0) { (void)hipEventDestroy(d.kb0); (void)hipEventDestroy(d.kb1); }
+        if (d.d_crc) (void)hipFree(d.d_crc);
         for (auto *v : {&d.pending, &d.free_events})
             for (auto &t : *v) {
                 (void)hipEventDestroy(t.k1s); (void)hipEventDestroy(t.k1e);
@@ -572,6 +574,148 @@ int32_t bsg_arena_load(bsg_ctx *ctx, const uint64_t *words, uint64_t n_words, co
         }
     }
     std::lock_guard<std::mutex> lk(ctx->mu);
+    const uint64_t id = ctx->next_id++;
+    ctx->arenas[id] = arena;
+    *out_arena_id = id;
+    return BSG_OK;
+}
+
+}  // extern "C"
+
+namespace {
+const bsg::CrcConsts &crc_consts()
+{
+    static bsg::CrcConsts c = [] {
+        bsg::CrcConsts t{};
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t v = i;
+            for (int j = 0; j < 8; ++j) v = (v & 1) ? (v >> 1) ^ bsg::kCrc32cPoly : v >> 1;
+            t.table[0][i] = v;
+        }
+        for (int k = 1; k < 8; ++k)
+            for (uint32_t i = 0; i < 256; ++i) t.table[k][i] = (t.table[k - 1][i] >> 8) ^ t.table[0][t.table[k - 1][i] & 0xFF];
+        uint32_t p = 1u << 30;   // x^1
+        t.x2n[0] = p;
+        for (int n = 1; n < 32; ++n) t.x2n[n] = p = bsg::crc_multmodp(p, p);
+        return t;
+    }();
+    return c;
+}
+inline uint64_t rd_be64(const uint8_t *p) { uint64_t v; memcpy(&v, p, 8); return __builtin_bswap64(v); }
+inline uint32_t rd_le32(const uint8_t *p) { uint32_t v; memcpy(&v, p, 4); return v; }
+}  // namespace
+
+extern "C" {
+
+// Arena straight from the on-disk bytes: the host only walks the section HEADERS (flags, lengths, m, k —
+// a few dozen bytes per block) to lay the arena out; CRC32C and the big-endian -> native word decode of
+// every filter run on the device (k_decode_sections).
+int32_t bsg_arena_load_sections(bsg_ctx *ctx, const uint8_t *region, uint64_t region_len, const uint64_t *sec_off,
+                                uint32_t n_blocks, int32_t *out_status, uint64_t *out_arena_id)
+{
+    if (!ctx || !out_arena_id || (n_blocks && (!sec_off || !out_status))) return fail(BSG_E_INVALID, "null argument");
+    if (ctx->devs.size() != 1) return fail(BSG_E_UNSUPPORTED, "bsg_arena_load_sections needs a single-device context");
+    if (region_len && !region) return fail(BSG_E_INVALID, "region is null");
+    for (uint32_t b = 0; b < n_blocks; ++b)
+        if (sec_off[b + 1] < sec_off[b] || sec_off[b + 1] > region_len) return fail(BSG_E_INVALID, "sec_off not monotone / outside region at %u", b);
+    auto arena = std::make_shared<Arena>();
+    arena->n_blocks = n_blocks;
+    arena->shards.resize(1);
+    ArenaShard &s = arena->shards[0];
+    s.n_blocks = n_blocks;
+    std::vector<bsg::SectionInfo> info(n_blocks);
+    std::vector<DevDesc> dd((size_t)n_blocks * 3);
+    uint64_t cursor = 0;
+    for (uint32_t b = 0; b < n_blocks; ++b) {
+        bsg::SectionInfo &si = info[b];
+        si = bsg::SectionInfo{};
+        const uint8_t *sec = region + sec_off[b];
+        const uint64_t len = sec_off[b + 1] - sec_off[b];
+        for (uint32_t c = 0; c < 3; ++c) dd[(size_t)b * 3 + c] = DevDesc{0, 0, 0, 0, 0};
+        out_status[b] = 0;
+        if (len == 0) continue;                                   // block without a section: all filters nil
+        if (len < 5 || len > 0xFFFFFFFFull) { out_status[b] = -1; continue; }   // parseFilterSection: too small
+        si.begin = sec_off[b];
+        si.len = (uint32_t)len;                                   // the device checks the CRC even if the structure is bad
+        const uint64_t plen = len - 4;
+        const uint8_t flags = sec[0];
+        if (flags & ~7u) { out_status[b] = -3; continue; }
+        uint64_t pos = 1;
+        int32_t st = 0;
+        DevDesc tmp[3] = {};
+        uint32_t woff[3] = {0, 0, 0}, nwv[3] = {0, 0, 0};
+        for (uint32_t c = 0; c < 3 && st == 0; ++c) {
+            if (!((flags >> c) & 1)) continue;
+            if (plen - pos < 4) { st = -4; break; }
+            const uint64_t flen = rd_le32(sec + pos);
+            pos += 4;
+            if (flen > plen - pos) { st = -4; break; }
+            if (flen < 24) { st = -5; break; }
+            const uint64_t m = rd_be64(sec + pos), k = rd_be64(sec + pos + 8), bl = rd_be64(sec + pos + 16);
+            const uint64_t nw = (bl + 63) / 64;
+            if (24 + 8 * nw > flen || m == 0 || k == 0 || k > 0xFFFFFFFFull || (m + 63) / 64 > nw) { st = -5; break; }
+            tmp[c] = DevDesc{0, m, barrett_magic(m), (uint32_t)k, 0};
+            woff[c] = (uint32_t)(pos + 24);
+            nwv[c] = (uint32_t)((m + 63) / 64);
+            pos += flen;
+        }
+        if (st == 0 && pos != plen) st = -6;
+        if (st) { out_status[b] = st; continue; }
+        for (uint32_t c = 0; c < 3; ++c) {
+            if (!tmp[c].m) continue;
+            tmp[c].word_off = cursor;
+            cursor += ((uint64_t)nwv[c] + kAlignWords - 1) / kAlignWords * kAlignWords;
+            dd[(size_t)b * 3 + c] = tmp[c];
+            si.present |= 1u << c;
+            si.woff[c] = woff[c]; si.nw[c] = nwv[c]; si.dst[c] = tmp[c].word_off;
+            s.sum_words[c] += nwv[c];
+            if (nwv[c] <= kLdsCapWords) s.max_staged_words[c] = std::max<uint64_t>(s.max_staged_words[c], nwv[c]);
+            if (s.fixed_m[c] == 0 && s.geometry_uniform[c]) { s.fixed_m[c] = tmp[c].m; s.fixed_k[c] = tmp[c].k; }
+            else if (s.fixed_m[c] != tmp[c].m || s.fixed_k[c] != tmp[c].k) s.geometry_uniform[c] = false;
+        }
+    }
+    s.n_words = cursor + kAlignWords;
+    Device &d = *ctx->devs[0];
+    std::lock_guard<std::mutex> lk(d.mu);
+    if (int32_t rc = use_device(d)) return rc;
+    uint8_t *d_region = nullptr;
+    bsg::SectionInfo *d_info = nullptr;
+    int32_t *d_status = nullptr;
+    auto cleanup = [&]() {
+        if (d_region) (void)hipFree(d_region);
+        if (d_info) (void)hipFree(d_info);
+        if (d_status) (void)hipFree(d_status);
+    };
+    hipError_t e = hipSuccess;
+    if (!d.d_crc) {
+        e = hipMalloc(reinterpret_cast<void **>(&d.d_crc), sizeof(bsg::CrcConsts));
+        if (e == hipSuccess) e = hipMemcpyAsync(d.d_crc, &crc_consts(), sizeof(bsg::CrcConsts), hipMemcpyHostToDevice, d.stream);
+    }
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&s.d_words), s.n_words * 8);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&s.d_desc), std::max<size_t>(dd.size(), 1) * sizeof(DevDesc));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_region), region_len + 64);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_info), std::max<size_t>(info.size(), 1) * sizeof(bsg::SectionInfo));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_status), std::max<size_t>(n_blocks, 1) * 4);
+    if (e == hipSuccess) e = hipMemsetAsync(s.d_words, 0, s.n_words * 8, d.stream);
+    if (e == hipSuccess && region_len) e = hipMemcpyAsync(d_region, region, region_len, hipMemcpyHostToDevice, d.stream);
+    if (e == hipSuccess && n_blocks) {
+        e = hipMemcpyAsync(s.d_desc, dd.data(), dd.size() * sizeof(DevDesc), hipMemcpyHostToDevice, d.stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_info, info.data(), info.size() * sizeof(bsg::SectionInfo), hipMemcpyHostToDevice, d.stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_status, out_status, (size_t)n_blocks * 4, hipMemcpyHostToDevice, d.stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(bsg::k_decode_sections, dim3(n_blocks), dim3(bsg::kDecodeThreads), 0, d.stream, (const uint8_t *)d_region,
+                               (const bsg::SectionInfo *)d_info, (const bsg::CrcConsts *)d.d_crc, s.d_words, s.d_desc, d_status);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(out_status, d_status, (size_t)n_blocks * 4, hipMemcpyDeviceToHost, d.stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(d.stream);
+    cleanup();
+    if (e != hipSuccess) {
+        free_arena(ctx, *arena);
+        return fail(e == hipErrorOutOfMemory ? BSG_E_NOMEM : BSG_E_HIP, "section upload/decode failed: %s", hipGetErrorString(e));
+    }
+    std::lock_guard<std::mutex> lk2(ctx->mu);
     const uint64_t id = ctx->next_id++;
     ctx->arenas[id] = arena;
     *out_arena_id = id;

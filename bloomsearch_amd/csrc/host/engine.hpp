@@ -71,6 +71,7 @@ struct BlockStats {                      // query_exec.go:63-72
 struct QueryResult {
     std::vector<std::string> rows;
     std::vector<BlockStats> block_stats;
+    std::vector<std::string> errors;     // per-block failures joined into Results.Err by the reference
     uint64_t files_considered = 0, files_bloom_skipped = 0;
 };
 
@@ -90,6 +91,21 @@ public:
     const std::vector<DataFile> &files() const { return files_; }
 
     void stop() { stopped_ = true; }
+
+    // Fault injection (the reference's tests use corrupting DataStore doubles): flip one byte of a stored section.
+    bool corrupt_section_byte(size_t file_index, int block_index, size_t byte_index)
+    {
+        if (file_index >= files_.size()) return false;
+        std::vector<uint8_t> *sec = &files_[file_index].filter_section;
+        if (block_index >= 0) {
+            if ((size_t)block_index >= files_[file_index].blocks.size()) return false;
+            sec = &files_[file_index].blocks[block_index].filter_section;
+        }
+        if (byte_index >= sec->size()) return false;
+        (*sec)[byte_index] ^= 0x5A;
+        drop_arenas();
+        return true;
+    }
 
     // rows: one marshaled JSON object per element.  Whole batch is validated before any buffer
     // is touched (ingest.go:378-397).
@@ -230,8 +246,11 @@ public:
                 return fail(kErrGpu, bsg_last_error(ctx_));
             size_t g = 0;
             for (size_t f = 0; f < files_.size(); ++f) {
-                file_ok[f] = (fs[f >> 6] >> (f & 63)) & 1;
-                for (size_t b = 0; b < files_[f].blocks.size(); ++b, ++g) block_ok[f][b] = (bs[g >> 6] >> (g & 63)) & 1;
+                file_ok[f] = (fs[f >> 6] >> (f & 63)) & 1;   // a corrupt file-level section decodes to nil filters: cannot disqualify
+                for (size_t b = 0; b < files_[f].blocks.size(); ++b, ++g) {
+                    block_ok[f][b] = (bs[g >> 6] >> (g & 63)) & 1;
+                    if (block_status_[g] != 0) block_ok[f][b] = 2;   // unreadable filters: neither pruned nor scanned (query_exec.go:580-590)
+                }
             }
         }
         RowMatcher matcher(expr);
@@ -244,6 +263,12 @@ public:
                 st.file_id = files_[f].file_id; st.block_offset = blk.block_offset;
                 st.total_rows = (int64_t)blk.rows.size();
                 st.total_bytes = (int64_t)(blk.row_bytes + blk.filter_section.size());
+                if (block_ok[f][b] == 2) {        // recordUnreadBlocks (query_exec.go:625-639): totals only, error surfaced
+                    out.errors.push_back("failed to read data block bloom filters: file " + std::to_string(files_[f].file_id) +
+                                         " block offset " + std::to_string(blk.block_offset) + ": invalid hash");
+                    out.block_stats.push_back(st);
+                    continue;
+                }
                 if (!block_ok[f][b]) {                                    // query_exec.go:607-614
                     st.bloom_filter_skipped = true;
                     out.block_stats.push_back(st);
@@ -277,6 +302,7 @@ private:
     std::string err_;
     uint64_t files_arena_ = 0, blocks_arena_ = 0, total_blocks_ = 0;
     bool arenas_valid_ = false;
+    std::vector<int32_t> file_status_, block_status_;   // parseFilterSection outcome per file / per block (0 ok)
 
     int32_t fail(int32_t code, std::string msg) { err_ = std::move(msg); return code; }
 
@@ -318,25 +344,15 @@ private:
         return kEngineOk;
     }
 
-    // Decode every stored section (parseFilterSection incl. CRC) into one word arena and upload it.
-    int32_t load_arena(const std::vector<const std::vector<uint8_t> *> &sections, uint64_t &arena_id)
+    // Hand the stored section bytes to the device as they are: CRC32C + big-endian decode run in
+    // k_decode_sections (bsg_arena_load_sections); the host never touches a filter word on the read path.
+    int32_t load_arena(const std::vector<const std::vector<uint8_t> *> &sections, uint64_t &arena_id, std::vector<int32_t> &status)
     {
-        std::vector<uint64_t> words;
-        std::vector<bsg_filter_desc> desc(sections.size() * 3);
-        for (size_t s = 0; s < sections.size(); ++s) {
-            ParsedFilter pf[3];
-            const int32_t rc = parse_filter_section(sections[s]->data(), sections[s]->size(), pf);
-            if (rc == kSectionBadHash) return fail(kErrInvalidHash, "filter section CRC32C mismatch");
-            if (rc) return fail(kErrInvalidHash, "malformed filter section (" + std::to_string(rc) + ")");
-            for (uint32_t c = 0; c < 3; ++c) {
-                if (!pf[c].present) { desc[s * 3 + c] = bsg_filter_desc{0, 0, 0, 0}; continue; }
-                desc[s * 3 + c] = bsg_filter_desc{words.size(), pf[c].m, (uint32_t)pf[c].k, 0};
-                words.insert(words.end(), pf[c].words.begin(), pf[c].words.end());
-                if (words.size() & 1) words.push_back(0);
-            }
-        }
-        if (words.empty()) words.push_back(0);
-        if (bsg_arena_load(ctx_, words.data(), words.size(), desc.data(), (uint32_t)sections.size(), &arena_id))
+        std::vector<uint8_t> region;
+        std::vector<uint64_t> off{0};
+        for (auto *sec : sections) { region.insert(region.end(), sec->begin(), sec->end()); off.push_back(region.size()); }
+        status.assign(std::max<size_t>(sections.size(), 1), 0);
+        if (bsg_arena_load_sections(ctx_, region.data(), region.size(), off.data(), (uint32_t)sections.size(), status.data(), &arena_id))
             return fail(kErrGpu, bsg_last_error(ctx_));
         return kEngineOk;
     }
@@ -347,8 +363,8 @@ private:
         std::vector<const std::vector<uint8_t> *> fsec, bsec;
         for (auto &f : files_) { fsec.push_back(&f.filter_section); for (auto &b : f.blocks) bsec.push_back(&b.filter_section); }
         total_blocks_ = bsec.size();
-        if (int32_t rc = load_arena(fsec, files_arena_)) return rc;
-        if (int32_t rc = load_arena(bsec, blocks_arena_)) { bsg_arena_free(ctx_, files_arena_); return rc; }
+        if (int32_t rc = load_arena(fsec, files_arena_, file_status_)) return rc;
+        if (int32_t rc = load_arena(bsec, blocks_arena_, block_status_)) { bsg_arena_free(ctx_, files_arena_); return rc; }
         arenas_valid_ = true;
         return kEngineOk;
     }

@@ -298,6 +298,8 @@ int32_t bse_query(bse_engine *e, const char *query_json, uint64_t len, char **ou
                ",\"TotalRows\":" + std::to_string(s.total_rows) + ",\"TotalBytes\":" + std::to_string(s.total_bytes) +
                ",\"BloomFilterSkipped\":" + (s.bloom_filter_skipped ? "true" : "false") + "}";
     }
+    out += "],\"Errors\":[";
+    for (size_t i = 0; i < res.errors.size(); ++i) { if (i) out.push_back(','); json_escape(out, res.errors[i]); }
     out += "],\"FilesConsidered\":" + std::to_string(res.files_considered) + ",\"FilesBloomSkipped\":" + std::to_string(res.files_bloom_skipped) + "}}";
     return give(out, out_json, out_len);
 }
@@ -338,6 +340,12 @@ int32_t bse_describe(bse_engine *e, char **out_json, uint64_t *out_len)
     }
     out += "]}";
     return give(out, out_json, out_len);
+}
+
+int32_t bse_corrupt_section_byte(bse_engine *e, uint32_t file_index, int32_t block_index, uint64_t byte_index)
+{
+    if (!e) return BSH_E_INVALID;
+    return e->eng->corrupt_section_byte(file_index, block_index, byte_index) ? 0 : BSH_E_INVALID;
 }
 
 int32_t bse_section_bytes(bse_engine *e, uint32_t file_index, int32_t block_index, uint8_t **out, uint64_t *out_len)

@@ -782,6 +782,119 @@ __global__ __launch_bounds__(kBuildThreads) void k_build(const BuildArgs a)
     }
 }
 
+// ---------------------------------------------------------------------------
+// decode_sections: filter sections exactly as stored on disk (encodeFilterSection,
+// file_format.go:343-384) -> arena words, on the device.  One workgroup per section:
+//   1. CRC32C (Castagnoli, reflected 0x82F63B78) of the payload: every thread runs slice-by-8 over its
+//      contiguous chunk with a zero initial value, partials are combined pairwise with the GF(2)
+//      "multiply by x^(8n) mod P" operator (chunks 1..255 have one common length, so each tree level
+//      needs a single squaring of the operator), then the initial/final 0xFFFFFFFF are folded in;
+//   2. every present filter's big-endian u64 words are byte-swapped into their 128-byte-aligned arena
+//      slot (bit i <-> words[i>>6] bit i&63, native little-endian).
+// A CRC mismatch marks the block (status -2 = ErrInvalidHash) and turns its filters into nil filters
+// (m = 0) so a corrupt section cannot poison the batch (query_exec.go:580-590 isolates it per block).
+// ---------------------------------------------------------------------------
+constexpr uint32_t kCrc32cPoly = 0x82F63B78u;
+
+struct CrcConsts {
+    uint32_t table[8][256];   // slice-by-8 tables
+    uint32_t x2n[32];         // x^(2^i) mod P, reflected (zlib's x2n_table construction)
+};
+
+__host__ __device__ inline uint32_t crc_multmodp(uint32_t a, uint32_t b)
+{
+    uint32_t m = 1u << 31, p = 0;
+    for (;;) {
+        if (a & m) {
+            p ^= b;
+            if ((a & (m - 1)) == 0) break;
+        }
+        m >>= 1;
+        b = (b & 1u) ? (b >> 1) ^ kCrc32cPoly : b >> 1;
+    }
+    return p;
+}
+
+// x^(n * 2^k) mod P
+__host__ __device__ inline uint32_t crc_x2nmodp(uint64_t n, uint32_t k, const uint32_t *x2n)
+{
+    uint32_t p = 1u << 31;   // x^0
+    while (n) {
+        if (n & 1) p = crc_multmodp(x2n[k & 31], p);
+        n >>= 1;
+        ++k;
+    }
+    return p;
+}
+
+struct SectionInfo {
+    uint64_t begin;          // byte offset of the section in the uploaded region
+    uint32_t len;            // section bytes incl. the 4-byte CRC trailer (0 => nothing to do)
+    uint32_t present;        // bit c set: filter c is decoded
+    uint32_t woff[3];        // byte offset of filter c's first big-endian word inside the section
+    uint32_t nw[3];          // words of filter c
+    uint64_t dst[3];         // word offset of filter c in the arena
+};
+
+constexpr int kDecodeThreads = 256;
+
+__global__ __launch_bounds__(kDecodeThreads) void k_decode_sections(const uint8_t *region, const SectionInfo *info,
+                                                                   const CrcConsts *consts, uint64_t *arena, DevDesc *desc,
+                                                                   int32_t *status)
+{
+    __shared__ uint32_t tab[8][256];
+    __shared__ uint32_t part[kDecodeThreads];
+    __shared__ uint32_t bad;
+    const uint32_t b = blockIdx.x, tid = threadIdx.x;
+    const SectionInfo si = info[b];
+    if (si.len < 5) return;
+    for (uint32_t i = tid; i < 8 * 256; i += kDecodeThreads) (&tab[0][0])[i] = (&consts->table[0][0])[i];
+    __syncthreads();
+    const uint8_t *sec = region + si.begin;
+    const uint32_t P = si.len - 4;
+    // chunks 1..255: C bytes each (multiple of 8); chunk 0 takes the remainder at the front
+    const uint32_t C = (P / kDecodeThreads) & ~7u;
+    const uint32_t len0 = P - (kDecodeThreads - 1) * C;
+    const uint32_t start = tid == 0 ? 0 : len0 + (tid - 1) * C;
+    const uint32_t n = tid == 0 ? len0 : C;
+    uint32_t crc = 0;
+    uint32_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+        const uint64_t v = load_u64_unaligned(sec + start + i);
+        const uint32_t lo = (uint32_t)v ^ crc, hi = (uint32_t)(v >> 32);
+        crc = tab[7][lo & 0xFF] ^ tab[6][(lo >> 8) & 0xFF] ^ tab[5][(lo >> 16) & 0xFF] ^ tab[4][lo >> 24] ^
+              tab[3][hi & 0xFF] ^ tab[2][(hi >> 8) & 0xFF] ^ tab[1][(hi >> 16) & 0xFF] ^ tab[0][hi >> 24];
+    }
+    for (; i < n; ++i) crc = tab[0][(crc ^ sec[start + i]) & 0xFF] ^ (crc >> 8);
+    part[tid] = crc;
+    // pairwise combine: crc(A || B) = crc(A) * x^(8 |B|) + crc(B)   (zero initial values)
+    uint32_t op = crc_x2nmodp(C, 3, consts->x2n);   // shift by C bytes
+    __syncthreads();
+    for (uint32_t step = 1; step < kDecodeThreads; step <<= 1) {
+        if ((tid & (2 * step - 1)) == 0) part[tid] = crc_multmodp(op, part[tid]) ^ part[tid + step];
+        op = crc_multmodp(op, op);
+        __syncthreads();
+    }
+    if (tid == 0) {
+        // fold in the 0xFFFFFFFF initial value (shifted over the whole payload) and the final xor
+        const uint32_t total = part[0] ^ crc_multmodp(crc_x2nmodp(P, 3, consts->x2n), 0xFFFFFFFFu) ^ 0xFFFFFFFFu;
+        const uint32_t want = (uint32_t)sec[P] | (uint32_t)sec[P + 1] << 8 | (uint32_t)sec[P + 2] << 16 | (uint32_t)sec[P + 3] << 24;
+        bad = total != want;
+        if (bad) {
+            status[b] = -2;
+            for (uint32_t c = 0; c < 3; ++c) desc[(uint64_t)b * 3 + c].m = 0;
+        }
+    }
+    __syncthreads();
+    if (bad) return;
+    for (uint32_t c = 0; c < 3; ++c) {
+        if (!((si.present >> c) & 1u)) continue;
+        const uint8_t *src = sec + si.woff[c];
+        uint64_t *dst = arena + si.dst[c];
+        for (uint32_t w = tid; w < si.nw[c]; w += kDecodeThreads) dst[w] = __builtin_bswap64(load_u64_unaligned(src + 8ull * w));
+    }
+}
+
 // dst[i] |= OR over s < n_src of src[s * n_words + i]
 __global__ __launch_bounds__(256) void k_or_words(uint64_t *dst, const uint64_t *src, uint64_t n_words,
                                                   uint32_t n_src, int overwrite)

@@ -100,6 +100,17 @@ class Context:
                                           C.byref(aid)))
         return int(aid.value)
 
+    def arena_load_sections(self, sections):
+        """sections: list[bytes] (b"" = block without a section) -> (arena_id, int32 status per block)."""
+        off = np.zeros(len(sections) + 1, dtype=np.uint64)
+        off[1:] = np.cumsum([len(x) for x in sections], dtype=np.uint64)
+        region = np.frombuffer(b"".join(sections), dtype=np.uint8)
+        status = np.zeros(max(len(sections), 1), dtype=np.int32)
+        aid = C.c_uint64()
+        self._check(self.L.bsg_arena_load_sections(self.h, _lib._ptr(region), len(region), _lib._ptr(off), len(sections),
+                                                   _lib._ptr(status), C.byref(aid)))
+        return int(aid.value), status[: len(sections)]
+
     def arena_free(self, arena_id: int):
         self._check(self.L.bsg_arena_free(self.h, arena_id))
 

@@ -17,7 +17,7 @@ HOST_EXPORTS = [
     "bsh_batch_new", "bsh_batch_free", "bsh_batch_add_query", "bsh_batch_sizes", "bsh_batch_export", "bsh_match_row",
     "bsh_section_encode", "bsh_section_parse", "bsh_crc32c",
     "bse_open", "bse_close", "bse_last_error", "bse_stop", "bse_ingest_rows", "bse_flush", "bse_merge", "bse_query",
-    "bse_describe", "bse_section_bytes",
+    "bse_describe", "bse_corrupt_section_byte", "bse_section_bytes",
 ]
 
 _H = None
@@ -63,6 +63,7 @@ def lib():
     L.bse_merge.argtypes = [vp]
     L.bse_query.argtypes = [vp, C.c_char_p, u64, pp, pu64]
     L.bse_describe.argtypes = [vp, pp, pu64]
+    L.bse_corrupt_section_byte.argtypes = [vp, u32, i32, u64]
     L.bse_section_bytes.argtypes = [vp, u32, i32, pp, pu64]
     for n in HOST_EXPORTS:
         f = getattr(L, n)
@@ -261,6 +262,9 @@ class Engine:
         p, n = C.c_void_p(), C.c_uint64()
         self._check(self.L.bse_describe(self.h, C.byref(p), C.byref(n)))
         return json.loads(_take(self.L, p, n))
+
+    def corrupt_section_byte(self, file_index: int, block_index: int, byte_index: int):
+        self._check(self.L.bse_corrupt_section_byte(self.h, file_index, block_index, byte_index))
 
     def section_bytes(self, file_index: int, block_index: int = -1) -> bytes:
         p, n = C.c_void_p(), C.c_uint64()

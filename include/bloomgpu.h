@@ -142,6 +142,15 @@ BSG_API int32_t bsg_build_hashed(bsg_ctx *ctx, const uint64_t *h, uint32_t n_ent
  * round-robin over the context's devices (block b -> device b % n_devices). */
 BSG_API int32_t bsg_arena_load(bsg_ctx *ctx, const uint64_t *words, uint64_t n_words,
                                const bsg_filter_desc *desc, uint32_t n_blocks, uint64_t *out_arena_id);
+/* Same, straight from the on-disk bytes: section b = region[sec_off[b] .. sec_off[b+1]) exactly as
+ * encodeFilterSection wrote it (file_format.go:343-384; an empty range = block without filters).
+ * CRC32C verification and the big-endian -> native decode run on the device; the host only reads the
+ * section headers.  out_status[b]: 0 ok, else parseFilterSection's failure for that block (-1 too small,
+ * -2 CRC mismatch = ErrInvalidHash, -3 unknown flags, -4 truncated, -5 bad filter, -6 trailing bytes);
+ * a failed block gets nil filters and never poisons the others (query_exec.go:580-590).  Single-device
+ * contexts. */
+BSG_API int32_t bsg_arena_load_sections(bsg_ctx *ctx, const uint8_t *region, uint64_t region_len, const uint64_t *sec_off,
+                                        uint32_t n_blocks, int32_t *out_status, uint64_t *out_arena_id);
 BSG_API int32_t bsg_arena_free(bsg_ctx *ctx, uint64_t arena_id);
 
 /* Compile + upload a batch of queries: n_terms distinct terms and, per query q,

@@ -85,11 +85,13 @@ BSG_API int32_t bse_flush(bse_engine *e);
 BSG_API int32_t bse_merge(bse_engine *e);
 /* query_json: {"Bloom":{"Expression":{...}}} (or {"Bloom":null}); result JSON:
  * {"rows":[...],"stats":{"BlockStats":[{"FileID","BlockOffset","RowsProcessed","BytesProcessed","TotalRows",
- *  "TotalBytes","BloomFilterSkipped"}],"FilesConsidered","FilesBloomSkipped"}} */
+ *  "TotalBytes","BloomFilterSkipped"}],"Errors":[..],"FilesConsidered","FilesBloomSkipped"}} */
 BSG_API int32_t bse_query(bse_engine *e, const char *query_json, uint64_t len, char **out_json, uint64_t *out_len);
 /* {"files":[{"FileID","BloomEntryCounts":{..},"section_bytes","blocks":[{"PartitionID","Rows","BloomEntryCounts":{..},
  *  "BloomFalsePositiveRate","BloomFilterSize","filters":[{"m","k"}|null x3]}]}]} */
 BSG_API int32_t bse_describe(bse_engine *e, char **out_json, uint64_t *out_len);
+/* fault injection (the reference's tests wrap its stores to corrupt reads): XOR one byte of a stored section */
+BSG_API int32_t bse_corrupt_section_byte(bse_engine *e, uint32_t file_index, int32_t block_index, uint64_t byte_index);
 /* raw filter-section bytes of (file index, block index); block index -1 = the file-level section */
 BSG_API int32_t bse_section_bytes(bse_engine *e, uint32_t file_index, int32_t block_index, uint8_t **out, uint64_t *out_len);
 

@@ -223,3 +223,26 @@ def test_flush_triggers(ctx):
     e.ingest_rows([go_marshal({"id": i}) for i in range(5)])     # buffer hit MaxBufferedRows (ingest.go:512-516)
     d = e.describe()
     assert len(d["files"]) == 1 and len(d["files"][0]["blocks"]) == 5
+
+
+def test_corrupt_block_section_is_isolated(ctx):
+    """A block whose stored filter section fails its CRC32C (checked on the device) is neither pruned nor scanned:
+    it gets a totals-only stats entry and the failure surfaces in the result's errors; every other block behaves
+    as before (query_exec.go:580-590, recordUnreadBlocks :625-639)."""
+    rows = [{"id": i, "partition": "p%d" % (i % 4), "msg": "only%d common" % (i % 4)} for i in range(40)]
+    e = new_engine(ctx, PartitionField="partition", MaxBufferedRows=100000, BloomFalsePositiveRate=1e-6)
+    ingest_and_flush(e, rows)
+    clean = e.query(Q.Token("only2"))
+    assert len(clean["rows"]) == 10 and clean["stats"]["Errors"] == []
+    assert sum(b["BloomFilterSkipped"] for b in clean["stats"]["BlockStats"]) == 3
+    e.corrupt_section_byte(0, 2, 40)           # the block that holds "only2"
+    res = e.query(Q.Token("only2"))
+    assert len(res["stats"]["Errors"]) == 1 and "invalid hash" in res["stats"]["Errors"][0]
+    assert res["rows"] == []                    # its rows are not scanned
+    stats = res["stats"]["BlockStats"]
+    assert len(stats) == 4
+    unread = [b for b in stats if not b["BloomFilterSkipped"] and b["RowsProcessed"] == 0]
+    assert len(unread) == 1 and unread[0]["TotalRows"] == 10
+    assert sum(b["BloomFilterSkipped"] for b in stats) == 3
+    other = e.query(Q.Token("only1"))           # other blocks still answer normally
+    assert len(other["rows"]) == 10 and len(other["stats"]["Errors"]) == 1

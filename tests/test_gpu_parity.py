@@ -287,3 +287,70 @@ def test_multi_device_context_shards_round_robin_and_gathers():
             assert np.array_equal(got, want)
             # fixed-geometry OR-reduce across the shards of a multi-device context
             mctx.arena_free(aid)
+
+
+def test_arena_load_sections_device_decode(ctx):
+    """Filter sections exactly as on disk -> arena on the device (CRC32C + BE decode in k_decode_sections):
+    probes equal those over the host-decoded arena; a corrupt section is isolated per block with
+    parseFilterSection's own error code and never poisons the others."""
+    import struct
+    rng = np.random.default_rng(91)
+    n_blocks = 90
+    plan, blocks_str, vocab = H.make_random_arena(rng, n_blocks, absent_frac=0.05, max_tokens=2000)
+    words = ctx.build(plan.blob, plan.off, plan.fstart, plan.desc, plan.n_words)
+    sections = []
+    for b in range(n_blocks):
+        fl = []
+        for c in range(3):
+            d = plan.desc[b * 3 + c]
+            if d["m"] == 0:
+                fl.append(None)
+            else:
+                nw = O.words_for(int(d["m"]))
+                fl.append(O.Filter(int(d["m"]), int(d["k"]), words[int(d["word_off"]): int(d["word_off"]) + nw]))
+        sections.append(O.encode_filter_section(fl))
+    cb = Q.compile_queries([None] + [H.random_expression(rng, vocab, None) for _ in range(400)])
+    ops, poff, _ = cb.arrays()
+    terms = H.gpu_terms(ctx, cb)
+    want = O.probe_batch(words, plan.desc.view(O.DESC_DTYPE), terms.view(O.TERM_DTYPE), ops, poff)
+    aid, status = ctx.arena_load_sections(sections)
+    assert not status.any()
+    assert np.array_equal(ctx.probe(aid, n_blocks, terms, ops, poff), want)
+    ctx.arena_free(aid)
+
+    # corruptions, one per block: flipped payload bit, flipped CRC byte, unknown flag bit (CRC fixed up),
+    # truncated body (CRC fixed up), trailing bytes (CRC fixed up), too small, empty (= block without filters)
+    def with_crc(payload):
+        return payload + struct.pack("<I", O.crc32c(payload))
+    bad = list(sections)
+    s5 = bytearray(sections[5]); s5[len(s5) // 2] ^= 0x10; bad[5] = bytes(s5)
+    s9 = bytearray(sections[9]); s9[-1] ^= 0xFF; bad[9] = bytes(s9)
+    bad[12] = with_crc(bytes([sections[12][0] | 0x40]) + sections[12][1:-4])
+    bad[20] = with_crc(sections[20][: len(sections[20]) // 2])
+    bad[33] = with_crc(sections[33][:-4] + b"\x00\x00\x00")
+    bad[40] = b"\x01\x02\x03"
+    bad[41] = b""
+    aid, status = ctx.arena_load_sections(bad)
+    expect = {5: -2, 9: -2, 12: -3, 40: -1, 41: 0, 33: -6}
+    for b, code in expect.items():
+        assert status[b] == code, (b, status[b])
+    assert status[20] in (-4, -5)
+    for b in range(n_blocks):          # oracle parse agrees on ok / not ok for every block
+        try:
+            O.parse_filter_section(bad[b]) if bad[b] else None
+            ok = True
+        except ValueError:
+            ok = False
+        assert ok == (status[b] == 0), b
+    got = ctx.probe(aid, n_blocks, terms, ops, poff)
+    ctx.arena_free(aid)
+    failed = {b for b in range(n_blocks) if status[b] != 0} | {41}
+    desc2 = plan.desc.copy()
+    for b in failed:
+        desc2["m"][b * 3: b * 3 + 3] = 0          # failed / missing sections behave as nil filters (fail-open)
+    want2 = O.probe_batch(words, desc2.view(O.DESC_DTYPE), terms.view(O.TERM_DTYPE), ops, poff)
+    assert np.array_equal(got, want2)
+    # untouched blocks are bit-identical to the clean run
+    mask = np.zeros(n_blocks, dtype=bool); mask[list(failed)] = True
+    bits = lambda a: np.unpackbits(a.view(np.uint8), axis=1, bitorder="little")[:, :n_blocks]
+    assert np.array_equal(bits(got)[:, ~mask], bits(want)[:, ~mask])
