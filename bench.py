@@ -126,6 +126,7 @@ def main():
     ap.add_argument("--fpr", type=float, default=0.001)
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU baseline work (0 = skip)")
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--no-decode", action="store_true", help="skip the device section-decode measurement")
     ap.add_argument("--scaled", type=int, default=64,
                     help="also time C2': the arena replicated this many times inside one launch (0/1 = skip)")
     ap.add_argument("--timed-every", type=int, default=8,
@@ -170,6 +171,35 @@ def main():
     build_bytes = len(plan.blob) + 4 * len(plan.off) + 4 * len(plan.fstart) + int(sum((int(m) + 63) // 64 * 8 for m in plan.desc["m"]))
     log("built %d filters (%.1f MB of bitsets) on the GPU in %.2fs; k_build %.1f us = %.0f GB/s algorithmic"
         % (3 * B, plan.n_words * 8 / 1e6, time.time() - t0, build_ms * 1e3, build_bytes / max(build_ms, 1e-6) / 1e6))
+
+    # the read side of a8 (file_format.go:392-448) on the device: the same 1 000 blocks as on-disk filter sections
+    # (big-endian words + CRC32C), uploaded as bytes and decoded by k_decode_sections
+    decode = None
+    if rank == 0 and not args.no_decode:
+        from bloomsearch_amd import host as Hst
+        t0 = time.time()
+        secs = []
+        for b in range(B):
+            fl = []
+            for c in range(3):
+                d = plan.desc[b * 3 + c]
+                nw = (int(d["m"]) + 63) // 64
+                fl.append((int(d["m"]), int(d["k"]), words[int(d["word_off"]): int(d["word_off"]) + nw]))
+            secs.append(Hst.section_encode(fl))
+        t1 = time.time()
+        sid, st = ctx.arena_load_sections(secs)
+        t2 = time.time()
+        dec_ms = ctx.last_kernel_ms()[2]
+        sec_bytes = sum(len(x) for x in secs)
+        if st.any():
+            sys.exit("device section decode reported failures on clean sections")
+        ctx.arena_free(sid)
+        decode = {"kernel": "k_decode_sections", "kernel_ms": dec_ms, "section_bytes": sec_bytes,
+                  "algorithmic_bytes": 2 * sec_bytes, "achieved": 2 * sec_bytes / max(dec_ms, 1e-6) / 1e6, "unit": "GB/s",
+                  "note": "CRC32C + BE->LE decode of %d filter sections on the device; bytes = sections read + words written" % B,
+                  "end_to_end_s_incl_h2d": t2 - t1}
+        log("device section decode: %.1f MB of sections in %.1f us kernel (%.0f GB/s), %.3fs incl. H2D (host encode for the test %.1fs)"
+            % (sec_bytes / 1e6, dec_ms * 1e3, decode["achieved"], t2 - t1, t1 - t0))
 
     exprs = make_queries(NQ, args.workload, seed=1234)
     cb = Q.compile_queries(exprs)
@@ -293,6 +323,8 @@ def main():
                         "algorithmic_bytes": build_bytes, "achieved": build_bytes / max(build_ms, 1e-6) / 1e6, "unit": "GB/s",
                         "frac": build_bytes / max(build_ms, 1e-6) / 1e6 / HBM_PEAK_GBPS,
                         "entries_per_s": (len(plan.off) - 1) / max(build_ms, 1e-6) * 1e3}
+        if decode:
+            out["decode"] = decode
         if scaled:
             out["roofline_scaled"] = dict(scaled, bound="hbm", kernel="k_probe_terms", peak=HBM_PEAK_GBPS, unit="GB/s",
                                           note="C2' of SURVEY 8d: same filters replicated x%d at distinct addresses, one launch" % args.scaled)

@@ -80,7 +80,7 @@ def load():
     L.bsg_probe.argtypes = [vp, u64, vp, u32, vp, vp, u32, vp]
     L.bsg_timing_read.argtypes = [vp, C.POINTER(Timing), i32]
     L.bsg_set_timed_stride.argtypes = [vp, u32]
-    L.bsg_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.bsg_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.bsg_or_reduce.argtypes = [vp, u64, u32, vp, u64]
     L.bsg_or_words_dev.argtypes = [vp, vp, vp, u64, u32]
     L.bsg_or_reduce_dev.argtypes = [vp, u64, u32, vp, u64]

@@ -96,7 +96,7 @@ struct Device {
     std::vector<EventTriple> free_events;
     bsg::CrcConsts *d_crc = nullptr;          // CRC32C slice-by-8 tables + x^(2^i) mod P (k_decode_sections)
     hipEvent_t kb0 = nullptr, kb1 = nullptr;  // start/stop timestamps of the last k_build / k_hash_entries dispatch
-    float last_build_ms = 0.f, last_hash_ms = 0.f;
+    float last_build_ms = 0.f, last_hash_ms = 0.f, last_decode_ms = 0.f;
 };
 
 struct ArenaShard {
@@ -687,6 +687,7 @@ int32_t bsg_arena_load_sections(bsg_ctx *ctx, const uint8_t *region, uint64_t re
         if (d_status) (void)hipFree(d_status);
     };
     hipError_t e = hipSuccess;
+    bool timed_decode = false;
     if (!d.d_crc) {
         e = hipMalloc(reinterpret_cast<void **>(&d.d_crc), sizeof(bsg::CrcConsts));
         if (e == hipSuccess) e = hipMemcpyAsync(d.d_crc, &crc_consts(), sizeof(bsg::CrcConsts), hipMemcpyHostToDevice, d.stream);
@@ -703,13 +704,20 @@ int32_t bsg_arena_load_sections(bsg_ctx *ctx, const uint8_t *region, uint64_t re
         if (e == hipSuccess) e = hipMemcpyAsync(d_info, info.data(), info.size() * sizeof(bsg::SectionInfo), hipMemcpyHostToDevice, d.stream);
         if (e == hipSuccess) e = hipMemcpyAsync(d_status, out_status, (size_t)n_blocks * 4, hipMemcpyHostToDevice, d.stream);
         if (e == hipSuccess) {
-            hipLaunchKernelGGL(bsg::k_decode_sections, dim3(n_blocks), dim3(bsg::kDecodeThreads), 0, d.stream, (const uint8_t *)d_region,
-                               (const bsg::SectionInfo *)d_info, (const bsg::CrcConsts *)d.d_crc, s.d_words, s.d_desc, d_status);
-            e = hipGetLastError();
+            if (!d.kb0) { e = hipEventCreate(&d.kb0); if (e == hipSuccess) e = hipEventCreate(&d.kb1); }
+            if (e == hipSuccess) {
+                hipExtLaunchKernelGGL(bsg::k_decode_sections, dim3(n_blocks), dim3(bsg::kDecodeThreads), 0, d.stream, d.kb0, d.kb1, 0,
+                                      (const uint8_t *)d_region, (const bsg::SectionInfo *)d_info, (const bsg::CrcConsts *)d.d_crc,
+                                      s.d_words, s.d_desc, d_status);
+                e = hipGetLastError();
+                timed_decode = e == hipSuccess;
+            }
         }
         if (e == hipSuccess) e = hipMemcpyAsync(out_status, d_status, (size_t)n_blocks * 4, hipMemcpyDeviceToHost, d.stream);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(d.stream);
+    d.last_decode_ms = 0.f;
+    if (e == hipSuccess && timed_decode) e = hipEventElapsedTime(&d.last_decode_ms, d.kb0, d.kb1);
     cleanup();
     if (e != hipSuccess) {
         free_arena(ctx, *arena);
@@ -1165,13 +1173,14 @@ int32_t bsg_probe(bsg_ctx *ctx, uint64_t arena_id, const bsg_term *terms, uint32
     return rc;
 }
 
-int32_t bsg_last_kernel_ms(bsg_ctx *ctx, float *build_ms, float *hash_ms)
+int32_t bsg_last_kernel_ms(bsg_ctx *ctx, float *build_ms, float *hash_ms, float *decode_ms)
 {
     if (!ctx) return fail(BSG_E_INVALID, "ctx is null");
     Device &d = *ctx->devs[0];
     std::lock_guard<std::mutex> lk(d.mu);
     if (build_ms) *build_ms = d.last_build_ms;
     if (hash_ms) *hash_ms = d.last_hash_ms;
+    if (decode_ms) *decode_ms = d.last_decode_ms;
     return BSG_OK;
 }
 

@@ -166,9 +166,9 @@ class Context:
         self._check(self.L.bsg_set_timed_stride(self.h, stride))
 
     def last_kernel_ms(self):
-        b, h = C.c_float(), C.c_float()
-        self._check(self.L.bsg_last_kernel_ms(self.h, C.byref(b), C.byref(h)))
-        return float(b.value), float(h.value)
+        b, h, dc = C.c_float(), C.c_float(), C.c_float()
+        self._check(self.L.bsg_last_kernel_ms(self.h, C.byref(b), C.byref(h), C.byref(dc)))
+        return float(b.value), float(h.value), float(dc.value)
 
     # ---- OR-reduce ----
     def or_reduce(self, arena_id: int, kind: int, n_words: int) -> np.ndarray:

@@ -185,9 +185,10 @@ BSG_API int32_t bsg_probe(bsg_ctx *ctx, uint64_t arena_id, const bsg_term *terms
 BSG_API int32_t bsg_timing_read(bsg_ctx *ctx, bsg_timing *out, int32_t reset);
 /* With BSG_PROBE_TIMED, bsg_probe_many timestamps only every stride-th probe (default 1 = all). */
 BSG_API int32_t bsg_set_timed_stride(bsg_ctx *ctx, uint32_t stride);
-/* Device time (the dispatch's own start/stop timestamps) of the most recent k_build / k_hash_entries
- * launch made through bsg_build* / bsg_hash_entries on the context's first device. */
-BSG_API int32_t bsg_last_kernel_ms(bsg_ctx *ctx, float *build_ms, float *hash_ms);
+/* Device time (the dispatch's own start/stop timestamps) of the most recent k_build / k_hash_entries /
+ * k_decode_sections launch made through bsg_build* / bsg_hash_entries / bsg_arena_load_sections on the
+ * context's first device (any pointer may be NULL). */
+BSG_API int32_t bsg_last_kernel_ms(bsg_ctx *ctx, float *build_ms, float *hash_ms, float *decode_ms);
 
 /* ---- fixed-geometry OR-reduce (extension) ----
  * All present filters of `kind` in the arena must share (m, k).  out_words

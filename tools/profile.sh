@@ -8,7 +8,7 @@ OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-ARGS="--steps 200 --warmup 20 --cpu-budget 0 --no-check $*"
+ARGS="--steps 200 --warmup 20 --cpu-budget 0 --no-check --no-decode $*"
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o bench -- python $REPO/bench.py $ARGS > $OUT/stats.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o bench -- python $REPO/bench.py $ARGS > $OUT/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o bench -- python $REPO/bench.py $ARGS > $OUT/write.log 2>&1
