@@ -246,3 +246,31 @@ def test_corrupt_block_section_is_isolated(ctx):
     assert sum(b["BloomFilterSkipped"] for b in stats) == 3
     other = e.query(Q.Token("only1"))           # other blocks still answer normally
     assert len(other["rows"]) == 10 and len(other["stats"]["Errors"]) == 1
+
+
+def test_c1_config_100k_rows_fieldtoken_level_error(ctx):
+    """BASELINE configs[0] (the reference's own CPU-runnable case) through the engine mirror: 100 000 synthetic log
+    rows, 10 flushes of 10 000 rows (10 files x 1 block), FieldToken("level", "error").  Every block holds the term,
+    so nothing is pruned; the delivered row set is exactly the rows whose level is "error" (~25 %)."""
+    import time
+    from bloomsearch_amd import synth
+    e = new_engine(ctx, MaxRowGroupRows=10000, MaxBufferedRows=10_000_000, MaxBufferedBytes=1 << 40)
+    t_ing = 0.0
+    for f in range(10):
+        rows = synth.rows_json(f * 10000, 10000)
+        t0 = time.perf_counter()
+        e.ingest_rows(rows)                     # 10 000th row of the partition triggers the flush
+        t_ing += time.perf_counter() - t0
+    d = e.describe()
+    assert len(d["files"]) == 10 and all(len(f["blocks"]) == 1 and f["blocks"][0]["Rows"] == 10000 for f in d["files"])
+    c = d["files"][0]["blocks"][0]["BloomEntryCounts"]
+    assert c["Fields"] == 9 and 19000 < c["Tokens"] < 20000 and 19000 < c["FieldTokens"] < 20000
+    res = e.query(Q.FieldToken("level", "error"))
+    want = int((synth.draws(0, 100000)["level"] == synth.LEVELS.index("error")).sum())
+    assert len(res["rows"]) == want and 0.24 < want / 100000 < 0.26
+    assert all(r["level"] == "error" for r in res["rows"])
+    st = res["stats"]["BlockStats"]
+    assert len(st) == 10 and not any(b["BloomFilterSkipped"] for b in st) and sum(b["RowsProcessed"] for b in st) == 100000
+    miss = e.query(Q.FieldToken("level", "fatal"))
+    assert miss["rows"] == [] and miss["stats"]["FilesBloomSkipped"] == 10 and miss["stats"]["BlockStats"] == []
+    print("ingest+flush (host walk/tokenize/dedup + GPU build): %.2f us/row" % (t_ing / 100000 * 1e6))
