@@ -129,7 +129,7 @@ def main():
     ap.add_argument("--no-decode", action="store_true", help="skip the device section-decode measurement")
     ap.add_argument("--scaled", type=int, default=64,
                     help="also time C2': the arena replicated this many times inside one launch (0/1 = skip)")
-    ap.add_argument("--timed-every", type=int, default=8,
+    ap.add_argument("--timed-every", type=int, default=16,
                     help="timestamp the kernels of every Nth step inside the timed region (0 = never)")
     args = ap.parse_args()
 

@@ -119,9 +119,8 @@ struct Arena {
 struct BatchDev {
     uint64_t *d_th = nullptr;
     uint32_t *d_prog = nullptr;
-    uint32_t *d_chunk_off = nullptr;
     uint32_t *d_chunk_len = nullptr;
-    uint32_t *d_cw_off = nullptr;
+    uint32_t *d_cw_cnt = nullptr;
     uint32_t *d_cw = nullptr;
 };
 
@@ -135,6 +134,7 @@ struct Batch {
     uint32_t n_chunks = 0;
     uint32_t max_depth = 1;
     uint32_t max_cw = 1;            // most verdict words any 256-query chunk references
+    uint32_t Lmax = 1;              // longest lowered program of the batch (uniform chunk stride)
     std::vector<BatchDev> dev;
 };
 
@@ -174,9 +174,8 @@ void free_batch(bsg_ctx *ctx, Batch &b)
         (void)hipSetDevice(ctx->devs[i]->id);
         if (b.dev[i].d_th) (void)hipFree(b.dev[i].d_th);
         if (b.dev[i].d_prog) (void)hipFree(b.dev[i].d_prog);
-        if (b.dev[i].d_chunk_off) (void)hipFree(b.dev[i].d_chunk_off);
         if (b.dev[i].d_chunk_len) (void)hipFree(b.dev[i].d_chunk_len);
-        if (b.dev[i].d_cw_off) (void)hipFree(b.dev[i].d_cw_off);
+        if (b.dev[i].d_cw_cnt) (void)hipFree(b.dev[i].d_cw_cnt);
         if (b.dev[i].d_cw) (void)hipFree(b.dev[i].d_cw);
     }
 }
@@ -787,51 +786,55 @@ int32_t bsg_batch_create(bsg_ctx *ctx, const bsg_term *terms, uint32_t n_terms, 
         term_pos[t] = pos;
         for (int j = 0; j < 4; ++j) th[(size_t)j * B.Tp + pos] = terms[t].h[j];
     }
-    // lower programs, pack per 256-query chunk in lane-interleaved (coalesced) order
+    // lower programs; pack per 256-query chunk in lane-interleaved (coalesced) order with ONE stride for all
+    // chunks (Lmax ops, NOP padded) and one stride for the per-chunk verdict-word lists (max_cw)
     B.n_chunks = (n_queries + bsg::kEvalThreads - 1) / bsg::kEvalThreads;
-    std::vector<uint32_t> chunk_off(std::max(B.n_chunks, 1u), 0), chunk_len(std::max(B.n_chunks, 1u), 0);
-    std::vector<uint32_t> packed;
-    std::vector<uint32_t> cw_off((size_t)B.n_chunks + 1, 0), cw;
-    std::vector<std::vector<uint32_t>> lowered(bsg::kEvalThreads);
+    std::vector<std::vector<uint32_t>> lowered(n_queries);
+    for (uint32_t q = 0; q < n_queries; ++q) {
+        if (prog_off[q + 1] < prog_off[q]) return fail(BSG_E_INVALID, "prog_off not monotone at %u", q);
+        const uint32_t n_ops = prog_off[q + 1] - prog_off[q];
+        if (n_ops && !prog_ops) return fail(BSG_E_INVALID, "prog_ops is null");
+        uint32_t depth = 1;
+        if (int32_t rc = lower_program(prog_ops + prog_off[q], n_ops, n_terms, term_pos, lowered[q], depth)) return rc;
+        B.max_depth = std::max(B.max_depth, depth);
+        B.Lmax = std::max<uint32_t>(B.Lmax, (uint32_t)lowered[q].size());
+    }
+    std::vector<uint32_t> chunk_len(std::max(B.n_chunks, 1u), 0), cw_cnt(std::max(B.n_chunks, 1u), 0);
+    std::vector<std::vector<uint32_t>> chunk_words(B.n_chunks);
     for (uint32_t c = 0; c < B.n_chunks; ++c) {
-        uint32_t maxlen = 0;
         const uint32_t q0 = c * bsg::kEvalThreads;
         const uint32_t nq = std::min<uint32_t>(bsg::kEvalThreads, n_queries - q0);
+        std::vector<uint32_t> &words = chunk_words[c];   // verdict words this chunk references -> slots
         for (uint32_t i = 0; i < nq; ++i) {
-            const uint32_t q = q0 + i;
-            if (prog_off[q + 1] < prog_off[q]) return fail(BSG_E_INVALID, "prog_off not monotone at %u", q);
-            const uint32_t n_ops = prog_off[q + 1] - prog_off[q];
-            if (n_ops && !prog_ops) return fail(BSG_E_INVALID, "prog_ops is null");
-            uint32_t depth = 1;
-            if (int32_t rc = lower_program(prog_ops + prog_off[q], n_ops, n_terms, term_pos, lowered[i], depth)) return rc;
-            B.max_depth = std::max(B.max_depth, depth);
-            maxlen = std::max<uint32_t>(maxlen, (uint32_t)lowered[i].size());
-        }
-        // verdict words this chunk references -> slots; TERM args become slot * 64 + bit
-        std::vector<uint32_t> words;
-        for (uint32_t i = 0; i < nq; ++i)
-            for (uint32_t op : lowered[i])
+            chunk_len[c] = std::max<uint32_t>(chunk_len[c], (uint32_t)lowered[q0 + i].size());
+            for (uint32_t op : lowered[q0 + i])
                 if ((op >> 28) == 0u) words.push_back((op & 0x0FFFFFFFu) >> 6);
+        }
         std::sort(words.begin(), words.end());
         words.erase(std::unique(words.begin(), words.end()), words.end());
-        cw_off[c] = (uint32_t)cw.size();
-        cw.insert(cw.end(), words.begin(), words.end());
+        cw_cnt[c] = (uint32_t)words.size();
         B.max_cw = std::max<uint32_t>(B.max_cw, (uint32_t)words.size());
-        chunk_off[c] = (uint32_t)packed.size();
-        chunk_len[c] = maxlen;
-        packed.resize(packed.size() + (size_t)maxlen * bsg::kEvalThreads, 7u << 28);
+    }
+    std::vector<uint32_t> packed((size_t)std::max(B.n_chunks, 1u) * B.Lmax * bsg::kEvalThreads, 7u << 28);
+    std::vector<uint32_t> cw((size_t)std::max(B.n_chunks, 1u) * B.max_cw, 0);
+    for (uint32_t c = 0; c < B.n_chunks; ++c) {
+        const uint32_t q0 = c * bsg::kEvalThreads;
+        const uint32_t nq = std::min<uint32_t>(bsg::kEvalThreads, n_queries - q0);
+        const std::vector<uint32_t> &words = chunk_words[c];
+        std::copy(words.begin(), words.end(), cw.begin() + (size_t)c * B.max_cw);
         for (uint32_t i = 0; i < nq; ++i)
-            for (size_t j = 0; j < lowered[i].size(); ++j) {
-                uint32_t op = lowered[i][j];
-                if ((op >> 28) == 0u) {
+            for (size_t j = 0; j < lowered[q0 + i].size(); ++j) {
+                uint32_t op = lowered[q0 + i][j];
+                if ((op >> 28) == 0u) {   // TERM args become slot * 64 + bit
                     const uint32_t pos = op & 0x0FFFFFFFu;
                     const uint32_t slot = (uint32_t)(std::lower_bound(words.begin(), words.end(), pos >> 6) - words.begin());
                     op = slot * 64 + (pos & 63);
                 }
-                packed[chunk_off[c] + j * bsg::kEvalThreads + i] = op;
+                packed[((size_t)c * B.Lmax + j) * bsg::kEvalThreads + i] = op;
             }
     }
-    cw_off[B.n_chunks] = (uint32_t)cw.size();
+    if (packed.size() > (1ull << 30))
+        return fail(BSG_E_UNSUPPORTED, "padded program table of %zu ops is too large; split the batch by program length", packed.size());
     const size_t lds_need = ((size_t)B.max_cw * 64 + (size_t)B.max_depth * bsg::kEvalThreads) * 8;
     if (lds_need > 64 * 1024)
         return fail(BSG_E_UNSUPPORTED, "a 256-query chunk needs %zu B of LDS (%u verdict words, stack depth %u)", lds_need,
@@ -852,16 +855,14 @@ int32_t bsg_batch_create(bsg_ctx *ctx, const bsg_term *terms, uint32_t n_terms, 
         if (int32_t rc = use_device(d)) { free_batch(ctx, B); return rc; }
         hipError_t e = hipMalloc(reinterpret_cast<void **>(&bd.d_th), th.size() * 8);
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&bd.d_prog), std::max<size_t>(packed.size(), 1) * 4);
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&bd.d_chunk_off), chunk_off.size() * 4);
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&bd.d_chunk_len), chunk_len.size() * 4);
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&bd.d_cw_off), cw_off.size() * 4);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&bd.d_cw_cnt), cw_cnt.size() * 4);
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&bd.d_cw), std::max<size_t>(cw.size(), 1) * 4);
-        if (e == hipSuccess) e = hipMemcpyAsync(bd.d_cw_off, cw_off.data(), cw_off.size() * 4, hipMemcpyHostToDevice, d.stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(bd.d_cw_cnt, cw_cnt.data(), cw_cnt.size() * 4, hipMemcpyHostToDevice, d.stream);
         if (e == hipSuccess && !cw.empty()) e = hipMemcpyAsync(bd.d_cw, cw.data(), cw.size() * 4, hipMemcpyHostToDevice, d.stream);
         if (e == hipSuccess) e = hipMemcpyAsync(bd.d_th, th.data(), th.size() * 8, hipMemcpyHostToDevice, d.stream);
         if (e == hipSuccess && !packed.empty())
             e = hipMemcpyAsync(bd.d_prog, packed.data(), packed.size() * 4, hipMemcpyHostToDevice, d.stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(bd.d_chunk_off, chunk_off.data(), chunk_off.size() * 4, hipMemcpyHostToDevice, d.stream);
         if (e == hipSuccess) e = hipMemcpyAsync(bd.d_chunk_len, chunk_len.data(), chunk_len.size() * 4, hipMemcpyHostToDevice, d.stream);
         if (e == hipSuccess) e = hipStreamSynchronize(d.stream);
         if (e != hipSuccess) {
@@ -944,9 +945,9 @@ int32_t make_eval_args(Device &d, const ArenaShard &s, const BatchDev &bd, const
     const uint32_t G = (s.n_blocks + 63) / 64;
     HIP_TRY(d.out[slot].reserve((size_t)B.n_queries * G));
     a = bsg::EvalArgs{};
-    a.V = d.V[slot].p; a.prog = bd.d_prog; a.chunk_off = bd.d_chunk_off; a.chunk_len = bd.d_chunk_len;
+    a.V = d.V[slot].p; a.prog = bd.d_prog; a.chunk_len = bd.d_chunk_len;
     a.out = d.out[slot].p; a.Wt = B.Wt; a.n_blocks = s.n_blocks; a.G = G; a.n_queries = B.n_queries;
-    a.cw_off = bd.d_cw_off; a.cw = bd.d_cw; a.max_cw = B.max_cw;
+    a.cw_cnt = bd.d_cw_cnt; a.cw = bd.d_cw; a.max_cw = B.max_cw; a.Lmax = B.Lmax;
     return BSG_OK;
 }
 

@@ -541,17 +541,17 @@ __global__ __launch_bounds__(kProbeThreads) void k_probe_terms(const ProbeArgs a
 // ---------------------------------------------------------------------------
 struct EvalArgs {
     const uint64_t *V;
-    const uint32_t *prog;        // chunk c: prog[chunk_off[c] + j * 256 + lane]
-    const uint32_t *chunk_off;
-    const uint32_t *chunk_len;
-    const uint32_t *cw_off;      // chunk c needs verdict words cw[cw_off[c] .. cw_off[c+1])
-    const uint32_t *cw;
+    const uint32_t *prog;        // chunk c, op j, lane l: prog[(c * Lmax + j) * 256 + l]  (uniform stride: no offset table to chase)
+    const uint32_t *chunk_len;   // ops actually used by chunk c (<= Lmax; the rest is NOP padding)
+    const uint32_t *cw;          // chunk c needs verdict words cw[c * max_cw .. + cw_cnt[c])  (padding entries are 0)
+    const uint32_t *cw_cnt;
     uint64_t *out;               // [n_queries][G]
     uint32_t Wt;
     uint32_t n_blocks;
     uint32_t G;
     uint32_t n_queries;
-    uint32_t max_cw;             // max words of any chunk (LDS carve)
+    uint32_t max_cw;             // max words of any chunk (LDS carve + cw stride)
+    uint32_t Lmax;               // max program length of any chunk (prog stride)
 };
 
 // LDS bytes one 256-query half needs: transposed verdict words + per-lane stack
@@ -579,13 +579,15 @@ __device__ __forceinline__ void eval_role(const EvalArgs &a, uint32_t g0, uint32
     uint32_t len = 0, cw0 = 0, ncw = 0;
     const uint32_t *P = a.prog;
     if (active) {
-        len = a.chunk_len[c];
-        P = a.prog + a.chunk_off[c] + htid;
-        // the program words do not depend on the verdicts: fetch them while V is in flight
+        // Everything that depends only on the chunk index is requested at once — program words (the padded
+        // layout makes their addresses computable without a table lookup), the chunk's op count and its word
+        // list — so the only dependent global round trip left is the verdict words themselves.
+        P = a.prog + (uint64_t)c * a.Lmax * kEvalThreads + htid;
 #pragma unroll
-        for (uint32_t j = 0; j < kPre; ++j) pre[j] = j < len ? P[(uint64_t)j * kEvalThreads] : (7u << 28);
-        cw0 = a.cw_off[c];
-        ncw = a.cw_off[c + 1] - cw0;
+        for (uint32_t j = 0; j < kPre; ++j) pre[j] = j < a.Lmax ? P[(uint64_t)j * kEvalThreads] : (7u << 28);
+        len = a.chunk_len[c];
+        cw0 = c * a.max_cw;
+        ncw = a.cw_cnt[c];
     }
     const uint32_t q = c * kEvalThreads + htid;
     uint64_t res[kEvalGroupTile];
