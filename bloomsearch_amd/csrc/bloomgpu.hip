@@ -135,6 +135,7 @@ struct Batch {
     uint32_t max_depth = 1;
     uint32_t max_cw = 1;            // most verdict words any 256-query chunk references
     uint32_t Lmax = 1;              // longest lowered program of the batch (uniform chunk stride)
+    bool identity_cw = false;       // few verdict words: every chunk transposes all of them, no per-chunk list
     std::vector<BatchDev> dev;
 };
 
@@ -799,6 +800,7 @@ int32_t bsg_batch_create(bsg_ctx *ctx, const bsg_term *terms, uint32_t n_terms, 
         B.max_depth = std::max(B.max_depth, depth);
         B.Lmax = std::max<uint32_t>(B.Lmax, (uint32_t)lowered[q].size());
     }
+    B.identity_cw = B.Wt >= 1 && B.Wt <= 8;
     std::vector<uint32_t> chunk_len(std::max(B.n_chunks, 1u), 0), cw_cnt(std::max(B.n_chunks, 1u), 0);
     std::vector<std::vector<uint32_t>> chunk_words(B.n_chunks);
     for (uint32_t c = 0; c < B.n_chunks; ++c) {
@@ -812,6 +814,7 @@ int32_t bsg_batch_create(bsg_ctx *ctx, const bsg_term *terms, uint32_t n_terms, 
         }
         std::sort(words.begin(), words.end());
         words.erase(std::unique(words.begin(), words.end()), words.end());
+        if (B.identity_cw) { words.resize(B.Wt); for (uint32_t w = 0; w < B.Wt; ++w) words[w] = w; }
         cw_cnt[c] = (uint32_t)words.size();
         B.max_cw = std::max<uint32_t>(B.max_cw, (uint32_t)words.size());
     }
@@ -947,7 +950,7 @@ int32_t make_eval_args(Device &d, const ArenaShard &s, const BatchDev &bd, const
     a = bsg::EvalArgs{};
     a.V = d.V[slot].p; a.prog = bd.d_prog; a.chunk_len = bd.d_chunk_len;
     a.out = d.out[slot].p; a.Wt = B.Wt; a.n_blocks = s.n_blocks; a.G = G; a.n_queries = B.n_queries;
-    a.cw_cnt = bd.d_cw_cnt; a.cw = bd.d_cw; a.max_cw = B.max_cw; a.Lmax = B.Lmax;
+    a.cw_cnt = bd.d_cw_cnt; a.cw = bd.d_cw; a.max_cw = B.max_cw; a.Lmax = B.Lmax; a.identity_cw = B.identity_cw ? 1u : 0u;
     return BSG_OK;
 }
 

@@ -552,6 +552,7 @@ struct EvalArgs {
     uint32_t n_queries;
     uint32_t max_cw;             // max words of any chunk (LDS carve + cw stride)
     uint32_t Lmax;               // max program length of any chunk (prog stride)
+    uint32_t identity_cw;        // 1: every chunk uses words 0..max_cw-1 in order (small batches): no list to load
 };
 
 // LDS bytes one 256-query half needs: transposed verdict words + per-lane stack
@@ -587,7 +588,7 @@ __device__ __forceinline__ void eval_role(const EvalArgs &a, uint32_t g0, uint32
         for (uint32_t j = 0; j < kPre; ++j) pre[j] = j < a.Lmax ? P[(uint64_t)j * kEvalThreads] : (7u << 28);
         len = a.chunk_len[c];
         cw0 = c * a.max_cw;
-        ncw = a.cw_cnt[c];
+        ncw = a.identity_cw ? a.max_cw : a.cw_cnt[c];
     }
     const uint32_t q = c * kEvalThreads + htid;
     uint64_t res[kEvalGroupTile];
@@ -599,7 +600,7 @@ __device__ __forceinline__ void eval_role(const EvalArgs &a, uint32_t g0, uint32
             if (active) {
                 const bool row_valid = (g * 64 + (uint32_t)lane) < a.n_blocks;
                 for (uint32_t s = wave; s < ncw; s += n_waves) {
-                    const uint32_t w = a.cw[cw0 + s];
+                    const uint32_t w = a.identity_cw ? s : a.cw[cw0 + s];
                     uint64_t x = row_valid ? a.V[((uint64_t)g * a.Wt + w) * 64 + lane] : 0ULL;
                     VT[s * 64 + lane] = wave_transpose64(x, lane);
                 }
