@@ -342,7 +342,17 @@ __device__ __forceinline__ void probe_rounds(const ProbeArgs &a, const DevDesc &
     const uint32_t w1 = min(n_tw, w0 + wpw);
     lds_u16 *q = queues + (uint32_t)w0 * 64;
     const uint32_t base = w0 * 64;
+#ifdef BSG_LAB_FAKE_TERM_LOADS   // lab only: synthesize the hashes from the index to isolate VALU+LDS from term-table loads
+    struct FakeRow { uint64_t salt; __device__ uint64_t operator[](uint32_t i) const { return (i + salt) * 0x9E3779B97F4A7C15ULL; } };
+    struct FakeTable {
+        uint64_t salt;
+        __device__ uint64_t operator[](uint32_t i) const { return (i + salt) * 0x9E3779B97F4A7C15ULL; }
+        __device__ FakeRow operator+(uint64_t off) const { return FakeRow{salt + off}; }
+    };
+    const FakeTable th{t0 + base};
+#else
     const uint64_t *th = a.th + t0 + base;   // this wave's slice of hash row 0
+#endif
     uint32_t qn = 0;
 
     auto compact = [&](bool hit, uint32_t value, uint32_t &count) {
@@ -365,19 +375,21 @@ __device__ __forceinline__ void probe_rounds(const ProbeArgs &a, const DevDesc &
 #pragma unroll
             for (uint32_t u = 0; u < kGroup; ++u) loc[u] = locate<M32>(d, h[u]);
         }
+        // all kGroup bit tests first (independent LDS reads in flight together), then the compactions: the queue
+        // writes may alias the bitset image as far as the compiler knows, so it will not hoist the reads itself
+        bool hit[kGroup];
 #pragma unroll
-        for (uint32_t u = 0; u < kGroup; ++u) {
-            if (w + u < w1) {   // wave-uniform
-                const uint32_t li = (w + u - w0) * 64 + lane;
-                compact(base + li < n_real && test_bit(bits, loc[u]), li, qn);
-            }
-        }
+        for (uint32_t u = 0; u < kGroup; ++u)
+            hit[u] = (w + u < w1) & (base + (w + u - w0) * 64 + lane < n_real) & test_bit(bits, loc[u]);   // branch-free: loc is always in range
+#pragma unroll
+        for (uint32_t u = 0; u < kGroup; ++u)
+            if (w + u < w1) compact(hit[u], (w + u - w0) * 64 + lane, qn);   // wave-uniform condition
     }
     // ---- rounds 1..kCompactRounds: one location per round, survivors compacted in place ----
     {
         uint32_t i = 1;
         for (; i < d.k && i <= kCompactRounds && qn != 0; ++i) {
-            const uint64_t *ra = th + (uint64_t)ha_row(i) * a.Tp, *rb = th + (uint64_t)hb_row(i) * a.Tp;
+            const auto ra = th + (uint64_t)ha_row(i) * a.Tp, rb = th + (uint64_t)hb_row(i) * a.Tp;
             uint32_t out = 0;
             for (uint32_t j = 0; j < qn; j += 64 * kGroup) {
                 uint32_t li[kGroup];
@@ -386,19 +398,19 @@ __device__ __forceinline__ void probe_rounds(const ProbeArgs &a, const DevDesc &
                 for (uint32_t u = 0; u < kGroup; ++u) li[u] = (j + u * 64 + lane < qn) ? (uint32_t)q[j + u * 64 + lane] : 0u;
 #pragma unroll
                 for (uint32_t u = 0; u < kGroup; ++u) x[u] = (j + u * 64 < qn) ? ra[li[u]] + (uint64_t)i * rb[li[u]] : 0;
+                bool hit[kGroup];
 #pragma unroll
-                for (uint32_t u = 0; u < kGroup; ++u) {
-                    if (j + u * 64 < qn) {   // wave-uniform
-                        const bool valid = j + u * 64 + lane < qn;
-                        compact(valid && test_bit(bits, locate<M32>(d, x[u])), li[u], out);   // out <= j: in place is safe
-                    }
-                }
+                for (uint32_t u = 0; u < kGroup; ++u)
+                    hit[u] = (j + u * 64 + lane < qn) & test_bit(bits, locate<M32>(d, x[u]));
+#pragma unroll
+                for (uint32_t u = 0; u < kGroup; ++u)
+                    if (j + u * 64 < qn) compact(hit[u], li[u], out);   // wave-uniform; out <= j: in place is safe
             }
             qn = out;
         }
         // ---- tail: remaining locations from registers, two chunks interleaved, wave-level early-out ----
         if (i < d.k && qn != 0) {
-            const uint64_t *r1 = th + (uint64_t)a.Tp, *r2 = th + 2ull * a.Tp, *r3 = th + 3ull * a.Tp;
+            const auto r1 = th + (uint64_t)a.Tp, r2 = th + 2ull * a.Tp, r3 = th + 3ull * a.Tp;
             const uint32_t i0 = i;
             for (uint32_t j = 0; j < qn; j += 128) {
                 const bool two = j + 64 < qn;

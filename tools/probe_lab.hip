@@ -133,6 +133,17 @@ int main(int argc, char **argv)
         }
         printf("same arena (MALL-resident) avg %.2f us\n", tot / iters * 1e3);
     }
+    for (int flag : {0, (int)hipExtAnyOrderLaunch}) {   // do back-to-back independent launches overlap their ramps?
+        for (int rep = 0; rep < 2; ++rep) {
+            CHECK(hipStreamSynchronize(st));
+            CHECK(hipEventRecord(e0, st));
+            const int N = 256;
+            for (int i = 0; i < N; ++i) { a.words = dw[i % R]; hipExtLaunchKernelGGL(k_probe_terms, dim3(B, 1), dim3(kProbeThreads), lds, st, nullptr, nullptr, flag, a); }
+            CHECK(hipEventRecord(e1, st)); CHECK(hipEventSynchronize(e1));
+            float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+            if (rep) printf("back-to-back x%d flag=%d: %.2f us per launch\n", N, flag, ms / N * 1e3);
+        }
+    }
     timeit("k_probe_terms", [&](int r, hipEvent_t a0, hipEvent_t a1) { a.words = dw[r]; hipExtLaunchKernelGGL(k_probe_terms, dim3(B, 1), dim3(kProbeThreads), lds, st, a0, a1, 0, a); });
     return 0;
 }
