@@ -57,6 +57,21 @@ def make_queries(n_queries, workload, seed):
     from bloomsearch_amd import query as Q, synth
     rng = np.random.default_rng(seed)
     exprs = []
+    if workload == "c4":
+        # BASELINE configs[3] / SURVEY C4: 8-term Or(FieldToken...) over the low-cardinality fields,
+        # every position absent with probability 1/2 (an Or of present values alone would keep every block).
+        def pick(field, present, absent):
+            return Q.FieldToken(field, present() if rng.random() >= 0.5 else absent())
+        for _ in range(n_queries):
+            w = lambda: synth.WORDS[rng.integers(0, len(synth.WORDS))]
+            nw = lambda: "absent-word-%d" % rng.integers(0, 8)
+            exprs.append(Q.Or(
+                pick("level", lambda: synth.LEVELS[rng.integers(0, 4)], lambda: "absent-level-%d" % rng.integers(0, 4)),
+                pick("service", lambda: synth.SERVICES[rng.integers(0, 5)], lambda: "absent-svc-%d" % rng.integers(0, 4)),
+                pick("nested.region", lambda: "region-%d" % rng.integers(0, 8), lambda: "region-%d" % rng.integers(8, 12)),
+                pick("nested.az", lambda: "az-%d" % rng.integers(0, 3), lambda: "az-%d" % rng.integers(3, 6)),
+                pick("tags", w, nw), pick("tags", w, nw), pick("message", w, nw), pick("message", w, nw)))
+        return exprs
     for _ in range(n_queries):
         lv = synth.LEVELS[rng.integers(0, 4)] if rng.random() >= 0.25 else "absent-level-%d" % rng.integers(0, 4)
         sv = synth.SERVICES[rng.integers(0, 5)] if rng.random() >= 0.25 else "absent-svc-%d" % rng.integers(0, 4)
@@ -69,7 +84,7 @@ def make_queries(n_queries, workload, seed):
     return exprs
 
 
-def cpu_baseline(words, desc, cb, ops, poff, n_blocks, budget_s, log):
+def cpu_baseline(words, desc, cb, ops, poff, n_blocks, budget_s, log, terms_per_query=3):
     """The reference's probe loop as the oracle restates it (parse section incl. CRC32C + BE decode,
     then short-circuit TestString with per-call re-hash), on a bounded sample, all host cores."""
     from oracle import oracle as O
@@ -104,7 +119,6 @@ def cpu_baseline(words, desc, cb, ops, poff, n_blocks, budget_s, log):
     nq2 = min(cb.n_queries, nq * scale)
     nq2 = max(cores, nq2 // cores * cores)
     t2, out = run(nq2)
-    terms_per_query = 3
     value = nq2 * n_blocks * terms_per_query / t2
     log("cpu_baseline: %d queries x %d blocks in %.2fs on %d threads" % (nq2, n_blocks, t2, cores))
     return {"value": value, "unit": "probes/s", "cores": cores, "kind": "port",
@@ -120,8 +134,8 @@ def main():
     ap.add_argument("--blocks", type=int, default=1000, help="blocks per GPU")
     ap.add_argument("--rows-per-block", type=int, default=10000)
     ap.add_argument("--queries", type=int, default=4096)
-    ap.add_argument("--workload", default="c2", choices=["c2", "needle"],
-                    help="c2: SURVEY 8d C2 And(FT(level), FT(service), FT(nested.region)); needle: third term is FT(user_id) (~4k distinct terms)")
+    ap.add_argument("--workload", default="c2", choices=["c2", "needle", "c4"],
+                    help="c2: SURVEY 8d C2 And(FT(level), FT(service), FT(nested.region)); needle: third term is FT(user_id) (~4k distinct terms); c4: SURVEY C4's 8-term Or(FieldToken...)")
     ap.add_argument("--replicas", type=int, default=0, help="address-distinct arena replicas (0 = auto)")
     ap.add_argument("--fpr", type=float, default=0.001)
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU baseline work (0 = skip)")
@@ -202,6 +216,7 @@ def main():
             % (sec_bytes / 1e6, dec_ms * 1e3, decode["achieved"], t2 - t1, t1 - t0))
 
     exprs = make_queries(NQ, args.workload, seed=1234)
+    terms_per_query = 8 if args.workload == "c4" else 3
     cb = Q.compile_queries(exprs)
     ops, poff, kinds = cb.arrays()
     terms = np.zeros(len(cb.term_strings), dtype=_lib.TERM_DTYPE)
@@ -277,13 +292,12 @@ def main():
         s_bytes = s_tm.stream_bytes / max(s_tm.n_probes, 1) + 33 * len(terms)
         s_ms = s_tm.ms_terms_kernel / max(s_tm.n_probes, 1)
         scaled = {"blocks": B * S, "steps": s_steps, "ms_per_step": s_elapsed / s_steps * 1e3,
-                  "value": NQ * B * S * 3 * s_steps / s_elapsed, "kernel_ms": s_ms,
+                  "value": NQ * B * S * terms_per_query * s_steps / s_elapsed, "kernel_ms": s_ms,
                   "eval_kernel_ms": s_tm.ms_eval_kernel / max(s_tm.n_probes, 1),
                   "algorithmic_bytes_per_launch": s_bytes, "achieved": s_bytes / (s_ms * 1e-3) / 1e9,
                   "frac": s_bytes / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
         ctx.arena_free(big)
 
-    terms_per_query = 3
     probes_per_step = NQ * B * terms_per_query * world
     value = probes_per_step * args.steps / elapsed
 
@@ -307,9 +321,11 @@ def main():
             "metric": "block-bloom probes/sec", "value": value, "unit": "probes/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "C2 probe: %d rows/block x %d blocks per GPU, Q=%d 3-term And(FieldToken) [%s], "
+            "config": {"workload": "%s probe: %d rows/block x %d blocks per GPU, Q=%d %s [%s], "
                                    "fpr %g, %d address-distinct arena replicas rotated per step"
-                                   % (rows, B, NQ, args.workload, args.fpr, R),
+                                   % ("C4" if args.workload == "c4" else "C2", rows, B, NQ,
+                                      "8-term Or(FieldToken)" if args.workload == "c4" else "3-term And(FieldToken)",
+                                      args.workload, args.fpr, R),
                        "blocks_per_gpu": B, "queries": NQ, "distinct_terms": int(len(terms)),
                        "probes_per_step": probes_per_step, "sharding": "round-robin blocks, no collective"},
             "roofline": {"bound": "hbm", "kernel": "k_probe_terms", "achieved": achieved, "peak": HBM_PEAK_GBPS,
@@ -329,7 +345,7 @@ def main():
             out["roofline_scaled"] = dict(scaled, bound="hbm", kernel="k_probe_terms", peak=HBM_PEAK_GBPS, unit="GB/s",
                                           note="C2' of SURVEY 8d: same filters replicated x%d at distinct addresses, one launch" % args.scaled)
         if args.cpu_budget > 0 and world == 1:
-            base, cpu_out, nq = cpu_baseline(words, plan.desc, cb, ops, poff, B, args.cpu_budget, log)
+            base, cpu_out, nq = cpu_baseline(words, plan.desc, cb, ops, poff, B, args.cpu_budget, log, terms_per_query)
             if not args.no_check and not np.array_equal(cpu_out, got[:nq]):
                 sys.exit("CPU baseline survivors differ from the GPU's")
             out["cpu_baseline"] = base
