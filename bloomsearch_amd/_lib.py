@@ -29,6 +29,12 @@ class Timing(C.Structure):
                 ("stream_bytes", C.c_uint64)]
 
 
+class IngestStats(C.Structure):
+    _fields_ = [("n_rows", C.c_uint32), ("n_fallback_rows", C.c_uint32), ("table_grows", C.c_uint32), ("reserved", C.c_uint32),
+                ("row_bytes", C.c_uint64), ("table_bytes", C.c_uint64), ("ms_walk", C.c_float), ("ms_union", C.c_float),
+                ("ms_build", C.c_float), ("reserved2", C.c_float)]
+
+
 class BloomGpuError(RuntimeError):
     def __init__(self, code: int, message: str):
         super().__init__(f"libbloomgpu error {code}: {message}")
@@ -45,6 +51,8 @@ EXPORTS = [
     "bsg_hash_entries", "bsg_build", "bsg_build_hashed", "bsg_arena_load", "bsg_arena_load_sections", "bsg_arena_free",
     "bsg_batch_create", "bsg_batch_free", "bsg_probe_batch", "bsg_probe_many", "bsg_probe", "bsg_timing_read", "bsg_set_timed_stride", "bsg_last_kernel_ms",
     "bsg_or_reduce", "bsg_or_words_dev", "bsg_or_reduce_dev",
+    "bsg_ingest_rows", "bsg_ingest_fallback_rows", "bsg_ingest_add_entries", "bsg_ingest_finish", "bsg_ingest_build",
+    "bsg_ingest_stats_read", "bsg_ingest_free",
 ]
 
 _lib = None
@@ -84,6 +92,13 @@ def load():
     L.bsg_or_reduce.argtypes = [vp, u64, u32, vp, u64]
     L.bsg_or_words_dev.argtypes = [vp, vp, vp, u64, u32]
     L.bsg_or_reduce_dev.argtypes = [vp, u64, u32, vp, u64]
+    L.bsg_ingest_rows.argtypes = [vp, vp, vp, u32, vp, u32, vp, u32, vp, C.POINTER(u64)]
+    L.bsg_ingest_fallback_rows.argtypes = [vp, u64, vp, u32, C.POINTER(u32)]
+    L.bsg_ingest_add_entries.argtypes = [vp, u64, vp, vp, u32, vp, vp]
+    L.bsg_ingest_finish.argtypes = [vp, u64, vp, vp]
+    L.bsg_ingest_build.argtypes = [vp, u64, vp, vp, u64]
+    L.bsg_ingest_stats_read.argtypes = [vp, u64, C.POINTER(IngestStats)]
+    L.bsg_ingest_free.argtypes = [vp, u64]
     for name in EXPORTS:
         if name != "bsg_last_error":
             getattr(L, name).restype = i32

@@ -7,6 +7,7 @@
 // entry point fails with BSG_E_NODEVICE / BSG_E_HIP.
 #include "bloomgpu.h"
 #include "kernels.hip.h"
+#include "ingest.hip.h"
 #include <hip/hip_ext.h>
 
 #include <algorithm>
@@ -139,6 +140,8 @@ struct Batch {
     std::vector<BatchDev> dev;
 };
 
+struct Ingest;   // ingest_api.inc
+
 }  // namespace
 
 struct bsg_ctx {
@@ -146,6 +149,7 @@ struct bsg_ctx {
     std::mutex mu;  // handle tables
     std::map<uint64_t, std::shared_ptr<Arena>> arenas;
     std::map<uint64_t, std::shared_ptr<Batch>> batches;
+    std::map<uint64_t, std::shared_ptr<Ingest>> ingests;
     uint64_t next_id = 1;
     bsg_timing timing{};
     uint32_t timed_stride = 1;   // with BSG_PROBE_TIMED, timestamp every timed_stride-th probe
@@ -153,6 +157,8 @@ struct bsg_ctx {
 };
 
 namespace {
+
+void free_all_ingests(bsg_ctx *ctx);   // ingest_api.inc
 
 int32_t use_device(Device &d)
 {
@@ -350,6 +356,7 @@ int32_t bsg_close(bsg_ctx *ctx)
     if (!ctx) return BSG_OK;
     for (auto &kv : ctx->arenas) free_arena(ctx, *kv.second);
     for (auto &kv : ctx->batches) free_batch(ctx, *kv.second);
+    free_all_ingests(ctx);
     for (auto &dp : ctx->devs) {
         Device &d = *dp;
         (void)hipSetDevice(d.id);
@@ -1282,3 +1289,5 @@ int32_t bsg_or_reduce(bsg_ctx *ctx, uint64_t arena_id, uint32_t kind, uint64_t *
 }
 
 }  // extern "C"
+
+#include "ingest_api.inc"

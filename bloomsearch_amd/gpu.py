@@ -10,7 +10,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import DESC_DTYPE, TERM_DTYPE, BloomGpuError, Timing
+from ._lib import DESC_DTYPE, TERM_DTYPE, BloomGpuError, IngestStats, Timing
 
 
 def pack_entries(entries):
@@ -181,3 +181,59 @@ class Context:
 
     def or_words_dev(self, d_dst_ptr: int, d_src_ptr: int, n_words: int, n_src: int):
         self._check(self.L.bsg_or_words_dev(self.h, C.c_void_p(d_dst_ptr), C.c_void_p(d_src_ptr), n_words, n_src))
+
+    # ---- device ingest (rows -> distinct entries -> counts -> bitsets) ----
+    def ingest_rows(self, rows, set_first_row, parent_of_set=None, n_parents: int = 0, slots_hint=None) -> int:
+        """rows: list[bytes] (or (u8 blob, u64 offsets[n+1])); returns the ingest id."""
+        if isinstance(rows, tuple):
+            blob, off = rows
+            blob = np.ascontiguousarray(blob, dtype=np.uint8)
+            off = np.ascontiguousarray(off, dtype=np.uint64)
+        else:
+            off = np.zeros(len(rows) + 1, dtype=np.uint64)
+            if rows:
+                off[1:] = np.cumsum([len(r) for r in rows], dtype=np.uint64)
+            blob = np.frombuffer(b"".join(rows), dtype=np.uint8)
+        sfr = np.ascontiguousarray(set_first_row, dtype=np.uint32)
+        pos = None if parent_of_set is None else np.ascontiguousarray(parent_of_set, dtype=np.uint32)
+        hint = None if slots_hint is None else np.ascontiguousarray(slots_hint, dtype=np.uint32)
+        out = C.c_uint64()
+        self._check(self.L.bsg_ingest_rows(self.h, _lib._ptr(blob), _lib._ptr(off), len(off) - 1, _lib._ptr(sfr), len(sfr) - 1,
+                                           _lib._ptr(pos), n_parents, _lib._ptr(hint), C.byref(out)))
+        return int(out.value)
+
+    def ingest_fallback_rows(self, ingest_id: int) -> np.ndarray:
+        n = C.c_uint32()
+        self._check(self.L.bsg_ingest_fallback_rows(self.h, ingest_id, None, 0, C.byref(n)))
+        out = np.zeros(n.value, dtype=np.uint32)
+        if n.value:
+            self._check(self.L.bsg_ingest_fallback_rows(self.h, ingest_id, _lib._ptr(out), n.value, C.byref(n)))
+        return out
+
+    def ingest_add_entries(self, ingest_id: int, entries, set_of_entry, kind_of_entry):
+        blob, off = pack_entries(entries)
+        so = np.ascontiguousarray(set_of_entry, dtype=np.uint32)
+        ko = np.ascontiguousarray(kind_of_entry, dtype=np.uint32)
+        self._check(self.L.bsg_ingest_add_entries(self.h, ingest_id, _lib._ptr(blob), _lib._ptr(off), len(off) - 1,
+                                                  _lib._ptr(so), _lib._ptr(ko)))
+
+    def ingest_finish(self, ingest_id: int, n_sets_total: int):
+        """-> (counts u64 [n_sets_total, 3], status u32 [n_sets_total])"""
+        counts = np.zeros((n_sets_total, 3), dtype=np.uint64)
+        status = np.zeros(n_sets_total, dtype=np.uint32)
+        self._check(self.L.bsg_ingest_finish(self.h, ingest_id, _lib._ptr(counts), _lib._ptr(status)))
+        return counts, status
+
+    def ingest_build(self, ingest_id: int, desc, n_words: int) -> np.ndarray:
+        desc = np.ascontiguousarray(desc, dtype=DESC_DTYPE)
+        out = np.zeros(n_words, dtype=np.uint64)
+        self._check(self.L.bsg_ingest_build(self.h, ingest_id, _lib._ptr(desc), _lib._ptr(out), n_words))
+        return out
+
+    def ingest_stats(self, ingest_id: int) -> IngestStats:
+        st = IngestStats()
+        self._check(self.L.bsg_ingest_stats_read(self.h, ingest_id, C.byref(st)))
+        return st
+
+    def ingest_free(self, ingest_id: int):
+        self._check(self.L.bsg_ingest_free(self.h, ingest_id))

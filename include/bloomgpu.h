@@ -202,6 +202,61 @@ BSG_API int32_t bsg_or_words_dev(bsg_ctx *ctx, void *d_dst, const void *d_src, u
 /* Per-device partial OR left on the device: writes n_words u64 at d_out. */
 BSG_API int32_t bsg_or_reduce_dev(bsg_ctx *ctx, uint64_t arena_id, uint32_t kind, void *d_out, uint64_t n_words);
 
+/* ---- device ingest: rows -> distinct bloom entries -> exact counts -> bitsets ----
+ * Replaces, on the flush / merge worker, the reference's per-row host loop
+ *   bloomEntrySets.indexRow (ingest.go:55-89: pathWalker.walk row_matcher.go:51-135, leafTokenInput
+ *   tokenizer.go:120-133, BasicWhitespaceLowerTokenizer tokenizer.go:141-143, addFieldToken ingest.go:95-102),
+ *   unionInto (ingest.go:105-115), counts (ingest.go:117-123) and buildFilters' AddString loop (ingest.go:127-145)
+ * for the DEFAULT tokenizer (the reference's own fast-path check, row_matcher.go:37-40; custom tokenizers
+ * keep the host path).  A "set" is one partition buffer's bloomEntrySets; set s owns rows
+ * [set_first_row[s], set_first_row[s+1]).  A "parent" is a file-level union (flush.go:221,253);
+ * parent_of_set[s] names it or is 0xFFFFFFFF.  Tables are indexed t = set * 3 + kind with parents
+ * numbered after the sets (set index n_sets + p).
+ *
+ * Call order:  bsg_ingest_rows -> [bsg_ingest_fallback_rows -> host walker -> bsg_ingest_add_entries]
+ *              -> bsg_ingest_finish (exact distinct counts; the caller sizes (m, k) with its own
+ *              EstimateParameters) -> bsg_ingest_build -> bsg_ingest_free.
+ * The device walker finishes rows of printable ASCII without backslashes (see ingest.hip.h); every other
+ * row is reported by bsg_ingest_fallback_rows and MUST be walked by the host and added back with
+ * bsg_ingest_add_entries before bsg_ingest_finish, or its entries are missing. */
+typedef struct bsg_ingest_stats {
+    uint32_t n_rows;
+    uint32_t n_fallback_rows;  /* rows left to the host walker */
+    uint32_t table_grows;      /* distinct-entry tables that had to be enlarged (x4 + rehash) */
+    uint32_t reserved;
+    uint64_t row_bytes;
+    uint64_t table_bytes;      /* HBM held by the distinct-entry tables */
+    float ms_walk;             /* k_ingest_rows dispatch time (sum over re-runs after a table grew) */
+    float ms_union;            /* k_ingest_union into the parents */
+    float ms_build;            /* k_build_sets */
+    float reserved2;
+} bsg_ingest_stats;
+
+/* rows: marshaled JSON, row r = rows[row_off[r] .. row_off[r+1]) without a trailing newline.
+ * slots_hint: optional initial table capacities [n_sets * 3] (0 = default: 256 for fields, 4 per row for
+ * tokens and field::tokens); tables grow on demand, a hint only saves the re-run. */
+BSG_API int32_t bsg_ingest_rows(bsg_ctx *ctx, const uint8_t *rows, const uint64_t *row_off, uint32_t n_rows,
+                                const uint32_t *set_first_row, uint32_t n_sets, const uint32_t *parent_of_set,
+                                uint32_t n_parents, const uint32_t *slots_hint, uint64_t *out_ingest_id);
+/* Row indices (ascending) the host walker must finish; rows_out may be NULL to query the count. */
+BSG_API int32_t bsg_ingest_fallback_rows(bsg_ctx *ctx, uint64_t ingest_id, uint32_t *rows_out, uint32_t cap,
+                                         uint32_t *n_out);
+/* Entries produced by the host walker for the fallback rows: packed like bsg_hash_entries, each tagged
+ * with its set (< n_sets) and kind. */
+BSG_API int32_t bsg_ingest_add_entries(bsg_ctx *ctx, uint64_t ingest_id, const uint8_t *bytes, const uint32_t *offsets,
+                                       uint32_t n_entries, const uint32_t *set_of_entry, const uint32_t *kind_of_entry);
+/* Unions the sets into their parents and returns the exact distinct counts
+ * out_counts[(n_sets + n_parents) * 3] (bloomEntrySets.counts).  out_status[n_sets + n_parents] (may be
+ * NULL): 0 ok, 2 = the set met an entry whose base hashes contain a zero word and must be rebuilt on
+ * the host path (probability 2^-62 per entry). */
+BSG_API int32_t bsg_ingest_finish(bsg_ctx *ctx, uint64_t ingest_id, uint64_t *out_counts, uint32_t *out_status);
+/* desc[(n_sets + n_parents) * 3]: geometry and output offsets of every table's filter (m == 0 skips it);
+ * out_words as bsg_build. */
+BSG_API int32_t bsg_ingest_build(bsg_ctx *ctx, uint64_t ingest_id, const bsg_filter_desc *desc, uint64_t *out_words,
+                                 uint64_t n_words);
+BSG_API int32_t bsg_ingest_stats_read(bsg_ctx *ctx, uint64_t ingest_id, bsg_ingest_stats *out);
+BSG_API int32_t bsg_ingest_free(bsg_ctx *ctx, uint64_t ingest_id);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,204 @@
+"""Device ingest (bsg_ingest_*: rows -> distinct entries -> exact counts -> bitsets) vs the oracle.
+
+The checker is the pure-Python walker oracle (oracle/walker_oracle.py: indexRow) for the entry sets and
+the C oracle (oracle/bloom_oracle.c) for the bitsets; the product path is k_ingest_rows /
+k_ingest_union / k_build_sets through the C-ABI, with the C++ host walker finishing the rows the
+device walker hands back.  Row tables follow tokenizer_test.go:86-190 and
+no_false_negatives_test.go:103-321 (same rows as tests/test_host_tables.py).
+"""
+import json
+
+import numpy as np
+import pytest
+
+from bloomsearch_amd import host as Hst, ingest as I, synth
+from oracle import oracle as O
+from oracle import walker_oracle as W
+from tests.test_host_tables import JSON_MATCHING, KEYS, _random_value, go_marshal
+
+pytestmark = pytest.mark.gpu
+
+FPR = 0.001
+
+
+def oracle_sets(rows):
+    sets = (set(), set(), set())
+    for r in rows:
+        W.index_row(r, sets)
+    return sets
+
+
+def check_against_sets(res, set_index, sets, what=""):
+    """counts exact and bitsets bit-identical to the oracle's build of the same entry sets"""
+    for kind in range(3):
+        assert int(res.counts[set_index, kind]) == len(sets[kind]), (what, kind, sorted(sets[kind])[:8])
+        want = O.build_sized(sorted(sets[kind]), FPR)
+        d = res.desc[set_index * 3 + kind]
+        assert (int(d["m"]), int(d["k"])) == (want.m, want.k)
+        assert np.array_equal(res.filter_words(set_index, kind), want.words), (what, kind)
+
+
+def test_synthetic_log_rows_three_blocks_and_file(ctx):
+    row_sets = [synth.rows_json(b * 700, 700) for b in range(3)]
+    res = I.device_ingest(ctx, row_sets, FPR, parent_of_set=[0, 0, 0], n_parents=1)
+    assert len(res.fallback_rows) == 0            # printable ASCII, no escapes: all on the device
+    assert res.stats.n_rows == 2100 and res.stats.ms_walk > 0
+    union = (set(), set(), set())
+    for b, rows in enumerate(row_sets):
+        sets = oracle_sets(rows)
+        check_against_sets(res, b, sets, "block %d" % b)
+        for u, s in zip(union, sets):
+            u |= s
+    check_against_sets(res, 3, union, "file")     # parent = unionInto of the three blocks (flush.go:221,253)
+    assert not res.status.any()
+
+
+ROWS_DEVICE = [  # inside the device walker's envelope
+    b'{"a":1}', b'{"a":{"b":{"c":"Deep VALUE here"}}}', b'{"a.b.c":"x","d":[1,2,[3,{"e":"f"}]]}',
+    b'{".a":"xyz","id":4}', b'{"trail.":"v","x..y":"w","":"empty key"}', b'{"":{"":{"":"n"}}}',
+    b'{"n":null,"t":true,"f":false,"z":0,"neg":-0.5e+3,"E":1E5,"big":9007199254740993}',
+    b'{ "spaced" : [ "  two   words  " , "" , " " ] , "o" : { } , "arr" : [ ] }',
+    b'{"a::b":"x::y","a":"b::c"}', b'{"dup":"A a A","dup":"b"}', b'[{"top":"array"},5,"str"]', b'"just a string"', b'12',
+    b'{"MiXeD":"CamelCase UPPER lower 123ABC"}', b'{"k":"!@#$%^&*() ~`[]{};:,./<>?"}',
+    b'{"user":{"name":"John Doe","tags":[{"type":"admin"},{"role":"user"}]}}',
+]
+ROWS_HOST = [    # must be handed to the host walker
+    b'{"m":"\\u003chtml\\u003e\\u0026amp; x"}', b'{"back\\\\slash":"v","q?x":"y"}', '{"héllo":"日本語 ÀB"}'.encode(),
+    b'{"t":"tab\\there","n":"new\\nline"}', b'{"raw":"ctl\x01char"}', b'{"a":\t1}', '{"nbsp":"a b c"}'.encode(),
+    ('{' + '"a":{' * 17 + '"x":1' + '}' * 17 + '}').encode(),
+    ('{"' + 'k' * 150 + '":{"' + 'j' * 60 + '":1}}').encode(),
+    b'{"s":"\xff\xfe bad utf8"}',
+]
+ROWS_MALFORMED = [b'{"a": [1, 2', b'{"a":"x" "b":1}', b'{"a":tru}', b'{"ok":"first","b":01x}', b'{"a":1}}', b'{"a":"unterminated',
+                  b'', b'   ', b'{"a":1,}', b'{"k" 1}', b'{"a":-}', b'{"a":1.}', b'{"a":1e}', b'{"x":"y"} trailing']
+
+
+def host_sets(rows):
+    s = Hst.EntrySets()
+    for r in rows:
+        try:
+            s.index_row(r)
+        except Hst.HostError:
+            pass
+    return s.as_python_sets()
+
+
+def test_row_tables_one_set_per_row(ctx):
+    rows = ROWS_DEVICE + ROWS_HOST + [r.encode() for r, _ in JSON_MATCHING]
+    res = I.device_ingest(ctx, [[r] for r in rows], FPR)
+    fb = set(int(x) for x in res.fallback_rows)
+    assert fb.isdisjoint(range(len(ROWS_DEVICE))), [rows[i] for i in sorted(fb) if i < len(ROWS_DEVICE)]
+    assert set(range(len(ROWS_DEVICE), len(ROWS_DEVICE) + len(ROWS_HOST))) <= fb
+    for i, r in enumerate(rows):
+        want = host_sets([r])
+        try:
+            assert want == W.index_row(r), r      # host walker == Python oracle wherever the oracle parses the row
+        except (ValueError, UnicodeDecodeError):
+            pass
+        check_against_sets(res, i, want, r)
+
+
+def test_malformed_rows_keep_what_the_host_walker_keeps(ctx):
+    # a flagged row may have inserted a prefix of its entries on the device; the host walker re-inserts its own
+    # (lenient) prefix and the union must equal the host-only result
+    res = I.device_ingest(ctx, [[r] for r in ROWS_MALFORMED], FPR)
+    fb = set(int(x) for x in res.fallback_rows)
+    for i, r in enumerate(ROWS_MALFORMED):
+        check_against_sets(res, i, host_sets([r]), r)
+    assert fb == set(range(len(ROWS_MALFORMED)))
+
+
+def test_random_rows_mixed_device_and_host(ctx):
+    # the property generator of no_false_negatives_test.go:398-459 (re-seeded): ~half the rows carry escapes / UTF-8
+    rng = np.random.default_rng(11)
+    row_sets, plain = [], 0
+    for s in range(12):
+        rows = []
+        for _ in range(40):
+            obj = {KEYS[rng.integers(0, len(KEYS))]: _random_value(rng, 0) for _ in range(rng.integers(1, 6))}
+            rows.append(go_marshal(obj))
+        row_sets.append(rows)
+    parents = [s % 2 for s in range(12)]
+    res = I.device_ingest(ctx, row_sets, FPR, parent_of_set=parents, n_parents=2)
+    n_rows = sum(len(r) for r in row_sets)
+    assert 0 < len(res.fallback_rows) < n_rows
+    unions = [(set(), set(), set()), (set(), set(), set())]
+    for s, rows in enumerate(row_sets):
+        sets = oracle_sets(rows)
+        check_against_sets(res, s, sets, "set %d" % s)
+        for u, x in zip(unions[parents[s]], sets):
+            u |= x
+    check_against_sets(res, 12, unions[0], "parent 0")
+    check_against_sets(res, 13, unions[1], "parent 1")
+
+
+def test_ascii_fuzz_all_on_device(ctx):
+    # random printable-ASCII documents with random spacing: nothing may fall back, everything must match
+    rng = np.random.default_rng(5)
+    alphabet = [chr(c) for c in range(0x20, 0x7F) if chr(c) not in '"\\']
+
+    def rand_text(n):
+        return "".join(alphabet[rng.integers(0, len(alphabet))] for _ in range(n))
+
+    def rand_value(depth):
+        r = rng.random()
+        if depth < 5 and r < 0.25:
+            return {rand_text(rng.integers(0, 9)): rand_value(depth + 1) for _ in range(rng.integers(0, 4))}
+        if depth < 5 and r < 0.4:
+            return [rand_value(depth + 1) for _ in range(rng.integers(0, 4))]
+        if r < 0.55:
+            return int(rng.integers(-10 ** 12, 10 ** 12))
+        if r < 0.6:
+            return [None, True, False][rng.integers(0, 3)]
+        return rand_text(rng.integers(0, 40))
+
+    rows = []
+    for _ in range(600):
+        obj = {rand_text(rng.integers(0, 12)): rand_value(0) for _ in range(rng.integers(0, 6))}
+        sep = [(",", ":"), (", ", ": "), (" , ", " : ")][rng.integers(0, 3)]
+        rows.append(json.dumps(obj, separators=sep).encode())
+    row_sets = [rows[i::6] for i in range(6)]
+    res = I.device_ingest(ctx, row_sets, FPR, parent_of_set=[0] * 6, n_parents=1)
+    assert len(res.fallback_rows) == 0
+    union = (set(), set(), set())
+    for s, rs in enumerate(row_sets):
+        sets = oracle_sets(rs)
+        check_against_sets(res, s, sets, "set %d" % s)
+        for u, x in zip(union, sets):
+            u |= x
+    check_against_sets(res, 6, union, "file")
+
+
+def test_tables_grow_from_a_tiny_hint(ctx):
+    rows = synth.rows_json(0, 1500)
+    res = I.device_ingest(ctx, [rows], FPR, parent_of_set=[0], n_parents=1, slots_hint=[64, 64, 64])
+    assert res.stats.table_grows >= 2
+    sets = oracle_sets(rows)
+    check_against_sets(res, 0, sets, "grown")
+    check_against_sets(res, 1, sets, "parent of one")
+
+
+def test_empty_sets_and_rowless_ingest(ctx):
+    res = I.device_ingest(ctx, [[], [b'{"a":"b"}'], []], FPR, parent_of_set=[0, 0, 1], n_parents=2)
+    empty = (set(), set(), set())
+    check_against_sets(res, 0, empty)             # n' = max(0, 1): m = 15 bits, none set (ingest.go:135-140)
+    check_against_sets(res, 1, oracle_sets([b'{"a":"b"}']))
+    check_against_sets(res, 2, empty)
+    check_against_sets(res, 3, oracle_sets([b'{"a":"b"}']))
+    check_against_sets(res, 4, empty)
+
+
+def test_ingest_argument_errors(ctx):
+    from bloomsearch_amd._lib import BloomGpuError
+    with pytest.raises(BloomGpuError):
+        ctx.ingest_rows([b'{}'], [0, 2])                      # set_first_row does not span the rows
+    with pytest.raises(BloomGpuError):
+        ctx.ingest_rows([b'{}'], [0, 1], parent_of_set=[3], n_parents=1)
+    with pytest.raises(BloomGpuError):
+        ctx.ingest_finish(123456, 1)
+    ing = ctx.ingest_rows([b'{"a":1}'], [0, 1])
+    with pytest.raises(BloomGpuError):
+        ctx.ingest_build(ing, np.zeros(3, dtype=I.DESC_DTYPE), 2)   # finish has not run
+    ctx.ingest_free(ing)
+    with pytest.raises(BloomGpuError):
+        ctx.ingest_free(ing)
