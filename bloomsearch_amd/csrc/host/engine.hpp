@@ -43,6 +43,10 @@ struct EngineConfig {           // BloomSearchEngineConfig (engine.go:82-147), t
     uint64_t max_buffered_bytes = 1ull * 1024 * 1024;
     double bloom_false_positive_rate = 0.001;
     std::string partition_field;  // PartitionFunc stand-in: top-level key whose text is the partition id ("" = none)
+    // true: rows are only validated and buffered at ingest; walking, tokenizing, dedup, counting and the filter
+    // build all run on the device at flush / merge time (bsg_ingest_*), the host walker only finishing the rows
+    // the device walker hands back.  false: indexRow on the host at ingest time, as the reference does.
+    bool device_ingest = false;
 };
 
 struct DataBlock {
@@ -127,7 +131,7 @@ public:
         bool should_flush = false;
         for (size_t i = 0; i < rows.size(); ++i) {
             PartitionBuffer &pb = buffers_[pids[i]];
-            pb.entries.index_row(rows[i]);          // HOT: walk + tokenize + dedup (ingest.go:450)
+            if (!cfg_.device_ingest) pb.entries.index_row(rows[i]);   // HOT: walk + tokenize + dedup (ingest.go:450)
             pb.rows.emplace_back(rows[i]);
             pb.bytes += rows[i].size() + 4;
             buffered_rows_ += 1;
@@ -151,22 +155,28 @@ public:
             blk.partition_id = kv.first;
             blk.rows = std::move(kv.second.rows);
             blk.row_bytes = kv.second.bytes;
-            blk.counts = kv.second.entries.counts();
             blk.fpr = cfg_.bloom_false_positive_rate;
-            kv.second.entries.union_into(file_entries);   // flush.go:221
+            if (!cfg_.device_ingest) {
+                blk.counts = kv.second.entries.counts();
+                kv.second.entries.union_into(file_entries);   // flush.go:221
+            }
             file.blocks.push_back(std::move(blk));
         }
-        for (auto &kv : buffers_) sets.push_back(&kv.second.entries);
-        sets.push_back(&file_entries);                    // file-level filters sized for the union (flush.go:253)
         std::vector<std::vector<uint8_t>> sections;
-        if (int32_t rc = build_sections(sets, sections)) return rc;
+        if (cfg_.device_ingest) {
+            if (int32_t rc = build_sections_device(file, sections)) return rc;
+        } else {
+            for (auto &kv : buffers_) sets.push_back(&kv.second.entries);
+            sets.push_back(&file_entries);                    // file-level filters sized for the union (flush.go:253)
+            if (int32_t rc = build_sections(sets, sections)) return rc;
+            file.counts = file_entries.counts();
+        }
         uint64_t off = 0;
         for (size_t b = 0; b < file.blocks.size(); ++b) {
             file.blocks[b].filter_section = std::move(sections[b]);
             file.blocks[b].block_offset = off;
             off += file.blocks[b].row_bytes;
         }
-        file.counts = file_entries.counts();
         file.filter_section = std::move(sections.back());
         files_.push_back(std::move(file));
         buffers_.clear();
@@ -191,8 +201,10 @@ public:
             DataBlock cur;
             auto start_block = [&]() { cur = DataBlock{}; cur.partition_id = kv.first; cur.fpr = cfg_.bloom_false_positive_rate; block_sets.push_back(std::make_unique<BloomEntrySets>()); };
             auto finish_block = [&]() {
-                cur.counts = block_sets.back()->counts();
-                block_sets.back()->union_into(file_entries);
+                if (!cfg_.device_ingest) {
+                    cur.counts = block_sets.back()->counts();
+                    block_sets.back()->union_into(file_entries);
+                }
                 out.blocks.push_back(std::move(cur));
             };
             start_block();
@@ -200,25 +212,29 @@ public:
                 if (!cur.rows.empty() && (cur.rows.size() + src->rows.size() > cfg_.max_row_group_rows ||
                                           cur.row_bytes + src->row_bytes > cfg_.max_row_group_bytes)) { finish_block(); start_block(); }
                 for (auto &r : src->rows) {
-                    block_sets.back()->index_row(r);      // merge.go:746
+                    if (!cfg_.device_ingest) block_sets.back()->index_row(r);      // merge.go:746
                     cur.row_bytes += r.size() + 4;
                     cur.rows.push_back(std::move(r));
                 }
             }
             finish_block();
         }
-        std::vector<const BloomEntrySets *> sets;
-        for (auto &s : block_sets) sets.push_back(s.get());
-        sets.push_back(&file_entries);
         std::vector<std::vector<uint8_t>> sections;
-        if (int32_t rc = build_sections(sets, sections)) return rc;
+        if (cfg_.device_ingest) {
+            if (int32_t rc = build_sections_device(out, sections)) return rc;
+        } else {
+            std::vector<const BloomEntrySets *> sets;
+            for (auto &s : block_sets) sets.push_back(s.get());
+            sets.push_back(&file_entries);
+            if (int32_t rc = build_sections(sets, sections)) return rc;
+            out.counts = file_entries.counts();
+        }
         uint64_t off = 0;
         for (size_t b = 0; b < out.blocks.size(); ++b) {
             out.blocks[b].filter_section = std::move(sections[b]);
             out.blocks[b].block_offset = off;
             off += out.blocks[b].row_bytes;
         }
-        out.counts = file_entries.counts();
         out.filter_section = std::move(sections.back());
         files_.clear();
         files_.push_back(std::move(out));
@@ -342,6 +358,96 @@ private:
             sections[s] = encode_filter_section(fv);
         }
         return kEngineOk;
+    }
+
+    // Device ingest of one file's blocks (flush.go:179-254 / merge.go:706-804 with a1-a5 on the GPU): rows ->
+    // bsg_ingest_rows, the rows it hands back -> host walker -> bsg_ingest_add_entries, exact counts ->
+    // EstimateParameters on the host -> bsg_ingest_build -> encodeFilterSection.  Fills the blocks' and the
+    // file's BloomEntryCounts.  sections = one per block, then the file-level one.
+    int32_t build_sections_device(DataFile &file, std::vector<std::vector<uint8_t>> &sections)
+    {
+        const size_t nb = file.blocks.size();
+        std::vector<uint8_t> bytes;
+        std::vector<uint64_t> row_off{0};
+        std::vector<uint32_t> first{0}, parent(nb, 0), set_of_row;
+        for (size_t b = 0; b < nb; ++b) {
+            for (const std::string &r : file.blocks[b].rows) {
+                bytes.insert(bytes.end(), r.begin(), r.end());
+                row_off.push_back(bytes.size());
+                set_of_row.push_back((uint32_t)b);
+            }
+            first.push_back((uint32_t)set_of_row.size());
+        }
+        uint64_t ing = 0;
+        if (bsg_ingest_rows(ctx_, bytes.data(), row_off.data(), (uint32_t)set_of_row.size(), first.data(), (uint32_t)nb,
+                            parent.data(), 1, nullptr, &ing))
+            return fail(kErrGpu, bsg_last_error(ctx_));
+        struct Free { bsg_ctx *c; uint64_t id; ~Free() { bsg_ingest_free(c, id); } } guard{ctx_, ing};
+        uint32_t n_fb = 0;
+        if (bsg_ingest_fallback_rows(ctx_, ing, nullptr, 0, &n_fb)) return fail(kErrGpu, bsg_last_error(ctx_));
+        if (n_fb) {
+            std::vector<uint32_t> fb(n_fb);
+            if (bsg_ingest_fallback_rows(ctx_, ing, fb.data(), n_fb, &n_fb)) return fail(kErrGpu, bsg_last_error(ctx_));
+            std::map<uint32_t, BloomEntrySets> per_set;
+            for (uint32_t r : fb) {
+                const uint32_t b = set_of_row[r];
+                per_set[b].index_row(file.blocks[b].rows[r - first[b]]);
+            }
+            std::vector<uint8_t> eb;
+            std::vector<uint32_t> eo{0}, es, ek;
+            for (auto &kv : per_set)
+                for (uint32_t c = 0; c < 3; ++c) {
+                    const size_t before = eo.size() - 1;
+                    pack_entries(kv.second.set_of(c), eb, eo);
+                    es.insert(es.end(), eo.size() - 1 - before, kv.first);
+                    ek.insert(ek.end(), eo.size() - 1 - before, c);
+                }
+            if (bsg_ingest_add_entries(ctx_, ing, eb.data(), eo.data(), (uint32_t)es.size(), es.data(), ek.data()))
+                return fail(kErrGpu, bsg_last_error(ctx_));
+        }
+        std::vector<uint64_t> counts((nb + 1) * 3);
+        std::vector<uint32_t> status(nb + 1);
+        if (bsg_ingest_finish(ctx_, ing, counts.data(), status.data())) return fail(kErrGpu, bsg_last_error(ctx_));
+        for (uint32_t st : status)
+            if (st != 0) return build_sections_host_rows(file, sections);   // a set the device tables cannot represent (2^-62/entry)
+        std::vector<bsg_filter_desc> desc((nb + 1) * 3);
+        uint64_t cursor = 0;
+        for (size_t i = 0; i < desc.size(); ++i) {
+            uint64_t m = 0, k = 0;
+            if (bsg_estimate_parameters(std::max<uint64_t>(counts[i], 1), cfg_.bloom_false_positive_rate, &m, &k))
+                return fail(kErrGpu, bsg_last_error(ctx_));
+            desc[i] = bsg_filter_desc{cursor, m, (uint32_t)k, 0};
+            cursor += ((m + 63) / 64 + 1) / 2 * 2;
+        }
+        std::vector<uint64_t> words(std::max<uint64_t>(cursor, 2));
+        if (bsg_ingest_build(ctx_, ing, desc.data(), words.data(), words.size())) return fail(kErrGpu, bsg_last_error(ctx_));
+        sections.resize(nb + 1);
+        for (size_t s = 0; s <= nb; ++s) {
+            FilterView fv[3];
+            for (uint32_t c = 0; c < 3; ++c) fv[c] = FilterView{words.data() + desc[s * 3 + c].word_off, desc[s * 3 + c].m, desc[s * 3 + c].k};
+            sections[s] = encode_filter_section(fv);
+            BloomEntryCounts &bc = s < nb ? file.blocks[s].counts : file.counts;
+            bc = BloomEntryCounts{counts[s * 3], counts[s * 3 + 1], counts[s * 3 + 2]};
+        }
+        return kEngineOk;
+    }
+
+    // Host walker over every row of the file (the reference's own order of work), filters still built on the GPU.
+    int32_t build_sections_host_rows(DataFile &file, std::vector<std::vector<uint8_t>> &sections)
+    {
+        std::vector<std::unique_ptr<BloomEntrySets>> block_sets;
+        BloomEntrySets file_entries;
+        std::vector<const BloomEntrySets *> sets;
+        for (auto &blk : file.blocks) {
+            block_sets.push_back(std::make_unique<BloomEntrySets>());
+            for (const std::string &r : blk.rows) block_sets.back()->index_row(r);
+            blk.counts = block_sets.back()->counts();
+            block_sets.back()->union_into(file_entries);
+            sets.push_back(block_sets.back().get());
+        }
+        sets.push_back(&file_entries);
+        file.counts = file_entries.counts();
+        return build_sections(sets, sections);
     }
 
     // Hand the stored section bytes to the device as they are: CRC32C + big-endian decode run in

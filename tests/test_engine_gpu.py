@@ -17,7 +17,20 @@ from tests.test_host_tables import KEYS, _random_value, go_marshal
 pytestmark = pytest.mark.gpu
 
 
+DEVICE_INGEST = False
+
+
+@pytest.fixture(autouse=True, params=[False, True], ids=["host-ingest", "device-ingest"])
+def ingest_mode(request):
+    """Every scenario runs twice: indexRow on the host at ingest time (the reference's order of work), and with
+    DeviceIngest (rows walked / tokenized / deduplicated / counted by k_ingest_rows at flush and merge time)."""
+    global DEVICE_INGEST
+    DEVICE_INGEST = request.param
+    yield
+
+
 def new_engine(ctx, **cfg):
+    cfg.setdefault("DeviceIngest", DEVICE_INGEST)
     return Hst.Engine(ctx, **cfg)
 
 
@@ -273,4 +286,36 @@ def test_c1_config_100k_rows_fieldtoken_level_error(ctx):
     assert len(st) == 10 and not any(b["BloomFilterSkipped"] for b in st) and sum(b["RowsProcessed"] for b in st) == 100000
     miss = e.query(Q.FieldToken("level", "fatal"))
     assert miss["rows"] == [] and miss["stats"]["FilesBloomSkipped"] == 10 and miss["stats"]["BlockStats"] == []
-    print("ingest+flush (host walk/tokenize/dedup + GPU build): %.2f us/row" % (t_ing / 100000 * 1e6))
+    print("ingest+flush (%s): %.2f us/row" % ("device ingest" if DEVICE_INGEST else "host walk/tokenize/dedup + GPU build",
+                                              t_ing / 100000 * 1e6))
+
+
+def test_device_ingest_writes_the_same_bytes_as_host_ingest(ctx):
+    """Same rows through both ingest modes, flush + second flush + merge: every stored filter section (block-level and
+    file-level) and every BloomEntryCounts stamp is byte-identical — the device walker changes where the work runs,
+    not one bit of what is written."""
+    rng = np.random.default_rng(23)
+    batches = []
+    for b in range(2):
+        rows = []
+        for i in range(400):
+            obj = {KEYS[rng.integers(0, len(KEYS))]: _random_value(rng, 0) for _ in range(rng.integers(1, 6))}
+            obj["partition"] = "p%d" % (i % 4)
+            obj["Msg"] = "Shared WORDS %d and MiXeD case" % (i % 17)
+            rows.append(go_marshal(obj))
+        batches.append(rows)
+    engines = [Hst.Engine(ctx, PartitionField="partition", MaxBufferedRows=100000, DeviceIngest=mode) for mode in (False, True)]
+    for e in engines:
+        for rows in batches:
+            e.ingest_rows(rows)
+            e.flush()
+
+    def snapshot(e):
+        d = e.describe()
+        return d, [[e.section_bytes(f, b) for b in range(-1, len(fl["blocks"]))] for f, fl in enumerate(d["files"])]
+    (d0, s0), (d1, s1) = snapshot(engines[0]), snapshot(engines[1])
+    assert d0 == d1 and s0 == s1 and len(d0["files"]) == 2 and len(d0["files"][0]["blocks"]) == 4
+    for e in engines:
+        e.merge()
+    (d0, s0), (d1, s1) = snapshot(engines[0]), snapshot(engines[1])
+    assert d0 == d1 and s0 == s1 and len(d0["files"]) == 1
