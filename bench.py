@@ -50,6 +50,60 @@ def generate_blocks(block_ids, rows, seed, workers):
         return pool.map(_gen_block, jobs, chunksize=max(1, len(jobs) // (workers * 4)))
 
 
+def _gen_rows(args):
+    from bloomsearch_amd import synth
+    b, rows, seed = args
+    rs = synth.rows_json(b * rows, rows, seed)
+    return b"".join(rs), np.asarray([len(r) for r in rs], dtype=np.uint32)
+
+
+def ingest_leg(ctx, n_blocks, rows, seed, workers, plan, words, fpr, log):
+    """C3 from the front of the path: the JSON rows of the first n_blocks blocks -> k_ingest_rows (walk, tokenize,
+    hash, dedup) -> k_ingest_union (file-level sets) -> exact counts -> k_build_sets.  The bitsets must equal the ones
+    bsg_build produced from the pre-extracted entry sets of the same blocks, bit for bit."""
+    import multiprocessing as mp
+    from bloomsearch_amd import ingest as I
+    t0 = time.time()
+    jobs = [(b, rows, seed) for b in range(n_blocks)]
+    with mp.get_context("fork").Pool(min(workers, n_blocks)) as pool:
+        parts = pool.map(_gen_rows, jobs)
+    blob = np.frombuffer(b"".join(p[0] for p in parts), dtype=np.uint8)
+    lens = np.concatenate([p[1] for p in parts])
+    off = np.zeros(len(lens) + 1, dtype=np.uint64)
+    np.cumsum(lens, out=off[1:])
+    first = np.arange(n_blocks + 1, dtype=np.uint32) * rows
+    t_gen = time.time() - t0
+    t0 = time.time()
+    ing = ctx.ingest_rows((blob, off), first, np.zeros(n_blocks, dtype=np.uint32), 1)
+    fb = ctx.ingest_fallback_rows(ing)
+    counts, status = ctx.ingest_finish(ing, n_blocks + 1)
+    desc, n_words = I.plan_desc(counts, fpr)
+    got = ctx.ingest_build(ing, desc, n_words)
+    t_e2e = time.time() - t0
+    st = ctx.ingest_stats(ing)
+    ctx.ingest_free(ing)
+    if len(fb) or status.any():
+        sys.exit("device ingest handed back %d synthetic rows / flagged a set" % len(fb))
+    for i in range(n_blocks * 3):
+        d, e = desc[i], plan.desc[i]
+        nw = (int(d["m"]) + 63) // 64
+        if (int(d["m"]), int(d["k"])) != (int(e["m"]), int(e["k"])) or not np.array_equal(
+                got[int(d["word_off"]): int(d["word_off"]) + nw], words[int(e["word_off"]): int(e["word_off"]) + nw]):
+            sys.exit("device ingest filter %d differs from bsg_build of the same block's entry sets" % i)
+    kern_ms = st.ms_walk + st.ms_union + st.ms_build
+    n_rows = n_blocks * rows
+    log("device ingest: %d rows (%.0f MB JSON) walk %.2f ms + union %.2f ms + build %.2f ms = %.1f M rows/s on-device; "
+        "%.3fs end to end incl. H2D (row generation %.1fs); filters bit-identical to bsg_build"
+        % (n_rows, st.row_bytes / 1e6, st.ms_walk, st.ms_union, st.ms_build, n_rows / kern_ms / 1e3, t_e2e, t_gen))
+    return {"workload": "C3 from rows: %d blocks x %d JSON rows -> %d block filters + 3 file-level filters" % (n_blocks, rows, 3 * n_blocks),
+            "kernels": {"k_ingest_rows_ms": st.ms_walk, "k_ingest_union_ms": st.ms_union, "k_build_sets_ms": st.ms_build},
+            "rows": n_rows, "row_bytes": int(st.row_bytes), "rows_per_s_device": n_rows / kern_ms * 1e3,
+            "row_gb_per_s_walk": st.row_bytes / max(st.ms_walk, 1e-6) / 1e6, "end_to_end_s_incl_h2d": t_e2e,
+            "table_bytes": int(st.table_bytes), "table_grows": int(st.table_grows), "fallback_rows": int(len(fb)),
+            "distinct_entries": int(counts[:n_blocks].sum()), "file_level_distinct": [int(x) for x in counts[n_blocks]],
+            "check": "bitsets and (m, k) identical to bsg_build of the same blocks' entry sets"}
+
+
 def make_queries(n_queries, workload, seed):
     """C2 query batch.  'needle': And(FT(level), FT(service), FT(user_id)) — a log search for one
     user's events; 'lowcard': SURVEY C2's And(FT(level), FT(service), FT(nested.region)).
@@ -141,6 +195,8 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU baseline work (0 = skip)")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--no-decode", action="store_true", help="skip the device section-decode measurement")
+    ap.add_argument("--ingest-blocks", type=int, default=100,
+                    help="blocks of JSON rows pushed through the device ingest path (k_ingest_rows ...), 0 = skip")
     ap.add_argument("--scaled", type=int, default=64,
                     help="also time C2': the arena replicated this many times inside one launch (0/1 = skip)")
     ap.add_argument("--timed-every", type=int, default=16,
@@ -214,6 +270,10 @@ def main():
                   "end_to_end_s_incl_h2d": t2 - t1}
         log("device section decode: %.1f MB of sections in %.1f us kernel (%.0f GB/s), %.3fs incl. H2D (host encode for the test %.1fs)"
             % (sec_bytes / 1e6, dec_ms * 1e3, decode["achieved"], t2 - t1, t1 - t0))
+
+    ingest = None
+    if rank == 0 and world == 1 and args.ingest_blocks > 0:
+        ingest = ingest_leg(ctx, min(args.ingest_blocks, B), rows, 0xB100F5EA4C4, workers, plan, words, args.fpr, log)
 
     exprs = make_queries(NQ, args.workload, seed=1234)
     terms_per_query = 8 if args.workload == "c4" else 3
@@ -341,6 +401,8 @@ def main():
                         "entries_per_s": (len(plan.off) - 1) / max(build_ms, 1e-6) * 1e3}
         if decode:
             out["decode"] = decode
+        if ingest:
+            out["ingest"] = ingest
         if scaled:
             out["roofline_scaled"] = dict(scaled, bound="hbm", kernel="k_probe_terms", peak=HBM_PEAK_GBPS, unit="GB/s",
                                           note="C2' of SURVEY 8d: same filters replicated x%d at distinct addresses, one launch" % args.scaled)

@@ -13,9 +13,8 @@
 // backslash, nesting <= kMaxDepth, paths <= kPathCap bytes.  A row that leaves that envelope — or is
 // malformed — is appended to the fallback list and finished by the host walker (walker.hpp), which
 // handles escapes, UTF-8, Unicode white space / case folding and the lenient error semantics.
-// Set semantics make the hand-over exact without a validation pre-pass: the device grammar is never
-// laxer than the host's and emits in the same document order, so whatever a row inserted before it was
-// flagged is a subset of what the host walker inserts for that row, and inserts are idempotent.
+// The kernel walks every row twice: a validation pass (automaton only, no hashing) decides whether the row is the
+// device's, and only rows that pass are walked again to emit — a row handed to the host has inserted nothing.
 //
 // A "set" is the distinct-entry state of one partition buffer (child) or of one file (parent, the
 // union of its children): three open-addressing tables of 32-byte slots holding the four bloom/v3 base
@@ -28,9 +27,9 @@
 namespace bsg {
 
 constexpr int kIngestThreads = 256;
-constexpr uint32_t kPathCap = 200;      // longest path the device walker keeps (bytes)
+constexpr uint32_t kPathCap = 96;       // longest path the device walker keeps (bytes)
 constexpr uint32_t kMaxDepth = 16;      // container nesting handled on the device
-constexpr uint32_t kLaneLds = 228;      // 200 path + 16 stack + pad = 57 dwords (odd stride: lanes spread over LDS banks)
+constexpr uint32_t kLaneLds = 116;      // 96 path + 16 stack + pad = 29 dwords (odd stride: lanes spread over LDS banks)
 constexpr uint32_t kMaxProbe = 96;      // linear-probe bound before a table is declared full
 constexpr uint32_t kSpinLimit = 4096;   // re-reads of a claimed slot whose h1..h3 are still in flight
 
@@ -94,65 +93,100 @@ __device__ __forceinline__ void st_agent(uint64_t *p, uint64_t v)
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Inserts the entry with base hashes h into table t.
+// One insert in flight: probe position and outcome.
+struct InsertState {
+    uint32_t idx, probes, spins;
+    bool done, present;   // present: the entry was found already stored (a duplicate)
+};
+
+__device__ __forceinline__ void insert_begin(InsertState &x, const IngestTable t, const uint64_t h[4], bool active, uint32_t *status)
+{
+    x.idx = (uint32_t)(h[1] >> 20) & t.mask;   // h0 is the claim word; index with bits of h1
+    x.probes = x.spins = 0;
+    x.present = false;
+    x.done = !active;
+    if (active && (h[0] == 0 || h[1] == 0 || h[2] == 0 || h[3] == 0)) {
+        __hip_atomic_store(status, kTableExotic, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        x.done = true;
+    }
+}
+
+// Inserts up to two entries per lane (A into ta, B into tb), their table round trips overlapped: each trip loads
+// both candidate slots (all four words: one cache line each), then issues both claims, then settles both.
+// present_x reports that the entry was found already stored (a duplicate), not that this call stored it.
 // SIMT note: the loop leaves only when EVERY active lane is done (wave-uniform __ballot exit) and the winner's
-// stores of h1..h3 sit inside the loop body.  With a per-lane exit the compiler places the winner's
-// "store, then leave" block after the loop — executed once the whole wave has left it — so lanes of the
-// same wave racing on one entry never see h1..h3 and insert duplicates (measured: 64 equal rows -> 64 "distinct").
-// Every trip does a bounded amount of work (no inner wait).
+// stores of h1..h3 sit inside the loop body.  With a per-lane exit the compiler places the winner's "store, then
+// leave" block after the loop — executed once the whole wave has left it — so lanes of the same wave racing on one
+// entry never see h1..h3 and insert duplicates (measured: 64 equal rows -> 64 "distinct").  Every trip does a
+// bounded amount of work (no inner wait).
+__device__ __forceinline__ void set_insert2(const IngestTable ta, const uint64_t ha[4], bool active_a, uint32_t *count_a, uint32_t *status_a,
+                                            bool &present_a,
+                                            const IngestTable tb, const uint64_t hb[4], bool active_b, uint32_t *count_b, uint32_t *status_b,
+                                            bool &present_b)
+{
+    InsertState A, B;
+    insert_begin(A, ta, ha, active_a, status_a);
+    insert_begin(B, tb, hb, active_b, status_b);
+    do {
+        uint64_t *sa = ta.slots + (uint64_t)A.idx * 4, *sb = tb.slots + (uint64_t)B.idx * 4;
+        uint64_t a0 = 0, a1 = 0, a2 = 0, a3 = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+        if (!A.done) { a0 = ld_agent(sa); a1 = ld_agent(sa + 1); a2 = ld_agent(sa + 2); a3 = ld_agent(sa + 3); }
+        if (!B.done) { b0 = ld_agent(sb); b1 = ld_agent(sb + 1); b2 = ld_agent(sb + 2); b3 = ld_agent(sb + 3); }
+        const bool cas_a = !A.done && a0 == 0, cas_b = !B.done && b0 == 0;
+        uint64_t old_a = 0, old_b = 0;
+        bool won_a = false, won_b = false;
+        if (cas_a) won_a = __hip_atomic_compare_exchange_strong(sa, &old_a, ha[0], __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cas_b) won_b = __hip_atomic_compare_exchange_strong(sb, &old_b, hb[0], __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#define BSG_SETTLE(X, won, cas, s, h, c0, c1, c2, c3, tab, count, status)                                              \
+        if (!X.done) {                                                                                                   \
+            if (won) {                                                                                                   \
+                st_agent(s + 1, h[1]); st_agent(s + 2, h[2]); st_agent(s + 3, h[3]);                                     \
+                __hip_atomic_fetch_add(count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                           \
+                X.done = true;            /* a first insert: present stays false, see the cache policy */               \
+            } else if (!cas) {            /* (a lost claim looks at the same slot again on the next trip) */             \
+                bool advance = true;                                                                                     \
+                if (c0 == h[0]) {                                                                                        \
+                    if (c1 == h[1] && c2 == h[2] && c3 == h[3]) { X.done = true; X.present = true; advance = false; }    \
+                    else if ((c1 == 0 || c2 == 0 || c3 == 0) && X.spins < kSpinLimit) { X.spins += 1; advance = false; } \
+                }                         /* else: a different entry (possibly with the same h0) */                      \
+                if (advance) {                                                                                           \
+                    X.idx = (X.idx + 1) & tab.mask;                                                                      \
+                    X.probes += 1;                                                                                       \
+                    if (X.probes > kMaxProbe) {                                                                          \
+                        __hip_atomic_store(status, kTableOverflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          \
+                        X.done = true;                                                                                   \
+                    } else if ((X.probes & 15u) == 0u &&                                                                 \
+                               __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != kTableOk) {      \
+                        X.done = true;    /* the table is already flagged: the launch is repeated after it has grown */  \
+                    }                                                                                                    \
+                }                                                                                                        \
+            }                                                                                                            \
+        }
+        BSG_SETTLE(A, won_a, cas_a, sa, ha, a0, a1, a2, a3, ta, count_a, status_a)
+        BSG_SETTLE(B, won_b, cas_b, sb, hb, b0, b1, b2, b3, tb, count_b, status_b)
+#undef BSG_SETTLE
+    } while (__ballot(!A.done || !B.done) != 0ull);
+    present_a = A.present;
+    present_b = B.present;
+}
+
 __device__ __forceinline__ void set_insert(const IngestTable t, const uint64_t h[4], uint32_t *count, uint32_t *status)
 {
-    bool done = __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != kTableOk;
-    if (!done && (h[0] == 0 || h[1] == 0 || h[2] == 0 || h[3] == 0)) {
-        __hip_atomic_store(status, kTableExotic, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        done = true;
-    }
-    uint32_t idx = (uint32_t)(h[1] >> 20) & t.mask;   // h0 is the claim word; index with bits of h1
-    uint32_t probes = 0, spins = 0;
-    do {
-        if (!done) {
-            uint64_t *slot = t.slots + (uint64_t)idx * 4;
-            uint64_t cur = ld_agent(slot);
-            if (cur == 0) {
-                uint64_t expected = 0;
-                if (__hip_atomic_compare_exchange_strong(slot, &expected, h[0], __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                         __HIP_MEMORY_SCOPE_AGENT)) {
-                    st_agent(slot + 1, h[1]);
-                    st_agent(slot + 2, h[2]);
-                    st_agent(slot + 3, h[3]);
-                    __hip_atomic_fetch_add(count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    done = true;
-                } else {
-                    cur = expected;
-                }
-            }
-            if (!done) {
-                bool advance = true;
-                if (cur == h[0]) {
-                    const uint64_t a = ld_agent(slot + 1), b = ld_agent(slot + 2), c = ld_agent(slot + 3);
-                    if (a == h[1] && b == h[2] && c == h[3]) {
-                        done = true;                      // duplicate
-                        advance = false;
-                    } else if ((a == 0 || b == 0 || c == 0) && spins < kSpinLimit) {
-                        spins += 1;                       // the claimer's h1..h3 are still in flight: look again
-                        advance = false;
-                    }                                     // else: a different entry with the same h0
-                }
-                if (advance) {
-                    idx = (idx + 1) & t.mask;
-                    if (++probes > kMaxProbe) {
-                        __hip_atomic_store(status, kTableOverflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        done = true;
-                    }
-                }
-            }
-        }
-    } while (__ballot(!done) != 0ull);
+    bool pa, pb;
+    set_insert2(t, h, true, count, status, pa, t, h, false, count, status, pb);
 }
 
 // ---------------- row walker ----------------
+// One lane per row.  The walker is a RESUMABLE byte automaton: walker_step() runs until the lane has a request
+// (hash this path / finish this word), has used up its 8-byte chunk of row bytes, is done, or must hand the row to
+// the host.  k_ingest_rows drives a wave in rounds:
+//     (A) every lane parses on (divergent, registers + LDS only; chunk loads converged) until it has a request
+//     (B) all requests are hashed and inserted together (murmur finalisations and table round trips for 64 lanes at once)
+// Measured on MI355X, 1 M log rows: inserts from inside the divergent parse 12.6 ms; hashing inside the parse with
+// converged inserts 18 ms (13x more VALU instructions than one lane needs: the finalisations ran a few lanes at a
+// time); this scheme: see profiles/.
 struct IngestArgs {
-    const uint8_t *rows;            // 8-byte aligned, >= 8 readable bytes after the last row
+    const uint8_t *rows;            // 8-byte aligned, >= 16 readable bytes after the last row
     const uint64_t *row_off;        // [n_rows + 1]
     const uint32_t *set_first_row;  // [n_sets + 1], ascending
     const IngestTable *tables;      // [n_sets_total * 3]
@@ -164,209 +198,348 @@ struct IngestArgs {
     uint32_t n_sets;
 };
 
-struct RowReader {
-    const uint8_t *base;
-    uint64_t chunk;
-    uint64_t chunk_pos;
-    __device__ __forceinline__ uint32_t at(uint64_t pos)
-    {
-        const uint64_t a = pos & ~7ULL;
-        if (a != chunk_pos) {
-            chunk = *reinterpret_cast<const uint64_t *>(base + a);
-            chunk_pos = a;
-        }
-        return (uint32_t)(chunk >> ((pos & 7u) * 8u)) & 0xFFu;
-    }
-};
-
 typedef __attribute__((address_space(3))) uint8_t lds_u8;
 
-struct Walker {
-    RowReader rd;
-    lds_u8 *path;            // this lane's path buffer [kPathCap] followed by the container stack [kMaxDepth]
-    const IngestTable *tab;  // the row's set: tables[set * 3 + kind]
-    uint32_t *counts;
-    uint32_t *status;
+enum : uint32_t {
+    S_VALUE, S_VALUE_OR_CLOSE, S_KEY_OR_CLOSE, S_KEY_OPEN, S_KEY, S_COLON, S_PREFIX, S_STR, S_NUM, S_LIT, S_AFTER
+};
+enum : uint32_t { R_CONTINUE, R_DONE, R_FAIL };
+// What a lane asks the converged part of the loop to do for it (hashing is the expensive part of an emission —
+// two murmur3 finalisations per hash — so it runs once per round for all lanes instead of inside the divergent parse).
+enum : uint32_t {
+    Q_NONE,
+    Q_FIELD,   // path[0, len) is a field entry (container path or key prefix)
+    Q_LEAF,    // path[0, len) is a field entry AND the leaf's words continue from hash state(path + "::")
+    Q_WORD,    // a word ended: tok -> token entry, ft -> field::token entry
+};
 
-    __device__ __forceinline__ void hash_path(uint32_t len, HashStream &s)
-    {
-        hs_init(s);
-        for (uint32_t i = 0; i < len; ++i) hs_absorb(s, path[i]);
-    }
-    __device__ __forceinline__ void emit_field(uint32_t len)
-    {
-        HashStream s;
-        hash_path(len, s);
-        uint64_t h[4];
-        hs_finish(s, h);
-        set_insert(tab[0], h, counts + 0, status + 0);
-    }
-    // leaf with text = row bytes [s, e): field entry, then one token + one field::token entry per word
-    __device__ __forceinline__ void emit_leaf(uint32_t path_len, uint64_t s, uint64_t e)
-    {
-        HashStream ps;
-        hash_path(path_len, ps);
-        uint64_t h[4];
-        hs_finish(ps, h);
-        set_insert(tab[0], h, counts + 0, status + 0);
-        hs_absorb(ps, ':');
-        hs_absorb(ps, ':');            // ps = state after path + "::" (makeFieldTokenKey, tokenizer.go:509-511)
-        uint64_t p = s;
-        while (p < e) {
-            while (p < e && rd.at(p) == ' ') ++p;      // only 0x20 can occur: other white space sent the row to the host
-            if (p >= e) break;
-            HashStream tk, ft = ps;
-            hs_init(tk);
-            while (p < e) {
-                uint32_t c = rd.at(p);
-                if (c == ' ') break;
-                if (c - 'A' < 26u) c += 32;            // ASCII fold (appendFoldedWord fast path)
-                hs_absorb(tk, c);
-                hs_absorb(ft, c);
-                ++p;
-            }
-            hs_finish(tk, h);
-            set_insert(tab[1], h, counts + 1, status + 1);
-            hs_finish(ft, h);
-            set_insert(tab[2], h, counts + 2, status + 2);
-        }
-    }
+struct Walker {
+    uint64_t pos, end;
+    uint64_t cur;            // row bytes [pos & ~7, +8)
+    lds_u8 *path;            // this lane's path buffer [kPathCap] followed by the container stack [kMaxDepth]
+    uint32_t path_len, depth, objmask, st;
+    uint32_t aux;            // S_PREFIX: scan index; S_NUM: phase; S_LIT: matched chars
+    uint32_t key_len;        // path length including the key being read (S_KEY .. S_PREFIX)
+    uint32_t lit;            // S_LIT: 0 true, 1 false, 2 null
+    uint32_t req, req_len;   // pending request
+    bool quiet;              // leaf without a path (scalars at the root): nothing is emitted
+    bool in_token;
+    HashStream ps, tok, ft;  // path + "::" prefix state; current word; current path::word
 };
 
 __device__ __forceinline__ bool is_plain(uint32_t c) { return c >= 0x20u && c < 0x7Fu && c != '\\'; }
 
-// Returns false when the host walker must take the row.
-__device__ __forceinline__ bool walk_row(Walker &w, uint64_t pos, const uint64_t end)
+// EMIT = false is the validation pass: same automaton, no hashing, no requests.
+template <bool EMIT>
+__device__ __forceinline__ void leaf_start(Walker &w)
+{
+    w.quiet = !EMIT || w.path_len == 0;
+    w.in_token = false;
+    if (!w.quiet) { w.req = Q_LEAF; w.req_len = w.path_len; }
+}
+
+__device__ __forceinline__ void word_byte(Walker &w, uint32_t c)
+{
+    if (w.quiet) return;
+    if (!w.in_token) { hs_init(w.tok); w.ft = w.ps; w.in_token = true; }
+    if (c - 'A' < 26u) c += 32;                    // ASCII fold (appendFoldedWord fast path, row_matcher.go:187-202)
+    hs_absorb(w.tok, c);
+    hs_absorb(w.ft, c);
+}
+
+__device__ __forceinline__ bool word_end(Walker &w)
+{
+    if (w.quiet || !w.in_token) return false;
+    w.in_token = false;
+    w.req = Q_WORD;
+    return true;
+}
+
+// Number grammar -? digits (. digits)? ([eE] [+-]? digits)? as phases: 7 start, 0 after '-', 1 int digits,
+// 2 after '.', 3 fraction digits, 4 after e, 5 after exponent sign, 6 exponent digits.  Next phase or 0xFF.
+__device__ __forceinline__ uint32_t num_next(uint32_t phase, uint32_t c)
+{
+    const bool digit = c - '0' <= 9u;
+    switch (phase) {
+    case 7: return digit ? 1u : (c == '-' ? 0u : 0xFFu);
+    case 0: return digit ? 1u : 0xFFu;
+    case 1: return digit ? 1u : (c == '.' ? 2u : ((c | 0x20u) == 'e' ? 4u : 0xFFu));
+    case 2: return digit ? 3u : 0xFFu;
+    case 3: return digit ? 3u : ((c | 0x20u) == 'e' ? 4u : 0xFFu);
+    case 4: return digit ? 6u : ((c == '+' || c == '-') ? 5u : 0xFFu);
+    case 5: return digit ? 6u : 0xFFu;
+    default: return digit ? 6u : 0xFFu;
+    }
+}
+__device__ __forceinline__ bool num_accepting(uint32_t phase) { return phase == 1u || phase == 3u || phase == 6u; }
+
+// Runs until the lane has a request pending (w.req), has used up its chunk, is done, or must go to the host.
+template <bool EMIT>
+__device__ __forceinline__ uint32_t walker_step(Walker &w)
 {
     lds_u8 *stack = w.path + kPathCap;
-    uint32_t path_len = 0, depth = 0, objmask = 0;
-    enum { VALUE, AFTER, KEY } st = VALUE;
+    const uint64_t chunk_end = (w.pos & ~7ULL) + 8;   // bytes of w.cur that may be consumed this step
     for (;;) {
-        while (pos < end && w.rd.at(pos) == ' ') ++pos;
-        if (st == VALUE) {
-            if (pos >= end) return false;
-            const uint32_t c = w.rd.at(pos);
+        if (w.st == S_PREFIX) {
+            // every "."-split prefix of the key is a field entry, empty paths skipped (row_matcher.go:103-135)
+            while (EMIT && w.aux < w.key_len) {
+                const uint32_t j = w.aux++;
+                if (w.path[j] == '.' && j > 0) { w.req = Q_FIELD; w.req_len = j; return R_CONTINUE; }
+            }
+            w.path_len = w.key_len;
+            w.st = S_VALUE;
+        }
+        if (w.pos >= w.end) {
+            if (w.st == S_NUM && num_accepting(w.aux)) {          // a number ends with the row
+                w.st = S_AFTER;
+                if (word_end(w)) return R_CONTINUE;
+            }
+            return (w.st == S_AFTER && w.depth == 0) ? R_DONE : R_FAIL;
+        }
+        if (w.pos >= chunk_end) return R_CONTINUE;                // the next chunk is loaded by the converged part of the loop
+        const uint32_t c = (uint32_t)(w.cur >> ((w.pos & 7u) * 8u)) & 0xFFu;
+        switch (w.st) {
+        case S_VALUE_OR_CLOSE:
+            if (c == ' ') { ++w.pos; break; }
+            if (c == ']') { ++w.pos; --w.depth; w.st = S_AFTER; break; }
+            w.st = S_VALUE;
+            break;
+        case S_KEY_OR_CLOSE:
+            if (c == ' ') { ++w.pos; break; }
+            if (c == '}') { ++w.pos; --w.depth; w.st = S_AFTER; break; }
+            w.st = S_KEY_OPEN;
+            break;
+        case S_VALUE:
+            if (c == ' ') { ++w.pos; break; }
             if (c == '{' || c == '[') {
-                if (path_len > 0) w.emit_field(path_len);       // container with a non-empty path: non-leaf emission
-                if (depth >= kMaxDepth) return false;
-                stack[depth] = (uint8_t)path_len;
-                if (c == '{') objmask |= 1u << depth; else objmask &= ~(1u << depth);
-                ++depth;
-                ++pos;
-                while (pos < end && w.rd.at(pos) == ' ') ++pos;
-                if (pos >= end) return false;
-                const uint32_t c2 = w.rd.at(pos);
-                if (c2 == (c == '{' ? '}' : ']')) { ++pos; --depth; st = AFTER; continue; }
-                st = (c == '{') ? KEY : VALUE;
-                continue;
+                if (w.depth >= kMaxDepth) return R_FAIL;
+                stack[w.depth] = (uint8_t)w.path_len;
+                if (c == '{') w.objmask |= 1u << w.depth; else w.objmask &= ~(1u << w.depth);
+                ++w.depth;
+                ++w.pos;
+                w.st = (c == '{') ? S_KEY_OR_CLOSE : S_VALUE_OR_CLOSE;
+                if (EMIT && w.path_len > 0) { w.req = Q_FIELD; w.req_len = w.path_len; return R_CONTINUE; }   // container path: non-leaf emission
+                break;
             }
-            uint64_t s = pos, e = pos;
-            bool has_text = true;
-            if (c == '"') {
-                s = ++pos;
-                for (;;) {
-                    if (pos >= end) return false;
-                    const uint32_t b = w.rd.at(pos);
-                    if (b == '"') break;
-                    if (!is_plain(b)) return false;
-                    ++pos;
-                }
-                e = pos++;
-            } else if (c == 't') {
-                if (end - pos < 4 || w.rd.at(pos + 1) != 'r' || w.rd.at(pos + 2) != 'u' || w.rd.at(pos + 3) != 'e') return false;
-                pos += 4; e = pos;
-            } else if (c == 'f') {
-                if (end - pos < 5 || w.rd.at(pos + 1) != 'a' || w.rd.at(pos + 2) != 'l' || w.rd.at(pos + 3) != 's' ||
-                    w.rd.at(pos + 4) != 'e') return false;
-                pos += 5; e = pos;
-            } else if (c == 'n') {
-                if (end - pos < 4 || w.rd.at(pos + 1) != 'u' || w.rd.at(pos + 2) != 'l' || w.rd.at(pos + 3) != 'l') return false;
-                pos += 4; has_text = false;                     // null: field existence only (tokenizer.go:130-131)
-            } else {
-                // number: -? digits (. digits)? ([eE] [+-]? digits)?  — the text is the RAW literal (tokenizer.go:124-125)
-                if (c == '-') ++pos;
-                if (pos >= end || w.rd.at(pos) - '0' > 9u) return false;
-                while (pos < end && w.rd.at(pos) - '0' <= 9u) ++pos;
-                if (pos < end && w.rd.at(pos) == '.') {
-                    ++pos;
-                    if (pos >= end || w.rd.at(pos) - '0' > 9u) return false;
-                    while (pos < end && w.rd.at(pos) - '0' <= 9u) ++pos;
-                }
-                if (pos < end && (w.rd.at(pos) | 0x20u) == 'e') {
-                    ++pos;
-                    if (pos < end && (w.rd.at(pos) == '+' || w.rd.at(pos) == '-')) ++pos;
-                    if (pos >= end || w.rd.at(pos) - '0' > 9u) return false;
-                    while (pos < end && w.rd.at(pos) - '0' <= 9u) ++pos;
-                }
-                e = pos;
+            // a primitive: its first byte stays unconsumed until the leaf request has been served (the words' hash
+            // state continues from the path's)
+            if (c == '"') { ++w.pos; w.st = S_STR; }
+            else if (c == 't' || c == 'f' || c == 'n') { w.lit = c == 't' ? 0u : (c == 'f' ? 1u : 2u); w.aux = 0; w.st = S_LIT; }
+            else if (c == '-' || c - '0' <= 9u) { w.aux = 7; w.st = S_NUM; }
+            else return R_FAIL;
+            leaf_start<EMIT>(w);
+            if (w.req != Q_NONE) return R_CONTINUE;
+            break;
+        case S_KEY_OPEN:
+            if (c == ' ') { ++w.pos; break; }
+            if (c != '"') return R_FAIL;
+            ++w.pos;
+            w.key_len = w.path_len;
+            if (w.key_len > 0) {
+                if (w.key_len >= kPathCap) return R_FAIL;
+                w.path[w.key_len++] = '.';
             }
-            if (path_len > 0) {
-                if (has_text) w.emit_leaf(path_len, s, e);
-                else w.emit_field(path_len);
+            w.aux = w.key_len;                                      // first byte of the key inside the path buffer
+            w.st = S_KEY;
+            break;
+        case S_KEY:
+            ++w.pos;
+            if (c == '"') { w.st = S_COLON; break; }
+            if (!is_plain(c) || w.key_len >= kPathCap) return R_FAIL;
+            w.path[w.key_len++] = (uint8_t)c;
+            break;
+        case S_COLON:
+            if (c == ' ') { ++w.pos; break; }
+            if (c != ':') return R_FAIL;
+            ++w.pos;
+            w.st = S_PREFIX;                                        // w.aux still points at the key's first byte
+            break;
+        case S_STR:
+            ++w.pos;
+            if (c == '"') { w.st = S_AFTER; if (word_end(w)) return R_CONTINUE; break; }
+            if (c == ' ') { if (word_end(w)) return R_CONTINUE; break; }   // only 0x20 can occur: other white space fails below
+            if (!is_plain(c)) return R_FAIL;
+            word_byte(w, c);
+            break;
+        case S_NUM: {                                               // the token is the RAW literal (tokenizer.go:124-125)
+            const uint32_t nx = num_next(w.aux, c);
+            if (nx != 0xFFu) { w.aux = nx; word_byte(w, c); ++w.pos; break; }
+            if (!num_accepting(w.aux)) return R_FAIL;
+            w.st = S_AFTER;                                         // c is not part of the number: S_AFTER looks at it
+            if (word_end(w)) return R_CONTINUE;
+            break;
+        }
+        case S_LIT: {
+            // "true" / "fals"(+e) / "null" packed little-endian: no table lookup in divergent code
+            const uint32_t packed = w.lit == 0u ? 0x65757274u : (w.lit == 1u ? 0x736c6166u : 0x6c6c756eu);
+            const uint32_t want = w.aux == 4u ? (uint32_t)'e' : ((packed >> (8u * w.aux)) & 0xFFu);
+            if (c != want) return R_FAIL;
+            ++w.pos;
+            ++w.aux;
+            if (w.lit != 2u) word_byte(w, c);                       // null: field existence only (tokenizer.go:130-131)
+            if (w.aux == (w.lit == 1u ? 5u : 4u)) {
+                w.st = S_AFTER;
+                if (word_end(w)) return R_CONTINUE;
             }
-            st = AFTER;
-            continue;
+            break;
         }
-        if (st == AFTER) {
-            if (depth == 0) return pos == end;                  // nothing but spaces may follow the row's value
-            path_len = stack[depth - 1];
-            if (pos >= end) return false;
-            const uint32_t c = w.rd.at(pos);
-            const bool obj = (objmask >> (depth - 1)) & 1u;
-            if (c == ',') { ++pos; st = obj ? KEY : VALUE; continue; }
-            if (c == (obj ? '}' : ']')) { ++pos; --depth; st = AFTER; continue; }
-            return false;
+        default: {  // S_AFTER
+            if (c == ' ') { ++w.pos; break; }
+            if (w.depth == 0) return R_FAIL;                        // nothing but spaces may follow the row's value
+            w.path_len = stack[w.depth - 1];                        // array elements reuse the array's path; members restart from the object's
+            const bool obj = (w.objmask >> (w.depth - 1)) & 1u;
+            if (c == ',') { ++w.pos; w.st = obj ? S_KEY_OPEN : S_VALUE; break; }
+            if (c == (obj ? '}' : ']')) { ++w.pos; --w.depth; break; }
+            return R_FAIL;
         }
-        // KEY: "key" ':' — child path = parent + "." + key, key-prefix paths first (row_matcher.go:103-135)
-        if (pos >= end || w.rd.at(pos) != '"') return false;
-        ++pos;
-        uint32_t pl = path_len;
-        if (pl > 0) {
-            if (pl >= kPathCap) return false;
-            w.path[pl++] = '.';
         }
-        const uint32_t key_start = pl;
-        for (;;) {
-            if (pos >= end) return false;
-            const uint32_t b = w.rd.at(pos);
-            if (b == '"') break;
-            if (!is_plain(b) || pl >= kPathCap) return false;
-            w.path[pl++] = (uint8_t)b;
-            ++pos;
-        }
-        ++pos;
-        while (pos < end && w.rd.at(pos) == ' ') ++pos;
-        if (pos >= end || w.rd.at(pos) != ':') return false;
-        ++pos;
-        for (uint32_t j = key_start; j < pl; ++j)
-            if (w.path[j] == '.' && j > 0) w.emit_field(j);     // every "."-split prefix of the key, empty paths skipped
-        path_len = pl;
-        st = VALUE;
     }
 }
 
-__global__ __launch_bounds__(kIngestThreads) void k_ingest_rows(const IngestArgs a)
+// ---------------- workgroup dedup cache ----------------
+// Most emissions repeat entries this workgroup has just inserted (field paths, levels, message words ...).
+// A direct-mapped LDS cache of confirmed inserts (all four hashes, the table folded into word 0) answers those
+// without touching the table.  Lanes update it without locking: a torn entry can only produce a false hit for
+// an entry that agrees with two unrelated entries on 128 hash bits each.
+constexpr uint32_t kCacheEntries = 512;
+constexpr uint32_t kIngestLdsBytes = kCacheEntries * 32 + kIngestThreads * kLaneLds;   // cache, then the lanes' path buffers
+typedef __attribute__((address_space(3))) uint64_t lds_u64i;
+
+__device__ __forceinline__ bool cache_hit(const lds_u64i *cache, uint32_t table_id, const uint64_t h[4])
+{
+    const uint64_t tag = h[0] ^ ((uint64_t)(table_id + 1) * 0x9E3779B97F4A7C15ULL);
+    const lds_u64i *e = cache + (size_t)((uint32_t)(h[1] >> 8) & (kCacheEntries - 1)) * 4;
+    return e[0] == tag && e[1] == h[1] && e[2] == h[2] && e[3] == h[3];
+}
+__device__ __forceinline__ void cache_put(lds_u64i *cache, uint32_t table_id, const uint64_t h[4])
+{
+    lds_u64i *e = cache + (size_t)((uint32_t)(h[1] >> 8) & (kCacheEntries - 1)) * 4;
+    e[0] = h[0] ^ ((uint64_t)(table_id + 1) * 0x9E3779B97F4A7C15ULL);
+    e[1] = h[1]; e[2] = h[2]; e[3] = h[3];
+}
+
+
+// lab only (-DBSG_INGEST_PROF): per-phase wave cycles accumulated behind *n_fallback (slots 1..7 as u64)
+#ifdef BSG_INGEST_PROF
+#define BSG_PROF_T(var) const uint64_t var = __builtin_readcyclecounter()
+#define BSG_PROF_ADD(slot, t0, t1) do { if ((threadIdx.x & 63u) == 0u) atomicAdd((unsigned long long *)a.n_fallback + (slot), (unsigned long long)((t1) - (t0))); } while (0)
+#else
+#define BSG_PROF_T(var)
+#define BSG_PROF_ADD(slot, t0, t1)
+#endif
+
+struct ChunkCursor {
+    const uint64_t *chunks;
+    uint64_t ci;     // index of the chunk in Walker::cur
+    uint64_t nxt;    // one chunk ahead: its latency hides behind the work on the current one
+};
+
+__device__ __forceinline__ void walker_reset(Walker &w, ChunkCursor &cc, uint64_t pos, uint64_t end, bool live)
+{
+    w.pos = pos; w.end = end;
+    w.path_len = w.depth = w.objmask = 0;
+    w.st = S_VALUE;
+    w.aux = w.key_len = w.lit = 0;
+    w.req = Q_NONE; w.req_len = 0;
+    w.quiet = true;
+    w.in_token = false;
+    cc.ci = pos >> 3;
+    w.cur = live ? cc.chunks[cc.ci] : 0;
+    cc.nxt = live ? cc.chunks[cc.ci + 1] : 0;
+}
+
+template <bool EMIT>
+__device__ __forceinline__ uint32_t advance(Walker &w, ChunkCursor &cc)
+{
+    if ((w.pos >> 3) != cc.ci) {                    // the step before ended on the chunk boundary
+        cc.ci += 1;
+        w.cur = cc.nxt;
+        cc.nxt = cc.chunks[cc.ci + 1];
+    }
+    return walker_step<EMIT>(w);
+}
+
+__global__ __launch_bounds__(kIngestThreads, 3) void k_ingest_rows(const IngestArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    lds_u64i *cache = (lds_u64i *)lds_raw;
+    for (uint32_t i = threadIdx.x; i < kCacheEntries * 4; i += kIngestThreads) cache[i] = 0;
+    __syncthreads();
     const uint32_t r = blockIdx.x * kIngestThreads + threadIdx.x;
-    if (r >= a.n_rows) return;
+    const bool live = r < a.n_rows;
     // the set this row belongs to: last s with set_first_row[s] <= r
     uint32_t lo = 0, hi = a.n_sets;
-    while (hi - lo > 1) {
+    while (live && hi - lo > 1) {
         const uint32_t mid = (lo + hi) >> 1;
         if (a.set_first_row[mid] <= r) lo = mid; else hi = mid;
     }
+    const uint32_t t0 = lo * 3;
+    const uint64_t row_begin = live ? a.row_off[r] : 0, row_end = live ? a.row_off[r + 1] : 0;
     Walker w;
-    w.rd.base = a.rows;
-    w.rd.chunk = 0;
-    w.rd.chunk_pos = ~0ULL;
-    w.path = (lds_u8 *)lds_raw + threadIdx.x * kLaneLds;
-    w.tab = a.tables + (uint64_t)lo * 3;
-    w.counts = a.counts + (uint64_t)lo * 3;
-    w.status = a.status + (uint64_t)lo * 3;
-    if (!walk_row(w, a.row_off[r], a.row_off[r + 1])) {
+    ChunkCursor cc;
+    cc.chunks = reinterpret_cast<const uint64_t *>(a.rows);
+    w.path = (lds_u8 *)lds_raw + kCacheEntries * 32 + threadIdx.x * kLaneLds;
+    hs_init(w.ps); hs_init(w.tok); hs_init(w.ft);
+
+    // pass 1: validate.  A row the device walker cannot finish contributes NOTHING here; it goes to the host walker whole.
+    BSG_PROF_T(p0);
+    walker_reset(w, cc, row_begin, row_end, live);
+    uint32_t res = live ? R_CONTINUE : R_DONE;
+    while (__ballot(res == R_CONTINUE) != 0ull)
+        if (res == R_CONTINUE) res = advance<false>(w, cc);
+    if (res == R_FAIL) {
         const uint32_t slot = __hip_atomic_fetch_add(a.n_fallback, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         a.fallback_rows[slot] = r;
+    }
+
+    // pass 2: emit.  Rounds of  (A) every lane parses on until it has a request,  (B) all requests are hashed and
+    // inserted together.
+    const bool go = live && res == R_DONE;
+    BSG_PROF_T(p1);
+    BSG_PROF_ADD(1, p0, p1);
+    walker_reset(w, cc, row_begin, row_end, go);
+    res = go ? R_CONTINUE : R_DONE;
+    while (__ballot(res == R_CONTINUE || w.req != Q_NONE) != 0ull) {
+        BSG_PROF_T(ta0);
+        while (__ballot(res == R_CONTINUE && w.req == Q_NONE) != 0ull)
+            if (res == R_CONTINUE && w.req == Q_NONE) res = advance<true>(w, cc);
+        BSG_PROF_T(ta1);
+        BSG_PROF_ADD(2, ta0, ta1);
+        BSG_PROF_ADD(5, 0, 1);
+        const uint32_t q = w.req;
+        w.req = Q_NONE;
+        // (B1) path hashes for Q_FIELD / Q_LEAF
+        HashStream s;
+        hs_init(s);
+        const uint32_t plen = (q == Q_FIELD || q == Q_LEAF) ? w.req_len : 0u;
+        for (uint32_t i = 0; __ballot(i < plen) != 0ull; ++i)
+            if (i < plen) hs_absorb(s, w.path[i]);
+        if (q == Q_WORD) s = w.tok;
+        uint64_t ha[4], hb[4];
+        if (q != Q_NONE) hs_finish(s, ha);
+        if (q == Q_LEAF) {                          // the leaf's words continue from path + "::" (makeFieldTokenKey, tokenizer.go:509-511)
+            w.ps = s;
+            hs_absorb(w.ps, ':');
+            hs_absorb(w.ps, ':');
+        }
+        if (q == Q_WORD) hs_finish(w.ft, hb);
+        BSG_PROF_T(tb1);
+        BSG_PROF_ADD(3, ta1, tb1);
+        // (B2) inserts.  Only entries met as duplicates are cached: a first insert is usually a row-unique value
+        // (timestamp, id) that would only push hot entries out of the cache.
+        const uint32_t ta = t0 + (q == Q_WORD ? 1u : 0u), tb = t0 + 2u;
+        const bool need_a = q != Q_NONE && !cache_hit(cache, ta, ha);
+        const bool need_b = q == Q_WORD && !cache_hit(cache, tb, hb);
+        if (__ballot(need_a || need_b) != 0ull) {
+            bool pa, pb;
+            set_insert2(a.tables[ta], ha, need_a, a.counts + ta, a.status + ta, pa,
+                        a.tables[tb], hb, need_b, a.counts + tb, a.status + tb, pb);
+            if (pa) cache_put(cache, ta, ha);
+            if (pb) cache_put(cache, tb, hb);
+            BSG_PROF_ADD(6, 0, 1);
+        }
+        BSG_PROF_T(tb2);
+        BSG_PROF_ADD(4, tb1, tb2);
     }
 }
 
