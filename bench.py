@@ -57,7 +57,7 @@ def _gen_rows(args):
     return b"".join(rs), np.asarray([len(r) for r in rs], dtype=np.uint32)
 
 
-def ingest_leg(ctx, n_blocks, rows, seed, workers, plan, words, fpr, log):
+def ingest_leg(ctx, n_blocks, rows, seed, workers, plan, words, fpr, log, trusted=1):
     """C3 from the front of the path: the JSON rows of the first n_blocks blocks -> k_ingest_rows (walk, tokenize,
     hash, dedup) -> k_ingest_union (file-level sets) -> exact counts -> k_build_sets.  The bitsets must equal the ones
     bsg_build produced from the pre-extracted entry sets of the same blocks, bit for bit."""
@@ -74,7 +74,7 @@ def ingest_leg(ctx, n_blocks, rows, seed, workers, plan, words, fpr, log):
     first = np.arange(n_blocks + 1, dtype=np.uint32) * rows
     t_gen = time.time() - t0
     t0 = time.time()
-    ing = ctx.ingest_rows((blob, off), first, np.zeros(n_blocks, dtype=np.uint32), 1)
+    ing = ctx.ingest_rows((blob, off), first, np.zeros(n_blocks, dtype=np.uint32), 1, flags=trusted)
     fb = ctx.ingest_fallback_rows(ing)
     counts, status = ctx.ingest_finish(ing, n_blocks + 1)
     desc, n_words = I.plan_desc(counts, fpr)

@@ -19,6 +19,7 @@ BSG_OK, BSG_E_INVALID, BSG_E_HIP, BSG_E_NOMEM, BSG_E_NOTFOUND, BSG_E_UNSUPPORTED
 KIND_FIELD, KIND_TOKEN, KIND_FIELD_TOKEN = 0, 1, 2
 OP_TERM, OP_AND, OP_OR, OP_TRUE, OP_FALSE = 0, 1, 2, 3, 4
 PROBE_ASYNC, PROBE_TIMED = 1, 2
+INGEST_TRUSTED_JSON = 1
 
 TERM_DTYPE = np.dtype([("h", "<u8", (4,)), ("kind", "<u4"), ("reserved", "<u4")])
 DESC_DTYPE = np.dtype([("word_off", "<u8"), ("m", "<u8"), ("k", "<u4"), ("reserved", "<u4")])
@@ -92,7 +93,7 @@ def load():
     L.bsg_or_reduce.argtypes = [vp, u64, u32, vp, u64]
     L.bsg_or_words_dev.argtypes = [vp, vp, vp, u64, u32]
     L.bsg_or_reduce_dev.argtypes = [vp, u64, u32, vp, u64]
-    L.bsg_ingest_rows.argtypes = [vp, vp, vp, u32, vp, u32, vp, u32, vp, C.POINTER(u64)]
+    L.bsg_ingest_rows.argtypes = [vp, vp, vp, u32, vp, u32, vp, u32, vp, u32, C.POINTER(u64)]
     L.bsg_ingest_fallback_rows.argtypes = [vp, u64, vp, u32, C.POINTER(u32)]
     L.bsg_ingest_add_entries.argtypes = [vp, u64, vp, vp, u32, vp, vp]
     L.bsg_ingest_finish.argtypes = [vp, u64, vp, vp]

@@ -380,7 +380,7 @@ private:
         }
         uint64_t ing = 0;
         if (bsg_ingest_rows(ctx_, bytes.data(), row_off.data(), (uint32_t)set_of_row.size(), first.data(), (uint32_t)nb,
-                            parent.data(), 1, nullptr, &ing))
+                            parent.data(), 1, nullptr, BSG_INGEST_TRUSTED_JSON /* ingest_rows validated every row */, &ing))
             return fail(kErrGpu, bsg_last_error(ctx_));
         struct Free { bsg_ctx *c; uint64_t id; ~Free() { bsg_ingest_free(c, id); } } guard{ctx_, ing};
         uint32_t n_fb = 0;

@@ -83,12 +83,57 @@ __device__ __forceinline__ void hs_finish(const HashStream &s, uint64_t h[4])
     }
 }
 
+// Absorbs n (1..8) bytes held little-endian in the low bytes of v (bytes above n must be zero).
+__device__ __forceinline__ void hs_absorb_n(HashStream &s, uint64_t v, uint32_t n)
+{
+    const uint32_t t = s.n & 15u;
+    s.n += n;
+    if (t < 8u) {
+        s.lo |= v << (t * 8u);
+        if (t != 0u && t + n > 8u) s.hi |= v >> ((8u - t) * 8u);
+    } else {
+        s.hi |= v << ((t - 8u) * 8u);
+        if (t + n >= 16u) {
+            bmix(s.h1, s.h2, s.lo, s.hi);
+            s.lo = (t + n > 16u) ? v >> ((16u - t) * 8u) : 0;   // t > 8 here, so the shift is < 64
+            s.hi = 0;
+        }
+    }
+}
+
+// SWAR over the 8 bytes of a chunk.  Each predicate returns 0x80 in the byte lanes that match; bits above the
+// LOWEST match may be false positives (borrow propagation), so only the lowest set bit is ever used.
+constexpr uint64_t kOnes = 0x0101010101010101ULL, kHighs = 0x8080808080808080ULL;
+__device__ __forceinline__ uint64_t swar_eq(uint64_t v, uint32_t c)
+{
+    const uint64_t x = v ^ (kOnes * c);
+    return (x - kOnes) & ~x & kHighs;
+}
+// bytes that end a run of word bytes inside a string: space, quote, backslash, DEL, controls (< 0x20), non-ASCII (>= 0x80)
+__device__ __forceinline__ uint64_t swar_str_stops(uint64_t v)
+{
+    return swar_eq(v, ' ') | swar_eq(v, '"') | swar_eq(v, '\\') | swar_eq(v, 0x7F) | ((v - kOnes * 0x20u) & ~v & kHighs) | (v & kHighs);
+}
+// bytes that end a run of key bytes: quote, backslash, DEL, controls, non-ASCII (a space is an ordinary key byte)
+__device__ __forceinline__ uint64_t swar_key_stops(uint64_t v)
+{
+    return swar_eq(v, '"') | swar_eq(v, '\\') | swar_eq(v, 0x7F) | ((v - kOnes * 0x20u) & ~v & kHighs) | (v & kHighs);
+}
+// ASCII A-Z -> a-z in every byte lane (all bytes < 0x80 here)
+__device__ __forceinline__ uint64_t swar_lower(uint64_t v)
+{
+    const uint64_t ge_a = v + kOnes * (0x80u - 'A'), gt_z = v + kOnes * (0x80u - 'Z' - 1u);
+    return v | (((ge_a & ~gt_z) & kHighs) >> 2);
+}
+
 // ---------------- distinct set insert ----------------
-__device__ __forceinline__ uint64_t ld_agent(const uint64_t *p)
+// table slots live in global memory: say so, or every access is a flat_* instruction (the pointer comes out of a struct)
+typedef __attribute__((address_space(1))) uint64_t glb_u64;
+__device__ __forceinline__ uint64_t ld_agent(const glb_u64 *p)
 {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void st_agent(uint64_t *p, uint64_t v)
+__device__ __forceinline__ void st_agent(glb_u64 *p, uint64_t v)
 {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -128,7 +173,7 @@ __device__ __forceinline__ void set_insert2(const IngestTable ta, const uint64_t
     insert_begin(A, ta, ha, active_a, status_a);
     insert_begin(B, tb, hb, active_b, status_b);
     do {
-        uint64_t *sa = ta.slots + (uint64_t)A.idx * 4, *sb = tb.slots + (uint64_t)B.idx * 4;
+        glb_u64 *sa = (glb_u64 *)ta.slots + (uint64_t)A.idx * 4, *sb = (glb_u64 *)tb.slots + (uint64_t)B.idx * 4;
         uint64_t a0 = 0, a1 = 0, a2 = 0, a3 = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0;
         if (!A.done) { a0 = ld_agent(sa); a1 = ld_agent(sa + 1); a2 = ld_agent(sa + 2); a3 = ld_agent(sa + 3); }
         if (!B.done) { b0 = ld_agent(sb); b1 = ld_agent(sb + 1); b2 = ld_agent(sb + 2); b3 = ld_agent(sb + 3); }
@@ -196,6 +241,7 @@ struct IngestArgs {
     uint32_t *n_fallback;
     uint32_t n_rows;
     uint32_t n_sets;
+    uint32_t validate;              // 1: run the validation pass first (rows of unknown provenance)
 };
 
 typedef __attribute__((address_space(3))) uint8_t lds_u8;
@@ -246,6 +292,18 @@ __device__ __forceinline__ void word_byte(Walker &w, uint32_t c)
     hs_absorb(w.tok, c);
     hs_absorb(w.ft, c);
 }
+
+// n (1..8) word bytes, little-endian in v, upper bytes zero
+__device__ __forceinline__ void word_run(Walker &w, uint64_t v, uint32_t n)
+{
+    if (w.quiet) return;
+    if (!w.in_token) { hs_init(w.tok); w.ft = w.ps; w.in_token = true; }
+    v = swar_lower(v);                             // ASCII fold (appendFoldedWord fast path, row_matcher.go:187-202)
+    hs_absorb_n(w.tok, v, n);
+    hs_absorb_n(w.ft, v, n);
+}
+
+__device__ __forceinline__ uint32_t c_at(uint64_t v, uint32_t i) { return (uint32_t)(v >> (i * 8u)) & 0xFFu; }
 
 __device__ __forceinline__ bool word_end(Walker &w)
 {
@@ -342,25 +400,54 @@ __device__ __forceinline__ uint32_t walker_step(Walker &w)
             w.aux = w.key_len;                                      // first byte of the key inside the path buffer
             w.st = S_KEY;
             break;
-        case S_KEY:
-            ++w.pos;
-            if (c == '"') { w.st = S_COLON; break; }
-            if (!is_plain(c) || w.key_len >= kPathCap) return R_FAIL;
-            w.path[w.key_len++] = (uint8_t)c;
+        case S_KEY: {
+            // the whole run of key bytes left in this chunk at once
+            const uint32_t k = (uint32_t)(w.pos & 7u);
+            uint32_t avail = 8u - k;
+            if (w.end - w.pos < avail) avail = (uint32_t)(w.end - w.pos);
+            const uint64_t v = w.cur >> (k * 8u);
+            const uint64_t stops = swar_key_stops(v);
+            uint32_t n = stops ? (uint32_t)(__builtin_ctzll(stops) >> 3) : 8u;
+            if (n > avail) n = avail;
+            if (w.key_len + n > kPathCap) return R_FAIL;
+            for (uint32_t i = 0; i < n; ++i) w.path[w.key_len + i] = (uint8_t)(v >> (i * 8u));
+            w.key_len += n;
+            w.pos += n;
+            if (n < avail) {                                        // stopped on a byte inside the chunk
+                if (c_at(v, n) != '"') return R_FAIL;
+                ++w.pos;
+                w.st = S_COLON;
+            }
             break;
+        }
         case S_COLON:
             if (c == ' ') { ++w.pos; break; }
             if (c != ':') return R_FAIL;
             ++w.pos;
             w.st = S_PREFIX;                                        // w.aux still points at the key's first byte
             break;
-        case S_STR:
-            ++w.pos;
-            if (c == '"') { w.st = S_AFTER; if (word_end(w)) return R_CONTINUE; break; }
-            if (c == ' ') { if (word_end(w)) return R_CONTINUE; break; }   // only 0x20 can occur: other white space fails below
-            if (!is_plain(c)) return R_FAIL;
-            word_byte(w, c);
+        case S_STR: {
+            // the run of word bytes left in this chunk goes into both hash streams at once
+            const uint32_t k = (uint32_t)(w.pos & 7u);
+            uint32_t avail = 8u - k;
+            if (w.end - w.pos < avail) avail = (uint32_t)(w.end - w.pos);
+            const uint64_t v = w.cur >> (k * 8u);
+            const uint64_t stops = swar_str_stops(v);
+            uint32_t n = stops ? (uint32_t)(__builtin_ctzll(stops) >> 3) : 8u;
+            if (n > avail) n = avail;
+            if (n != 0u) {
+                word_run(w, n == 8u ? v : (v & ((1ULL << (n * 8u)) - 1ULL)), n);
+                w.pos += n;
+            }
+            if (n < avail) {                                        // stopped on a byte inside the chunk
+                const uint32_t b = c_at(v, n);
+                ++w.pos;
+                if (b == '"') { w.st = S_AFTER; if (word_end(w)) return R_CONTINUE; }
+                else if (b == ' ') { if (word_end(w)) return R_CONTINUE; }   // only 0x20 can occur: other white space fails here
+                else return R_FAIL;
+            }
             break;
+        }
         case S_NUM: {                                               // the token is the RAW literal (tokenizer.go:124-125)
             const uint32_t nx = num_next(w.aux, c);
             if (nx != 0xFFu) { w.aux = nx; word_byte(w, c); ++w.pos; break; }
@@ -401,7 +488,13 @@ __device__ __forceinline__ uint32_t walker_step(Walker &w)
 // A direct-mapped LDS cache of confirmed inserts (all four hashes, the table folded into word 0) answers those
 // without touching the table.  Lanes update it without locking: a torn entry can only produce a false hit for
 // an entry that agrees with two unrelated entries on 128 hash bits each.
-constexpr uint32_t kCacheEntries = 512;
+#ifndef BSG_INGEST_CACHE
+#define BSG_INGEST_CACHE 512
+#endif
+#ifndef BSG_INGEST_WPE
+#define BSG_INGEST_WPE 3
+#endif
+constexpr uint32_t kCacheEntries = BSG_INGEST_CACHE;   // lab: -DBSG_INGEST_CACHE / -DBSG_INGEST_WPE (waves per SIMD the kernel is compiled for)
 constexpr uint32_t kIngestLdsBytes = kCacheEntries * 32 + kIngestThreads * kLaneLds;   // cache, then the lanes' path buffers
 typedef __attribute__((address_space(3))) uint64_t lds_u64i;
 
@@ -459,7 +552,7 @@ __device__ __forceinline__ uint32_t advance(Walker &w, ChunkCursor &cc)
     return walker_step<EMIT>(w);
 }
 
-__global__ __launch_bounds__(kIngestThreads, 3) void k_ingest_rows(const IngestArgs a)
+__global__ __launch_bounds__(kIngestThreads, BSG_INGEST_WPE) void k_ingest_rows(const IngestArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     lds_u64i *cache = (lds_u64i *)lds_raw;
@@ -483,13 +576,16 @@ __global__ __launch_bounds__(kIngestThreads, 3) void k_ingest_rows(const IngestA
 
     // pass 1: validate.  A row the device walker cannot finish contributes NOTHING here; it goes to the host walker whole.
     BSG_PROF_T(p0);
-    walker_reset(w, cc, row_begin, row_end, live);
-    uint32_t res = live ? R_CONTINUE : R_DONE;
-    while (__ballot(res == R_CONTINUE) != 0ull)
-        if (res == R_CONTINUE) res = advance<false>(w, cc);
-    if (res == R_FAIL) {
-        const uint32_t slot = __hip_atomic_fetch_add(a.n_fallback, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        a.fallback_rows[slot] = r;
+    uint32_t res = R_DONE;
+    if (a.validate) {
+        walker_reset(w, cc, row_begin, row_end, live);
+        res = live ? R_CONTINUE : R_DONE;
+        while (__ballot(res == R_CONTINUE) != 0ull)
+            if (res == R_CONTINUE) res = advance<false>(w, cc);
+        if (res == R_FAIL) {
+            const uint32_t slot = __hip_atomic_fetch_add(a.n_fallback, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            a.fallback_rows[slot] = r;
+        }
     }
 
     // pass 2: emit.  Rounds of  (A) every lane parses on until it has a request,  (B) all requests are hashed and
@@ -540,6 +636,12 @@ __global__ __launch_bounds__(kIngestThreads, 3) void k_ingest_rows(const IngestA
         }
         BSG_PROF_T(tb2);
         BSG_PROF_ADD(4, tb1, tb2);
+    }
+    // without the validation pass a row is flagged when the emitting walk gives up on it: what it inserted before that
+    // is a subset of what the host walker inserts for it PROVIDED the row is valid JSON (the caller's promise)
+    if (!a.validate && res == R_FAIL) {
+        const uint32_t slot = __hip_atomic_fetch_add(a.n_fallback, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a.fallback_rows[slot] = r;
     }
 }
 

@@ -183,7 +183,7 @@ class Context:
         self._check(self.L.bsg_or_words_dev(self.h, C.c_void_p(d_dst_ptr), C.c_void_p(d_src_ptr), n_words, n_src))
 
     # ---- device ingest (rows -> distinct entries -> counts -> bitsets) ----
-    def ingest_rows(self, rows, set_first_row, parent_of_set=None, n_parents: int = 0, slots_hint=None) -> int:
+    def ingest_rows(self, rows, set_first_row, parent_of_set=None, n_parents: int = 0, slots_hint=None, flags: int = 0) -> int:
         """rows: list[bytes] (or (u8 blob, u64 offsets[n+1])); returns the ingest id."""
         if isinstance(rows, tuple):
             blob, off = rows
@@ -199,7 +199,7 @@ class Context:
         hint = None if slots_hint is None else np.ascontiguousarray(slots_hint, dtype=np.uint32)
         out = C.c_uint64()
         self._check(self.L.bsg_ingest_rows(self.h, _lib._ptr(blob), _lib._ptr(off), len(off) - 1, _lib._ptr(sfr), len(sfr) - 1,
-                                           _lib._ptr(pos), n_parents, _lib._ptr(hint), C.byref(out)))
+                                           _lib._ptr(pos), n_parents, _lib._ptr(hint), flags, C.byref(out)))
         return int(out.value)
 
     def ingest_fallback_rows(self, ingest_id: int) -> np.ndarray:

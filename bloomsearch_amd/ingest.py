@@ -65,12 +65,12 @@ def host_walk_entries(rows, row_ids, set_of_row):
 
 
 def device_ingest(ctx: Context, row_sets, fpr: float, parent_of_set=None, n_parents: int = 0, slots_hint=None,
-                  keep: bool = False) -> IngestResult:
+                  keep: bool = False, flags: int = 0) -> IngestResult:
     """row_sets: list (one per set) of lists of row bytes."""
     rows = [r for rs in row_sets for r in rs]
     first = np.zeros(len(row_sets) + 1, dtype=np.uint32)
     first[1:] = np.cumsum([len(rs) for rs in row_sets])
-    ing = ctx.ingest_rows(rows, first, parent_of_set, n_parents, slots_hint)
+    ing = ctx.ingest_rows(rows, first, parent_of_set, n_parents, slots_hint, flags)
     try:
         fb = ctx.ingest_fallback_rows(ing)
         if len(fb):

@@ -232,12 +232,18 @@ typedef struct bsg_ingest_stats {
     float reserved2;
 } bsg_ingest_stats;
 
+/* flags for bsg_ingest_rows.  BSG_INGEST_TRUSTED_JSON: every row is known to be valid JSON (it came out of
+ * json.Marshal, or the caller validated it): the device skips its validation pass.  Without the flag a row the
+ * device walker hands back has inserted nothing; with it, such a row may already have inserted some of its
+ * entries — all of which the host walker inserts again for a valid row, so the result is the same. */
+#define BSG_INGEST_TRUSTED_JSON 1u
+
 /* rows: marshaled JSON, row r = rows[row_off[r] .. row_off[r+1]) without a trailing newline.
  * slots_hint: optional initial table capacities [n_sets * 3] (0 = default: 256 for fields, 4 per row for
  * tokens and field::tokens); tables grow on demand, a hint only saves the re-run. */
 BSG_API int32_t bsg_ingest_rows(bsg_ctx *ctx, const uint8_t *rows, const uint64_t *row_off, uint32_t n_rows,
                                 const uint32_t *set_first_row, uint32_t n_sets, const uint32_t *parent_of_set,
-                                uint32_t n_parents, const uint32_t *slots_hint, uint64_t *out_ingest_id);
+                                uint32_t n_parents, const uint32_t *slots_hint, uint32_t flags, uint64_t *out_ingest_id);
 /* Row indices (ascending) the host walker must finish; rows_out may be NULL to query the count. */
 BSG_API int32_t bsg_ingest_fallback_rows(bsg_ctx *ctx, uint64_t ingest_id, uint32_t *rows_out, uint32_t cap,
                                          uint32_t *n_out);

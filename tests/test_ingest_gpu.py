@@ -19,6 +19,13 @@ from tests.test_host_tables import JSON_MATCHING, KEYS, _random_value, go_marsha
 pytestmark = pytest.mark.gpu
 
 FPR = 0.001
+TRUSTED = 1   # BSG_INGEST_TRUSTED_JSON
+
+
+@pytest.fixture(params=[0, TRUSTED], ids=["validated", "trusted"])
+def flags(request):
+    """Valid-JSON scenarios run with and without the device's validation pass."""
+    return request.param
 
 
 def oracle_sets(rows):
@@ -38,9 +45,9 @@ def check_against_sets(res, set_index, sets, what=""):
         assert np.array_equal(res.filter_words(set_index, kind), want.words), (what, kind)
 
 
-def test_synthetic_log_rows_three_blocks_and_file(ctx):
+def test_synthetic_log_rows_three_blocks_and_file(ctx, flags):
     row_sets = [synth.rows_json(b * 700, 700) for b in range(3)]
-    res = I.device_ingest(ctx, row_sets, FPR, parent_of_set=[0, 0, 0], n_parents=1)
+    res = I.device_ingest(ctx, row_sets, FPR, parent_of_set=[0, 0, 0], n_parents=1, flags=flags)
     assert len(res.fallback_rows) == 0            # printable ASCII, no escapes: all on the device
     assert res.stats.n_rows == 2100 and res.stats.ms_walk > 0
     union = (set(), set(), set())
@@ -83,9 +90,9 @@ def host_sets(rows):
     return s.as_python_sets()
 
 
-def test_row_tables_one_set_per_row(ctx):
+def test_row_tables_one_set_per_row(ctx, flags):
     rows = ROWS_DEVICE + ROWS_HOST + [r.encode() for r, _ in JSON_MATCHING]
-    res = I.device_ingest(ctx, [[r] for r in rows], FPR)
+    res = I.device_ingest(ctx, [[r] for r in rows], FPR, flags=flags)
     fb = set(int(x) for x in res.fallback_rows)
     assert fb.isdisjoint(range(len(ROWS_DEVICE))), [rows[i] for i in sorted(fb) if i < len(ROWS_DEVICE)]
     assert set(range(len(ROWS_DEVICE), len(ROWS_DEVICE) + len(ROWS_HOST))) <= fb
@@ -108,7 +115,7 @@ def test_malformed_rows_keep_what_the_host_walker_keeps(ctx):
     assert fb == set(range(len(ROWS_MALFORMED)))
 
 
-def test_random_rows_mixed_device_and_host(ctx):
+def test_random_rows_mixed_device_and_host(ctx, flags):
     # the property generator of no_false_negatives_test.go:398-459 (re-seeded): ~half the rows carry escapes / UTF-8
     rng = np.random.default_rng(11)
     row_sets, plain = [], 0
@@ -119,7 +126,7 @@ def test_random_rows_mixed_device_and_host(ctx):
             rows.append(go_marshal(obj))
         row_sets.append(rows)
     parents = [s % 2 for s in range(12)]
-    res = I.device_ingest(ctx, row_sets, FPR, parent_of_set=parents, n_parents=2)
+    res = I.device_ingest(ctx, row_sets, FPR, parent_of_set=parents, n_parents=2, flags=flags)
     n_rows = sum(len(r) for r in row_sets)
     assert 0 < len(res.fallback_rows) < n_rows
     unions = [(set(), set(), set()), (set(), set(), set())]
@@ -132,7 +139,7 @@ def test_random_rows_mixed_device_and_host(ctx):
     check_against_sets(res, 13, unions[1], "parent 1")
 
 
-def test_ascii_fuzz_all_on_device(ctx):
+def test_ascii_fuzz_all_on_device(ctx, flags):
     # random printable-ASCII documents with random spacing: nothing may fall back, everything must match
     rng = np.random.default_rng(5)
     alphabet = [chr(c) for c in range(0x20, 0x7F) if chr(c) not in '"\\']
@@ -158,7 +165,7 @@ def test_ascii_fuzz_all_on_device(ctx):
         sep = [(",", ":"), (", ", ": "), (" , ", " : ")][rng.integers(0, 3)]
         rows.append(json.dumps(obj, separators=sep).encode())
     row_sets = [rows[i::6] for i in range(6)]
-    res = I.device_ingest(ctx, row_sets, FPR, parent_of_set=[0] * 6, n_parents=1)
+    res = I.device_ingest(ctx, row_sets, FPR, parent_of_set=[0] * 6, n_parents=1, flags=flags)
     assert len(res.fallback_rows) == 0
     union = (set(), set(), set())
     for s, rs in enumerate(row_sets):
@@ -169,9 +176,9 @@ def test_ascii_fuzz_all_on_device(ctx):
     check_against_sets(res, 6, union, "file")
 
 
-def test_tables_grow_from_a_tiny_hint(ctx):
+def test_tables_grow_from_a_tiny_hint(ctx, flags):
     rows = synth.rows_json(0, 1500)
-    res = I.device_ingest(ctx, [rows], FPR, parent_of_set=[0], n_parents=1, slots_hint=[64, 64, 64])
+    res = I.device_ingest(ctx, [rows], FPR, parent_of_set=[0], n_parents=1, slots_hint=[64, 64, 64], flags=flags)
     assert res.stats.table_grows >= 2
     sets = oracle_sets(rows)
     check_against_sets(res, 0, sets, "grown")

@@ -16,6 +16,7 @@ from bloomsearch_amd.gpu import Context
 n_blocks = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rows = int(sys.argv[2]) if len(sys.argv) > 2 else 10000
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+flags = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 # in-process generation: a forked pool under rocprofv3 hangs at exit (the children inherit the tool)
 parts = [bench._gen_rows((b, rows, 0xB100F5EA4C4)) for b in range(n_blocks)]
 blob = np.frombuffer(b"".join(p[0] for p in parts), dtype=np.uint8)
@@ -26,7 +27,7 @@ first = np.arange(n_blocks + 1, dtype=np.uint32) * rows
 ctx = Context((0,))
 for rep in range(reps):
     t0 = time.time()
-    ing = ctx.ingest_rows((blob, off), first, np.zeros(n_blocks, dtype=np.uint32), 1)
+    ing = ctx.ingest_rows((blob, off), first, np.zeros(n_blocks, dtype=np.uint32), 1, flags=flags)
     counts, status = ctx.ingest_finish(ing, n_blocks + 1)
     desc, n_words = I.plan_desc(counts, 0.001)
     ctx.ingest_build(ing, desc, n_words)
