@@ -142,13 +142,34 @@ __device__ __forceinline__ void st_agent(glb_u64 *p, uint64_t v)
 struct InsertState {
     uint32_t idx, probes, spins;
     bool done, present;   // present: the entry was found already stored (a duplicate)
+    bool fresh;           // this call stored it
 };
+
+// *count += 1 for every lane with `flag`.  The flagged lanes of a wave nearly always share the counter (a wave's rows
+// belong to one set; a union workgroup feeds one parent): then one lane adds the popcount.  A single parent counter
+// took 1.1 M same-address atomics per 100 blocks before this (k_ingest_union 4.5 ms, all of it that counter).
+__device__ __forceinline__ void count_add(uint32_t *count, bool flag)
+{
+    if (flag) {
+        const uint64_t p = (uint64_t)count;
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)p), hi = __builtin_amdgcn_readfirstlane((uint32_t)(p >> 32));
+        const uint64_t p0 = ((uint64_t)hi << 32) | lo;
+        const uint64_t active = __ballot(true);
+        if (__ballot(p != p0) == 0ull) {
+            if (__lane_id() == (uint32_t)__builtin_ctzll(active))
+                __hip_atomic_fetch_add(count, (uint32_t)__popcll(active), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            __hip_atomic_fetch_add(count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
 
 __device__ __forceinline__ void insert_begin(InsertState &x, const IngestTable t, const uint64_t h[4], bool active, uint32_t *status)
 {
     x.idx = (uint32_t)(h[1] >> 20) & t.mask;   // h0 is the claim word; index with bits of h1
     x.probes = x.spins = 0;
     x.present = false;
+    x.fresh = false;
     x.done = !active;
     if (active && (h[0] == 0 || h[1] == 0 || h[2] == 0 || h[3] == 0)) {
         __hip_atomic_store(status, kTableExotic, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -182,12 +203,11 @@ __device__ __forceinline__ void set_insert2(const IngestTable ta, const uint64_t
         bool won_a = false, won_b = false;
         if (cas_a) won_a = __hip_atomic_compare_exchange_strong(sa, &old_a, ha[0], __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (cas_b) won_b = __hip_atomic_compare_exchange_strong(sb, &old_b, hb[0], __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#define BSG_SETTLE(X, won, cas, s, h, c0, c1, c2, c3, tab, count, status)                                              \
+#define BSG_SETTLE(X, won, cas, s, h, c0, c1, c2, c3, tab, status)                                              \
         if (!X.done) {                                                                                                   \
             if (won) {                                                                                                   \
                 st_agent(s + 1, h[1]); st_agent(s + 2, h[2]); st_agent(s + 3, h[3]);                                     \
-                __hip_atomic_fetch_add(count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                           \
-                X.done = true;            /* a first insert: present stays false, see the cache policy */               \
+                X.done = true; X.fresh = true;   /* a first insert: present stays false, see the cache policy */         \
             } else if (!cas) {            /* (a lost claim looks at the same slot again on the next trip) */             \
                 bool advance = true;                                                                                     \
                 if (c0 == h[0]) {                                                                                        \
@@ -207,10 +227,12 @@ __device__ __forceinline__ void set_insert2(const IngestTable ta, const uint64_t
                 }                                                                                                        \
             }                                                                                                            \
         }
-        BSG_SETTLE(A, won_a, cas_a, sa, ha, a0, a1, a2, a3, ta, count_a, status_a)
-        BSG_SETTLE(B, won_b, cas_b, sb, hb, b0, b1, b2, b3, tb, count_b, status_b)
+        BSG_SETTLE(A, won_a, cas_a, sa, ha, a0, a1, a2, a3, ta, status_a)
+        BSG_SETTLE(B, won_b, cas_b, sb, hb, b0, b1, b2, b3, tb, status_b)
 #undef BSG_SETTLE
     } while (__ballot(!A.done || !B.done) != 0ull);
+    count_add(count_a, A.fresh);
+    count_add(count_b, B.fresh);
     present_a = A.present;
     present_b = B.present;
 }
@@ -227,9 +249,8 @@ __device__ __forceinline__ void set_insert(const IngestTable t, const uint64_t h
 // the host.  k_ingest_rows drives a wave in rounds:
 //     (A) every lane parses on (divergent, registers + LDS only; chunk loads converged) until it has a request
 //     (B) all requests are hashed and inserted together (murmur finalisations and table round trips for 64 lanes at once)
-// Measured on MI355X, 1 M log rows: inserts from inside the divergent parse 12.6 ms; hashing inside the parse with
-// converged inserts 18 ms (13x more VALU instructions than one lane needs: the finalisations ran a few lanes at a
-// time); this scheme: see profiles/.
+// Measured on MI355X, 1 M log rows: inserts from inside the divergent parse 12.6 ms; this scheme 10.8 ms; with one
+// counter add per wave instead of one per stored entry (count_add) 2.85 ms — see profiles/README.md.
 struct IngestArgs {
     const uint8_t *rows;            // 8-byte aligned, >= 16 readable bytes after the last row
     const uint64_t *row_off;        // [n_rows + 1]
