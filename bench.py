@@ -104,6 +104,77 @@ def ingest_leg(ctx, n_blocks, rows, seed, workers, plan, words, fpr, log, truste
             "check": "bitsets and (m, k) identical to bsg_build of the same blocks' entry sets"}
 
 
+def or_reduce_leg(ctx, plan, B, fpr, n_union, world, log):
+    """BASELINE configs[4] / SURVEY C5: OR-reduce of this rank's B fixed-geometry token filters into one partial
+    file-level bitset (k_or_reduce_blocks), then — for world > 1 — the one real exchange of the path: all_gather of the
+    partials over RCCL + a local OR (k_or_words).  Geometry = EstimateParameters(n_union, fpr) for every block, which
+    is what makes OR_b build(S_b, m, k) == build(U S_b, m, k) hold."""
+    import torch
+    from bloomsearch_amd import parallel as P
+    from bloomsearch_amd._lib import DESC_DTYPE
+    from bloomsearch_amd.gpu import estimate_parameters
+    m, k = estimate_parameters(n_union, fpr)
+    nw = (m + 63) // 64
+    stride = (nw + 15) // 16 * 16
+    desc = np.zeros(B * 3, dtype=DESC_DTYPE)
+    for b in range(B):
+        desc[b * 3 + 1] = (b * stride, m, k, 0)        # token filters only; field / field::token left nil
+    t0 = time.time()
+    words = ctx.build(plan.blob, plan.off, plan.fstart, desc, B * stride)
+    aid = ctx.arena_load(words, desc)
+    t_setup = time.time() - t0
+    out = torch.zeros(nw, dtype=torch.int64, device="cuda")
+    ms = []
+    for _ in range(12):
+        ctx.or_reduce_dev(aid, 1, out.data_ptr(), nw)
+        ms.append(ctx.last_or_ms())
+    local_ms = float(np.median(ms[2:]))
+    # check: the OR equals one build of the union's entries at the same geometry (different kernel, same arithmetic),
+    # and holds every token of the first and last block (oracle bit tests are in tests/test_gpu_parity.py)
+    off64 = plan.off.astype(np.int64)
+    blobs, lens = [], []
+    for blk in range(B):                                  # a block's token entries are contiguous in the plan's blob
+        e0, e1 = int(plan.fstart[blk * 3 + 1]), int(plan.fstart[blk * 3 + 2])
+        blobs.append(plan.blob[off64[e0]: off64[e1]])
+        lens.append(np.diff(off64[e0: e1 + 1]))
+    ublob = np.concatenate(blobs)
+    lens = np.concatenate(lens)
+    idx = lens                                            # (one entry per element)
+    uoff = np.zeros(len(lens) + 1, dtype=np.uint32)
+    np.cumsum(lens, out=uoff[1:])
+    udesc = np.zeros(1, dtype=DESC_DTYPE)
+    udesc[0] = (0, m, k, 0)
+    want = ctx.build(ublob, uoff, np.asarray([0, len(idx)], dtype=np.uint32), udesc, stride)[:nw]
+    got = out.cpu().numpy().view(np.uint64)
+    if not np.array_equal(got, want):
+        sys.exit("OR-reduce of the block filters differs from the build of the union at the same geometry")
+    res = {"workload": "C5 OR-reduce: %d fixed-geometry token filters per GPU (m = %d bits, k = %d; %d entries) -> one partial bitset"
+                       % (B, m, k, len(idx)),
+           "kernel": "k_or_reduce_blocks", "kernel_ms": local_ms, "algorithmic_bytes": B * nw * 8 + nw * 8,
+           "achieved": (B * nw * 8 + nw * 8) / max(local_ms, 1e-6) / 1e6, "unit": "GB/s", "bound": "hbm",
+           "check": "equals bsg_build(union of the blocks' entries, m, k) bit for bit"}
+    res["frac"] = res["achieved"] / HBM_PEAK_GBPS
+    if world > 1:
+        import torch.distributed as dist
+        ts = []
+        for _ in range(6):
+            part = out.clone()
+            dist.barrier()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            P.or_allreduce_(part, ctx)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t1)
+        res["allreduce_ms"] = float(np.median(ts[1:])) * 1e3
+        res["allreduce_wire_bytes_in_per_gpu"] = (world - 1) * nw * 8
+        res["allreduce"] = "all_gather (RCCL) of %d partials + k_or_words" % world
+    ctx.arena_free(aid)
+    log("OR-reduce: %d filters x %.0f KB in %.1f us = %.0f GB/s (%.0f%% of peak)%s; setup %.1fs"
+        % (B, nw * 8 / 1e3, local_ms * 1e3, res["achieved"], 100 * res["frac"],
+           ("; all-reduce over %d ranks %.2f ms" % (world, res["allreduce_ms"])) if world > 1 else "", t_setup))
+    return res
+
+
 def make_queries(n_queries, workload, seed):
     """C2 query batch.  'needle': And(FT(level), FT(service), FT(user_id)) — a log search for one
     user's events; 'lowcard': SURVEY C2's And(FT(level), FT(service), FT(nested.region)).
@@ -195,6 +266,8 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU baseline work (0 = skip)")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--no-decode", action="store_true", help="skip the device section-decode measurement")
+    ap.add_argument("--or-union", type=int, default=200000,
+                    help="distinct-entry count the fixed OR-reduce geometry is sized for (C5 leg); 0 = skip")
     ap.add_argument("--ingest-blocks", type=int, default=100,
                     help="blocks of JSON rows pushed through the device ingest path (k_ingest_rows ...), 0 = skip")
     ap.add_argument("--scaled", type=int, default=64,
@@ -270,6 +343,10 @@ def main():
                   "end_to_end_s_incl_h2d": t2 - t1}
         log("device section decode: %.1f MB of sections in %.1f us kernel (%.0f GB/s), %.3fs incl. H2D (host encode for the test %.1fs)"
             % (sec_bytes / 1e6, dec_ms * 1e3, decode["achieved"], t2 - t1, t1 - t0))
+
+    or_reduce = None
+    if args.or_union > 0:
+        or_reduce = or_reduce_leg(ctx, plan, B, args.fpr, args.or_union, world, log)
 
     ingest = None
     if rank == 0 and world == 1 and args.ingest_blocks > 0:
@@ -403,6 +480,8 @@ def main():
             out["decode"] = decode
         if ingest:
             out["ingest"] = ingest
+        if or_reduce:
+            out["or_reduce"] = or_reduce
         if scaled:
             out["roofline_scaled"] = dict(scaled, bound="hbm", kernel="k_probe_terms", peak=HBM_PEAK_GBPS, unit="GB/s",
                                           note="C2' of SURVEY 8d: same filters replicated x%d at distinct addresses, one launch" % args.scaled)

@@ -51,7 +51,7 @@ EXPORTS = [
     "bsg_device_count", "bsg_open", "bsg_close", "bsg_last_error", "bsg_sync", "bsg_estimate_parameters",
     "bsg_hash_entries", "bsg_build", "bsg_build_hashed", "bsg_arena_load", "bsg_arena_load_sections", "bsg_arena_free",
     "bsg_batch_create", "bsg_batch_free", "bsg_probe_batch", "bsg_probe_many", "bsg_probe", "bsg_timing_read", "bsg_set_timed_stride", "bsg_last_kernel_ms",
-    "bsg_or_reduce", "bsg_or_words_dev", "bsg_or_reduce_dev",
+    "bsg_or_reduce", "bsg_or_words_dev", "bsg_or_reduce_dev", "bsg_last_or_ms",
     "bsg_ingest_rows", "bsg_ingest_fallback_rows", "bsg_ingest_add_entries", "bsg_ingest_finish", "bsg_ingest_build",
     "bsg_ingest_stats_read", "bsg_ingest_free",
 ]
@@ -93,6 +93,7 @@ def load():
     L.bsg_or_reduce.argtypes = [vp, u64, u32, vp, u64]
     L.bsg_or_words_dev.argtypes = [vp, vp, vp, u64, u32]
     L.bsg_or_reduce_dev.argtypes = [vp, u64, u32, vp, u64]
+    L.bsg_last_or_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.bsg_ingest_rows.argtypes = [vp, vp, vp, u32, vp, u32, vp, u32, vp, u32, C.POINTER(u64)]
     L.bsg_ingest_fallback_rows.argtypes = [vp, u64, vp, u32, C.POINTER(u32)]
     L.bsg_ingest_add_entries.argtypes = [vp, u64, vp, vp, u32, vp, vp]

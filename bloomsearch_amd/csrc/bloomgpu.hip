@@ -97,7 +97,8 @@ struct Device {
     std::vector<EventTriple> free_events;
     bsg::CrcConsts *d_crc = nullptr;          // CRC32C slice-by-8 tables + x^(2^i) mod P (k_decode_sections)
     hipEvent_t kb0 = nullptr, kb1 = nullptr;  // start/stop timestamps of the last k_build / k_hash_entries dispatch
-    float last_build_ms = 0.f, last_hash_ms = 0.f, last_decode_ms = 0.f;
+    float last_build_ms = 0.f, last_hash_ms = 0.f, last_decode_ms = 0.f, last_or_ms = 0.f;
+    bool or_pending = false;   // kb0/kb1 hold an un-read k_or_reduce_blocks dispatch
 };
 
 struct ArenaShard {
@@ -1197,6 +1198,15 @@ int32_t bsg_last_kernel_ms(bsg_ctx *ctx, float *build_ms, float *hash_ms, float 
     return BSG_OK;
 }
 
+int32_t bsg_last_or_ms(bsg_ctx *ctx, float *or_ms)
+{
+    if (!ctx || !or_ms) return fail(BSG_E_INVALID, "null argument");
+    Device &d = *ctx->devs[0];
+    std::lock_guard<std::mutex> lk(d.mu);
+    *or_ms = d.last_or_ms;
+    return BSG_OK;
+}
+
 int32_t bsg_timing_read(bsg_ctx *ctx, bsg_timing *out, int32_t reset)
 {
     if (!ctx || !out) return fail(BSG_E_INVALID, "null argument");
@@ -1219,10 +1229,16 @@ static int32_t or_reduce_shard(bsg_ctx *ctx, Arena &arena, uint32_t di, uint32_t
     if (s.fixed_m[kind] != 0 && (s.fixed_m[kind] + 63) / 64 != n_words)
         return fail(BSG_E_INVALID, "n_words %llu does not match m %llu", (unsigned long long)n_words,
                     (unsigned long long)s.fixed_m[kind]);
-    const uint32_t grid = (uint32_t)std::min<uint64_t>((n_words + 255) / 256, 4096);
-    hipLaunchKernelGGL(bsg::k_or_reduce_blocks, dim3(std::max(grid, 1u)), dim3(256), 0, d.stream, s.d_words, s.d_desc,
-                       s.n_blocks, kind, n_words, d_out);
+    const uint32_t gx = (uint32_t)(((n_words + 1) / 2 + 255) / 256);
+    uint32_t group = bsg::kOrBlocksPerGroup;
+    if (const char *e = getenv("BSG_LAB_OR_GROUP")) group = std::max(1, atoi(e));   // lab only
+    const uint32_t gy = std::max(1u, (s.n_blocks + group - 1) / group);
+    if (gy > 1) HIP_TRY(hipMemsetAsync(d_out, 0, n_words * 8, d.stream));
+    if (!d.kb0) { HIP_TRY(hipEventCreate(&d.kb0)); HIP_TRY(hipEventCreate(&d.kb1)); }
+    hipExtLaunchKernelGGL(bsg::k_or_reduce_blocks, dim3(std::max(gx, 1u), gy), dim3(256), 0, d.stream, d.kb0, d.kb1, 0,
+                          s.d_words, s.d_desc, s.n_blocks, kind, n_words, d_out, group);
     HIP_TRY(hipGetLastError());
+    d.or_pending = true;
     return BSG_OK;
 }
 
@@ -1238,6 +1254,7 @@ int32_t bsg_or_reduce_dev(bsg_ctx *ctx, uint64_t arena_id, uint32_t kind, void *
     if (int32_t rc = use_device(d)) return rc;
     if (int32_t rc = or_reduce_shard(ctx, *arena, 0, kind, n_words, static_cast<uint64_t *>(d_out))) return rc;
     HIP_TRY(hipStreamSynchronize(d.stream));
+    if (d.or_pending) { HIP_TRY(hipEventElapsedTime(&d.last_or_ms, d.kb0, d.kb1)); d.or_pending = false; }
     return BSG_OK;
 }
 
@@ -1283,6 +1300,7 @@ int32_t bsg_or_reduce(bsg_ctx *ctx, uint64_t arena_id, uint32_t kind, uint64_t *
         if (int32_t rc = or_reduce_shard(ctx, *arena, di, kind, n_words, d.stage_words.p)) return rc;
         HIP_TRY(hipMemcpyAsync(part.data(), d.stage_words.p, n_words * 8, hipMemcpyDeviceToHost, d.stream));
         HIP_TRY(hipStreamSynchronize(d.stream));
+        if (d.or_pending) { HIP_TRY(hipEventElapsedTime(&d.last_or_ms, d.kb0, d.kb1)); d.or_pending = false; }
         for (uint64_t i = 0; i < n_words; ++i) out_words[i] |= part[i];
     }
     return BSG_OK;

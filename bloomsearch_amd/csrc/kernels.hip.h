@@ -923,19 +923,40 @@ __global__ __launch_bounds__(256) void k_or_words(uint64_t *dst, const uint64_t 
 }
 
 // OR of one kind's filter across all blocks of a shard (fixed geometry):
-// out[i] = OR_b words[desc[b*3+kind].word_off + i]
+// out[i] = OR_b words[desc[b*3+kind].word_off + i].
+// grid.x covers the words two at a time (16-byte loads; filters start on 128-byte boundaries), grid.y covers groups of
+// kOrBlocksPerGroup blocks: a thread issues that many independent loads, ORs them and — when there is more than one
+// group — merges into the zeroed output with atomicOr (distinct addresses per lane: nothing hot).
+constexpr uint32_t kOrBlocksPerGroup = 64;   // measured at 1 000 x 360 KB filters: 16 -> 97 us, 32 -> 94, 64 -> 79, 128 -> 117, one group -> 687
+
 __global__ __launch_bounds__(256) void k_or_reduce_blocks(const uint64_t *words, const DevDesc *desc,
                                                           uint32_t n_blocks, uint32_t kind, uint64_t n_words,
-                                                          uint64_t *out)
+                                                          uint64_t *out, uint32_t group)
 {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += stride) {
-        uint64_t acc = 0;
-        for (uint32_t b = 0; b < n_blocks; ++b) {
-            const DevDesc d = desc[(uint64_t)b * 3 + kind];
-            if (d.m != 0) acc |= words[d.word_off + i];
+    const uint64_t pair = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;   // words 2*pair, 2*pair + 1
+    if (pair * 2 >= n_words) return;
+    const uint32_t b0 = blockIdx.y * group;
+    const uint32_t b1 = min(n_blocks, b0 + group);
+    const bool two = pair * 2 + 1 < n_words;
+    uint64_t lo = 0, hi = 0;
+#pragma unroll 4
+    for (uint32_t b = b0; b < b1; ++b) {
+        const DevDesc d = desc[(uint64_t)b * 3 + kind];
+        if (d.m == 0) continue;
+        const uint64_t *p = words + d.word_off + pair * 2;
+        if (two) {
+            const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(p);
+            lo |= v.x; hi |= v.y;
+        } else {
+            lo |= p[0];
         }
-        out[i] = acc;
+    }
+    if (gridDim.y == 1) {
+        out[pair * 2] = lo;
+        if (two) out[pair * 2 + 1] = hi;
+    } else {
+        if (lo) atomicOr((unsigned long long *)&out[pair * 2], (unsigned long long)lo);
+        if (two && hi) atomicOr((unsigned long long *)&out[pair * 2 + 1], (unsigned long long)hi);
     }
 }
 

@@ -179,6 +179,11 @@ class Context:
     def or_reduce_dev(self, arena_id: int, kind: int, d_out_ptr: int, n_words: int):
         self._check(self.L.bsg_or_reduce_dev(self.h, arena_id, kind, C.c_void_p(d_out_ptr), n_words))
 
+    def last_or_ms(self) -> float:
+        v = C.c_float()
+        self._check(self.L.bsg_last_or_ms(self.h, C.byref(v)))
+        return float(v.value)
+
     def or_words_dev(self, d_dst_ptr: int, d_src_ptr: int, n_words: int, n_src: int):
         self._check(self.L.bsg_or_words_dev(self.h, C.c_void_p(d_dst_ptr), C.c_void_p(d_src_ptr), n_words, n_src))
 

@@ -201,6 +201,8 @@ BSG_API int32_t bsg_or_reduce(bsg_ctx *ctx, uint64_t arena_id, uint32_t kind, ui
 BSG_API int32_t bsg_or_words_dev(bsg_ctx *ctx, void *d_dst, const void *d_src, uint64_t n_words, uint32_t n_src);
 /* Per-device partial OR left on the device: writes n_words u64 at d_out. */
 BSG_API int32_t bsg_or_reduce_dev(bsg_ctx *ctx, uint64_t arena_id, uint32_t kind, void *d_out, uint64_t n_words);
+/* Device time of the most recent k_or_reduce_blocks dispatch on the context's first device. */
+BSG_API int32_t bsg_last_or_ms(bsg_ctx *ctx, float *or_ms);
 
 /* ---- device ingest: rows -> distinct bloom entries -> exact counts -> bitsets ----
  * Replaces, on the flush / merge worker, the reference's per-row host loop
