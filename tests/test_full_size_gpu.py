@@ -110,3 +110,61 @@ def test_full_size_probe_properties(ctx, c2):
     assert not (got[:, -1] >> np.uint64(40)).any()
     ctx.batch_free(bid)
     ctx.arena_free(aid)
+
+
+def _gen_rows(b):
+    rs = synth.rows_json(b * ROWS, ROWS)
+    return b"".join(rs), np.asarray([len(r) for r in rs], dtype=np.uint32)
+
+
+def test_full_size_device_ingest_equals_entry_set_route(ctx, c2):
+    """BASELINE configs[2] from the front of the path: the JSON rows of 40 full-size blocks (400 000 rows) through
+    k_ingest_rows / k_ingest_union / k_build_sets.  Block filters must equal, bit for bit, the ones bsg_build made from
+    the pre-extracted entry sets of the same blocks (which test_full_size_bitsets pins against the oracle); the
+    file-level counts must equal the size of the union of the blocks' entry sets, and the file-level token filter must
+    contain every token of a sampled block (no false negatives) at the union's geometry."""
+    import multiprocessing as mp
+    from bloomsearch_amd import ingest as I
+    plan, words = c2
+    nb = 40
+    with mp.get_context("fork").Pool(min(32, os.cpu_count() or 1)) as pool:
+        parts = pool.map(_gen_rows, range(nb))
+    blob = np.frombuffer(b"".join(p[0] for p in parts), dtype=np.uint8)
+    lens = np.concatenate([p[1] for p in parts])
+    off = np.zeros(len(lens) + 1, dtype=np.uint64)
+    np.cumsum(lens, out=off[1:])
+    first = np.arange(nb + 1, dtype=np.uint32) * ROWS
+    for flags in (0, 1):
+        ing = ctx.ingest_rows((blob, off), first, np.zeros(nb, dtype=np.uint32), 1, flags=flags)
+        assert len(ctx.ingest_fallback_rows(ing)) == 0
+        counts, status = ctx.ingest_finish(ing, nb + 1)
+        assert not status.any()
+        assert np.array_equal(counts[:nb].astype(np.int64), plan.counts[:nb])
+        desc, n_words = I.plan_desc(counts, 0.001)
+        got = ctx.ingest_build(ing, desc, n_words)
+        ctx.ingest_free(ing)
+        for i in range(nb * 3):
+            d, e = desc[i], plan.desc[i]
+            nw = (int(e["m"]) + 63) // 64
+            assert (int(d["m"]), int(d["k"])) == (int(e["m"]), int(e["k"]))
+            assert np.array_equal(got[int(d["word_off"]): int(d["word_off"]) + nw], words[int(e["word_off"]): int(e["word_off"]) + nw]), i
+    # file level: exact union counts, right-sized geometry, members present
+    raw = plan.blob.tobytes()
+    union = [set(), set(), set()]
+    for f in range(nb * 3):
+        for e in range(int(plan.fstart[f]), int(plan.fstart[f + 1])):
+            union[f % 3].add(raw[int(plan.off[e]): int(plan.off[e + 1])])
+    assert [int(x) for x in counts[nb]] == [len(u) for u in union]
+    for c in range(3):
+        d = desc[nb * 3 + c]
+        assert (int(d["m"]), int(d["k"])) == O.estimate_parameters(len(union[c]), 0.001)
+    d = desc[nb * 3 + 1]
+    filt = O.Filter(int(d["m"]), int(d["k"]), got[int(d["word_off"]): int(d["word_off"]) + O.words_for(int(d["m"]))])
+    sample = sorted(union[1])[::997]
+    assert all(filt.test(t) for t in sample)
+    want = O.Filter(int(d["m"]), int(d["k"]))          # and the file-level field filter entirely (9 entries)
+    df = desc[nb * 3]
+    ff = O.Filter(int(df["m"]), int(df["k"]))
+    for t in union[0]:
+        ff.add(t)
+    assert np.array_equal(ff.words, got[int(df["word_off"]): int(df["word_off"]) + O.words_for(int(df["m"]))])
