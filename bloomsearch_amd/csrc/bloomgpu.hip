@@ -345,6 +345,7 @@ int32_t bsg_open(const int32_t *device_ids, int32_t n_devices, bsg_ctx **out_ctx
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(bsg::k_probe_terms), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(bsg::k_probe_fused), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(bsg::k_build), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(bsg::k_build_sets), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
 
         ctx->devs.push_back(std::move(d));
     }

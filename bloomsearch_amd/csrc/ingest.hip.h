@@ -185,10 +185,12 @@ __device__ __forceinline__ void insert_begin(InsertState &x, const IngestTable t
 // leave" block after the loop — executed once the whole wave has left it — so lanes of the same wave racing on one
 // entry never see h1..h3 and insert duplicates (measured: 64 equal rows -> 64 "distinct").  Every trip does a
 // bounded amount of work (no inner wait).
+// COUNT = false leaves the distinct counters alone and reports through fresh_x instead (the caller aggregates).
+template <bool COUNT = true>
 __device__ __forceinline__ void set_insert2(const IngestTable ta, const uint64_t ha[4], bool active_a, uint32_t *count_a, uint32_t *status_a,
                                             bool &present_a,
                                             const IngestTable tb, const uint64_t hb[4], bool active_b, uint32_t *count_b, uint32_t *status_b,
-                                            bool &present_b)
+                                            bool &present_b, bool *fresh_a = nullptr, bool *fresh_b = nullptr)
 {
     InsertState A, B;
     insert_begin(A, ta, ha, active_a, status_a);
@@ -231,8 +233,13 @@ __device__ __forceinline__ void set_insert2(const IngestTable ta, const uint64_t
         BSG_SETTLE(B, won_b, cas_b, sb, hb, b0, b1, b2, b3, tb, status_b)
 #undef BSG_SETTLE
     } while (__ballot(!A.done || !B.done) != 0ull);
-    count_add(count_a, A.fresh);
-    count_add(count_b, B.fresh);
+    if (COUNT) {
+        count_add(count_a, A.fresh);
+        count_add(count_b, B.fresh);
+    } else {
+        *fresh_a = A.fresh;
+        *fresh_b = B.fresh;
+    }
     present_a = A.present;
     present_b = B.present;
 }
@@ -684,18 +691,38 @@ struct UnionItem { uint32_t src, dst; };
 __global__ __launch_bounds__(256) void k_ingest_union(const IngestTable *src_tables, const IngestTable *dst_tables,
                                                       const UnionItem *items, uint32_t *dst_counts, uint32_t *dst_status)
 {
+    __shared__ uint32_t wg_fresh;
+    if (threadIdx.x == 0) wg_fresh = 0;
+    __syncthreads();
     const UnionItem it = items[blockIdx.y];
     const IngestTable s = src_tables[it.src];
     const IngestTable d = dst_tables[it.dst];
     const uint64_t cap = (uint64_t)s.mask + 1;
-    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < cap; i += (uint64_t)gridDim.x * 256) {
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    uint32_t fresh = 0;
+    // two source slots per trip (both halves of both loaded up front), their inserts overlapped by set_insert2
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < cap; i += 2 * stride) {
+        const uint64_t j = i + stride;
         const ulonglong2 *p = reinterpret_cast<const ulonglong2 *>(s.slots + i * 4);
-        const ulonglong2 x = p[0];
-        if (x.x == 0) continue;
-        const ulonglong2 y = p[1];
-        const uint64_t h[4] = {x.x, x.y, y.x, y.y};
-        set_insert(d, h, dst_counts + it.dst, dst_status + it.dst);
+        const ulonglong2 x0 = p[0], y0 = p[1];
+        ulonglong2 x1 = make_ulonglong2(0, 0), y1 = x1;
+        if (j < cap) {
+            const ulonglong2 *q = reinterpret_cast<const ulonglong2 *>(s.slots + j * 4);
+            x1 = q[0]; y1 = q[1];
+        }
+        const uint64_t ha[4] = {x0.x, x0.y, y0.x, y0.y}, hb[4] = {x1.x, x1.y, y1.x, y1.y};
+        const bool act_a = x0.x != 0, act_b = x1.x != 0;
+        if (__ballot(act_a || act_b) != 0ull) {
+            bool pa, pb, fa, fb;
+            set_insert2<false>(d, ha, act_a, nullptr, dst_status + it.dst, pa, d, hb, act_b, nullptr, dst_status + it.dst, pb, &fa, &fb);
+            fresh += (uint32_t)fa + (uint32_t)fb;
+        }
     }
+    // one counter add per workgroup (a parent's counter is a single address for the whole launch)
+    if (fresh) atomicAdd(&wg_fresh, fresh);
+    __syncthreads();
+    if (threadIdx.x == 0 && wg_fresh)
+        __hip_atomic_fetch_add(dst_counts + it.dst, wg_fresh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---------------- bitsets from distinct sets ----------------
@@ -712,20 +739,33 @@ struct SetBuildArgs {
     uint64_t *out;
 };
 
+constexpr uint32_t kBuildSetsThreads = 1024;   // one workgroup per table: 16 waves keep more slot loads in flight than 8 (1.16 -> see profiles)
+
 template <bool M32, typename BITS32>
 __device__ __forceinline__ void build_from_slots(const IngestTable t, const SetBuildItem &it, const DevDesc &d, BITS32 bits, uint32_t tid)
 {
-    for (uint64_t i = it.slot_begin + tid; i < it.slot_end; i += kBuildThreads) {
+    // two slots per trip, all four 16-byte halves loaded before the first is used
+    for (uint64_t i = it.slot_begin + tid; i < it.slot_end; i += 2 * kBuildSetsThreads) {
+        const uint64_t j = i + kBuildSetsThreads;
         const ulonglong2 *p = reinterpret_cast<const ulonglong2 *>(t.slots + i * 4);
-        const ulonglong2 x = p[0];
-        if (x.x == 0) continue;
-        const ulonglong2 y = p[1];
-        const uint64_t h[4] = {x.x, x.y, y.x, y.y};
-        set_entry_bits<M32>(bits, d, h);
+        const ulonglong2 x0 = p[0], y0 = p[1];
+        ulonglong2 x1 = make_ulonglong2(0, 0), y1 = x1;
+        if (j < it.slot_end) {
+            const ulonglong2 *q = reinterpret_cast<const ulonglong2 *>(t.slots + j * 4);
+            x1 = q[0]; y1 = q[1];
+        }
+        if (x0.x != 0) {
+            const uint64_t h[4] = {x0.x, x0.y, y0.x, y0.y};
+            set_entry_bits<M32>(bits, d, h);
+        }
+        if (x1.x != 0) {
+            const uint64_t h[4] = {x1.x, x1.y, y1.x, y1.y};
+            set_entry_bits<M32>(bits, d, h);
+        }
     }
 }
 
-__global__ __launch_bounds__(kBuildThreads) void k_build_sets(const SetBuildArgs a)
+__global__ __launch_bounds__(kBuildSetsThreads) void k_build_sets(const SetBuildArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
     const SetBuildItem it = a.items[blockIdx.x];
@@ -736,14 +776,14 @@ __global__ __launch_bounds__(kBuildThreads) void k_build_sets(const SetBuildArgs
     const uint64_t nw = (d.m + 63) >> 6;
     const bool m32 = d.m < (1ull << 31);
     if (it.staged) {
-        for (uint32_t i = tid; i < nw; i += kBuildThreads) lds64[i] = 0;
+        for (uint32_t i = tid; i < nw; i += kBuildSetsThreads) lds64[i] = 0;
         __syncthreads();
         lds_u32 *bits = (lds_u32 *)lds64;
         if (m32) build_from_slots<true>(t, it, d, bits, tid);
         else     build_from_slots<false>(t, it, d, bits, tid);
         __syncthreads();
         uint64_t *dst = a.out + d.word_off;
-        for (uint32_t i = tid; i < nw; i += kBuildThreads) dst[i] = lds64[i];
+        for (uint32_t i = tid; i < nw; i += kBuildSetsThreads) dst[i] = lds64[i];
     } else {
         uint32_t *bits = reinterpret_cast<uint32_t *>(a.out + d.word_off);
         if (m32) build_from_slots<true>(t, it, d, bits, tid);
