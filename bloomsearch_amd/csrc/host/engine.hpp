@@ -118,15 +118,12 @@ public:
         if (stopped_) return fail(kErrEngineStopped, "engine stopped");
         if (rows.empty()) return kEngineOk;  // ingest.go:356-359
         std::vector<std::string> pids(rows.size());
+        std::string scratch;
         for (size_t i = 0; i < rows.size(); ++i) {
-            JNode dom;
-            if (!parse_dom(rows[i], dom) || dom.type != JType::Object) return fail(kErrInvalidRow, "row " + std::to_string(i) + " is not a JSON object");
-            if (!cfg_.partition_field.empty()) {
-                const JNode *v = dom.get(cfg_.partition_field);
-                if (v && (v->type == JType::String || v->type == JType::Number)) pids[i] = v->text;
-                else if (v && v->type == JType::True) pids[i] = "true";
-                else if (v && v->type == JType::False) pids[i] = "false";
-            }
+            bool has_pid = false;
+            if (!validate_object_row(rows[i], cfg_.partition_field, pids[i], has_pid, scratch))
+                return fail(kErrInvalidRow, "row " + std::to_string(i) + " is not a JSON object");
+            if (!has_pid) pids[i].clear();
         }
         bool should_flush = false;
         for (size_t i = 0; i < rows.size(); ++i) {

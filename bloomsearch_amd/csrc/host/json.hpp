@@ -199,6 +199,95 @@ inline bool parse_dom_value(JScanner &sc, JNode &out, int depth = 0)
     }
 }
 
+// Validation without a DOM (the ingest path checks every row of a batch before touching a buffer,
+// ingest.go:378-397): accepts exactly what parse_dom accepts.  `scratch` is reused for decoded strings.
+inline bool validate_value(JScanner &sc, std::string &scratch, int depth = 0)
+{
+    if (depth > 512) return sc.fail();
+    sc.skip_ws();
+    if (sc.p >= sc.end) return sc.fail();
+    switch (*sc.p) {
+    case '{':
+        ++sc.p;
+        sc.skip_ws();
+        if (sc.p < sc.end && *sc.p == '}') { ++sc.p; return true; }
+        for (;;) {
+            sc.skip_ws();
+            scratch.clear();
+            if (!sc.parse_string(scratch)) return false;
+            sc.skip_ws();
+            if (sc.p >= sc.end || *sc.p != ':') return sc.fail();
+            ++sc.p;
+            if (!validate_value(sc, scratch, depth + 1)) return false;
+            sc.skip_ws();
+            if (sc.p < sc.end && *sc.p == ',') { ++sc.p; continue; }
+            if (sc.p < sc.end && *sc.p == '}') { ++sc.p; return true; }
+            return sc.fail();
+        }
+    case '[':
+        ++sc.p;
+        sc.skip_ws();
+        if (sc.p < sc.end && *sc.p == ']') { ++sc.p; return true; }
+        for (;;) {
+            if (!validate_value(sc, scratch, depth + 1)) return false;
+            sc.skip_ws();
+            if (sc.p < sc.end && *sc.p == ',') { ++sc.p; continue; }
+            if (sc.p < sc.end && *sc.p == ']') { ++sc.p; return true; }
+            return sc.fail();
+        }
+    case '"': scratch.clear(); return sc.parse_string(scratch);
+    case 't': return sc.parse_literal("true");
+    case 'f': return sc.parse_literal("false");
+    case 'n': return sc.parse_literal("null");
+    default: { std::string_view raw; return sc.parse_number(raw); }
+    }
+}
+
+// A row must be one JSON object and nothing else.  When `want_key` is non-empty, the text of the FIRST top-level
+// member with that key is returned in `text` if it is a string, number (raw literal), true or false (JNode::get
+// semantics of the DOM path it replaces); has_text tells whether there was one.
+inline bool validate_object_row(std::string_view row, std::string_view want_key, std::string &text, bool &has_text, std::string &scratch)
+{
+    has_text = false;
+    JScanner sc(row.data(), row.size());
+    sc.skip_ws();
+    if (sc.p >= sc.end || *sc.p != '{') return false;
+    ++sc.p;
+    sc.skip_ws();
+    bool seen = false;
+    if (sc.p < sc.end && *sc.p == '}') { ++sc.p; }
+    else {
+        for (;;) {
+            sc.skip_ws();
+            scratch.clear();
+            if (!sc.parse_string(scratch)) return false;
+            const bool mine = !seen && !want_key.empty() && scratch == want_key;
+            sc.skip_ws();
+            if (sc.p >= sc.end || *sc.p != ':') return false;
+            ++sc.p;
+            if (mine) {
+                seen = true;
+                sc.skip_ws();
+                const char *v0 = sc.p;
+                const char c = sc.p < sc.end ? *sc.p : 0;
+                if (!validate_value(sc, scratch, 1)) return false;
+                if (c == '"') { text = scratch; has_text = true; }
+                else if (c == 't') { text = "true"; has_text = true; }
+                else if (c == 'f') { text = "false"; has_text = true; }
+                else if (c == '-' || (c >= '0' && c <= '9')) { text.assign(v0, sc.p - v0); has_text = true; }
+            } else if (!validate_value(sc, scratch, 1)) {
+                return false;
+            }
+            sc.skip_ws();
+            if (sc.p < sc.end && *sc.p == ',') { ++sc.p; continue; }
+            if (sc.p < sc.end && *sc.p == '}') { ++sc.p; break; }
+            return false;
+        }
+    }
+    sc.skip_ws();
+    return sc.ok && sc.p == sc.end;
+}
+
 inline bool parse_dom(std::string_view json, JNode &out)
 {
     JScanner sc(json.data(), json.size());
