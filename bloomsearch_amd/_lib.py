@@ -33,7 +33,7 @@ class Timing(C.Structure):
 class IngestStats(C.Structure):
     _fields_ = [("n_rows", C.c_uint32), ("n_fallback_rows", C.c_uint32), ("table_grows", C.c_uint32), ("reserved", C.c_uint32),
                 ("row_bytes", C.c_uint64), ("table_bytes", C.c_uint64), ("ms_walk", C.c_float), ("ms_union", C.c_float),
-                ("ms_build", C.c_float), ("reserved2", C.c_float)]
+                ("ms_build", C.c_float), ("ms_encode", C.c_float)]
 
 
 class BloomGpuError(RuntimeError):
@@ -53,7 +53,8 @@ EXPORTS = [
     "bsg_batch_create", "bsg_batch_free", "bsg_probe_batch", "bsg_probe_many", "bsg_probe", "bsg_timing_read", "bsg_set_timed_stride", "bsg_last_kernel_ms",
     "bsg_or_reduce", "bsg_or_words_dev", "bsg_or_reduce_dev", "bsg_last_or_ms",
     "bsg_ingest_rows", "bsg_ingest_fallback_rows", "bsg_ingest_add_entries", "bsg_ingest_finish", "bsg_ingest_build",
-    "bsg_ingest_stats_read", "bsg_ingest_free",
+    "bsg_ingest_stats_read", "bsg_ingest_free", "bsg_ingest_build_sections",
+    "bsg_sections_size", "bsg_build_sections", "bsg_last_encode_ms",
 ]
 
 _lib = None
@@ -101,6 +102,10 @@ def load():
     L.bsg_ingest_build.argtypes = [vp, u64, vp, vp, u64]
     L.bsg_ingest_stats_read.argtypes = [vp, u64, C.POINTER(IngestStats)]
     L.bsg_ingest_free.argtypes = [vp, u64]
+    L.bsg_ingest_build_sections.argtypes = [vp, u64, vp, u64, vp, u64, vp]
+    L.bsg_sections_size.argtypes = [vp, u32, C.POINTER(u64)]
+    L.bsg_build_sections.argtypes = [vp, vp, vp, u32, vp, vp, u32, u64, vp, u64, vp]
+    L.bsg_last_encode_ms.argtypes = [vp, C.POINTER(C.c_float)]
     for name in EXPORTS:
         if name != "bsg_last_error":
             getattr(L, name).restype = i32

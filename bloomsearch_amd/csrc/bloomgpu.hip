@@ -93,11 +93,12 @@ struct Device {
     DevBuf<DevDesc> stage_desc;
     DevBuf<bsg::BuildItem> stage_items;
     DevBuf<uint64_t> stage_words;
+    DevBuf<uint8_t> stage_region;  // encoded filter sections
     std::vector<EventTriple> pending;
     std::vector<EventTriple> free_events;
     bsg::CrcConsts *d_crc = nullptr;          // CRC32C slice-by-8 tables + x^(2^i) mod P (k_decode_sections)
     hipEvent_t kb0 = nullptr, kb1 = nullptr;  // start/stop timestamps of the last k_build / k_hash_entries dispatch
-    float last_build_ms = 0.f, last_hash_ms = 0.f, last_decode_ms = 0.f, last_or_ms = 0.f;
+    float last_build_ms = 0.f, last_hash_ms = 0.f, last_decode_ms = 0.f, last_or_ms = 0.f, last_encode_ms = 0.f;
     bool or_pending = false;   // kb0/kb1 hold an un-read k_or_reduce_blocks dispatch
 };
 
@@ -160,6 +161,10 @@ struct bsg_ctx {
 namespace {
 
 void free_all_ingests(bsg_ctx *ctx);   // ingest_api.inc
+
+struct SectionsOut { uint8_t *region; uint64_t cap; uint64_t *sec_off; };   // encode_api.inc
+int32_t encode_sections_device(Device &d, const uint64_t *d_words, const bsg_filter_desc *desc, uint32_t n_blocks,
+                               uint8_t *out_region, uint64_t region_cap, uint64_t *out_sec_off, float *ms);
 
 int32_t use_device(Device &d)
 {
@@ -371,7 +376,7 @@ int32_t bsg_close(bsg_ctx *ctx)
                 (void)hipEventDestroy(t.k2s); (void)hipEventDestroy(t.k2e);
             }
         d.V[0].release(); d.V[1].release(); d.out[0].release(); d.out[1].release(); d.stage_a.release(); d.stage_off.release(); d.stage_h.release();
-        d.stage_fstart.release(); d.stage_desc.release(); d.stage_items.release(); d.stage_words.release();
+        d.stage_fstart.release(); d.stage_desc.release(); d.stage_items.release(); d.stage_words.release(); d.stage_region.release();
         if (d.stream) (void)hipStreamDestroy(d.stream);
     }
     delete ctx;
@@ -433,11 +438,11 @@ int32_t bsg_hash_entries(bsg_ctx *ctx, const uint8_t *bytes, const uint32_t *off
 
 static int32_t build_common(bsg_ctx *ctx, const uint8_t *bytes, const uint32_t *offsets, const uint64_t *h,
                             uint32_t n_entries, const uint32_t *fstart, const bsg_filter_desc *desc,
-                            uint32_t n_filters, uint64_t *out_words, uint64_t n_words)
+                            uint32_t n_filters, uint64_t *out_words, uint64_t n_words, const SectionsOut *sections = nullptr)
 {
     if (!ctx) return fail(BSG_E_INVALID, "ctx is null");
-    if (n_filters == 0) return BSG_OK;
-    if (!fstart || !desc || !out_words) return fail(BSG_E_INVALID, "null argument");
+    if (n_filters == 0) { if (sections) sections->sec_off[0] = 0; return BSG_OK; }
+    if (!fstart || !desc || (!out_words && !sections)) return fail(BSG_E_INVALID, "null argument");
     if (int32_t rc = validate_descs(desc, n_filters, n_words)) return rc;
     if (fstart[n_filters] != n_entries) return fail(BSG_E_INVALID, "filter_entry_start[n_filters] != n_entries");
     for (uint32_t f = 0; f < n_filters; ++f)
@@ -501,8 +506,13 @@ static int32_t build_common(bsg_ctx *ctx, const uint8_t *bytes, const uint32_t *
         HIP_TRY(hipGetLastError());
         launched = true;
     }
-    HIP_TRY(hipMemcpyAsync(out_words, d.stage_words.p, n_words * 8, hipMemcpyDeviceToHost, d.stream));
-    HIP_TRY(hipStreamSynchronize(d.stream));
+    if (sections) {      // the words never leave the device: encodeFilterSection runs there too
+        if (int32_t rc = encode_sections_device(d, d.stage_words.p, desc, n_filters / 3, sections->region, sections->cap,
+                                                sections->sec_off, nullptr)) return rc;
+    } else {
+        HIP_TRY(hipMemcpyAsync(out_words, d.stage_words.p, n_words * 8, hipMemcpyDeviceToHost, d.stream));
+        HIP_TRY(hipStreamSynchronize(d.stream));
+    }
     d.last_build_ms = 0.f;
     if (launched) HIP_TRY(hipEventElapsedTime(&d.last_build_ms, d.kb0, d.kb1));
     return BSG_OK;
@@ -1309,4 +1319,5 @@ int32_t bsg_or_reduce(bsg_ctx *ctx, uint64_t arena_id, uint32_t kind, uint64_t *
 
 }  // extern "C"
 
+#include "encode_api.inc"
 #include "ingest_api.inc"

@@ -6,7 +6,8 @@
 //   Query       (query_exec.go:201-444: file stage over file-level filters, evaluateBlockFilters per
 //                candidate block with BloomFilterSkipped stats, final matchRowBytes scan)
 //   Merge       (merge.go:440-817 rebuild semantics: re-index every row, right-size, never OR)
-// The bloom arithmetic runs on the GPU through the C-ABI (bsg_build / bsg_arena_load / bsg_probe);
+// The bloom arithmetic AND both directions of the filter-section codec run on the GPU through the C-ABI
+// (bsg_build_sections / bsg_ingest_* / bsg_arena_load_sections / bsg_probe);
 // there is no CPU bloom path here.  Storage, compression, durability, goroutines and the
 // DataStore / MetaStore plugins are out of scope: "files" are kept in memory with the reference's
 // filter-section bytes (section_codec.hpp) so the wire layout is exercised end to end.
@@ -344,17 +345,23 @@ private:
                 pack_entries(set, bytes, offsets);
                 fstart.push_back((uint32_t)offsets.size() - 1);
             }
-        std::vector<uint64_t> words(std::max<uint64_t>(cursor, 2));
-        if (bsg_build(ctx_, bytes.data(), offsets.data(), (uint32_t)offsets.size() - 1, fstart.data(), desc.data(),
-                      (uint32_t)desc.size(), words.data(), words.size()))
+        // build + encodeFilterSection both on the device: only the section bytes cross PCIe
+        uint64_t total = 0;
+        if (bsg_sections_size(desc.data(), (uint32_t)sets.size(), &total)) return fail(kErrGpu, bsg_last_error(ctx_));
+        std::vector<uint8_t> region(total);
+        std::vector<uint64_t> sec_off(sets.size() + 1);
+        if (bsg_build_sections(ctx_, bytes.data(), offsets.data(), (uint32_t)offsets.size() - 1, fstart.data(), desc.data(),
+                               (uint32_t)desc.size(), std::max<uint64_t>(cursor, 2), region.data(), region.size(), sec_off.data()))
             return fail(kErrGpu, bsg_last_error(ctx_));
-        sections.resize(sets.size());
-        for (size_t s = 0; s < sets.size(); ++s) {
-            FilterView fv[3];
-            for (uint32_t c = 0; c < 3; ++c) fv[c] = FilterView{words.data() + desc[s * 3 + c].word_off, desc[s * 3 + c].m, desc[s * 3 + c].k};
-            sections[s] = encode_filter_section(fv);
-        }
+        split_sections(region, sec_off, sections);
         return kEngineOk;
+    }
+
+    static void split_sections(const std::vector<uint8_t> &region, const std::vector<uint64_t> &sec_off,
+                               std::vector<std::vector<uint8_t>> &sections)
+    {
+        sections.resize(sec_off.size() - 1);
+        for (size_t s = 0; s + 1 < sec_off.size(); ++s) sections[s].assign(region.begin() + sec_off[s], region.begin() + sec_off[s + 1]);
     }
 
     // Device ingest of one file's blocks (flush.go:179-254 / merge.go:706-804 with a1-a5 on the GPU): rows ->
@@ -416,13 +423,14 @@ private:
             desc[i] = bsg_filter_desc{cursor, m, (uint32_t)k, 0};
             cursor += ((m + 63) / 64 + 1) / 2 * 2;
         }
-        std::vector<uint64_t> words(std::max<uint64_t>(cursor, 2));
-        if (bsg_ingest_build(ctx_, ing, desc.data(), words.data(), words.size())) return fail(kErrGpu, bsg_last_error(ctx_));
-        sections.resize(nb + 1);
+        uint64_t total = 0;
+        if (bsg_sections_size(desc.data(), (uint32_t)nb + 1, &total)) return fail(kErrGpu, bsg_last_error(ctx_));
+        std::vector<uint8_t> region(total);
+        std::vector<uint64_t> sec_off(nb + 2);
+        if (bsg_ingest_build_sections(ctx_, ing, desc.data(), std::max<uint64_t>(cursor, 2), region.data(), region.size(), sec_off.data()))
+            return fail(kErrGpu, bsg_last_error(ctx_));
+        split_sections(region, sec_off, sections);
         for (size_t s = 0; s <= nb; ++s) {
-            FilterView fv[3];
-            for (uint32_t c = 0; c < 3; ++c) fv[c] = FilterView{words.data() + desc[s * 3 + c].word_off, desc[s * 3 + c].m, desc[s * 3 + c].k};
-            sections[s] = encode_filter_section(fv);
             BloomEntryCounts &bc = s < nb ? file.blocks[s].counts : file.counts;
             bc = BloomEntryCounts{counts[s * 3], counts[s * 3 + 1], counts[s * 3 + 2]};
         }

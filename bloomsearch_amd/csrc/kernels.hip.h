@@ -910,6 +910,87 @@ __global__ __launch_bounds__(kDecodeThreads) void k_decode_sections(const uint8_
     }
 }
 
+// ---------------------------------------------------------------------------
+// encode_sections: arena words -> filter sections exactly as encodeFilterSection writes them
+// (file_format.go:343-384): [u8 flags] then per present filter [u32 LE len = 24 + 8 nw][u64 BE m][u64 BE k]
+// [u64 BE m (bitset length)][nw x u64 BE words], then [u32 LE CRC32C of everything before it].
+// Two launches so the checksum pass reads the payload after a kernel boundary: k_encode_payload
+// (one workgroup per section) and k_crc_sections (same CRC scheme as k_decode_sections).
+// ---------------------------------------------------------------------------
+struct EncodeInfo {
+    uint64_t begin;          // byte offset of the section in the output region
+    uint32_t len;            // section bytes incl. the CRC trailer
+    uint32_t present;        // bit c set: filter c is written
+    uint64_t src[3];         // word offset of filter c in the device word arena
+    uint64_t m[3];
+    uint32_t k[3];
+    uint32_t nw[3];
+};
+
+__device__ __forceinline__ void store_u64_unaligned(uint8_t *p, uint64_t v) { __builtin_memcpy(p, &v, 8); }
+__device__ __forceinline__ void store_u32_unaligned(uint8_t *p, uint32_t v) { __builtin_memcpy(p, &v, 4); }
+
+__global__ __launch_bounds__(256) void k_encode_payload(const uint64_t *words, const EncodeInfo *info, uint8_t *region)
+{
+    const EncodeInfo e = info[blockIdx.x];
+    uint8_t *sec = region + e.begin;
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) sec[0] = (uint8_t)e.present;
+    uint32_t o = 1;
+    for (uint32_t c = 0; c < 3; ++c) {
+        if (!((e.present >> c) & 1u)) continue;
+        if (tid == 0) {
+            store_u32_unaligned(sec + o, 24u + 8u * e.nw[c]);
+            store_u64_unaligned(sec + o + 4, __builtin_bswap64(e.m[c]));
+            store_u64_unaligned(sec + o + 12, __builtin_bswap64((uint64_t)e.k[c]));
+            store_u64_unaligned(sec + o + 20, __builtin_bswap64(e.m[c]));
+        }
+        const uint64_t *src = words + e.src[c];
+        uint8_t *dst = sec + o + 28;
+        for (uint32_t w = tid; w < e.nw[c]; w += 256) store_u64_unaligned(dst + 8ull * w, __builtin_bswap64(src[w]));
+        o += 28u + 8u * e.nw[c];
+    }
+}
+
+// CRC32C of region[begin, begin + len - 4) written little-endian at its end.  Shares the chunk / combine scheme
+// with k_decode_sections.
+__global__ __launch_bounds__(kDecodeThreads) void k_crc_sections(uint8_t *region, const EncodeInfo *info, const CrcConsts *consts)
+{
+    __shared__ uint32_t tab[8][256];
+    __shared__ uint32_t part[kDecodeThreads];
+    const uint32_t tid = threadIdx.x;
+    const EncodeInfo e = info[blockIdx.x];
+    for (uint32_t i = tid; i < 8 * 256; i += kDecodeThreads) (&tab[0][0])[i] = (&consts->table[0][0])[i];
+    __syncthreads();
+    uint8_t *sec = region + e.begin;
+    const uint32_t P = e.len - 4;
+    const uint32_t C = (P / kDecodeThreads) & ~7u;
+    const uint32_t len0 = P - (kDecodeThreads - 1) * C;
+    const uint32_t start = tid == 0 ? 0 : len0 + (tid - 1) * C;
+    const uint32_t n = tid == 0 ? len0 : C;
+    uint32_t crc = 0;
+    uint32_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+        const uint64_t v = load_u64_unaligned(sec + start + i);
+        const uint32_t lo = (uint32_t)v ^ crc, hi = (uint32_t)(v >> 32);
+        crc = tab[7][lo & 0xFF] ^ tab[6][(lo >> 8) & 0xFF] ^ tab[5][(lo >> 16) & 0xFF] ^ tab[4][lo >> 24] ^
+              tab[3][hi & 0xFF] ^ tab[2][(hi >> 8) & 0xFF] ^ tab[1][(hi >> 16) & 0xFF] ^ tab[0][hi >> 24];
+    }
+    for (; i < n; ++i) crc = tab[0][(crc ^ sec[start + i]) & 0xFF] ^ (crc >> 8);
+    part[tid] = crc;
+    uint32_t op = crc_x2nmodp(C, 3, consts->x2n);
+    __syncthreads();
+    for (uint32_t step = 1; step < kDecodeThreads; step <<= 1) {
+        if ((tid & (2 * step - 1)) == 0) part[tid] = crc_multmodp(op, part[tid]) ^ part[tid + step];
+        op = crc_multmodp(op, op);
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const uint32_t total = part[0] ^ crc_multmodp(crc_x2nmodp(P, 3, consts->x2n), 0xFFFFFFFFu) ^ 0xFFFFFFFFu;
+        store_u32_unaligned(sec + P, total);
+    }
+}
+
 // dst[i] |= OR over s < n_src of src[s * n_words + i]
 __global__ __launch_bounds__(256) void k_or_words(uint64_t *dst, const uint64_t *src, uint64_t n_words,
                                                   uint32_t n_src, int overwrite)

@@ -235,6 +235,41 @@ class Context:
         self._check(self.L.bsg_ingest_build(self.h, ingest_id, _lib._ptr(desc), _lib._ptr(out), n_words))
         return out
 
+    def sections_size(self, desc) -> int:
+        desc = np.ascontiguousarray(desc, dtype=DESC_DTYPE)
+        total = C.c_uint64()
+        self._check(self.L.bsg_sections_size(_lib._ptr(desc), len(desc) // 3, C.byref(total)))
+        return int(total.value)
+
+    def _split_sections(self, region: np.ndarray, sec_off: np.ndarray):
+        raw = region.tobytes()
+        return [raw[int(sec_off[i]): int(sec_off[i + 1])] for i in range(len(sec_off) - 1)]
+
+    def build_sections(self, blob, off, filter_entry_start, desc, n_words: int):
+        """bsg_build + encodeFilterSection on the device -> list of section bytes (one per block)."""
+        desc = np.ascontiguousarray(desc, dtype=DESC_DTYPE)
+        fstart = np.ascontiguousarray(filter_entry_start, dtype=np.uint32)
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.uint32)
+        region = np.zeros(self.sections_size(desc), dtype=np.uint8)
+        sec_off = np.zeros(len(desc) // 3 + 1, dtype=np.uint64)
+        self._check(self.L.bsg_build_sections(self.h, _lib._ptr(blob), _lib._ptr(off), len(off) - 1, _lib._ptr(fstart), _lib._ptr(desc),
+                                              len(desc), n_words, _lib._ptr(region), len(region), _lib._ptr(sec_off)))
+        return self._split_sections(region, sec_off)
+
+    def ingest_build_sections(self, ingest_id: int, desc, n_words: int):
+        desc = np.ascontiguousarray(desc, dtype=DESC_DTYPE)
+        region = np.zeros(self.sections_size(desc), dtype=np.uint8)
+        sec_off = np.zeros(len(desc) // 3 + 1, dtype=np.uint64)
+        self._check(self.L.bsg_ingest_build_sections(self.h, ingest_id, _lib._ptr(desc), n_words, _lib._ptr(region), len(region),
+                                                     _lib._ptr(sec_off)))
+        return self._split_sections(region, sec_off)
+
+    def last_encode_ms(self) -> float:
+        v = C.c_float()
+        self._check(self.L.bsg_last_encode_ms(self.h, C.byref(v)))
+        return float(v.value)
+
     def ingest_stats(self, ingest_id: int) -> IngestStats:
         st = IngestStats()
         self._check(self.L.bsg_ingest_stats_read(self.h, ingest_id, C.byref(st)))

@@ -204,6 +204,20 @@ BSG_API int32_t bsg_or_reduce_dev(bsg_ctx *ctx, uint64_t arena_id, uint32_t kind
 /* Device time of the most recent k_or_reduce_blocks dispatch on the context's first device. */
 BSG_API int32_t bsg_last_or_ms(bsg_ctx *ctx, float *or_ms);
 
+/* ---- filter sections written on the device (encodeFilterSection, file_format.go:343-384) ----
+ * Section b = the three filters desc[3b .. 3b+2] (m == 0 => absent, flag bit clear):
+ *   [u8 flags] { [u32 LE 24 + 8 nw] [u64 BE m] [u64 BE k] [u64 BE m] [nw x u64 BE words] }* [u32 LE CRC32C of all before]
+ * byte for byte what bloom/v3 WriteTo + the reference's framing produce, so the host appends the region to the file
+ * as it is.  bsg_sections_size tells how large out_region must be (a function of the geometry alone). */
+BSG_API int32_t bsg_sections_size(const bsg_filter_desc *desc, uint32_t n_blocks, uint64_t *out_total);
+/* bsg_build followed by the encode, without the words crossing PCIe: n_filters = 3 * n_blocks; n_words sizes the
+ * device arena the descriptors' word_off address; out_sec_off[n_blocks + 1] receives each section's byte offset. */
+BSG_API int32_t bsg_build_sections(bsg_ctx *ctx, const uint8_t *bytes, const uint32_t *offsets, uint32_t n_entries,
+                                   const uint32_t *filter_entry_start, const bsg_filter_desc *desc, uint32_t n_filters,
+                                   uint64_t n_words, uint8_t *out_region, uint64_t region_cap, uint64_t *out_sec_off);
+/* Device time of the most recent k_encode_payload + k_crc_sections pair on the context's first device. */
+BSG_API int32_t bsg_last_encode_ms(bsg_ctx *ctx, float *encode_ms);
+
 /* ---- device ingest: rows -> distinct bloom entries -> exact counts -> bitsets ----
  * Replaces, on the flush / merge worker, the reference's per-row host loop
  *   bloomEntrySets.indexRow (ingest.go:55-89: pathWalker.walk row_matcher.go:51-135, leafTokenInput
@@ -231,7 +245,7 @@ typedef struct bsg_ingest_stats {
     float ms_walk;             /* k_ingest_rows dispatch time (sum over re-runs after a table grew) */
     float ms_union;            /* k_ingest_union into the parents */
     float ms_build;            /* k_build_sets */
-    float reserved2;
+    float ms_encode;           /* k_encode_payload + k_crc_sections (bsg_ingest_build_sections) */
 } bsg_ingest_stats;
 
 /* flags for bsg_ingest_rows.  BSG_INGEST_TRUSTED_JSON: every row is known to be valid JSON (it came out of
@@ -262,6 +276,10 @@ BSG_API int32_t bsg_ingest_finish(bsg_ctx *ctx, uint64_t ingest_id, uint64_t *ou
  * out_words as bsg_build. */
 BSG_API int32_t bsg_ingest_build(bsg_ctx *ctx, uint64_t ingest_id, const bsg_filter_desc *desc, uint64_t *out_words,
                                  uint64_t n_words);
+/* As bsg_ingest_build, but the words never leave the device: every set's three filters are serialised there as one
+ * filter section (see bsg_build_sections) and only the section bytes come back.  out_sec_off[n_sets + n_parents + 1]. */
+BSG_API int32_t bsg_ingest_build_sections(bsg_ctx *ctx, uint64_t ingest_id, const bsg_filter_desc *desc, uint64_t n_words,
+                                          uint8_t *out_region, uint64_t region_cap, uint64_t *out_sec_off);
 BSG_API int32_t bsg_ingest_stats_read(bsg_ctx *ctx, uint64_t ingest_id, bsg_ingest_stats *out);
 BSG_API int32_t bsg_ingest_free(bsg_ctx *ctx, uint64_t ingest_id);
 

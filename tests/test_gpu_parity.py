@@ -54,6 +54,43 @@ def test_build_bit_exact_small_medium_large_empty_absent(ctx):
         assert (int(plan.desc["m"][3 * 3 + 1]) + 63) // 64 * 8 > 144 * 1024
 
 
+def test_build_sections_bytes_equal_oracle_and_host_codec(ctx):
+    """encodeFilterSection on the device (k_encode_payload + k_crc_sections): every section is byte-identical to the
+    oracle's encode of the oracle's filters and to the C++ host codec; absent filters clear their flag bit; the
+    sections round-trip through the device decoder (bsg_arena_load_sections) with clean status."""
+    from bloomsearch_amd import host as Hst
+    blocks = [
+        entry_sets_from_strings(["a", "b.c"], ["x%d" % i for i in range(300)], []),
+        entry_sets_from_strings(["f%d" % i for i in range(9)], ["t%d" % i for i in range(20000)], ["f::t%d" % i for i in range(20000)]),
+        entry_sets_from_strings(["only"], ["big%d" % i for i in range(60000)], ["k::v"]),
+        entry_sets_from_strings(["only"], ["huge%d" % i for i in range(160000)], ["k::v"]),
+        entry_sets_from_strings([], [], []),
+        entry_sets_from_strings(["z"], ["one"], ["z::one"]),
+    ]
+    for fpr, absent in ((0.001, {(4, 1)}), (0.01, {(0, 0), (0, 1), (0, 2), (5, 2)})):
+        plan = plan_blocks(blocks, fpr, absent=absent)
+        secs = ctx.build_sections(plan.blob, plan.off, plan.fstart, plan.desc, plan.n_words)
+        assert ctx.last_encode_ms() > 0
+        words = H.oracle_words(plan)
+        assert ctx.sections_size(plan.desc) == sum(len(x) for x in secs)
+        for b in range(len(blocks)):
+            fl_o, fl_h = [], []
+            for c in range(3):
+                d = plan.desc[b * 3 + c]
+                if int(d["m"]) == 0:
+                    fl_o.append(None); fl_h.append(None)
+                    continue
+                w = words[int(d["word_off"]): int(d["word_off"]) + O.words_for(int(d["m"]))]
+                fl_o.append(O.Filter(int(d["m"]), int(d["k"]), w))
+                fl_h.append((int(d["m"]), int(d["k"]), w))
+            want = O.encode_filter_section(fl_o)
+            assert secs[b] == want, (fpr, b)
+            assert Hst.section_encode(fl_h) == want
+        aid, status = ctx.arena_load_sections(secs)
+        assert not status.any()
+        ctx.arena_free(aid)
+
+
 def test_build_hashed_equals_build(ctx):
     blocks = [entry_sets_from_strings(["p"], ["w%d" % i for i in range(5000)], ["p::w%d" % i for i in range(5000)])]
     plan = plan_blocks(blocks, 0.001)
