@@ -155,23 +155,28 @@ def or_reduce_leg(ctx, plan, B, fpr, n_union, world, log):
            "check": "equals bsg_build(union of the blocks' entries, m, k) bit for bit"}
     res["frac"] = res["achieved"] / HBM_PEAK_GBPS
     if world > 1:
-        import torch.distributed as dist
-        ts = []
-        for _ in range(6):
-            part = out.clone()
-            dist.barrier()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            P.or_allreduce_(part, ctx)
-            torch.cuda.synchronize()
-            ts.append(time.perf_counter() - t1)
-        res["allreduce_ms"] = float(np.median(ts[1:])) * 1e3
-        res["allreduce_wire_bytes_in_per_gpu"] = (world - 1) * nw * 8
-        res["allreduce"] = "all_gather (RCCL) of %d partials + k_or_words" % world
+        # the exchange half; a failure here must not take the probe measurement down with it
+        try:
+            import torch.distributed as dist
+            ts = []
+            for _ in range(6):
+                part = out.clone()
+                dist.barrier()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                P.or_allreduce_(part, ctx)
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t1)
+            res["allreduce_ms"] = float(np.median(ts[1:])) * 1e3
+            res["allreduce_wire_bytes_in_per_gpu"] = (world - 1) * nw * 8
+            res["allreduce"] = "all_gather (RCCL) of %d partials + k_or_words" % world
+        except Exception as exc:  # noqa: BLE001 - reported, not swallowed
+            res["allreduce_error"] = repr(exc)
+            log("OR all-reduce failed: %r" % (exc,))
     ctx.arena_free(aid)
     log("OR-reduce: %d filters x %.0f KB in %.1f us = %.0f GB/s (%.0f%% of peak)%s; setup %.1fs"
         % (B, nw * 8 / 1e3, local_ms * 1e3, res["achieved"], 100 * res["frac"],
-           ("; all-reduce over %d ranks %.2f ms" % (world, res["allreduce_ms"])) if world > 1 else "", t_setup))
+           ("; all-reduce over %d ranks %.2f ms" % (world, res["allreduce_ms"])) if "allreduce_ms" in res else "", t_setup))
     return res
 
 
