@@ -1,0 +1,80 @@
+"""The C-ABI is re-entrant on one context (file-worker goroutines call bsg_probe concurrently — up to
+MaxQueryConcurrency of them — while the flush worker builds): many host threads drive one bsg_ctx at once through
+every family of entry points, and every result must still equal the oracle's, bit for bit.  ctypes releases the GIL
+for the duration of each C call, so the calls really overlap."""
+import threading
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+from bloomsearch_amd import ingest as I, query as Q, synth
+from oracle import oracle as O
+from oracle import walker_oracle as W
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+N_THREADS = 8
+ROUNDS = 6
+
+
+def _probe_job(ctx, seed):
+    rng = np.random.default_rng(seed)
+    plan, _, vocab = H.make_random_arena(rng, int(rng.integers(3, 150)), absent_frac=0.03)
+    cb = Q.compile_queries([None] + [H.random_expression(rng, vocab, None) for _ in range(int(rng.integers(1, 400)))])
+    ops, poff, _ = cb.arrays()
+    want_words = H.oracle_words(plan)
+    want = O.probe_batch(want_words, plan.desc.view(O.DESC_DTYPE), H.oracle_terms(cb).view(O.TERM_DTYPE), ops, poff)
+    for _ in range(ROUNDS):
+        words = ctx.build(plan.blob, plan.off, plan.fstart, plan.desc, plan.n_words)
+        assert np.array_equal(words, want_words)
+        terms = H.gpu_terms(ctx, cb)
+        aid = ctx.arena_load(words, plan.desc)
+        bid = ctx.batch_create(terms, ops, poff)
+        got = ctx.probe_batch(aid, bid, cb.n_queries, plan.n_blocks)
+        many = ctx.probe_many([aid, aid, aid], bid, 0, cb.n_queries, [plan.n_blocks] * 3)
+        one = ctx.probe(aid, plan.n_blocks, terms, ops, poff)
+        ctx.batch_free(bid)
+        ctx.arena_free(aid)
+        assert np.array_equal(got, want) and np.array_equal(one, want)
+        assert all(np.array_equal(m, want) for m in many)
+    return True
+
+
+def _ingest_job(ctx, seed):
+    rows = [synth.rows_json(seed * 1000 + b * 300, 300) for b in range(3)]
+    sets = []
+    for rs in rows:
+        s = (set(), set(), set())
+        for r in rs:
+            W.index_row(r, s)
+        sets.append(s)
+    for _ in range(ROUNDS):
+        res = I.device_ingest(ctx, rows, 0.001, parent_of_set=[0, 0, 0], n_parents=1, flags=seed & 1)
+        for i, s in enumerate(sets):
+            for kind in range(3):
+                assert int(res.counts[i, kind]) == len(s[kind])
+                want = O.build_sized(sorted(s[kind]), 0.001)
+                assert np.array_equal(res.filter_words(i, kind), want.words)
+        union = [set().union(*(s[k] for s in sets)) for k in range(3)]
+        assert [int(x) for x in res.counts[3]] == [len(u) for u in union]
+    return True
+
+
+def test_many_threads_one_context(ctx):
+    errors = []
+    barrier = threading.Barrier(N_THREADS)
+
+    def run(i):
+        try:
+            barrier.wait(timeout=60)
+            return _probe_job(ctx, 100 + i) if i % 4 != 3 else _ingest_job(ctx, 7 + i)
+        except BaseException as exc:  # noqa: BLE001 - reported below with the thread index
+            errors.append((i, repr(exc)))
+            return False
+
+    with ThreadPoolExecutor(N_THREADS) as pool:
+        results = list(pool.map(run, range(N_THREADS)))
+    assert not errors, errors
+    assert all(results)
