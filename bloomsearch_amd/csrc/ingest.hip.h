@@ -9,10 +9,11 @@
 //   bloomEntrySets.indexRow / addFieldToken / unionInto / counts  ingest.go:24-123 (key: tokenizer.go:509-511)
 //   buildFilters' AddString loop ............................. ingest.go:127-145
 //
-// Scope of the device walker ("walker-lite"): rows made of printable ASCII (0x20..0x7E) without any
-// backslash, nesting <= kMaxDepth, paths <= kPathCap bytes.  A row that leaves that envelope — or is
-// malformed — is appended to the fallback list and finished by the host walker (walker.hpp), which
-// handles escapes, UTF-8, Unicode white space / case folding and the lenient error semantics.
+// Scope of the device walker ("walker-lite"): rows whose raw bytes are printable ASCII (0x20..0x7E), whose JSON
+// escapes are the simple ones (\" \\ \/ \b \f \n \r \t) or \uXXXX below 0x80 (json.Marshal's \u003c \u003e \u0026),
+// nesting <= kMaxDepth, paths <= kPathCap bytes.  A row that leaves that envelope — or is malformed — is appended to
+// the fallback list and finished by the host walker (walker.hpp), which handles UTF-8, non-ASCII escapes, Unicode
+// white space / case folding and the lenient error semantics.
 // The kernel walks every row twice: a validation pass (automaton only, no hashing) decides whether the row is the
 // device's, and only rows that pass are walked again to emit — a row handed to the host has inserted nothing.
 //
@@ -275,7 +276,8 @@ struct IngestArgs {
 typedef __attribute__((address_space(3))) uint8_t lds_u8;
 
 enum : uint32_t {
-    S_VALUE, S_VALUE_OR_CLOSE, S_KEY_OR_CLOSE, S_KEY_OPEN, S_KEY, S_COLON, S_PREFIX, S_STR, S_NUM, S_LIT, S_AFTER
+    S_VALUE, S_VALUE_OR_CLOSE, S_KEY_OR_CLOSE, S_KEY_OPEN, S_KEY, S_COLON, S_PREFIX, S_STR, S_NUM, S_LIT, S_AFTER,
+    S_STR_ESC, S_STR_U, S_KEY_ESC, S_KEY_U   // after a backslash / inside \uXXXX, in a string value / in a key
 };
 enum : uint32_t { R_CONTINUE, R_DONE, R_FAIL };
 // What a lane asks the converged part of the loop to do for it (hashing is the expensive part of an emission —
@@ -294,7 +296,7 @@ struct Walker {
     uint32_t path_len, depth, objmask, st;
     uint32_t aux;            // S_PREFIX: scan index; S_NUM: phase; S_LIT: matched chars
     uint32_t key_len;        // path length including the key being read (S_KEY .. S_PREFIX)
-    uint32_t lit;            // S_LIT: 0 true, 1 false, 2 null
+    uint32_t lit;            // S_LIT: 0 true, 1 false, 2 null; S_*_U: hex digits seen << 16 | value so far
     uint32_t req, req_len;   // pending request
     bool quiet;              // leaf without a path (scalars at the root): nothing is emitted
     bool in_token;
@@ -358,6 +360,40 @@ __device__ __forceinline__ uint32_t num_next(uint32_t phase, uint32_t c)
     }
 }
 __device__ __forceinline__ bool num_accepting(uint32_t phase) { return phase == 1u || phase == 3u || phase == 6u; }
+
+// JSON escapes the device decodes itself: \" \\ \/ \b \f \n \r \t and \u00XX below 0x80 (Go's json.Marshal writes <, >, &
+// as \u003c, \u003e, \u0026, so ordinary log text is full of them).  Anything that decodes to a non-ASCII rune goes to
+// the host walker, which owns UTF-8 encoding and the Unicode space / case tables.
+__device__ __forceinline__ uint32_t simple_escape(uint32_t c)
+{
+    switch (c) {
+    case '"': return '"';
+    case '\\': return '\\';
+    case '/': return '/';
+    case 'b': return 0x08;
+    case 'f': return 0x0C;
+    case 'n': return 0x0A;
+    case 'r': return 0x0D;
+    case 't': return 0x09;
+    default: return 0xFFFFu;
+    }
+}
+__device__ __forceinline__ uint32_t hex_value(uint32_t c)
+{
+    if (c - '0' <= 9u) return c - '0';
+    const uint32_t l = c | 0x20u;
+    return (l - 'a' <= 5u) ? l - 'a' + 10u : 0xFFu;
+}
+// unicode.IsSpace below 0x80: \t \n \v \f \r and space (forEachWord, row_matcher.go:142-181)
+__device__ __forceinline__ bool ascii_space(uint32_t b) { return b == ' ' || (b - 9u) <= 4u; }
+
+// a decoded (escaped) byte of a string value: white space ends the word, anything else belongs to it
+__device__ __forceinline__ bool str_decoded_byte(Walker &w, uint32_t b)
+{
+    if (ascii_space(b)) return word_end(w);
+    word_byte(w, b);
+    return false;
+}
 
 // Runs until the lane has a request pending (w.req), has used up its chunk, is done, or must go to the host.
 template <bool EMIT>
@@ -442,9 +478,46 @@ __device__ __forceinline__ uint32_t walker_step(Walker &w)
             w.key_len += n;
             w.pos += n;
             if (n < avail) {                                        // stopped on a byte inside the chunk
-                if (c_at(v, n) != '"') return R_FAIL;
+                const uint32_t b = c_at(v, n);
                 ++w.pos;
-                w.st = S_COLON;
+                if (b == '"') w.st = S_COLON;
+                else if (b == '\\') w.st = S_KEY_ESC;
+                else return R_FAIL;
+            }
+            break;
+        }
+        case S_KEY_ESC:
+        case S_STR_ESC: {
+            ++w.pos;
+            const bool key = w.st == S_KEY_ESC;
+            if (c == 'u') { w.lit = 0; w.st = key ? S_KEY_U : S_STR_U; break; }
+            const uint32_t b = simple_escape(c);
+            if (b == 0xFFFFu) return R_FAIL;
+            w.st = key ? S_KEY : S_STR;
+            if (key) {
+                if (w.key_len >= kPathCap) return R_FAIL;
+                w.path[w.key_len++] = (uint8_t)b;
+            } else if (str_decoded_byte(w, b)) {
+                return R_CONTINUE;
+            }
+            break;
+        }
+        case S_KEY_U:
+        case S_STR_U: {
+            const uint32_t h = hex_value(c);
+            if (h == 0xFFu) return R_FAIL;
+            ++w.pos;
+            const uint32_t seen = (w.lit >> 16) + 1, value = ((w.lit & 0xFFFFu) << 4) | h;
+            w.lit = (seen << 16) | value;
+            if (seen < 4) break;
+            if (value >= 0x80u) return R_FAIL;                      // non-ASCII rune: the host walker's business
+            const bool key = w.st == S_KEY_U;
+            w.st = key ? S_KEY : S_STR;
+            if (key) {
+                if (w.key_len >= kPathCap) return R_FAIL;
+                w.path[w.key_len++] = (uint8_t)value;
+            } else if (str_decoded_byte(w, value)) {
+                return R_CONTINUE;
             }
             break;
         }
@@ -471,7 +544,8 @@ __device__ __forceinline__ uint32_t walker_step(Walker &w)
                 const uint32_t b = c_at(v, n);
                 ++w.pos;
                 if (b == '"') { w.st = S_AFTER; if (word_end(w)) return R_CONTINUE; }
-                else if (b == ' ') { if (word_end(w)) return R_CONTINUE; }   // only 0x20 can occur: other white space fails here
+                else if (b == ' ') { if (word_end(w)) return R_CONTINUE; }   // raw white space other than 0x20 fails here
+                else if (b == '\\') w.st = S_STR_ESC;
                 else return R_FAIL;
             }
             break;

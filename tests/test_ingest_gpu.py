@@ -68,16 +68,21 @@ ROWS_DEVICE = [  # inside the device walker's envelope
     b'{"a::b":"x::y","a":"b::c"}', b'{"dup":"A a A","dup":"b"}', b'[{"top":"array"},5,"str"]', b'"just a string"', b'12',
     b'{"MiXeD":"CamelCase UPPER lower 123ABC"}', b'{"k":"!@#$%^&*() ~`[]{};:,./<>?"}',
     b'{"user":{"name":"John Doe","tags":[{"type":"admin"},{"role":"user"}]}}',
+    # JSON escapes that decode below 0x80 are the device's too (json.Marshal writes <, >, & as \\u003c, \\u003e, \\u0026)
+    b'{"m":"\\u003chtml\\u003e\\u0026amp; x"}', b'{"back\\\\slash":"v","q?x":"y"}', b'{"t":"tab\\there","n":"new\\nline \\r\\f\\b x"}',
+    b'{"q":"say \\"Hi\\" ok","s":"a\\/b"}', b'{"u":"\\u0041BC \\u0061\\u0020\\u0062 \\u003C\\u003c","z":"nul\\u0000in"}',
+    b'{"a\\u002eb":"dot in key","k\\"q":1,"sp\\u0020ace":[true]}', b'{"e":"\\\\","f":"\\\\\\"x"}',
 ]
 ROWS_HOST = [    # must be handed to the host walker
-    b'{"m":"\\u003chtml\\u003e\\u0026amp; x"}', b'{"back\\\\slash":"v","q?x":"y"}', '{"héllo":"日本語 ÀB"}'.encode(),
-    b'{"t":"tab\\there","n":"new\\nline"}', b'{"raw":"ctl\x01char"}', b'{"a":\t1}', '{"nbsp":"a b c"}'.encode(),
+    '{"héllo":"日本語 ÀB"}'.encode(), b'{"raw":"ctl\x01char"}', b'{"a":\t1}', '{"nbsp":"a\u00a0b\u2003c"}'.encode(),
+    b'{"e":"caf\\u00e9 \\u00c0"}', b'{"emoji":"\\ud83d\\ude00 x"}', b'{"nbsp":"a\\u00a0b"}',
     ('{' + '"a":{' * 17 + '"x":1' + '}' * 17 + '}').encode(),
     ('{"' + 'k' * 150 + '":{"' + 'j' * 60 + '":1}}').encode(),
     b'{"s":"\xff\xfe bad utf8"}',
 ]
 ROWS_MALFORMED = [b'{"a": [1, 2', b'{"a":"x" "b":1}', b'{"a":tru}', b'{"ok":"first","b":01x}', b'{"a":1}}', b'{"a":"unterminated',
-                  b'', b'   ', b'{"a":1,}', b'{"k" 1}', b'{"a":-}', b'{"a":1.}', b'{"a":1e}', b'{"x":"y"} trailing']
+                  b'', b'   ', b'{"a":1,}', b'{"k" 1}', b'{"a":-}', b'{"a":1.}', b'{"a":1e}', b'{"x":"y"} trailing',
+                  b'{"a":"bad \\x escape"}', b'{"a":"short \\u12"}', b'{"a":"\\u00zz"}', b'{"k\\q":1}', b'{"a":"ok","b":"dangling\\']
 
 
 def host_sets(rows):
