@@ -102,7 +102,7 @@ def load():
     L.bsg_ingest_build.argtypes = [vp, u64, vp, vp, u64]
     L.bsg_ingest_stats_read.argtypes = [vp, u64, C.POINTER(IngestStats)]
     L.bsg_ingest_free.argtypes = [vp, u64]
-    L.bsg_ingest_build_sections.argtypes = [vp, u64, vp, u64, vp, u64, vp]
+    L.bsg_ingest_build_sections.argtypes = [vp, u64, vp, vp, u64, vp, C.POINTER(u64), C.POINTER(u64)]
     L.bsg_sections_size.argtypes = [vp, u32, C.POINTER(u64)]
     L.bsg_build_sections.argtypes = [vp, vp, vp, u32, vp, vp, u32, u64, vp, u64, vp]
     L.bsg_last_encode_ms.argtypes = [vp, C.POINTER(C.c_float)]

@@ -65,6 +65,11 @@ struct DataFile {
     std::vector<DataBlock> blocks;
     BloomEntryCounts counts;
     std::vector<uint8_t> filter_section; // file-level filters
+    // the file's block filters as a resident probe arena: left on the device by the flush / merge that built them
+    // (DeviceIngest), or decoded from the stored sections on first use; kept until the file goes away
+    uint64_t arena = 0;
+    bool arena_valid = false;
+    std::vector<int32_t> block_status;   // parseFilterSection outcome per block (0 ok); all 0 for a flush-resident arena
 };
 
 struct BlockStats {                      // query_exec.go:63-72
@@ -108,7 +113,8 @@ public:
         }
         if (byte_index >= sec->size()) return false;
         (*sec)[byte_index] ^= 0x5A;
-        drop_arenas();
+        if (block_index >= 0) drop_file_arena(files_[file_index]);   // re-read (and re-checked) from the stored bytes on next use
+        else drop_files_arena();
         return true;
     }
 
@@ -179,7 +185,7 @@ public:
         files_.push_back(std::move(file));
         buffers_.clear();
         buffered_rows_ = buffered_bytes_ = 0;
-        drop_arenas();
+        drop_files_arena();          // one more file-level "block"; the other files' block arenas stay where they are
         return kEngineOk;
     }
 
@@ -234,9 +240,10 @@ public:
             off += out.blocks[b].row_bytes;
         }
         out.filter_section = std::move(sections.back());
+        for (auto &f : files_) drop_file_arena(f);
         files_.clear();
         files_.push_back(std::move(out));
-        drop_arenas();
+        drop_files_arena();
         return kEngineOk;
     }
 
@@ -248,23 +255,40 @@ public:
         std::vector<std::vector<uint8_t>> block_ok(files_.size());
         for (size_t f = 0; f < files_.size(); ++f) block_ok[f].assign(files_[f].blocks.size(), 1);
         if (expr && !files_.empty()) {
-            if (int32_t rc = ensure_arenas()) return rc;
             QueryBatch qb;
             qb.add_query(expr);
             std::vector<bsg_term> terms;
             if (int32_t rc = hash_terms(qb, terms)) return rc;
-            std::vector<uint64_t> fs((files_.size() + 63) / 64), bs((total_blocks_ + 63) / 64);
-            if (bsg_probe(ctx_, files_arena_, terms.data(), (uint32_t)terms.size(), qb.prog_ops.data(), qb.prog_off.data(), 1, fs.data()))
+            uint64_t batch = 0;
+            if (bsg_batch_create(ctx_, terms.data(), (uint32_t)terms.size(), qb.prog_ops.data(), qb.prog_off.data(), 1, &batch))
                 return fail(kErrGpu, bsg_last_error(ctx_));
-            if (bsg_probe(ctx_, blocks_arena_, terms.data(), (uint32_t)terms.size(), qb.prog_ops.data(), qb.prog_off.data(), 1, bs.data()))
-                return fail(kErrGpu, bsg_last_error(ctx_));
-            size_t g = 0;
+            struct FreeBatch { bsg_ctx *c; uint64_t id; ~FreeBatch() { bsg_batch_free(c, id); } } guard{ctx_, batch};
+            // file stage (query_exec.go:399-406): one probe over the file-level filters, one "block" per file
+            if (int32_t rc = ensure_files_arena()) return rc;
+            std::vector<uint64_t> fs((files_.size() + 63) / 64);
+            if (bsg_probe_batch(ctx_, files_arena_, batch, 0, fs.data())) return fail(kErrGpu, bsg_last_error(ctx_));
+            // block stage: only the files that passed, each through its own resident arena, one pipelined call
+            std::vector<uint64_t> ids;
+            std::vector<size_t> which;
+            size_t words = 0;
             for (size_t f = 0; f < files_.size(); ++f) {
                 file_ok[f] = (fs[f >> 6] >> (f & 63)) & 1;   // a corrupt file-level section decodes to nil filters: cannot disqualify
-                for (size_t b = 0; b < files_[f].blocks.size(); ++b, ++g) {
-                    block_ok[f][b] = (bs[g >> 6] >> (g & 63)) & 1;
-                    if (block_status_[g] != 0) block_ok[f][b] = 2;   // unreadable filters: neither pruned nor scanned (query_exec.go:580-590)
+                if (!file_ok[f] || files_[f].blocks.empty()) continue;
+                if (int32_t rc = ensure_file_arena(files_[f])) return rc;
+                ids.push_back(files_[f].arena);
+                which.push_back(f);
+                words += (files_[f].blocks.size() + 63) / 64;
+            }
+            std::vector<uint64_t> bs(std::max<size_t>(words, 1));
+            if (!ids.empty() && bsg_probe_many(ctx_, ids.data(), (uint32_t)ids.size(), batch, 0, bs.data()))
+                return fail(kErrGpu, bsg_last_error(ctx_));
+            size_t o = 0;
+            for (size_t f : which) {
+                for (size_t b = 0; b < files_[f].blocks.size(); ++b) {
+                    block_ok[f][b] = (bs[o + (b >> 6)] >> (b & 63)) & 1;
+                    if (files_[f].block_status[b] != 0) block_ok[f][b] = 2;   // unreadable filters: neither pruned nor scanned (query_exec.go:580-590)
                 }
+                o += (files_[f].blocks.size() + 63) / 64;
             }
         }
         RowMatcher matcher(expr);
@@ -314,16 +338,26 @@ private:
     uint64_t next_file_id_ = 1;
     bool stopped_ = false;
     std::string err_;
-    uint64_t files_arena_ = 0, blocks_arena_ = 0, total_blocks_ = 0;
-    bool arenas_valid_ = false;
-    std::vector<int32_t> file_status_, block_status_;   // parseFilterSection outcome per file / per block (0 ok)
+    uint64_t files_arena_ = 0;           // the file-level filters of all files, one "block" per file
+    bool files_arena_valid_ = false;
+    std::vector<int32_t> file_status_;   // parseFilterSection outcome per file (0 ok)
 
     int32_t fail(int32_t code, std::string msg) { err_ = std::move(msg); return code; }
 
+    void drop_files_arena()
+    {
+        if (files_arena_valid_) bsg_arena_free(ctx_, files_arena_);
+        files_arena_valid_ = false;
+    }
+    void drop_file_arena(DataFile &f)
+    {
+        if (f.arena_valid) bsg_arena_free(ctx_, f.arena);
+        f.arena_valid = false;
+    }
     void drop_arenas()
     {
-        if (arenas_valid_) { bsg_arena_free(ctx_, files_arena_); bsg_arena_free(ctx_, blocks_arena_); }
-        arenas_valid_ = false;
+        drop_files_arena();
+        for (auto &f : files_) drop_file_arena(f);
     }
 
     // buildFilters for many entry-set triples at once: sizes via EstimateParameters(max(n,1), fpr),
@@ -427,8 +461,12 @@ private:
         if (bsg_sections_size(desc.data(), (uint32_t)nb + 1, &total)) return fail(kErrGpu, bsg_last_error(ctx_));
         std::vector<uint8_t> region(total);
         std::vector<uint64_t> sec_off(nb + 2);
-        if (bsg_ingest_build_sections(ctx_, ing, desc.data(), std::max<uint64_t>(cursor, 2), region.data(), region.size(), sec_off.data()))
+        // the block filters stay on the device as this file's probe arena: a query right after the flush uploads nothing
+        drop_file_arena(file);
+        if (bsg_ingest_build_sections(ctx_, ing, desc.data(), region.data(), region.size(), sec_off.data(), &file.arena, nullptr))
             return fail(kErrGpu, bsg_last_error(ctx_));
+        file.arena_valid = true;
+        file.block_status.assign(nb, 0);
         split_sections(region, sec_off, sections);
         for (size_t s = 0; s <= nb; ++s) {
             BloomEntryCounts &bc = s < nb ? file.blocks[s].counts : file.counts;
@@ -468,15 +506,23 @@ private:
         return kEngineOk;
     }
 
-    int32_t ensure_arenas()
+    int32_t ensure_files_arena()
     {
-        if (arenas_valid_) return kEngineOk;
-        std::vector<const std::vector<uint8_t> *> fsec, bsec;
-        for (auto &f : files_) { fsec.push_back(&f.filter_section); for (auto &b : f.blocks) bsec.push_back(&b.filter_section); }
-        total_blocks_ = bsec.size();
+        if (files_arena_valid_) return kEngineOk;
+        std::vector<const std::vector<uint8_t> *> fsec;
+        for (auto &f : files_) fsec.push_back(&f.filter_section);
         if (int32_t rc = load_arena(fsec, files_arena_, file_status_)) return rc;
-        if (int32_t rc = load_arena(bsec, blocks_arena_, block_status_)) { bsg_arena_free(ctx_, files_arena_); return rc; }
-        arenas_valid_ = true;
+        files_arena_valid_ = true;
+        return kEngineOk;
+    }
+
+    int32_t ensure_file_arena(DataFile &f)
+    {
+        if (f.arena_valid) return kEngineOk;
+        std::vector<const std::vector<uint8_t> *> bsec;
+        for (auto &b : f.blocks) bsec.push_back(&b.filter_section);
+        if (int32_t rc = load_arena(bsec, f.arena, f.block_status)) return rc;
+        f.arena_valid = true;
         return kEngineOk;
     }
 

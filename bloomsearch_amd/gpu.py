@@ -257,13 +257,16 @@ class Context:
                                               len(desc), n_words, _lib._ptr(region), len(region), _lib._ptr(sec_off)))
         return self._split_sections(region, sec_off)
 
-    def ingest_build_sections(self, ingest_id: int, desc, n_words: int):
+    def ingest_build_sections(self, ingest_id: int, desc, arenas: bool = False):
+        """-> sections (list of bytes, sets then parents); with arenas=True also (sets_arena_id, parents_arena_id)."""
         desc = np.ascontiguousarray(desc, dtype=DESC_DTYPE)
         region = np.zeros(self.sections_size(desc), dtype=np.uint8)
         sec_off = np.zeros(len(desc) // 3 + 1, dtype=np.uint64)
-        self._check(self.L.bsg_ingest_build_sections(self.h, ingest_id, _lib._ptr(desc), n_words, _lib._ptr(region), len(region),
-                                                     _lib._ptr(sec_off)))
-        return self._split_sections(region, sec_off)
+        a, b = C.c_uint64(), C.c_uint64()
+        self._check(self.L.bsg_ingest_build_sections(self.h, ingest_id, _lib._ptr(desc), _lib._ptr(region), len(region),
+                                                     _lib._ptr(sec_off), C.byref(a) if arenas else None, C.byref(b) if arenas else None))
+        secs = self._split_sections(region, sec_off)
+        return (secs, int(a.value), int(b.value)) if arenas else secs
 
     def last_encode_ms(self) -> float:
         v = C.c_float()

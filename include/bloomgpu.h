@@ -277,9 +277,14 @@ BSG_API int32_t bsg_ingest_finish(bsg_ctx *ctx, uint64_t ingest_id, uint64_t *ou
 BSG_API int32_t bsg_ingest_build(bsg_ctx *ctx, uint64_t ingest_id, const bsg_filter_desc *desc, uint64_t *out_words,
                                  uint64_t n_words);
 /* As bsg_ingest_build, but the words never leave the device: every set's three filters are serialised there as one
- * filter section (see bsg_build_sections) and only the section bytes come back.  out_sec_off[n_sets + n_parents + 1]. */
-BSG_API int32_t bsg_ingest_build_sections(bsg_ctx *ctx, uint64_t ingest_id, const bsg_filter_desc *desc, uint64_t n_words,
-                                          uint8_t *out_region, uint64_t region_cap, uint64_t *out_sec_off);
+ * filter section (see bsg_build_sections) and only the section bytes come back.  desc gives (m, k) per table (word_off
+ * is ignored: the device lays the words out itself); out_sec_off[n_sets + n_parents + 1].
+ * out_sets_arena_id / out_parents_arena_id (either may be NULL): the filters just built are also left RESIDENT as
+ * probe arenas — "block" i of the first = set i, "block" p of the second = parent p — so the file that is being
+ * written can be queried without its sections ever being uploaded or decoded again (single-device contexts). */
+BSG_API int32_t bsg_ingest_build_sections(bsg_ctx *ctx, uint64_t ingest_id, const bsg_filter_desc *desc, uint8_t *out_region,
+                                          uint64_t region_cap, uint64_t *out_sec_off, uint64_t *out_sets_arena_id,
+                                          uint64_t *out_parents_arena_id);
 BSG_API int32_t bsg_ingest_stats_read(bsg_ctx *ctx, uint64_t ingest_id, bsg_ingest_stats *out);
 BSG_API int32_t bsg_ingest_free(bsg_ctx *ctx, uint64_t ingest_id);
 

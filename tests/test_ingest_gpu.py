@@ -204,6 +204,54 @@ def test_large_sets_lds_staged_above_64k_and_global_atomics(ctx):
     check_against_sets(res, 2, tuple(a | b for a, b in zip(*want)), "parent")
 
 
+def test_resident_arenas_equal_reloaded_sections(ctx):
+    """bsg_ingest_build_sections leaves the filters it just wrote resident as probe arenas: probing them must give the
+    same survivors as uploading + decoding the returned section bytes, and the oracle's answer; the sections themselves
+    must be the oracle's bytes."""
+    from bloomsearch_amd import query as Q
+    from tests import helpers as H
+    row_sets = [synth.rows_json(b * 400, 400) for b in range(5)] + [[]]
+    first = np.zeros(len(row_sets) + 1, dtype=np.uint32)
+    first[1:] = np.cumsum([len(r) for r in row_sets])
+    ing = ctx.ingest_rows([r for rs in row_sets for r in rs], first, [0, 0, 0, 1, 1, 1], 2, flags=TRUSTED)
+    counts, _ = ctx.ingest_finish(ing, 8)
+    desc, _ = I.plan_desc(counts, FPR)
+    secs, a_sets, a_parents = ctx.ingest_build_sections(ing, desc, arenas=True)
+    ctx.ingest_free(ing)
+    assert len(secs) == 8
+    sets = [oracle_sets(rs) for rs in row_sets]
+    sets += [tuple(set().union(*(sets[i][k] for i in grp)) for k in range(3)) for grp in ((0, 1, 2), (3, 4, 5))]
+    for i, ss in enumerate(sets):
+        assert secs[i] == O.encode_filter_section([O.build_sized(sorted(ss[k]), FPR) for k in range(3)]), i
+    d = synth.draws(0, 40)
+    exprs = [Q.And(Q.FieldToken("level", synth.LEVELS[d["level"][i]]), Q.FieldToken("user_id", str(int(d["user_id"][i]))))
+             for i in range(40)] + [Q.Token("absent-token"), Q.Field("nested.az"), None]
+    cb = Q.compile_queries(exprs)
+    ops, poff, _ = cb.arrays()
+    terms = H.gpu_terms(ctx, cb)
+    bid = ctx.batch_create(terms, ops, poff)
+    for arena, lo, n in ((a_sets, 0, 6), (a_parents, 6, 2)):
+        got = ctx.probe_batch(arena, bid, cb.n_queries, n)
+        reloaded, status = ctx.arena_load_sections(secs[lo: lo + n])
+        assert not status.any()
+        assert np.array_equal(got, ctx.probe_batch(reloaded, bid, cb.n_queries, n))
+        ctx.arena_free(reloaded)
+        for q, e in enumerate(exprs):               # oracle: evaluate the expression over the sets' filters
+            for b in range(n):
+                fl = [O.build_sized(sorted(sets[lo + b][k]), FPR) for k in range(3)]
+                def ev(x):
+                    if x is None:
+                        return True
+                    if x["ExpressionType"] == "CONDITION":
+                        kind, sv = Q.term_of(x["Condition"])
+                        return fl[kind].test(sv)
+                    vals = [ev(c) for c in x["Children"]]
+                    return all(vals) if x["ExpressionType"] == "AND" else any(vals)
+                assert bool((int(got[q, b >> 6]) >> (b & 63)) & 1) == ev(e), (q, b)
+        ctx.arena_free(arena)
+    ctx.batch_free(bid)
+
+
 def test_empty_sets_and_rowless_ingest(ctx):
     res = I.device_ingest(ctx, [[], [b'{"a":"b"}'], []], FPR, parent_of_set=[0, 0, 1], n_parents=2)
     empty = (set(), set(), set())
