@@ -9,11 +9,13 @@
 //   bloomEntrySets.indexRow / addFieldToken / unionInto / counts  ingest.go:24-123 (key: tokenizer.go:509-511)
 //   buildFilters' AddString loop ............................. ingest.go:127-145
 //
-// Scope of the device walker ("walker-lite"): rows whose raw bytes are printable ASCII (0x20..0x7E), whose JSON
-// escapes are the simple ones (\" \\ \/ \b \f \n \r \t) or \uXXXX below 0x80 (json.Marshal's \u003c \u003e \u0026),
-// nesting <= kMaxDepth, paths <= kPathCap bytes.  A row that leaves that envelope — or is malformed — is appended to
-// the fallback list and finished by the host walker (walker.hpp), which handles UTF-8, non-ASCII escapes, Unicode
-// white space / case folding and the lenient error semantics.
+// Scope of the device walker ("walker-lite"): rows of valid UTF-8 whose string VALUES hold no rune with a lower-case
+// mapping above 0x7F (ASCII A-Z is folded here; Unicode white space splits words here), no raw control bytes, and whose
+// JSON escapes are the simple ones (\" \\ \/ \b \f \n \r \t) or \uXXXX outside the surrogate range (json.Marshal's
+// \u003c \u003e \u0026 included); nesting <= kMaxDepth, paths <= kPathCap bytes.  Keys are copied as they are, like the
+// host does.  A row that leaves that envelope — or is malformed — is appended to the fallback list and finished by the
+// host walker (walker.hpp), which owns Unicode case folding (a lower-case form may even differ in length), invalid
+// UTF-8 (U+FFFD per byte), surrogate escapes and the lenient error semantics.
 // The kernel walks every row twice: a validation pass (automaton only, no hashing) decides whether the row is the
 // device's, and only rows that pass are walked again to emit — a row handed to the host has inserted nothing.
 //
@@ -115,10 +117,14 @@ __device__ __forceinline__ uint64_t swar_str_stops(uint64_t v)
 {
     return swar_eq(v, ' ') | swar_eq(v, '"') | swar_eq(v, '\\') | swar_eq(v, 0x7F) | ((v - kOnes * 0x20u) & ~v & kHighs) | (v & kHighs);
 }
-// bytes that end a run of key bytes: quote, backslash, DEL, controls, non-ASCII (a space is an ordinary key byte)
+// bytes that end a run of key bytes: quote, backslash, DEL, controls (a space is an ordinary key byte, and so is any
+// byte >= 0x80: keys are never tokenized, the host copies them undecoded too).  Non-ASCII bytes are replaced by 'a'
+// before the comparisons, which are only exact for bytes < 0x80.
 __device__ __forceinline__ uint64_t swar_key_stops(uint64_t v)
 {
-    return swar_eq(v, '"') | swar_eq(v, '\\') | swar_eq(v, 0x7F) | ((v - kOnes * 0x20u) & ~v & kHighs) | (v & kHighs);
+    const uint64_t mm = ((v & kHighs) >> 7) * 0xFFu;         // 0xFF in every non-ASCII byte lane
+    const uint64_t x = (v & ~mm) | (mm & (kOnes * 'a'));
+    return swar_eq(x, '"') | swar_eq(x, '\\') | swar_eq(x, 0x7F) | ((x - kOnes * 0x20u) & ~x & kHighs);
 }
 // ASCII A-Z -> a-z in every byte lane (all bytes < 0x80 here)
 __device__ __forceinline__ uint64_t swar_lower(uint64_t v)
@@ -268,6 +274,7 @@ struct IngestArgs {
     uint32_t *status;               // per table
     uint32_t *fallback_rows;        // rows the host walker must finish
     uint32_t *n_fallback;
+    const uint32_t *cased;          // bitmap over code points < 0x20000: unicode.ToLower(cp) != cp
     uint32_t n_rows;
     uint32_t n_sets;
     uint32_t validate;              // 1: run the validation pass first (rows of unknown provenance)
@@ -277,7 +284,8 @@ typedef __attribute__((address_space(3))) uint8_t lds_u8;
 
 enum : uint32_t {
     S_VALUE, S_VALUE_OR_CLOSE, S_KEY_OR_CLOSE, S_KEY_OPEN, S_KEY, S_COLON, S_PREFIX, S_STR, S_NUM, S_LIT, S_AFTER,
-    S_STR_ESC, S_STR_U, S_KEY_ESC, S_KEY_U   // after a backslash / inside \uXXXX, in a string value / in a key
+    S_STR_ESC, S_STR_U, S_KEY_ESC, S_KEY_U,  // after a backslash / inside \uXXXX, in a string value / in a key
+    S_STR_UTF8                               // inside a multi-byte UTF-8 sequence of a string value
 };
 enum : uint32_t { R_CONTINUE, R_DONE, R_FAIL };
 // What a lane asks the converged part of the loop to do for it (hashing is the expensive part of an emission —
@@ -298,6 +306,7 @@ struct Walker {
     uint32_t key_len;        // path length including the key being read (S_KEY .. S_PREFIX)
     uint32_t lit;            // S_LIT: 0 true, 1 false, 2 null; S_*_U: hex digits seen << 16 | value so far
     uint32_t req, req_len;   // pending request
+    const uint32_t *cased;   // IngestArgs::cased
     bool quiet;              // leaf without a path (scalars at the root): nothing is emitted
     bool in_token;
     HashStream ps, tok, ft;  // path + "::" prefix state; current word; current path::word
@@ -393,6 +402,37 @@ __device__ __forceinline__ bool str_decoded_byte(Walker &w, uint32_t b)
     if (ascii_space(b)) return word_end(w);
     word_byte(w, b);
     return false;
+}
+
+// unicode.IsSpace above 0x7F (text.hpp is_space)
+__device__ __forceinline__ bool rune_space(uint32_t r)
+{
+    return r == 0x85u || r == 0xA0u || r == 0x1680u || (r - 0x2000u) <= 0xAu || r == 0x2028u || r == 0x2029u || r == 0x202Fu ||
+           r == 0x205Fu || r == 0x3000u;
+}
+// UTF-8 encoding of a rune >= 0x80 (not a surrogate, <= 0x10FFFF) as little-endian bytes in a u32; n = its length
+__device__ __forceinline__ uint32_t rune_utf8(uint32_t r, uint32_t &n)
+{
+    if (r < 0x800u) { n = 2; return (0xC0u | (r >> 6)) | ((0x80u | (r & 0x3Fu)) << 8); }
+    if (r < 0x10000u) { n = 3; return (0xE0u | (r >> 12)) | ((0x80u | ((r >> 6) & 0x3Fu)) << 8) | ((0x80u | (r & 0x3Fu)) << 16); }
+    n = 4;
+    return (0xF0u | (r >> 18)) | ((0x80u | ((r >> 12) & 0x3Fu)) << 8) | ((0x80u | ((r >> 6) & 0x3Fu)) << 16) | ((0x80u | (r & 0x3Fu)) << 24);
+}
+// A non-ASCII rune of a string value (raw UTF-8 or \uXXXX): Unicode white space ends the word; a rune without a
+// lower-case mapping joins it as its UTF-8 bytes; one WITH a mapping (whose lower case may even have another length)
+// is the host walker's.  Returns R_CONTINUE + request, 0xFF = keep going, or R_FAIL.
+__device__ __forceinline__ uint32_t str_rune(Walker &w, uint32_t r)
+{
+    if (rune_space(r)) return word_end(w) ? R_CONTINUE : 0xFFu;
+    if (r < 0x20000u && ((w.cased[r >> 5] >> (r & 31u)) & 1u)) return R_FAIL;   // (also in the validation pass: it decides who owns the row)
+    if (!w.quiet) {
+        uint32_t n;
+        const uint32_t bytes = rune_utf8(r, n);
+        if (!w.in_token) { hs_init(w.tok); w.ft = w.ps; w.in_token = true; }
+        hs_absorb_n(w.tok, bytes, n);
+        hs_absorb_n(w.ft, bytes, n);
+    }
+    return 0xFFu;
 }
 
 // Runs until the lane has a request pending (w.req), has used up its chunk, is done, or must go to the host.
@@ -510,15 +550,33 @@ __device__ __forceinline__ uint32_t walker_step(Walker &w)
             const uint32_t seen = (w.lit >> 16) + 1, value = ((w.lit & 0xFFFFu) << 4) | h;
             w.lit = (seen << 16) | value;
             if (seen < 4) break;
-            if (value >= 0x80u) return R_FAIL;                      // non-ASCII rune: the host walker's business
+            if ((value - 0xD800u) < 0x800u) return R_FAIL;          // surrogates (pairs, or lone ones -> U+FFFD): the host walker's
             const bool key = w.st == S_KEY_U;
             w.st = key ? S_KEY : S_STR;
             if (key) {
-                if (w.key_len >= kPathCap) return R_FAIL;
-                w.path[w.key_len++] = (uint8_t)value;
-            } else if (str_decoded_byte(w, value)) {
-                return R_CONTINUE;
+                uint32_t n = 1, bytes = value;
+                if (value >= 0x80u) bytes = rune_utf8(value, n);
+                if (w.key_len + n > kPathCap) return R_FAIL;
+                for (uint32_t i = 0; i < n; ++i) w.path[w.key_len++] = (uint8_t)(bytes >> (8u * i));
+            } else if (value < 0x80u) {
+                if (str_decoded_byte(w, value)) return R_CONTINUE;
+            } else {
+                const uint32_t r = str_rune(w, value);
+                if (r != 0xFFu) return r;
             }
+            break;
+        }
+        case S_STR_UTF8: {
+            // w.lit: bytes still expected << 28 | lowest / highest value allowed for THIS byte << 8 / << 16 (the second byte
+            // of E0, ED, F0, F4 is restricted: no overlongs, no surrogates, nothing above U+10FFFF) ; w.aux: rune so far
+            const uint32_t lo = (w.lit >> 8) & 0xFFu, hi = (w.lit >> 16) & 0xFFu, left = w.lit >> 28;
+            if (c < lo || c > hi) return R_FAIL;                    // invalid UTF-8 becomes U+FFFD per byte: the host walker's
+            ++w.pos;
+            w.aux = (w.aux << 6) | (c & 0x3Fu);
+            if (left > 1) { w.lit = ((left - 1) << 28) | (0xBFu << 16) | (0x80u << 8); break; }
+            w.st = S_STR;
+            const uint32_t r = str_rune(w, w.aux);
+            if (r != 0xFFu) return r;
             break;
         }
         case S_COLON:
@@ -546,6 +604,14 @@ __device__ __forceinline__ uint32_t walker_step(Walker &w)
                 if (b == '"') { w.st = S_AFTER; if (word_end(w)) return R_CONTINUE; }
                 else if (b == ' ') { if (word_end(w)) return R_CONTINUE; }   // raw white space other than 0x20 fails here
                 else if (b == '\\') w.st = S_STR_ESC;
+                else if (b >= 0xC2u && b <= 0xF4u) {                // UTF-8 lead byte (decode_rune, text.hpp)
+                    uint32_t left, lo = 0x80u, hi = 0xBFu;
+                    if (b < 0xE0u) { left = 1; w.aux = b & 0x1Fu; }
+                    else if (b < 0xF0u) { left = 2; w.aux = b & 0x0Fu; if (b == 0xE0u) lo = 0xA0u; if (b == 0xEDu) hi = 0x9Fu; }
+                    else { left = 3; w.aux = b & 0x07u; if (b == 0xF0u) lo = 0x90u; if (b == 0xF4u) hi = 0x8Fu; }
+                    w.lit = (left << 28) | (hi << 16) | (lo << 8);
+                    w.st = S_STR_UTF8;
+                }
                 else return R_FAIL;
             }
             break;
@@ -674,6 +740,7 @@ __global__ __launch_bounds__(kIngestThreads, BSG_INGEST_WPE) void k_ingest_rows(
     ChunkCursor cc;
     cc.chunks = reinterpret_cast<const uint64_t *>(a.rows);
     w.path = (lds_u8 *)lds_raw + kCacheEntries * 32 + threadIdx.x * kLaneLds;
+    w.cased = a.cased;
     hs_init(w.ps); hs_init(w.tok); hs_init(w.ft);
 
     // pass 1: validate.  A row the device walker cannot finish contributes NOTHING here; it goes to the host walker whole.
@@ -740,8 +807,9 @@ __global__ __launch_bounds__(kIngestThreads, BSG_INGEST_WPE) void k_ingest_rows(
         BSG_PROF_ADD(4, tb1, tb2);
     }
     // without the validation pass a row is flagged when the emitting walk gives up on it: what it inserted before that
-    // is a subset of what the host walker inserts for it PROVIDED the row is valid JSON (the caller's promise)
-    if (!a.validate && res == R_FAIL) {
+    // is a subset of what the host walker inserts for it PROVIDED the row is valid JSON (the caller's promise).
+    // (After a validation pass the emitting walk cannot fail — both run the same automaton — but a row is never dropped.)
+    if (res == R_FAIL) {
         const uint32_t slot = __hip_atomic_fetch_add(a.n_fallback, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         a.fallback_rows[slot] = r;
     }
