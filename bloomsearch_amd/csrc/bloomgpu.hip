@@ -97,7 +97,7 @@ struct Device {
     DevBuf<uint8_t> stage_region;  // encoded filter sections
     std::vector<EventTriple> pending;
     std::vector<EventTriple> free_events;
-    uint32_t *d_cased = nullptr;              // runes with a lower-case mapping (k_ingest_rows)
+    uint32_t *d_lower = nullptr;              // unicode.ToLower table for k_ingest_rows (512 KB)
     bsg::CrcConsts *d_crc = nullptr;          // CRC32C slice-by-8 tables + x^(2^i) mod P (k_decode_sections)
     hipEvent_t kb0 = nullptr, kb1 = nullptr;  // start/stop timestamps of the last k_build / k_hash_entries dispatch
     float last_build_ms = 0.f, last_hash_ms = 0.f, last_decode_ms = 0.f, last_or_ms = 0.f, last_encode_ms = 0.f;
@@ -372,7 +372,7 @@ int32_t bsg_close(bsg_ctx *ctx)
         if (d.stream) (void)hipStreamSynchronize(d.stream);
         if (d.kb0) { (void)hipEventDestroy(d.kb0); (void)hipEventDestroy(d.kb1); }
         if (d.d_crc) (void)hipFree(d.d_crc);
-        if (d.d_cased) (void)hipFree(d.d_cased);
+        if (d.d_lower) (void)hipFree(d.d_lower);
         for (auto *v : {&d.pending, &d.free_events})
             for (auto &t : *v) {
                 (void)hipEventDestroy(t.k1s); (void)hipEventDestroy(t.k1e);

@@ -9,13 +9,13 @@
 //   bloomEntrySets.indexRow / addFieldToken / unionInto / counts  ingest.go:24-123 (key: tokenizer.go:509-511)
 //   buildFilters' AddString loop ............................. ingest.go:127-145
 //
-// Scope of the device walker ("walker-lite"): rows of valid UTF-8 whose string VALUES hold no rune with a lower-case
-// mapping above 0x7F (ASCII A-Z is folded here; Unicode white space splits words here), no raw control bytes, and whose
-// JSON escapes are the simple ones (\" \\ \/ \b \f \n \r \t) or \uXXXX outside the surrogate range (json.Marshal's
-// \u003c \u003e \u0026 included); nesting <= kMaxDepth, paths <= kPathCap bytes.  Keys are copied as they are, like the
-// host does.  A row that leaves that envelope — or is malformed — is appended to the fallback list and finished by the
-// host walker (walker.hpp), which owns Unicode case folding (a lower-case form may even differ in length), invalid
-// UTF-8 (U+FFFD per byte), surrogate escapes and the lenient error semantics.
+// Scope of the device walker ("walker-lite"): rows of valid UTF-8 without raw control bytes, whose JSON escapes are the
+// simple ones (\" \\ \/ \b \f \n \r \t) or \uXXXX outside the surrogate range (json.Marshal's \u003c \u003e \u0026 included);
+// nesting <= kMaxDepth, paths <= kPathCap bytes.  Words are split on Unicode white space and lower-cased with
+// unicode.ToLower's one-rune mapping (a 512 KB direct table built from the host walker's own data); keys are copied as
+// they are, like the host does.  A row that leaves that envelope — or is malformed — is appended to the fallback list
+// and finished by the host walker (walker.hpp), which owns invalid UTF-8 (U+FFFD per byte), surrogate escapes and the
+// lenient error semantics.
 // The kernel walks every row twice: a validation pass (automaton only, no hashing) decides whether the row is the
 // device's, and only rows that pass are walked again to emit — a row handed to the host has inserted nothing.
 //
@@ -274,7 +274,7 @@ struct IngestArgs {
     uint32_t *status;               // per table
     uint32_t *fallback_rows;        // rows the host walker must finish
     uint32_t *n_fallback;
-    const uint32_t *cased;          // bitmap over code points < 0x20000: unicode.ToLower(cp) != cp
+    const uint32_t *lower;          // [0x20000]: unicode.ToLower(cp) where it differs from cp, else 0 (no cased rune lies above)
     uint32_t n_rows;
     uint32_t n_sets;
     uint32_t validate;              // 1: run the validation pass first (rows of unknown provenance)
@@ -306,7 +306,7 @@ struct Walker {
     uint32_t key_len;        // path length including the key being read (S_KEY .. S_PREFIX)
     uint32_t lit;            // S_LIT: 0 true, 1 false, 2 null; S_*_U: hex digits seen << 16 | value so far
     uint32_t req, req_len;   // pending request
-    const uint32_t *cased;   // IngestArgs::cased
+    const uint32_t *lower;   // IngestArgs::lower
     bool quiet;              // leaf without a path (scalars at the root): nothing is emitted
     bool in_token;
     HashStream ps, tok, ft;  // path + "::" prefix state; current word; current path::word
@@ -418,16 +418,20 @@ __device__ __forceinline__ uint32_t rune_utf8(uint32_t r, uint32_t &n)
     n = 4;
     return (0xF0u | (r >> 18)) | ((0x80u | ((r >> 12) & 0x3Fu)) << 8) | ((0x80u | ((r >> 6) & 0x3Fu)) << 16) | ((0x80u | (r & 0x3Fu)) << 24);
 }
-// A non-ASCII rune of a string value (raw UTF-8 or \uXXXX): Unicode white space ends the word; a rune without a
-// lower-case mapping joins it as its UTF-8 bytes; one WITH a mapping (whose lower case may even have another length)
-// is the host walker's.  Returns R_CONTINUE + request, 0xFF = keep going, or R_FAIL.
+// A non-ASCII rune of a string value (raw UTF-8 or \uXXXX): Unicode white space ends the word; anything else joins it
+// as the UTF-8 bytes of unicode.ToLower(rune) — the simple one-rune mapping, looked up in the table the host walker
+// folds with (the lower-case form may be shorter or longer than the original, or plain ASCII: U+212A -> 'k').
+// Returns R_CONTINUE + request, or 0xFF = keep going.
 __device__ __forceinline__ uint32_t str_rune(Walker &w, uint32_t r)
 {
     if (rune_space(r)) return word_end(w) ? R_CONTINUE : 0xFFu;
-    if (r < 0x20000u && ((w.cased[r >> 5] >> (r & 31u)) & 1u)) return R_FAIL;   // (also in the validation pass: it decides who owns the row)
     if (!w.quiet) {
-        uint32_t n;
-        const uint32_t bytes = rune_utf8(r, n);
+        if (r < 0x20000u) {
+            const uint32_t lo = w.lower[r];
+            if (lo != 0u) r = lo;
+        }
+        uint32_t n = 1, bytes = r;
+        if (r >= 0x80u) bytes = rune_utf8(r, n);
         if (!w.in_token) { hs_init(w.tok); w.ft = w.ps; w.in_token = true; }
         hs_absorb_n(w.tok, bytes, n);
         hs_absorb_n(w.ft, bytes, n);
@@ -740,7 +744,7 @@ __global__ __launch_bounds__(kIngestThreads, BSG_INGEST_WPE) void k_ingest_rows(
     ChunkCursor cc;
     cc.chunks = reinterpret_cast<const uint64_t *>(a.rows);
     w.path = (lds_u8 *)lds_raw + kCacheEntries * 32 + threadIdx.x * kLaneLds;
-    w.cased = a.cased;
+    w.lower = a.lower;
     hs_init(w.ps); hs_init(w.tok); hs_init(w.ft);
 
     // pass 1: validate.  A row the device walker cannot finish contributes NOTHING here; it goes to the host walker whole.

@@ -232,7 +232,7 @@ BSG_API int32_t bsg_last_encode_ms(bsg_ctx *ctx, float *encode_ms);
  * Call order:  bsg_ingest_rows -> [bsg_ingest_fallback_rows -> host walker -> bsg_ingest_add_entries]
  *              -> bsg_ingest_finish (exact distinct counts; the caller sizes (m, k) with its own
  *              EstimateParameters) -> bsg_ingest_build -> bsg_ingest_free.
- * The device walker finishes rows of valid UTF-8 without cased non-ASCII runes in their values (see ingest.hip.h); every other
+ * The device walker finishes rows of valid UTF-8 (see ingest.hip.h for the few exceptions); every other
  * row is reported by bsg_ingest_fallback_rows and MUST be walked by the host and added back with
  * bsg_ingest_add_entries before bsg_ingest_finish, or its entries are missing. */
 typedef struct bsg_ingest_stats {
