@@ -10,11 +10,11 @@
 //   buildFilters' AddString loop ............................. ingest.go:127-145
 //
 // Scope of the device walker ("walker-lite"): rows of valid UTF-8 without raw control bytes, whose JSON escapes are the
-// simple ones (\" \\ \/ \b \f \n \r \t) or \uXXXX outside the surrogate range (json.Marshal's \u003c \u003e \u0026 included);
+// simple ones (\" \\ \/ \b \f \n \r \t) or \uXXXX incl. well-formed surrogate pairs (json.Marshal's \u003c \u003e \u0026 included);
 // nesting <= kMaxDepth, paths <= kPathCap bytes.  Words are split on Unicode white space and lower-cased with
 // unicode.ToLower's one-rune mapping (a 512 KB direct table built from the host walker's own data); keys are copied as
 // they are, like the host does.  A row that leaves that envelope — or is malformed — is appended to the fallback list
-// and finished by the host walker (walker.hpp), which owns invalid UTF-8 (U+FFFD per byte), surrogate escapes and the
+// and finished by the host walker (walker.hpp), which owns invalid UTF-8 (U+FFFD per byte), lone surrogate escapes and the
 // lenient error semantics.
 // The kernel walks every row twice: a validation pass (automaton only, no hashing) decides whether the row is the
 // device's, and only rows that pass are walked again to emit — a row handed to the host has inserted nothing.
@@ -285,7 +285,9 @@ typedef __attribute__((address_space(3))) uint8_t lds_u8;
 enum : uint32_t {
     S_VALUE, S_VALUE_OR_CLOSE, S_KEY_OR_CLOSE, S_KEY_OPEN, S_KEY, S_COLON, S_PREFIX, S_STR, S_NUM, S_LIT, S_AFTER,
     S_STR_ESC, S_STR_U, S_KEY_ESC, S_KEY_U,  // after a backslash / inside \uXXXX, in a string value / in a key
-    S_STR_UTF8                               // inside a multi-byte UTF-8 sequence of a string value
+    S_STR_UTF8,                              // inside a multi-byte UTF-8 sequence of a string value
+    S_STR_SUR_BS, S_STR_SUR_U,               // after a \uD8xx high surrogate of a string value: the backslash and the 'u' of its low half
+    S_KEY_SUR_BS, S_KEY_SUR_U                // the same inside a key
 };
 enum : uint32_t { R_CONTINUE, R_DONE, R_FAIL };
 // What a lane asks the converged part of the loop to do for it (hashing is the expensive part of an emission —
@@ -534,7 +536,7 @@ __device__ __forceinline__ uint32_t walker_step(Walker &w)
         case S_STR_ESC: {
             ++w.pos;
             const bool key = w.st == S_KEY_ESC;
-            if (c == 'u') { w.lit = 0; w.st = key ? S_KEY_U : S_STR_U; break; }
+            if (c == 'u') { w.lit = 0; w.req_len = 0; w.st = key ? S_KEY_U : S_STR_U; break; }   // req_len (free while no request is pending) = high surrogate waiting
             const uint32_t b = simple_escape(c);
             if (b == 0xFFFFu) return R_FAIL;
             w.st = key ? S_KEY : S_STR;
@@ -554,22 +556,45 @@ __device__ __forceinline__ uint32_t walker_step(Walker &w)
             const uint32_t seen = (w.lit >> 16) + 1, value = ((w.lit & 0xFFFFu) << 4) | h;
             w.lit = (seen << 16) | value;
             if (seen < 4) break;
-            if ((value - 0xD800u) < 0x800u) return R_FAIL;          // surrogates (pairs, or lone ones -> U+FFFD): the host walker's
             const bool key = w.st == S_KEY_U;
+            uint32_t cp = value;
+            if (w.req_len != 0u) {                                  // second half of a surrogate pair
+                if ((value - 0xDC00u) >= 0x400u) return R_FAIL;     // not a low surrogate: the high one was lone (-> U+FFFD): host
+                cp = 0x10000u + ((w.req_len - 0xD800u) << 10) + (value - 0xDC00u);
+                w.req_len = 0;
+            } else if ((value - 0xD800u) < 0x800u) {
+                if (value >= 0xDC00u) return R_FAIL;                // a lone low surrogate: the host walker's
+                w.req_len = value;                                  // a high surrogate: its low half must follow immediately
+                w.st = key ? S_KEY_SUR_BS : S_STR_SUR_BS;
+                break;
+            }
             w.st = key ? S_KEY : S_STR;
             if (key) {
-                uint32_t n = 1, bytes = value;
-                if (value >= 0x80u) bytes = rune_utf8(value, n);
+                uint32_t n = 1, bytes = cp;
+                if (cp >= 0x80u) bytes = rune_utf8(cp, n);
                 if (w.key_len + n > kPathCap) return R_FAIL;
                 for (uint32_t i = 0; i < n; ++i) w.path[w.key_len++] = (uint8_t)(bytes >> (8u * i));
-            } else if (value < 0x80u) {
-                if (str_decoded_byte(w, value)) return R_CONTINUE;
+            } else if (cp < 0x80u) {
+                if (str_decoded_byte(w, cp)) return R_CONTINUE;
             } else {
-                const uint32_t r = str_rune(w, value);
+                const uint32_t r = str_rune(w, cp);
                 if (r != 0xFFu) return r;
             }
             break;
         }
+        case S_KEY_SUR_BS:
+        case S_STR_SUR_BS:
+            if (c != '\\') return R_FAIL;
+            ++w.pos;
+            w.st = w.st == S_KEY_SUR_BS ? S_KEY_SUR_U : S_STR_SUR_U;
+            break;
+        case S_KEY_SUR_U:
+        case S_STR_SUR_U:
+            if (c != 'u') return R_FAIL;
+            ++w.pos;
+            w.lit = 0;
+            w.st = w.st == S_KEY_SUR_U ? S_KEY_U : S_STR_U;         // w.req_len != 0 tells S_*_U which half this is
+            break;
         case S_STR_UTF8: {
             // w.lit: bytes still expected << 28 | lowest / highest value allowed for THIS byte << 8 / << 16 (the second byte
             // of E0, ED, F0, F4 is restricted: no overlongs, no surrogates, nothing above U+10FFFF) ; w.aux: rune so far

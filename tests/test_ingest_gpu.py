@@ -74,12 +74,13 @@ ROWS_DEVICE = [  # inside the device walker's envelope
     b'{"a\\u002eb":"dot in key","k\\"q":1,"sp\\u0020ace":[true]}', b'{"e":"\\\\","f":"\\\\\\"x"}',
 ]
 ROWS_UTF8_DEVICE = [   # valid UTF-8: Unicode white space, Unicode lower-casing, non-ASCII keys and \\uXXXX are the device's too
-    '{"héllo":"日本語 ÀB"}'.encode(), '{"k":"über Ωmega ǅ İstanbul K"}'.encode(), '{"k":"Привет МИР"}'.encode(), b'{"e":"caf\\u00e9 \\u00c0 \\u212a"}',
+    '{"héllo":"日本語 ÀB"}'.encode(), '{"k":"über Ωmega ǅ İstanbul K"}'.encode(), '{"k":"Привет МИР"}'.encode(), b'{"e":"caf\\u00e9 \\u00c0 \\u212a"}', b'{"emoji":"\\ud83d\\ude00 x\\ud83c\\udf89y \\uD83D\\uDE80"}', b'{"\\ud83d\\ude00k":"surrogate pair in a key"}',
     '{"héllo":"日本語 café ñ 😀 ß straße"}'.encode(), '{"nbsp":"a\u00a0b\u2003c\u3000d\u0085e"}'.encode(), b'{"nbsp":"a\\u00a0b \\u00e9t\\u00e9 \\u4e2d\\u2028x"}',
     '{"ключ":"значение и ещё","مفتاح":"قيمة","k\\u00e9y":"v"}'.encode(), '{"mixed":"ASCII Upper ünï 中文 END"}'.encode(),
 ]
 ROWS_HOST = [    # must be handed to the host walker
-    b'{"raw":"ctl\x01char"}', b'{"a":\t1}', b'{"emoji":"\\ud83d\\ude00 x"}', b'{"lone":"\\ud800 x"}',
+    b'{"raw":"ctl\x01char"}', b'{"a":\t1}', b'{"lone":"\\ud800 x"}', b'{"lone":"low first \\ude00\\ud83d"}', b'{"lone":"\\ud83d\\u0041"}',
+
     ('{' + '"a":{' * 17 + '"x":1' + '}' * 17 + '}').encode(),
     ('{"' + 'k' * 150 + '":{"' + 'j' * 60 + '":1}}').encode(),
     b'{"s":"\xff\xfe bad utf8"}', b'{"s":"overlong \xc0\xaf"}', b'{"s":"surrogate \xed\xa0\x80"}', b'{"s":"too big \xf5\x80\x80\x80"}',
@@ -212,7 +213,7 @@ def test_unicode_fuzz_device_and_host_agree_with_the_oracle(ctx, flags):
         row_sets.append(rows)
     res = I.device_ingest(ctx, row_sets, FPR, parent_of_set=[0] * 8, n_parents=1, flags=flags)
     n_rows = sum(len(r) for r in row_sets)
-    assert 0 < len(res.fallback_rows) < n_rows / 2      # only surrogate-pair escapes (ensure_ascii emoji) go to the host
+    assert len(res.fallback_rows) == 0                  # valid UTF-8 and well-formed escapes: all on the device
     union = (set(), set(), set())
     for s_, rows in enumerate(row_sets):
         sets = oracle_sets(rows)
