@@ -17,6 +17,7 @@ n_blocks = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rows = int(sys.argv[2]) if len(sys.argv) > 2 else 10000
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 flags = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+n_par = int(sys.argv[5]) if len(sys.argv) > 5 else 1
 # in-process generation: a forked pool under rocprofv3 hangs at exit (the children inherit the tool)
 parts = [bench._gen_rows((b, rows, 0xB100F5EA4C4)) for b in range(n_blocks)]
 blob = np.frombuffer(b"".join(p[0] for p in parts), dtype=np.uint8)
@@ -27,12 +28,12 @@ first = np.arange(n_blocks + 1, dtype=np.uint32) * rows
 ctx = Context((0,))
 for rep in range(reps):
     t0 = time.time()
-    ing = ctx.ingest_rows((blob, off), first, np.zeros(n_blocks, dtype=np.uint32), 1, flags=flags)
-    counts, status = ctx.ingest_finish(ing, n_blocks + 1)
+    ing = ctx.ingest_rows((blob, off), first, np.zeros(n_blocks, dtype=np.uint32) if n_par else None, n_par, flags=flags)
+    counts, status = ctx.ingest_finish(ing, n_blocks + n_par)
     desc, n_words = I.plan_desc(counts, 0.001)
     ctx.ingest_build(ing, desc, n_words)
     st = ctx.ingest_stats(ing)
     ctx.ingest_free(ing)
     print("rep %d: %d rows %.0f MB  walk %.2f ms  union %.2f ms  build %.2f ms  grows %d  fallback %d  tables %.0f MB  e2e %.3fs  file counts %s"
           % (rep, n_blocks * rows, st.row_bytes / 1e6, st.ms_walk, st.ms_union, st.ms_build, st.table_grows, st.n_fallback_rows,
-             st.table_bytes / 1e6, time.time() - t0, counts[n_blocks].tolist()))
+             st.table_bytes / 1e6, time.time() - t0, counts[-1].tolist()))
