@@ -34,7 +34,8 @@ constexpr uint32_t kPathCap = 96;       // longest path the device walker keeps 
 constexpr uint32_t kMaxDepth = 16;      // container nesting handled on the device
 constexpr uint32_t kLaneLds = 116;      // 96 path + 16 stack + pad = 29 dwords (odd stride: lanes spread over LDS banks)
 constexpr uint32_t kMaxProbe = 96;      // linear-probe bound before a table is declared full
-constexpr uint32_t kSpinLimit = 4096;   // re-reads of a claimed slot whose h1..h3 are still in flight
+constexpr uint32_t kSpinLimit = 1u << 20;   // re-reads of a claimed slot whose h1..h3 are still in flight (a claimer writes them right
+                                        // after its CAS; only a wave that was context-switched out in between can make this run long)
 
 constexpr uint32_t kTableOk = 0, kTableOverflow = 1, kTableExotic = 2;
 
@@ -221,7 +222,13 @@ __device__ __forceinline__ void set_insert2(const IngestTable ta, const uint64_t
                 bool advance = true;                                                                                     \
                 if (c0 == h[0]) {                                                                                        \
                     if (c1 == h[1] && c2 == h[2] && c3 == h[3]) { X.done = true; X.present = true; advance = false; }    \
-                    else if ((c1 == 0 || c2 == 0 || c3 == 0) && X.spins < kSpinLimit) { X.spins += 1; advance = false; } \
+                    else if (c1 == 0 || c2 == 0 || c3 == 0) {      /* the claimer's h1..h3 are still in flight */           \
+                        advance = false;                                                                                 \
+                        if (++X.spins > kSpinLimit) {              /* never a duplicate slot: give the set to the host */ \
+                            __hip_atomic_store(status, kTableExotic, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);        \
+                            X.done = true;                                                                               \
+                        }                                                                                                \
+                    }                                                                                                    \
                 }                         /* else: a different entry (possibly with the same h0) */                      \
                 if (advance) {                                                                                           \
                     X.idx = (X.idx + 1) & tab.mask;                                                                      \

@@ -269,8 +269,9 @@ BSG_API int32_t bsg_ingest_add_entries(bsg_ctx *ctx, uint64_t ingest_id, const u
                                        uint32_t n_entries, const uint32_t *set_of_entry, const uint32_t *kind_of_entry);
 /* Unions the sets into their parents and returns the exact distinct counts
  * out_counts[(n_sets + n_parents) * 3] (bloomEntrySets.counts).  out_status[n_sets + n_parents] (may be
- * NULL): 0 ok, 2 = the set met an entry whose base hashes contain a zero word and must be rebuilt on
- * the host path (probability 2^-62 per entry). */
+ * NULL): 0 ok, 2 = the set cannot be represented and must be rebuilt on the host path: it met an entry whose
+ * base hashes contain a zero word (probability 2^-62 per entry), or a slot claim that was never completed
+ * (a wave context-switched out for ~seconds between its CAS and its stores). */
 BSG_API int32_t bsg_ingest_finish(bsg_ctx *ctx, uint64_t ingest_id, uint64_t *out_counts, uint32_t *out_status);
 /* desc[(n_sets + n_parents) * 3]: geometry and output offsets of every table's filter (m == 0 skips it);
  * out_words as bsg_build. */

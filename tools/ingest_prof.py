@@ -29,11 +29,18 @@ ctx = Context((0,))
 for rep in range(reps):
     t0 = time.time()
     ing = ctx.ingest_rows((blob, off), first, np.zeros(n_blocks, dtype=np.uint32) if n_par else None, n_par, flags=flags)
+    t1 = time.time()
     counts, status = ctx.ingest_finish(ing, n_blocks + n_par)
+    t2 = time.time()
     desc, n_words = I.plan_desc(counts, 0.001)
+    t3 = time.time()
     ctx.ingest_build(ing, desc, n_words)
+    t4 = time.time()
     st = ctx.ingest_stats(ing)
     ctx.ingest_free(ing)
+    t5 = time.time()
+    print("    host wall: ingest_rows %.1f ms (kernel %.1f), finish %.1f ms (kernel %.1f), plan_desc %.1f ms, build %.1f ms (kernel %.1f), free %.1f ms"
+          % ((t1 - t0) * 1e3, st.ms_walk, (t2 - t1) * 1e3, st.ms_union, (t3 - t2) * 1e3, (t4 - t3) * 1e3, st.ms_build, (t5 - t4) * 1e3))
     print("rep %d: %d rows %.0f MB  walk %.2f ms  union %.2f ms  build %.2f ms  grows %d  fallback %d  tables %.0f MB  e2e %.3fs  file counts %s"
           % (rep, n_blocks * rows, st.row_bytes / 1e6, st.ms_walk, st.ms_union, st.ms_build, st.table_grows, st.n_fallback_rows,
              st.table_bytes / 1e6, time.time() - t0, counts[-1].tolist()))
