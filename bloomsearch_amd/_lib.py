@@ -23,6 +23,7 @@ INGEST_TRUSTED_JSON = 1
 
 TERM_DTYPE = np.dtype([("h", "<u8", (4,)), ("kind", "<u4"), ("reserved", "<u4")])
 DESC_DTYPE = np.dtype([("word_off", "<u8"), ("m", "<u8"), ("k", "<u4"), ("reserved", "<u4")])
+MATCH_COND_DTYPE = np.dtype([("hf", "<u8", (4,)), ("ht", "<u8", (4,)), ("kind", "<u4"), ("reserved", "<u4")])
 
 
 class Timing(C.Structure):
@@ -55,6 +56,7 @@ EXPORTS = [
     "bsg_ingest_rows", "bsg_ingest_fallback_rows", "bsg_ingest_add_entries", "bsg_ingest_finish", "bsg_ingest_build",
     "bsg_ingest_stats_read", "bsg_ingest_free", "bsg_ingest_build_sections",
     "bsg_sections_size", "bsg_build_sections", "bsg_last_encode_ms",
+    "bsg_match_rows", "bsg_last_match_ms",
 ]
 
 _lib = None
@@ -106,6 +108,8 @@ def load():
     L.bsg_sections_size.argtypes = [vp, u32, C.POINTER(u64)]
     L.bsg_build_sections.argtypes = [vp, vp, vp, u32, vp, vp, u32, u64, vp, u64, vp]
     L.bsg_last_encode_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    L.bsg_match_rows.argtypes = [vp, vp, vp, u32, vp, u32, vp, u32, vp, vp, u32, C.POINTER(u32)]
+    L.bsg_last_match_ms.argtypes = [vp, C.POINTER(C.c_float)]
     for name in EXPORTS:
         if name != "bsg_last_error":
             getattr(L, name).restype = i32

@@ -32,8 +32,9 @@ def sources():
 
 
 def _deps():
-    return sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "host", "*.h*")) + \
-        glob.glob(os.path.join(CSRC, "host", "*.inc")) + glob.glob(os.path.join(INCLUDE, "*.h"))
+    return sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.inc")) + \
+        glob.glob(os.path.join(CSRC, "host", "*.h*")) + glob.glob(os.path.join(CSRC, "host", "*.inc")) + \
+        glob.glob(os.path.join(INCLUDE, "*.h"))
 
 
 def needs_build() -> bool:

@@ -8,6 +8,7 @@
 #include "bloomgpu.h"
 #include "kernels.hip.h"
 #include "ingest.hip.h"
+#include "match.hip.h"
 #include "host/text.hpp"   // the host walker's Unicode tables: the device defers to the same data
 #include <hip/hip_ext.h>
 
@@ -100,7 +101,7 @@ struct Device {
     uint32_t *d_lower = nullptr;              // unicode.ToLower table for k_ingest_rows (512 KB)
     bsg::CrcConsts *d_crc = nullptr;          // CRC32C slice-by-8 tables + x^(2^i) mod P (k_decode_sections)
     hipEvent_t kb0 = nullptr, kb1 = nullptr;  // start/stop timestamps of the last k_build / k_hash_entries dispatch
-    float last_build_ms = 0.f, last_hash_ms = 0.f, last_decode_ms = 0.f, last_or_ms = 0.f, last_encode_ms = 0.f;
+    float last_build_ms = 0.f, last_hash_ms = 0.f, last_decode_ms = 0.f, last_or_ms = 0.f, last_encode_ms = 0.f, last_match_ms = 0.f;
     bool or_pending = false;   // kb0/kb1 hold an un-read k_or_reduce_blocks dispatch
 };
 
@@ -163,6 +164,7 @@ struct bsg_ctx {
 namespace {
 
 void free_all_ingests(bsg_ctx *ctx);   // ingest_api.inc
+int32_t ensure_lower_table(Device &d);   // ingest_api.inc: the unicode.ToLower table the walkers fold with
 
 struct SectionsOut { uint8_t *region; uint64_t cap; uint64_t *sec_off; };   // encode_api.inc
 int32_t encode_sections_device(Device &d, const uint64_t *d_words, const bsg_filter_desc *desc, uint32_t n_blocks,
@@ -1324,3 +1326,4 @@ int32_t bsg_or_reduce(bsg_ctx *ctx, uint64_t arena_id, uint32_t kind, uint64_t *
 
 #include "encode_api.inc"
 #include "ingest_api.inc"
+#include "match_api.inc"

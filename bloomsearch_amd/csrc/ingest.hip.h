@@ -318,6 +318,7 @@ struct Walker {
     const uint32_t *lower;   // IngestArgs::lower
     bool quiet;              // leaf without a path (scalars at the root): nothing is emitted
     bool in_token;
+    bool ft_on;              // keep the path::word stream (the ingest walker); the row matcher only needs the word's own hash
     HashStream ps, tok, ft;  // path + "::" prefix state; current word; current path::word
 };
 
@@ -338,7 +339,7 @@ __device__ __forceinline__ void word_byte(Walker &w, uint32_t c)
     if (!w.in_token) { hs_init(w.tok); w.ft = w.ps; w.in_token = true; }
     if (c - 'A' < 26u) c += 32;                    // ASCII fold (appendFoldedWord fast path, row_matcher.go:187-202)
     hs_absorb(w.tok, c);
-    hs_absorb(w.ft, c);
+    if (w.ft_on) hs_absorb(w.ft, c);
 }
 
 // n (1..8) word bytes, little-endian in v, upper bytes zero
@@ -348,7 +349,7 @@ __device__ __forceinline__ void word_run(Walker &w, uint64_t v, uint32_t n)
     if (!w.in_token) { hs_init(w.tok); w.ft = w.ps; w.in_token = true; }
     v = swar_lower(v);                             // ASCII fold (appendFoldedWord fast path, row_matcher.go:187-202)
     hs_absorb_n(w.tok, v, n);
-    hs_absorb_n(w.ft, v, n);
+    if (w.ft_on) hs_absorb_n(w.ft, v, n);
 }
 
 __device__ __forceinline__ uint32_t c_at(uint64_t v, uint32_t i) { return (uint32_t)(v >> (i * 8u)) & 0xFFu; }
@@ -443,7 +444,7 @@ __device__ __forceinline__ uint32_t str_rune(Walker &w, uint32_t r)
         if (r >= 0x80u) bytes = rune_utf8(r, n);
         if (!w.in_token) { hs_init(w.tok); w.ft = w.ps; w.in_token = true; }
         hs_absorb_n(w.tok, bytes, n);
-        hs_absorb_n(w.ft, bytes, n);
+        if (w.ft_on) hs_absorb_n(w.ft, bytes, n);
     }
     return 0xFFu;
 }
@@ -777,6 +778,7 @@ __global__ __launch_bounds__(kIngestThreads, BSG_INGEST_WPE) void k_ingest_rows(
     cc.chunks = reinterpret_cast<const uint64_t *>(a.rows);
     w.path = (lds_u8 *)lds_raw + kCacheEntries * 32 + threadIdx.x * kLaneLds;
     w.lower = a.lower;
+    w.ft_on = true;
     hs_init(w.ps); hs_init(w.tok); hs_init(w.ft);
 
     // pass 1: validate.  A row the device walker cannot finish contributes NOTHING here; it goes to the host walker whole.

@@ -273,6 +273,38 @@ class Context:
         self._check(self.L.bsg_last_encode_ms(self.h, C.byref(v)))
         return float(v.value)
 
+    # ---- final row test on the device ----
+    def match_rows(self, rows, matcher):
+        """rows: list[bytes] or (u8 blob, u64 offsets); matcher: query.CompiledMatcher.
+        -> (bool array [n_rows], sorted u32 array of rows the host matcher must decide)."""
+        if isinstance(rows, tuple):
+            blob = np.ascontiguousarray(rows[0], dtype=np.uint8)
+            off = np.ascontiguousarray(rows[1], dtype=np.uint64)
+        else:
+            off = np.zeros(len(rows) + 1, dtype=np.uint64)
+            if rows:
+                off[1:] = np.cumsum([len(r) for r in rows], dtype=np.uint64)
+            blob = np.frombuffer(b"".join(rows), dtype=np.uint8)
+        n = len(off) - 1
+        conds = np.zeros(len(matcher.kinds), dtype=_lib.MATCH_COND_DTYPE)
+        if len(conds):
+            conds["hf"] = self.hash_strings(matcher.fields)
+            conds["ht"] = self.hash_strings(matcher.tokens)
+            conds["kind"] = np.asarray(matcher.kinds, dtype=np.uint32)
+        ops = np.asarray(matcher.prog_ops, dtype=np.uint32)
+        bits = np.zeros((n + 63) // 64, dtype=np.uint64)
+        fb = np.zeros(max(n, 1), dtype=np.uint32)
+        nfb = C.c_uint32()
+        self._check(self.L.bsg_match_rows(self.h, _lib._ptr(blob), _lib._ptr(off), n, _lib._ptr(conds), len(conds), _lib._ptr(ops), len(ops),
+                                          _lib._ptr(bits), _lib._ptr(fb), len(fb), C.byref(nfb)))
+        match = np.unpackbits(bits.view(np.uint8), bitorder="little")[:n].astype(bool)
+        return match, fb[: nfb.value].copy()
+
+    def last_match_ms(self) -> float:
+        v = C.c_float()
+        self._check(self.L.bsg_last_match_ms(self.h, C.byref(v)))
+        return float(v.value)
+
     def ingest_stats(self, ingest_id: int) -> IngestStats:
         st = IngestStats()
         self._check(self.L.bsg_ingest_stats_read(self.h, ingest_id, C.byref(st)))

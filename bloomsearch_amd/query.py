@@ -142,3 +142,43 @@ def compile_queries(expressions) -> CompiledBatch:
     for e in expressions:
         cb.add_query(e)
     return cb
+
+
+class CompiledMatcher:
+    """One expression for the device row matcher (include/bloomgpu.h bsg_match_rows): its conditions — field and token
+    strings kept APART, because FieldToken is a (path, token) pair at one leaf, not the joined bloom key
+    (row_matcher.go:587) — and the postfix program over condition indices."""
+
+    def __init__(self, expression):
+        self.kinds: list[int] = []
+        self.fields: list[bytes] = []
+        self.tokens: list[bytes] = []
+        self.prog_ops: list[int] = []
+        if expression is not None:
+            self._emit(expression)
+
+    def _emit(self, e) -> None:
+        if e is None:
+            self.prog_ops.append(op(OP_TRUE))
+            return
+        et = e.get("ExpressionType")
+        if et == EXPR_CONDITION:
+            cond = e.get("Condition")
+            if cond is None:                # nil condition => true (row_matcher.go:257-290)
+                self.prog_ops.append(op(OP_TRUE))
+                return
+            t = cond.get("Type")
+            if t not in (BLOOM_FIELD, BLOOM_TOKEN, BLOOM_FIELD_TOKEN):
+                self.prog_ops.append(op(OP_FALSE))
+                return
+            self.prog_ops.append(op(OP_TERM, len(self.kinds)))
+            self.kinds.append({BLOOM_FIELD: KIND_FIELD, BLOOM_TOKEN: KIND_TOKEN, BLOOM_FIELD_TOKEN: KIND_FIELD_TOKEN}[t])
+            self.fields.append(cond.get("Field", "").encode("utf-8", "surrogatepass"))
+            self.tokens.append(cond.get("Token", "").encode("utf-8", "surrogatepass"))
+        elif et in (EXPR_AND, EXPR_OR):
+            kids = e.get("Children") or []
+            for c in kids:
+                self._emit(c)
+            self.prog_ops.append(op(OP_AND if et == EXPR_AND else OP_OR, len(kids)))
+        else:
+            self.prog_ops.append(op(OP_FALSE))

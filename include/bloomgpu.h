@@ -289,6 +289,31 @@ BSG_API int32_t bsg_ingest_build_sections(bsg_ctx *ctx, uint64_t ingest_id, cons
 BSG_API int32_t bsg_ingest_stats_read(bsg_ctx *ctx, uint64_t ingest_id, bsg_ingest_stats *out);
 BSG_API int32_t bsg_ingest_free(bsg_ctx *ctx, uint64_t ingest_id);
 
+/* ---- final row test on the device (compileRowMatcher / matchRowBytes, row_matcher.go:257-626) ----
+ * One expression over Field / Token / FieldToken conditions, evaluated for every row of the surviving blocks.
+ * conds[i]: kind (BSG_KIND_*), hf = base hashes of the FIELD string (Field, FieldToken), ht = base hashes of the TOKEN
+ * string (Token, FieldToken) — both from bsg_hash_entries; FieldToken is the (path, token) PAIR at one leaf, not the
+ * joined "path::token" key (row_matcher.go:587).  prog_ops: the public postfix program over condition indices
+ * (BSG_OP_TERM i / AND n / OR n / TRUE / FALSE; n_ops == 0 = nil expression = every row matches; a nil condition
+ * lowers to TRUE, an unknown condition or expression type to FALSE, as evalMatcherNode does).
+ * out_bits[ceil(n_rows / 64)]: bit r & 63 of word r >> 6 set <=> row r matches.  Rows outside the device walker's
+ * envelope (see bsg_ingest_rows) are listed in out_fallback_rows (ascending; their bit is 0) and must be decided by
+ * the host matcher.  Target tokens are never normalised (Token("ALICE") misses, row_matcher_test.go:99-100).
+ * Limits: 64 conditions, expression depth 64 (BSG_E_UNSUPPORTED beyond). */
+typedef struct bsg_match_cond {
+    uint64_t hf[4];
+    uint64_t ht[4];
+    uint32_t kind;
+    uint32_t reserved;
+} bsg_match_cond;
+
+BSG_API int32_t bsg_match_rows(bsg_ctx *ctx, const uint8_t *rows, const uint64_t *row_off, uint32_t n_rows,
+                               const bsg_match_cond *conds, uint32_t n_conds, const uint32_t *prog_ops, uint32_t n_ops,
+                               uint64_t *out_bits, uint32_t *out_fallback_rows, uint32_t fallback_cap,
+                               uint32_t *out_n_fallback);
+/* Device time of the most recent k_match_rows dispatch on the context's first device. */
+BSG_API int32_t bsg_last_match_ms(bsg_ctx *ctx, float *match_ms);
+
 #ifdef __cplusplus
 }
 #endif
