@@ -95,7 +95,23 @@ def ingest_leg(ctx, n_blocks, rows, seed, workers, plan, words, fpr, log, truste
     log("device ingest: %d rows (%.0f MB JSON) walk %.2f ms + union %.2f ms + build %.2f ms = %.1f M rows/s on-device; "
         "%.3fs end to end incl. H2D (row generation %.1fs); filters bit-identical to bsg_build"
         % (n_rows, st.row_bytes / 1e6, st.ms_walk, st.ms_union, st.ms_build, n_rows / kern_ms / 1e3, t_e2e, t_gen))
+    # the final row test (BASELINE configs[0]'s query, FieldToken("level", "error"), row_matcher.go) over the same rows on
+    # the device; truth = the generator's own draws
+    from bloomsearch_amd import query as Q, synth
+    t0 = time.time()
+    hits, mfb = ctx.match_rows((blob, off), Q.CompiledMatcher(Q.FieldToken("level", "error")))
+    t_match = time.time() - t0
+    match_ms = ctx.last_match_ms()
+    truth = np.concatenate([synth.draws(b * rows, rows, seed)["level"] == synth.LEVELS.index("error") for b in range(n_blocks)])
+    if len(mfb) or not np.array_equal(hits, truth):
+        sys.exit("device row matcher disagrees with the generator's ground truth")
+    log("device row match: %d rows in %.2f ms = %.0f M rows/s (%.0f GB/s of JSON), %d matches; %.3fs end to end incl. H2D"
+        % (n_rows, match_ms, n_rows / match_ms / 1e3, st.row_bytes / match_ms / 1e6, int(hits.sum()), t_match))
+    match = {"workload": "final row test FieldToken(level, error) over the same %d rows" % n_rows, "kernel": "k_match_rows",
+             "kernel_ms": match_ms, "rows_per_s_device": n_rows / match_ms * 1e3, "row_gb_per_s": st.row_bytes / match_ms / 1e6,
+             "matches": int(hits.sum()), "end_to_end_s_incl_h2d": t_match, "check": "equals the generator's draws row for row"}
     return {"workload": "C3 from rows: %d blocks x %d JSON rows -> %d block filters + 3 file-level filters" % (n_blocks, rows, 3 * n_blocks),
+            "match": match,
             "kernels": {"k_ingest_rows_ms": st.ms_walk, "k_ingest_union_ms": st.ms_union, "k_build_sets_ms": st.ms_build},
             "rows": n_rows, "row_bytes": int(st.row_bytes), "rows_per_s_device": n_rows / kern_ms * 1e3,
             "row_gb_per_s_walk": st.row_bytes / max(st.ms_walk, 1e-6) / 1e6, "end_to_end_s_incl_h2d": t_e2e,

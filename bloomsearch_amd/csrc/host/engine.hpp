@@ -14,6 +14,7 @@
 #pragma once
 #include <algorithm>
 #include <cstdint>
+#include <cstring>
 #include <map>
 #include <memory>
 #include <string>
@@ -48,6 +49,9 @@ struct EngineConfig {           // BloomSearchEngineConfig (engine.go:82-147), t
     // build all run on the device at flush / merge time (bsg_ingest_*), the host walker only finishing the rows
     // the device walker hands back.  false: indexRow on the host at ingest time, as the reference does.
     bool device_ingest = false;
+    // true: the final row test of the surviving blocks (matchRowBytes, query_exec.go:751) runs on the device too
+    // (bsg_match_rows); rows it hands back, and expressions beyond its limits, go through the host matcher.
+    bool device_match = false;
 };
 
 struct DataBlock {
@@ -292,6 +296,8 @@ public:
             }
         }
         RowMatcher matcher(expr);
+        // the scan list: every row of every block that survived both stages, in file / block order
+        std::vector<const std::string *> scan;
         for (size_t f = 0; f < files_.size(); ++f) {
             out.files_considered++;
             if (!file_ok[f]) { out.files_bloom_skipped++; continue; }   // file stage prune: no BlockStats for its blocks
@@ -315,11 +321,20 @@ public:
                 for (const std::string &row : blk.rows) {
                     st.rows_processed++;
                     st.bytes_processed += (int64_t)row.size() + 4;
-                    if (matcher.match(row)) out.rows.push_back(row);
+                    scan.push_back(&row);
                 }
                 out.block_stats.push_back(st);
             }
         }
+        std::vector<uint8_t> hit(scan.size(), 0);
+        bool on_device = false;
+        if (cfg_.device_match && expr && !scan.empty()) {
+            if (int32_t rc = match_rows_device(expr, scan, matcher, hit, on_device)) return rc;
+        }
+        if (!on_device)
+            for (size_t i = 0; i < scan.size(); ++i) hit[i] = matcher.match(*scan[i]);
+        for (size_t i = 0; i < scan.size(); ++i)
+            if (hit[i]) out.rows.push_back(*scan[i]);
         return kEngineOk;
     }
 
@@ -491,6 +506,44 @@ private:
         sets.push_back(&file_entries);
         file.counts = file_entries.counts();
         return build_sections(sets, sections);
+    }
+
+    // matchRowBytes for the whole scan list in one bsg_match_rows call.  on_device stays false (and the host matcher
+    // takes over) when the expression is beyond the device matcher's limits.
+    int32_t match_rows_device(const BloomExpression *expr, const std::vector<const std::string *> &scan, RowMatcher &host_matcher,
+                              std::vector<uint8_t> &hit, bool &on_device)
+    {
+        MatcherProgram mp(expr);
+        if (mp.kinds.size() > 64) return kEngineOk;
+        std::vector<bsg_match_cond> conds(mp.kinds.size());
+        if (!conds.empty()) {
+            std::vector<uint8_t> bytes;
+            std::vector<uint32_t> offsets{0};
+            for (auto &f : mp.fields) { bytes.insert(bytes.end(), f.begin(), f.end()); offsets.push_back((uint32_t)bytes.size()); }
+            for (auto &t : mp.tokens) { bytes.insert(bytes.end(), t.begin(), t.end()); offsets.push_back((uint32_t)bytes.size()); }
+            std::vector<uint64_t> h(conds.size() * 8);
+            if (bsg_hash_entries(ctx_, bytes.data(), offsets.data(), (uint32_t)conds.size() * 2, h.data())) return fail(kErrGpu, bsg_last_error(ctx_));
+            for (size_t c = 0; c < conds.size(); ++c) {
+                memcpy(conds[c].hf, &h[c * 4], 32);
+                memcpy(conds[c].ht, &h[(conds.size() + c) * 4], 32);
+                conds[c].kind = mp.kinds[c];
+                conds[c].reserved = 0;
+            }
+        }
+        std::vector<uint8_t> bytes;
+        std::vector<uint64_t> row_off{0};
+        for (const std::string *r : scan) { bytes.insert(bytes.end(), r->begin(), r->end()); row_off.push_back(bytes.size()); }
+        std::vector<uint64_t> bits((scan.size() + 63) / 64);
+        std::vector<uint32_t> fb(scan.size());
+        uint32_t n_fb = 0;
+        const int32_t rc = bsg_match_rows(ctx_, bytes.data(), row_off.data(), (uint32_t)scan.size(), conds.data(), (uint32_t)conds.size(),
+                                          mp.prog_ops.data(), (uint32_t)mp.prog_ops.size(), bits.data(), fb.data(), (uint32_t)fb.size(), &n_fb);
+        if (rc == BSG_E_UNSUPPORTED) return kEngineOk;      // expression too deep / long: host matcher
+        if (rc) return fail(kErrGpu, bsg_last_error(ctx_));
+        for (size_t i = 0; i < scan.size(); ++i) hit[i] = (bits[i >> 6] >> (i & 63)) & 1;
+        for (uint32_t i = 0; i < n_fb; ++i) hit[fb[i]] = host_matcher.match(*scan[fb[i]]);   // rows outside the device walker's envelope
+        on_device = true;
+        return kEngineOk;
     }
 
     // Hand the stored section bytes to the device as they are: CRC32C + big-endian decode run in

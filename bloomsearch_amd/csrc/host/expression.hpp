@@ -170,6 +170,41 @@ private:
 };
 
 // ---- final exact row test ----
+// The same tree lowered for the device row matcher (bloomgpu.h bsg_match_rows): conditions keep their field and
+// token strings APART (FieldToken is a (path, token) pair at one leaf, row_matcher.go:587), the program refers to
+// conditions by index.  nil condition => TRUE, unknown condition / expression => FALSE (row_matcher.go:257-290).
+class MatcherProgram {
+public:
+    std::vector<uint32_t> kinds;
+    std::vector<std::string> fields, tokens;
+    std::vector<uint32_t> prog_ops;
+
+    explicit MatcherProgram(const BloomExpression *expression) { if (expression) emit(*expression); }
+
+private:
+    void emit(const BloomExpression &e)
+    {
+        switch (e.type) {
+        case ExprType::Condition:
+            if (!e.has_condition) { prog_ops.push_back(BSG_OP(BSG_OP_TRUE, 0)); return; }
+            if (e.condition.type == CondType::Unknown) { prog_ops.push_back(BSG_OP(BSG_OP_FALSE, 0)); return; }
+            prog_ops.push_back(BSG_OP(BSG_OP_TERM, (uint32_t)kinds.size()));
+            kinds.push_back(e.condition.type == CondType::Field ? BSG_KIND_FIELD
+                                                                 : (e.condition.type == CondType::Token ? BSG_KIND_TOKEN : BSG_KIND_FIELD_TOKEN));
+            fields.push_back(e.condition.field);
+            tokens.push_back(e.condition.token);
+            return;
+        case ExprType::And:
+        case ExprType::Or:
+            for (auto &c : e.children) emit(c);
+            prog_ops.push_back(BSG_OP(e.type == ExprType::And ? BSG_OP_AND : BSG_OP_OR, (uint32_t)e.children.size()));
+            return;
+        default:
+            prog_ops.push_back(BSG_OP(BSG_OP_FALSE, 0));
+        }
+    }
+};
+
 class RowMatcher {
 public:
     explicit RowMatcher(const BloomExpression *expression)

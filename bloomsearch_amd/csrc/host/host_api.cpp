@@ -233,6 +233,7 @@ int32_t bse_open(const char *config_json, uint64_t len, bsg_ctx *ctx, bse_engine
         if (const JNode *n = dom.get("BloomFalsePositiveRate")) { if (n->type == JType::Number) cfg.bloom_false_positive_rate = strtod(n->text.c_str(), nullptr); }
         if (const JNode *n = dom.get("PartitionField")) { if (n->type == JType::String) cfg.partition_field = n->text; }
         if (const JNode *n = dom.get("DeviceIngest")) cfg.device_ingest = n->type == JType::True;
+        if (const JNode *n = dom.get("DeviceMatch")) cfg.device_match = n->type == JType::True;
     }
     std::string err;
     if (int32_t rc = BloomSearchEngine::validate(cfg, err)) return rc;

@@ -74,10 +74,12 @@ BSG_API uint32_t bsh_crc32c(const uint8_t *data, uint64_t len);
 /* ---- engine mirror ---- */
 typedef struct bse_engine bse_engine;
 /* config_json: {"MaxRowGroupRows":..,"MaxRowGroupBytes":..,"MaxBufferedRows":..,"MaxBufferedBytes":..,
- *               "BloomFalsePositiveRate":..,"PartitionField":"..","DeviceIngest":true|false}; missing keys take the
+ *               "BloomFalsePositiveRate":..,"PartitionField":"..","DeviceIngest":true|false,"DeviceMatch":true|false}; missing keys take the
  *               reference defaults.  DeviceIngest (default false): rows are walked / tokenized / deduplicated /
  *               counted on the GPU at flush and merge time (bloomgpu.h bsg_ingest_*) instead of by indexRow on the
- *               host at ingest time; the files it writes are byte-identical either way. */
+ *               host at ingest time; the files it writes are byte-identical either way.  DeviceMatch (default false): the
+ *               final row test of the surviving blocks runs on the GPU (bsg_match_rows) instead of in the host matcher;
+ *               the delivered row set is the same. */
 BSG_API int32_t bse_open(const char *config_json, uint64_t len, bsg_ctx *ctx, bse_engine **out);
 BSG_API void bse_close(bse_engine *e);
 BSG_API const char *bse_last_error(bse_engine *e);

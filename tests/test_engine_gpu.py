@@ -18,19 +18,22 @@ pytestmark = pytest.mark.gpu
 
 
 DEVICE_INGEST = False
+DEVICE_MATCH = False
 
 
-@pytest.fixture(autouse=True, params=[False, True], ids=["host-ingest", "device-ingest"])
+@pytest.fixture(autouse=True, params=[(False, False), (True, False), (True, True)], ids=["host", "device-ingest", "device-ingest+match"])
 def ingest_mode(request):
-    """Every scenario runs twice: indexRow on the host at ingest time (the reference's order of work), and with
-    DeviceIngest (rows walked / tokenized / deduplicated / counted by k_ingest_rows at flush and merge time)."""
-    global DEVICE_INGEST
-    DEVICE_INGEST = request.param
+    """Every scenario runs three ways: indexRow and matchRowBytes on the host (the reference's order of work); DeviceIngest
+    (rows walked / tokenized / deduplicated / counted by k_ingest_rows at flush and merge time); and DeviceMatch on top
+    (the final row test of the surviving blocks by k_match_rows)."""
+    global DEVICE_INGEST, DEVICE_MATCH
+    DEVICE_INGEST, DEVICE_MATCH = request.param
     yield
 
 
 def new_engine(ctx, **cfg):
     cfg.setdefault("DeviceIngest", DEVICE_INGEST)
+    cfg.setdefault("DeviceMatch", DEVICE_MATCH)
     return Hst.Engine(ctx, **cfg)
 
 
