@@ -39,6 +39,9 @@ for rep in range(reps):
     st = ctx.ingest_stats(ing)
     ctx.ingest_free(ing)
     t5 = time.time()
+    from bloomsearch_amd import query as Q
+    hits, handed_back = ctx.match_rows((blob, off), Q.CompiledMatcher(Q.FieldToken("level", "error")))
+    print("    match: k_match_rows %.2f ms, %d matches, %d handed back, %.1f ms wall" % (ctx.last_match_ms(), int(hits.sum()), len(handed_back), (time.time() - t5) * 1e3))
     print("    host wall: ingest_rows %.1f ms (kernel %.1f), finish %.1f ms (kernel %.1f), plan_desc %.1f ms, build %.1f ms (kernel %.1f), free %.1f ms"
           % ((t1 - t0) * 1e3, st.ms_walk, (t2 - t1) * 1e3, st.ms_union, (t3 - t2) * 1e3, (t4 - t3) * 1e3, st.ms_build, (t5 - t4) * 1e3))
     print("rep %d: %d rows %.0f MB  walk %.2f ms  union %.2f ms  build %.2f ms  grows %d  fallback %d  tables %.0f MB  e2e %.3fs  file counts %s"
