@@ -62,6 +62,17 @@ def _ingest_job(ctx, seed):
     return True
 
 
+def _match_job(ctx, seed):
+    rows = synth.rows_json(seed * 777, 2000)
+    d = synth.draws(seed * 777, 2000)
+    e = Q.Or(Q.And(Q.FieldToken("level", "warn"), Q.FieldToken("nested.az", "az-1")), Q.Token("region-7"))
+    want = ((d["level"] == synth.LEVELS.index("warn")) & (d["az"] == 1)) | (d["region"] == 7)
+    for _ in range(ROUNDS):
+        got, handed_back = ctx.match_rows(rows, Q.CompiledMatcher(e))
+        assert len(handed_back) == 0 and np.array_equal(got, want)
+    return True
+
+
 def test_many_threads_one_context(ctx):
     errors = []
     barrier = threading.Barrier(N_THREADS)
@@ -69,7 +80,7 @@ def test_many_threads_one_context(ctx):
     def run(i):
         try:
             barrier.wait(timeout=60)
-            return _probe_job(ctx, 100 + i) if i % 4 != 3 else _ingest_job(ctx, 7 + i)
+            return (_probe_job, _probe_job, _match_job, _ingest_job)[i % 4](ctx, 100 + i)
         except BaseException as exc:  # noqa: BLE001 - reported below with the thread index
             errors.append((i, repr(exc)))
             return False
