@@ -82,6 +82,18 @@ def ingest_leg(ctx, n_blocks, rows, seed, workers, plan, words, fpr, log, truste
     t_e2e = time.time() - t0
     st = ctx.ingest_stats(ing)
     ctx.ingest_free(ing)
+    # the same again with the rows marshalled into pinned host memory (bsg_pinned_alloc): the copy becomes a plain DMA
+    pinned = ctx.pinned_array(len(blob))
+    pinned[:] = blob
+    t0 = time.time()
+    ing2 = ctx.ingest_rows((pinned, off), first, np.zeros(n_blocks, dtype=np.uint32), 1, flags=trusted)
+    counts2, _ = ctx.ingest_finish(ing2, n_blocks + 1)
+    got2 = ctx.ingest_build(ing2, desc, n_words)
+    t_e2e_pinned = time.time() - t0
+    ctx.ingest_free(ing2)
+    ctx.pinned_free(pinned)
+    if not (np.array_equal(counts2, counts) and np.array_equal(got2, got)):
+        sys.exit("device ingest from pinned rows differs from the pageable run")
     if len(fb) or status.any():
         sys.exit("device ingest handed back %d synthetic rows / flagged a set" % len(fb))
     for i in range(n_blocks * 3):
@@ -93,8 +105,8 @@ def ingest_leg(ctx, n_blocks, rows, seed, workers, plan, words, fpr, log, truste
     kern_ms = st.ms_walk + st.ms_union + st.ms_build
     n_rows = n_blocks * rows
     log("device ingest: %d rows (%.0f MB JSON) walk %.2f ms + union %.2f ms + build %.2f ms = %.1f M rows/s on-device; "
-        "%.3fs end to end incl. H2D (row generation %.1fs); filters bit-identical to bsg_build"
-        % (n_rows, st.row_bytes / 1e6, st.ms_walk, st.ms_union, st.ms_build, n_rows / kern_ms / 1e3, t_e2e, t_gen))
+        "%.3fs end to end incl. H2D (%.3fs from pinned rows; row generation %.1fs); filters bit-identical to bsg_build"
+        % (n_rows, st.row_bytes / 1e6, st.ms_walk, st.ms_union, st.ms_build, n_rows / kern_ms / 1e3, t_e2e, t_e2e_pinned, t_gen))
     # the final row test (BASELINE configs[0]'s query, FieldToken("level", "error"), row_matcher.go) over the same rows on
     # the device; truth = the generator's own draws
     from bloomsearch_amd import query as Q, synth
@@ -115,6 +127,7 @@ def ingest_leg(ctx, n_blocks, rows, seed, workers, plan, words, fpr, log, truste
             "kernels": {"k_ingest_rows_ms": st.ms_walk, "k_ingest_union_ms": st.ms_union, "k_build_sets_ms": st.ms_build},
             "rows": n_rows, "row_bytes": int(st.row_bytes), "rows_per_s_device": n_rows / kern_ms * 1e3,
             "row_gb_per_s_walk": st.row_bytes / max(st.ms_walk, 1e-6) / 1e6, "end_to_end_s_incl_h2d": t_e2e,
+            "end_to_end_s_incl_h2d_pinned_rows": t_e2e_pinned,
             "table_bytes": int(st.table_bytes), "table_grows": int(st.table_grows), "fallback_rows": int(len(fb)),
             "distinct_entries": int(counts[:n_blocks].sum()), "file_level_distinct": [int(x) for x in counts[n_blocks]],
             "check": "bitsets and (m, k) identical to bsg_build of the same blocks' entry sets"}

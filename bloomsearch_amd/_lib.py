@@ -56,7 +56,7 @@ EXPORTS = [
     "bsg_ingest_rows", "bsg_ingest_fallback_rows", "bsg_ingest_add_entries", "bsg_ingest_finish", "bsg_ingest_build",
     "bsg_ingest_stats_read", "bsg_ingest_free", "bsg_ingest_build_sections",
     "bsg_sections_size", "bsg_build_sections", "bsg_last_encode_ms",
-    "bsg_match_rows", "bsg_last_match_ms",
+    "bsg_match_rows", "bsg_last_match_ms", "bsg_pinned_alloc", "bsg_pinned_free",
 ]
 
 _lib = None
@@ -110,6 +110,8 @@ def load():
     L.bsg_last_encode_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.bsg_match_rows.argtypes = [vp, vp, vp, u32, vp, u32, vp, u32, vp, vp, u32, C.POINTER(u32)]
     L.bsg_last_match_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    L.bsg_pinned_alloc.argtypes = [vp, u64, C.POINTER(vp)]
+    L.bsg_pinned_free.argtypes = [vp, vp]
     for name in EXPORTS:
         if name != "bsg_last_error":
             getattr(L, name).restype = i32

@@ -273,6 +273,18 @@ class Context:
         self._check(self.L.bsg_last_encode_ms(self.h, C.byref(v)))
         return float(v.value)
 
+    # ---- pinned host memory ----
+    def pinned_array(self, n_bytes: int) -> np.ndarray:
+        """A u8 numpy view of n_bytes of pinned host memory (freed by pinned_free(array))."""
+        p = C.c_void_p()
+        self._check(self.L.bsg_pinned_alloc(self.h, n_bytes, C.byref(p)))
+        buf = (C.c_uint8 * max(n_bytes, 1)).from_address(p.value)
+        arr = np.frombuffer(buf, dtype=np.uint8, count=n_bytes)
+        return arr
+
+    def pinned_free(self, arr: np.ndarray):
+        self._check(self.L.bsg_pinned_free(self.h, C.c_void_p(arr.ctypes.data)))
+
     # ---- final row test on the device ----
     def match_rows(self, rows, matcher):
         """rows: list[bytes] or (u8 blob, u64 offsets); matcher: query.CompiledMatcher.

@@ -295,6 +295,24 @@ def test_resident_arenas_equal_reloaded_sections(ctx):
     ctx.batch_free(bid)
 
 
+def test_rows_from_pinned_host_memory(ctx):
+    rows = synth.rows_json(0, 800)
+    blob = np.frombuffer(b"".join(rows), dtype=np.uint8)
+    off = np.zeros(len(rows) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(r) for r in rows])
+    pinned = ctx.pinned_array(len(blob))
+    pinned[:] = blob
+    ing = ctx.ingest_rows((pinned, off), [0, 800], flags=TRUSTED)
+    counts, status = ctx.ingest_finish(ing, 1)
+    desc, n_words = I.plan_desc(counts, FPR)
+    words = ctx.ingest_build(ing, desc, n_words)
+    ctx.ingest_free(ing)
+    ctx.pinned_free(pinned)
+    sets = oracle_sets(rows)
+    res = I.IngestResult(counts, status, desc, words, None, np.zeros(0, dtype=np.uint32))
+    check_against_sets(res, 0, sets, "pinned")
+
+
 def test_empty_sets_and_rowless_ingest(ctx):
     res = I.device_ingest(ctx, [[], [b'{"a":"b"}'], []], FPR, parent_of_set=[0, 0, 1], n_parents=2)
     empty = (set(), set(), set())
