@@ -57,3 +57,68 @@ def test_product_package_never_imports_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".h", ".hpp")):
                 src = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "oracle" not in src.replace("no oracle", ""), os.path.join(dirpath, f)
+
+
+C_PROGRAM = r"""
+/* A plain C99 caller of the boundary: no C++, no Python, no torch — what a cgo / JNI / FFI binding sees. */
+#include <stdio.h>
+#include <string.h>
+#include "bloomgpu.h"
+#include "bloomsearch_host.h"
+
+int main(void)
+{
+    uint64_t m = 0, k = 0, total = 0;
+    bsg_filter_desc d[3];
+    bsg_term t;
+    bsg_match_cond c;
+    bsg_ingest_stats st;
+    bsg_ctx *ctx = NULL;
+    int32_t ids[1] = {0};
+    int32_t rc;
+    memset(d, 0, sizeof d); memset(&t, 0, sizeof t); memset(&c, 0, sizeof c); memset(&st, 0, sizeof st);
+    if (bsg_estimate_parameters(100, 0.01, &m, &k) != BSG_OK || m != 959 || k != 7) return 2;
+    d[1].m = m; d[1].k = (uint32_t)k;
+    if (bsg_sections_size(d, 1, &total) != BSG_OK || total != 1 + 4 + 24 + 8 * ((m + 63) / 64) + 4) return 3;
+    if (sizeof(bsg_term) != 40 || sizeof(bsg_filter_desc) != 24 || sizeof(bsg_match_cond) != 72) return 4;
+    rc = bsg_open(ids, 1, &ctx);
+    printf("devices=%d open=%d crc=%08x\n", (int)bsg_device_count(), (int)rc, (unsigned)bsh_crc32c((const uint8_t *)"123456789", 9));
+    if (rc == BSG_OK) {
+        uint64_t h[4] = {0, 0, 0, 0};
+        const uint32_t off[2] = {0, 5};
+        if (bsg_hash_entries(ctx, (const uint8_t *)"hello", off, 1, h) != BSG_OK) return 5;
+        printf("hello=%016llx %016llx\n", (unsigned long long)h[0], (unsigned long long)h[1]);
+        bsg_close(ctx);
+    } else if (rc != BSG_E_NODEVICE) {
+        return 6;
+    }
+    return 0;
+}
+"""
+
+
+def run_c_caller(tmp_path):
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if not gcc:
+        pytest.skip("no gcc")
+    src = tmp_path / "caller.c"
+    src.write_text(C_PROGRAM)
+    exe = tmp_path / "caller"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.check_call([gcc, "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                           "-L", libdir, "-l:libbloomgpu.so", "-Wl,-rpath," + libdir])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
+    assert "crc=e3069283" in out.stdout.splitlines()[0]                      # CRC-32C check value
+    return out.stdout
+
+
+def test_plain_c99_program_links_against_the_boundary(lib, tmp_path):
+    """include/*.h are C99 headers and libbloomgpu.so is an ordinary shared library: a C program compiled with gcc
+    (-std=c99 -Wall -Werror -pedantic) links, runs, sizes sections on the host and — without a GPU — is refused by
+    bsg_open with BSG_E_NODEVICE.  (tests/test_gpu_parity.py runs the same program where a GPU is present.)"""
+    out = run_c_caller(tmp_path)
+    if lib.bsg_device_count() == 0:
+        assert "open=-6" in out

@@ -23,6 +23,14 @@ def test_hash_entries_bit_exact(ctx):
     assert np.array_equal(got, want)
 
 
+def test_plain_c99_caller_hashes_on_the_gpu(tmp_path):
+    """The C program of tests/test_cabi.py, where a GPU is present: bsg_open succeeds and bsg_hash_entries returns the
+    public MurmurHash3_x64_128 vector for "hello" — the boundary works without Python or torch in the process."""
+    from tests.test_cabi import run_c_caller
+    out = run_c_caller(tmp_path)
+    assert "open=0" in out and "hello=cbd8a7b341bd9b02 5b1e906a48ae1d19" in out
+
+
 def test_hash_entries_large_batch(ctx):
     rng = np.random.default_rng(12)
     ents = [b"tok%d" % i for i in rng.integers(0, 1 << 40, size=50000)]
