@@ -480,7 +480,7 @@ private:
         drop_file_arena(file);
         if (bsg_ingest_build_sections(ctx_, ing, desc.data(), region.data(), region.size(), sec_off.data(), &file.arena, nullptr))
             return fail(kErrGpu, bsg_last_error(ctx_));
-        file.arena_valid = true;
+        file.arena_valid = file.arena != 0;      // 0: the context does not keep single-device arenas; decoded from the sections on first use
         file.block_status.assign(nb, 0);
         split_sections(region, sec_off, sections);
         for (size_t s = 0; s <= nb; ++s) {
