@@ -337,3 +337,27 @@ def test_ingest_argument_errors(ctx):
     ctx.ingest_free(ing)
     with pytest.raises(BloomGpuError):
         ctx.ingest_free(ing)
+
+
+def test_every_chunk_alignment(ctx):
+    """The walker reads rows in 8-byte chunks wherever they start: every tricky row is placed at all eight alignments
+    (a filler row of varying length in front), alone in its set, and must give the host walker's entry sets each time —
+    escapes, UTF-8 sequences, numbers and literals cut by chunk boundaries at every possible byte."""
+    tricky = ROWS_DEVICE + ROWS_UTF8_DEVICE + [r.encode() for r, _ in JSON_MATCHING[:12]]
+    rows, sets_of = [], []
+    for t in tricky:
+        for pad in range(8):
+            rows.append(b'{"f":"' + b"x" * (pad + 1) + b'"}')
+            rows.append(t)
+    res = I.device_ingest(ctx, [[r] for r in rows], FPR, flags=TRUSTED)
+    assert len(res.fallback_rows) == 0
+    cache = {}
+    for i, r in enumerate(rows):
+        if r not in cache:
+            cache[r] = host_sets([r])
+        want = cache[r]
+        for kind in range(3):
+            assert int(res.counts[i, kind]) == len(want[kind]), (r, kind)
+    # bitsets of one alignment family in full
+    for i in range(1, 16, 2):
+        check_against_sets(res, i, cache[rows[i]], rows[i])
