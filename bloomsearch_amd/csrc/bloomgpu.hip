@@ -1162,7 +1162,9 @@ extern "C" int32_t bsg_probe_many(bsg_ctx *ctx, const uint64_t *arena_ids, uint3
             const ArenaShard &s = arenas[i]->shards[di];
             if (s.n_blocks == 0) continue;
             const uint32_t slot = n_done & 1;
-            tflag[i] = timed && (ctx->timed_stride <= 1 || (ctx->timed_counter++ % ctx->timed_stride) == 0);
+            // the sampled probe sits in the MIDDLE of each stride: the first probe of a bsg_probe_many call follows a host
+            // round trip (the GPU may have gone idle for a moment), which is launch jitter, not the kernel
+            tflag[i] = timed && (ctx->timed_stride <= 1 || (ctx->timed_counter++ % ctx->timed_stride) == ctx->timed_stride / 2);
             if (tflag[i]) if (int32_t rc = take_events(ctx, d, evs[i])) return rc;
             EventTriple *ev = tflag[i] ? &evs[i] : nullptr;
             // timestamped probes are never fused: each of their two kernels keeps its own dispatch, so its own
