@@ -131,3 +131,33 @@ def test_block_of_log_rows_and_limits(ctx):
     with pytest.raises(BloomGpuError):
         ctx.match_rows(rows[:2], Q.CompiledMatcher(Q.And(*[Q.Token("t%d" % i) for i in range(65)])))   # > 64 conditions
     assert ctx.match_rows([], Q.CompiledMatcher(Q.Token("x")))[0].shape == (0,)
+
+
+def test_compiled_matcher_equivalence_with_derived_queries(ctx):
+    """row_matcher_test.go:31-172 (TestCompiledMatcherEquivalence): random rows plus the Unicode folding rows (U+212A,
+    U+0130, NBSP), ~15 queries derived from each row's own entries (so most are positives) — the device matcher, the
+    host matcher and (where no "::" is involved) the set-based oracle must agree on every (row, query)."""
+    rng = np.random.default_rng(11)
+    rows = [go_marshal({KEYS[rng.integers(0, len(KEYS))]: _random_value(rng, 0) for _ in range(rng.integers(1, 6))}) for _ in range(50)]
+    rows += ['{"unit":"10 K","city":"İstanbul İZMİR","sp":"a b c"}'.encode(), '{"k":"Straße ÄÖÜ Ω"}'.encode()]
+    queries = []
+    for r in rows:
+        fields, tokens, fts = (sorted(x) for x in W.index_row(r))
+        qs = [Q.Field(f) for f in fields[:3]] + [Q.Token(t) for t in tokens[:3]]
+        qs += [Q.FieldToken(*ft.split("::", 1)) for ft in fts[:3] if ft.count("::") == 1]
+        if fields and tokens:
+            qs += [Q.And(Q.Field(fields[0]), Q.Token(tokens[-1])), Q.Or(Q.Token("zz-absent"), Q.Field(fields[-1])),
+                   Q.And(Q.Token(tokens[0]), Q.Or(Q.Field("nope"), Q.Token(tokens[-1]))), Q.Token(tokens[0].upper() + "X"),
+                   Q.And(Q.Field(fields[0]), Q.Token("zz-absent")), Q.FieldToken(fields[-1], tokens[0])]
+        queries.append(qs)
+    # one device call per query over ALL rows: each query is a positive for its own row and mostly a negative elsewhere
+    n_pos = 0
+    for i, qs in enumerate(queries):
+        for q in qs:
+            got, fb = device_match(ctx, rows, q)
+            want = [Hst.match_row(q, r) for r in rows]
+            assert list(map(bool, got)) == want, (rows[i], q)
+            if "::" not in json.dumps(q) and all(b"::" not in r for r in rows):
+                assert [W.matches_bloom_expression(r, q) for r in rows] == want
+            n_pos += sum(want)
+    assert n_pos > 400
