@@ -14,9 +14,19 @@ To keep every step streaming from HBM instead of the 256 MiB Infinity Cache,
 the arena is loaded at R distinct addresses and step i probes replica i % R
 (R x streamed bytes >= 2 x 256 MiB).
 
+bsg_probe_many covers up to 32 arenas with ONE dispatch (a 35 MB arena streams in about the time a
+dispatch takes to ramp up and complete), so consecutive steps are handed to it together and a launch
+probes min(steps, 32) arenas; `roofline` is computed over exactly those launches, `roofline_single_launch`
+over launches of one 1 000-block arena each.
+
 Multi-GPU (torchrun, one process per GPU): blocks shard round-robin across
 ranks with no data-path collective (weak scaling: every rank holds a full
 1 000-block shard of an N x 1 000-block set); value = total probes / max time.
+`host_gather` repeats the timed steps with every rank's survivors delivered into
+one shared, page-locked host segment that rank 0 reads (the host-side gather of
+the north star; each GPU uses its own PCIe link, no collective).  The `c4` object is BASELINE
+configs[3] at every N: 10 000 blocks in total, block b on rank b % N (strong scaling), Q = 4096
+8-term Or(FieldToken) queries, with and without the host gather inside the timed steps.
 """
 from __future__ import annotations
 
@@ -209,40 +219,6 @@ def or_reduce_leg(ctx, plan, B, fpr, n_union, world, log):
     return res
 
 
-def make_queries(n_queries, workload, seed):
-    """C2 query batch.  'needle': And(FT(level), FT(service), FT(user_id)) — a log search for one
-    user's events; 'lowcard': SURVEY C2's And(FT(level), FT(service), FT(nested.region)).
-    Every position draws an absent value with probability 1/4."""
-    from bloomsearch_amd import query as Q, synth
-    rng = np.random.default_rng(seed)
-    exprs = []
-    if workload == "c4":
-        # BASELINE configs[3] / SURVEY C4: 8-term Or(FieldToken...) over the low-cardinality fields,
-        # every position absent with probability 1/2 (an Or of present values alone would keep every block).
-        def pick(field, present, absent):
-            return Q.FieldToken(field, present() if rng.random() >= 0.5 else absent())
-        for _ in range(n_queries):
-            w = lambda: synth.WORDS[rng.integers(0, len(synth.WORDS))]
-            nw = lambda: "absent-word-%d" % rng.integers(0, 8)
-            exprs.append(Q.Or(
-                pick("level", lambda: synth.LEVELS[rng.integers(0, 4)], lambda: "absent-level-%d" % rng.integers(0, 4)),
-                pick("service", lambda: synth.SERVICES[rng.integers(0, 5)], lambda: "absent-svc-%d" % rng.integers(0, 4)),
-                pick("nested.region", lambda: "region-%d" % rng.integers(0, 8), lambda: "region-%d" % rng.integers(8, 12)),
-                pick("nested.az", lambda: "az-%d" % rng.integers(0, 3), lambda: "az-%d" % rng.integers(3, 6)),
-                pick("tags", w, nw), pick("tags", w, nw), pick("message", w, nw), pick("message", w, nw)))
-        return exprs
-    for _ in range(n_queries):
-        lv = synth.LEVELS[rng.integers(0, 4)] if rng.random() >= 0.25 else "absent-level-%d" % rng.integers(0, 4)
-        sv = synth.SERVICES[rng.integers(0, 5)] if rng.random() >= 0.25 else "absent-svc-%d" % rng.integers(0, 4)
-        if workload == "needle":
-            third = Q.FieldToken("user_id", str(int(rng.integers(0, synth.N_USERS * 4 // 3))))
-        else:
-            rg = "region-%d" % rng.integers(0, 8) if rng.random() >= 0.25 else "region-%d" % rng.integers(8, 12)
-            third = Q.FieldToken("nested.region", rg)
-        exprs.append(Q.And(Q.FieldToken("level", lv), Q.FieldToken("service", sv), third))
-    return exprs
-
-
 def cpu_baseline(words, desc, cb, ops, poff, n_blocks, budget_s, log, terms_per_query=3):
     """The reference's probe loop as the oracle restates it (parse section incl. CRC32C + BE decode,
     then short-circuit TestString with per-call re-hash), on a bounded sample, all host cores."""
@@ -285,6 +261,309 @@ def cpu_baseline(words, desc, cb, ops, poff, n_blocks, budget_s, log, terms_per_
                       "evaluateBloomFilters per (query, block), %d threads, %.1fs)" % (nq2, cb.n_queries, n_blocks, cores, t2)}, out, nq2
 
 
+class SharedHost:
+    """One POSIX shared-memory segment mapped by every rank; rank r's survivors are DMA-ed into slice r
+    (page-locked with bsg_host_register), so rank 0 reads every shard's bitsets from host memory after the
+    closing barrier: the host-side gather, without a collective and with every GPU on its own PCIe link."""
+
+    def __init__(self, ctx, bytes_per_rank, rank, world, tag):
+        import mmap
+        self.ctx, self.rank, self.world = ctx, rank, world
+        self.bytes_per_rank = (int(bytes_per_rank) + 4095) // 4096 * 4096
+        self.path = "/dev/shm/bsg_%s_%s" % (os.environ.get("MASTER_PORT", "0"), tag)
+        total = self.bytes_per_rank * world
+        if rank == 0:
+            with open(self.path, "wb") as f:
+                f.truncate(total)
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        self.f = open(self.path, "r+b")
+        self.mm = mmap.mmap(self.f.fileno(), total)
+        self.all = np.frombuffer(self.mm, dtype=np.uint64)
+        w = self.bytes_per_rank // 8
+        self.mine = self.all[rank * w: (rank + 1) * w]
+        self.mine[:] = 0                      # touch the pages before locking them
+        try:
+            ctx.host_register(self.mine)
+            self.registered = True
+        except Exception as exc:              # noqa: BLE001 - the copies still work (staged by the driver), only slower
+            print("[bench] hipHostRegister of the shared segment failed: %r" % (exc,), file=sys.stderr, flush=True)
+            self.registered = False
+
+    def part(self, r):
+        w = self.bytes_per_rank // 8
+        return self.all[r * w: (r + 1) * w]
+
+    def close(self):
+        if self.registered:
+            self.ctx.host_unregister(self.mine)
+        del self.mine, self.all
+        try:
+            self.mm.close()
+        except BufferError:
+            pass
+        self.f.close()
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        if self.rank == 0:
+            try:
+                os.unlink(self.path)
+            except OSError:
+                pass
+
+
+def kernel_stats(tm, n_terms):
+    """Per-kernel roofline inputs from the library's dispatch timestamps (bsg_timing)."""
+    out = {}
+    if tm.n_probes:
+        ms = tm.ms_terms_kernel / tm.n_probes
+        by = tm.stream_bytes / tm.n_probes + 33 * n_terms
+        out["k_probe_terms"] = {"samples": int(tm.n_probes), "arenas_per_launch": tm.n_probe_arenas / tm.n_probes,
+                                "kernel_ms": ms, "algorithmic_bytes_per_launch": by, "achieved": by / ms / 1e6,
+                                "frac": by / ms / 1e6 / HBM_PEAK_GBPS}
+    if tm.n_fused:
+        ms = tm.ms_fused_kernel / tm.n_fused
+        by = tm.fused_stream_bytes / tm.n_fused + 33 * n_terms
+        out["k_probe_fused"] = {"samples": int(tm.n_fused), "arenas_per_launch": tm.n_fused_arenas / tm.n_fused,
+                                "kernel_ms": ms, "algorithmic_bytes_per_launch": by, "achieved": by / ms / 1e6,
+                                "frac": by / ms / 1e6 / HBM_PEAK_GBPS,
+                                "note": "probe role of group i + program evaluation of group i-1 in one dispatch; bytes count the probe role's bitsets only"}
+    if tm.n_eval:
+        out["k_eval_programs"] = {"samples": int(tm.n_eval), "kernel_ms": tm.ms_eval_kernel / tm.n_eval}
+    return out
+
+
+def merge_timing(a, b):
+    """Sum of two bsg_timing records (same launch shape)."""
+    from bloomsearch_amd._lib import Timing
+    t = Timing()
+    for f, _ in Timing._fields_:
+        setattr(t, f, getattr(a, f) + getattr(b, f))
+    return t
+
+
+class Prober:
+    """Drives bsg_probe_many over a list of steps (each step = the arena ids probed once)."""
+
+    def __init__(self, ctx, bid, world, log):
+        self.ctx, self.bid, self.world, self.log = ctx, bid, world, log
+
+    def sync_all(self):
+        import torch
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def run(self, steps, per_call, flags, out=None, words_per_step=0):
+        """Enqueue every step; `per_call` consecutive steps share one bsg_probe_many call."""
+        from bloomsearch_amd import _lib
+        o = 0
+        for i in range(0, len(steps), per_call):
+            ids = [a for st in steps[i: i + per_call] for a in st]
+            if out is None:
+                self.ctx.probe_many(ids, self.bid, flags | _lib.PROBE_ASYNC)
+            else:
+                n = words_per_step * len(steps[i: i + per_call])
+                self.ctx.probe_many_into(ids, self.bid, out[o: o + n], flags | _lib.PROBE_ASYNC)
+                o += n
+
+    def measure(self, make_step, steps, warmup, per_call, timed=True, out=None, words_per_step=0, nofuse=False):
+        import torch
+        from bloomsearch_amd import _lib
+        flags = (_lib.PROBE_TIMED if timed else 0) | (_lib.PROBE_NOFUSE if nofuse else 0)
+        self.ctx.set_timed_stride(1)
+        self.run([make_step(i) for i in range(warmup)], per_call, flags, out, words_per_step)
+        self.ctx.sync()
+        self.ctx.timing_read(reset=True)
+        self.sync_all()
+        t0 = time.perf_counter()
+        self.run([make_step(i) for i in range(steps)], per_call, flags, out, words_per_step)
+        t_enq = time.perf_counter() - t0
+        self.ctx.sync()
+        self.sync_all()
+        dt = time.perf_counter() - t0
+        if self.world > 1:
+            import torch.distributed as dist
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        self.log("%d steps: host enqueue %.2f us/step, wall %.2f us/step%s"
+                 % (steps, t_enq / steps * 1e6, dt / steps * 1e6, " (survivors delivered to host memory)" if out is not None else ""))
+        return dt, self.ctx.timing_read()
+
+
+def q1_latency(ctx, arena, B, n_terms_hash, log):
+    """SURVEY 8d C2's Q = 1 case: one 3-term And(FieldToken) query against the 1 000-block arena, survivors returned
+    to the host — the latency a single interactive query sees — in both regimes: bitsets streamed into LDS
+    (35 MB for 30 bit tests per block) and gathered (<= terms x k sector reads per block)."""
+    from bloomsearch_amd import _lib, query as Q, synth
+    cb = Q.compile_queries([Q.And(Q.FieldToken("level", "error"), Q.FieldToken("service", "payment"),
+                                  Q.FieldToken("nested.region", "region-3"))])
+    ops, poff, kinds = cb.arrays()
+    terms = np.zeros(len(cb.term_strings), dtype=_lib.TERM_DTYPE)
+    terms["h"] = ctx.hash_strings(cb.term_strings)
+    terms["kind"] = kinds
+    bid = ctx.batch_create(terms, ops, poff)
+    res = {}
+    first = None
+    out = np.zeros((1, (B + 63) // 64), dtype=np.uint64)
+    ids = [arena]
+
+    def lat_loop(n):
+        lat = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            ctx.probe_many_into(ids, bid, out.reshape(-1))
+            lat.append(time.perf_counter() - t0)
+        return lat
+    for name, cost, spin in (("gather", 256, 0), ("gather_spin_wait", 256, 100), ("stream", 0, 0)):
+        ctx.set_gather_cost(cost)
+        ctx.set_spin_wait(spin)
+        lat_loop(50)
+        lat = lat_loop(300)                                 # wall latency of a synchronous query, no timestamps
+        ctx.timing_read(reset=True)
+        for _ in range(32):
+            got = ctx.probe_batch(arena, bid, 1, B, flags=_lib.PROBE_TIMED)
+        tm = ctx.timing_read()
+        if first is None:
+            first = got
+        if not (np.array_equal(first, got) and np.array_equal(first, out)):
+            sys.exit("Q=1: gathered and streamed probes disagree")
+        res[name] = {"latency_us_median": float(np.median(lat)) * 1e6, "latency_us_p90": float(np.percentile(lat, 90)) * 1e6,
+                     "k_probe_terms_us": tm.ms_terms_kernel / max(tm.n_probes, 1) * 1e3,
+                     "k_eval_programs_us": tm.ms_eval_kernel / max(tm.n_eval, 1) * 1e3}
+    ctx.set_spin_wait(0)
+    ctx.set_gather_cost(256)
+    ctx.batch_free(bid)
+    k = 10
+    alg = k * 8 * len(terms) * B                      # SURVEY 8d gather regime: k x 8 B per (block, term) probe
+    g = res["gather"]
+    g["algorithmic_bytes"] = alg
+    g["achieved"] = alg / (g["k_probe_terms_us"] * 1e-6) / 1e9
+    g["frac_of_hbm_peak"] = g["achieved"] / HBM_PEAK_GBPS
+    g["note"] = "8-byte words out of 64-byte sectors: 12.5% of peak is the ceiling of this regime; at Q = 1 the kernel is launch-latency-bound"
+    log("Q=1: %.1f us per synchronous query gathered (kernel %.1f us), %.1f us streamed (kernel %.1f us)"
+        % (g["latency_us_median"], g["k_probe_terms_us"], res["stream"]["latency_us_median"], res["stream"]["k_probe_terms_us"]))
+    return {"workload": "Q = 1: And(FT(level,error), FT(service,payment), FT(nested.region,region-3)) x %d blocks, survivors to host" % B,
+            "survivors": int(sum(bin(int(x)).count("1") for x in first.ravel())), **res}
+
+
+def c4_leg(ctx, args, rank, world, workers, log):
+    """BASELINE configs[3] / SURVEY C4: 100 M rows / 10 000 blocks as 10 files of 1 000 blocks, block b on rank b % N
+    (strong scaling: the total is fixed), Q = 4096 8-term Or(FieldToken) queries.  One step probes the whole set once;
+    every rank probes the blocks it holds of every file with bsg_probe_many (one arena per file)."""
+    import torch
+    from bloomsearch_amd import _lib, query as Q, synth
+    from bloomsearch_amd.arena import plan_blocks
+    n_files, per_file, rows, NQ = args.c4_files, args.c4_blocks_per_file, args.rows_per_block, args.queries
+    total_blocks = n_files * per_file
+    exprs = synth.make_queries(NQ, "c4", seed=4321)
+    cb = Q.compile_queries(exprs)
+    ops, poff, kinds = cb.arrays()
+    terms = np.zeros(len(cb.term_strings), dtype=_lib.TERM_DTYPE)
+    terms["h"] = ctx.hash_strings(cb.term_strings)
+    terms["kind"] = kinds
+    bid = ctx.batch_create(terms, ops, poff)
+    t0 = time.time()
+    files, ft_bytes, local_blocks = [], 0, []
+    from oracle import oracle as O
+    ok = True
+    for f in range(n_files):
+        gids = np.arange(f * per_file, (f + 1) * per_file, dtype=np.int64)
+        gids = gids[gids % world == rank]
+        blocks = generate_blocks(gids, rows, 0xB100F5EA4C4, workers)
+        plan = plan_blocks(blocks, args.fpr)
+        del blocks
+        words = ctx.build(plan.blob, plan.off, plan.fstart, plan.desc, plan.n_words)
+        files.append((words, plan.desc))
+        local_blocks.append(len(gids))
+        ft_bytes += int(sum((int(m) + 63) // 64 * 8 for m in plan.desc["m"][2::3]))
+        del plan
+    R = max(2, int(np.ceil(2 * 256 * 2 ** 20 / max(ft_bytes, 1))))
+    reps = [[ctx.arena_load(w, d) for (w, d) in files] for _ in range(R)]
+    log("c4: %d files x %d blocks (%d held by this rank, %.1f MB of FT bitsets per step), %d replicas, %d distinct terms; setup %.1fs"
+        % (n_files, per_file, sum(local_blocks), ft_bytes / 1e6, R, len(terms), time.time() - t0))
+    G = [(nb + 63) // 64 for nb in local_blocks]
+    words_per_step = NQ * sum(G)
+    # correctness: this rank's shard of every file against the oracle (first queries), outside the timed region
+    got = ctx.probe_many(reps[0], bid, 0, NQ, local_blocks)
+    nchk = min(16, NQ)
+    if not args.no_check:
+        for f in range(n_files):
+            if local_blocks[f] == 0:
+                continue
+            w, d = files[f]
+            want = O.probe_batch(w, d.view(O.DESC_DTYPE), terms.view(O.TERM_DTYPE), ops[: poff[nchk]], poff[: nchk + 1])
+            if not np.array_equal(got[f][:nchk], want):
+                ok = False
+    if world > 1:
+        import torch.distributed as dist
+        flag = torch.tensor([1 if ok else 0], device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        ok = bool(flag.item())
+    if not ok:
+        sys.exit("c4: survivor sets differ from the oracle — refusing to report")
+    files = None
+    pr = Prober(ctx, bid, world, log)
+    steps = max(4, min(args.steps, 60))
+    per_call = max(1, 32 // max(n_files, 1))           # steps handed to one bsg_probe_many call (<= 32 arenas per dispatch)
+    make = lambda i: reps[i % R]
+    dt, tm = pr.measure(make, steps, max(2, min(args.warmup, 8)), per_call)
+    probes = NQ * total_blocks * 8
+    res = {"workload": "C4: %d rows/block x %d blocks in %d files, block b on rank b %% %d, Q=%d 8-term Or(FieldToken), %d distinct terms; "
+                       "%d address-distinct replicas rotated per step" % (rows, total_blocks, n_files, world, NQ, len(terms), R),
+           "scaling": "strong", "n_gpus": world, "steps": steps, "ms_per_step": dt / steps * 1e3, "value": probes * steps / dt,
+           "unit": "probes/s", "probes_per_step": probes, "stream_bytes_per_step_per_gpu": ft_bytes,
+           "kernels": kernel_stats(tm, len(terms)),
+           "check": "every rank's shard of every file bit-exact vs the oracle on the first %d queries" % nchk}
+    # the same steps with the host-side gather inside the timed region
+    slot_words = words_per_step * per_call
+    n_slots = 2
+    sh = SharedHost(ctx, slot_words * 8 * n_slots, rank, world, "c4")
+    ring = sh.mine
+
+    class RingOut:          # successive calls write successive slots of the shared segment (only the last ones survive)
+        def __init__(self):
+            self.i, self.last = 0, 0
+
+        def __getitem__(self, sl):
+            self.last = (self.i % n_slots) * slot_words
+            self.i += 1
+            return ring[self.last: self.last + (sl.stop - sl.start)]
+    ro = RingOut()
+    dt2, _ = pr.measure(make, steps, 2, per_call, timed=False, out=ro, words_per_step=words_per_step)
+    res["host_gather"] = {"ms_per_step": dt2 / steps * 1e3, "value": probes * steps / dt2,
+                          "survivor_bytes_per_step_per_gpu": words_per_step * 8, "page_locked": sh.registered,
+                          "note": "every rank's survivors DMA-ed into one shared page-locked host segment that rank 0 reads "
+                                  "(copy stream, overlapped with the next dispatch)"}
+    if rank == 0:
+        # what the consumer does: rank 0 reads every rank's slice of the segment and interleaves global block order
+        from bloomsearch_amd import parallel as P
+        mine = sh.part(0)[ro.last: ro.last + words_per_step]
+        o = 0
+        for f in range(n_files):
+            if not np.array_equal(mine[o: o + NQ * G[f]].reshape(NQ, G[f]), got[f]):
+                sys.exit("c4: survivors delivered to the shared host segment differ from the direct probe")
+            o += NQ * G[f]
+        if per_file % world == 0 and n_files > 0:
+            parts = [sh.part(r)[ro.last: ro.last + NQ * G[0]].reshape(NQ, G[0]) for r in range(world)]
+            glob = P.interleave_survivors(parts, per_file)
+            if not np.array_equal(np.ascontiguousarray(glob[:, : 1]) & np.uint64(1), got[0][:, :1] & np.uint64(1)):
+                sys.exit("c4: global block 0 of file 0 (held by rank 0) changed in the interleave")
+            res["host_gather"]["rank0_view"] = "file 0: %d ranks' bitsets interleaved into [%d][%d] global words" % (world, NQ, glob.shape[1])
+    sh.close()
+    log("c4: %.1f us/step = %.3g probes/s device-resident; %.1f us/step = %.3g probes/s with the host gather"
+        % (dt / steps * 1e6, res["value"], dt2 / steps * 1e6, res["host_gather"]["value"]))
+    for rep in reps:
+        for a in rep:
+            ctx.arena_free(a)
+    ctx.batch_free(bid)
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -306,8 +585,12 @@ def main():
                     help="blocks of JSON rows pushed through the device ingest path (k_ingest_rows ...), 0 = skip")
     ap.add_argument("--scaled", type=int, default=64,
                     help="also time C2': the arena replicated this many times inside one launch (0/1 = skip)")
-    ap.add_argument("--timed-every", type=int, default=16,
-                    help="timestamp the kernels of every Nth step inside the timed region (0 = never)")
+    ap.add_argument("--group", type=int, default=32, help="arenas one probe dispatch may cover (bsg_set_probe_group, <= 32)")
+    ap.add_argument("--samples", type=int, default=16, help="timestamped dispatches of each kernel beyond the timed region")
+    ap.add_argument("--c4-files", type=int, default=10, help="files of the c4 leg (0 = skip the leg)")
+    ap.add_argument("--c4-blocks-per-file", type=int, default=1000)
+    ap.add_argument("--no-q1", action="store_true", help="skip the Q = 1 latency leg")
+    ap.add_argument("--no-single", action="store_true", help="skip the one-arena-per-launch sampling pass")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -331,6 +614,7 @@ def main():
     from bloomsearch_amd.gpu import Context
 
     ctx = Context((local_rank,))
+    ctx.set_probe_group(args.group)
     B, rows, NQ = args.blocks, args.rows_per_block, args.queries
 
     # ---- untimed setup: this rank's shard = global blocks rank, rank + world, ... (round-robin) ----
@@ -395,7 +679,8 @@ def main():
     if rank == 0 and world == 1 and args.ingest_blocks > 0:
         ingest = ingest_leg(ctx, min(args.ingest_blocks, B), rows, 0xB100F5EA4C4, workers, plan, words, args.fpr, log)
 
-    exprs = make_queries(NQ, args.workload, seed=1234)
+    from bloomsearch_amd import synth
+    exprs = synth.make_queries(NQ, args.workload, seed=1234)
     terms_per_query = 8 if args.workload == "c4" else 3
     cb = Q.compile_queries(exprs)
     ops, poff, kinds = cb.arrays()
@@ -418,45 +703,75 @@ def main():
         want = O.probe_batch(words, plan.desc.view(O.DESC_DTYPE), terms.view(O.TERM_DTYPE), ops[: poff[nchk]], poff[: nchk + 1])
         if not np.array_equal(got[:nchk], want):
             sys.exit("survivor sets differ from the oracle — refusing to report a number")
-        log("check: first %d queries bit-exact vs oracle; %.2f%% of (query, block) pairs survive"
+        # a grouped launch (several arenas behind one dispatch) must return exactly what one launch per arena returns
+        many = ctx.probe_many(arenas[: min(R, 5)], bid, 0, NQ, [B] * min(R, 5))
+        if not all(np.array_equal(m, got) for m in many):
+            sys.exit("grouped probe differs from the single-arena probe")
+        log("check: first %d queries bit-exact vs oracle; grouped launch identical; %.2f%% of (query, block) pairs survive"
             % (nchk, 100.0 * sum(bin(int(x)).count("1") for x in got.ravel()) / (NQ * B)))
 
-    def sync_all():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+    # One step = one arena probed once.  Consecutive steps are handed to bsg_probe_many together (the library covers up to
+    # --group arenas with one dispatch), every dispatch inside the timed region carries its own start/stop timestamps
+    # (BSG_PROBE_TIMED: the dispatch's own begin/end, i.e. what a rocprofv3 kernel trace reports for it).
+    pr = Prober(ctx, bid, world, log)
+    G0 = max(1, min(args.steps, args.group))          # arenas per dispatch in the timed region
+    per_call = max(G0, (64 // G0) * G0)
+    make = lambda i: [arenas[i % R]]
+    # untimed setup: one call of the timed region's shape sizes the library's verdict / survivor scratch (the warmup steps
+    # may be fewer than one dispatch covers)
+    pr.run([make(i) for i in range(min(per_call, args.steps))], per_call, 0)
+    ctx.sync()
+    elapsed, tm = pr.measure(make, args.steps, args.warmup, per_call)
+    timed_region = kernel_stats(tm, len(terms))
 
-    # steps are enqueued through bsg_probe_many, 32 per C call (one step = one arena probe), so the
-    # Python/ctypes call overhead is not what is being measured.  Every te-th step's kernels are
-    # individually timestamped inside the timed region (BSG_PROBE_TIMED: the dispatches' own start/stop
-    # timestamps, i.e. what a rocprofv3 kernel trace reports for them).
-    def run_steps(ids, te):
-        ctx.set_timed_stride(max(te, 1))
-        flags = _lib.PROBE_ASYNC | (_lib.PROBE_TIMED if te > 0 else 0)
-        for i in range(0, len(ids), 64):
-            ctx.probe_many(ids[i: i + 64], bid, flags)
+    # the same steps with the host-side gather inside the timed region: survivors of every step DMA-ed into a shared,
+    # page-locked host segment (a ring: only the last calls' survivors are kept)
+    wps = NQ * ((B + 63) // 64)
+    ring_steps = min(max(args.steps, 1), 2 * per_call)
+    sh = SharedHost(ctx, wps * 8 * ring_steps, rank, world, "c2")
+    ring = sh.mine
 
-    def measure(arena_list, steps, warmup, te):
-        run_steps([arena_list[i % len(arena_list)] for i in range(warmup)], te)
-        ctx.sync()
-        ctx.timing_read(reset=True)
-        sync_all()
-        t0 = time.perf_counter()
-        run_steps([arena_list[i % len(arena_list)] for i in range(steps)], te)
-        t_enq = time.perf_counter() - t0
-        ctx.sync()
-        sync_all()
-        dt = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        log("%d steps: host enqueue %.2f us/step, wall %.2f us/step" % (steps, t_enq / steps * 1e6, dt / steps * 1e6))
-        return dt, ctx.timing_read()
+    class RingOut:
+        def __init__(self): self.o = 0
+        def __getitem__(self, sl):
+            n = sl.stop - sl.start
+            if self.o + n > len(ring):
+                self.o = 0
+            v = ring[self.o: self.o + n]
+            self.o += n
+            return v
+    h_elapsed, _ = pr.measure(make, args.steps, min(args.warmup, 4), per_call, timed=False, out=RingOut(), words_per_step=wps)
+    if rank == 0 and not args.no_check:
+        # the ring's first slot holds some step's survivors of this rank: every replica holds the same filters
+        if not np.array_equal(sh.part(0)[:wps].reshape(NQ, -1), got):
+            sys.exit("survivors delivered to the shared host segment differ from the direct probe")
+    page_locked = sh.registered
+    sh.close()
 
-    elapsed, tm = measure(arenas, args.steps, args.warmup, args.timed_every)
+    # ---- kernel sampling beyond the timed region: the driver's --steps may cover a single dispatch, the number of record
+    # must not depend on it.  Same launch shape (G0 arenas per dispatch, rotating replicas), every dispatch timestamped.
+    samples = {}
+    if args.samples > 0:
+        n = args.samples
+        _, t_s = pr.measure(make, n * G0, G0, G0)      # n dispatches of each kernel, one call (one group) each
+        samples = kernel_stats(t_s, len(terms))
+        all_t = merge_timing(t_s, tm)
+    else:
+        all_t = tm
+    allk = kernel_stats(all_t, len(terms))
 
-    # ---- C2' (SURVEY 8d): the same arena replicated x S inside ONE launch so steady-state streaming
+    single = None
+    if not args.no_single and world == 1:
+        ctx.set_probe_group(1)
+        _, t1 = pr.measure(make, 64, 8, 64, nofuse=True)
+        ctx.set_probe_group(args.group)
+        single = kernel_stats(t1, len(terms))
+
+    q1 = None
+    if not args.no_q1 and rank == 0 and world == 1:
+        q1 = q1_latency(ctx, arenas[0], B, None, log)
+
+    # ---- C2' (SURVEY 8d): the same arena replicated x S inside ONE arena so steady-state streaming
     # bandwidth is visible next to the launch-latency-bound 35 MB case (N=1 only) ----
     scaled = None
     if args.scaled > 1 and world == 1:
@@ -468,33 +783,44 @@ def main():
         big = ctx.arena_load(words, np.tile(plan.desc, S))       # S address-distinct copies of every filter
         log("scaled arena: %d blocks (%.2f GB of FT bitsets per launch) loaded in %.1fs" % (B * S, ft_bytes * S / 1e9, time.time() - t0))
         s_steps = max(4, min(args.steps, 20))
-        s_elapsed, s_tm = measure([big], s_steps, 2, 1)
+        ctx.set_probe_group(1)
+        s_elapsed, s_tm = pr.measure(lambda i: [big], s_steps, 2, 1, nofuse=True)
+        ctx.set_probe_group(args.group)
         s_bytes = s_tm.stream_bytes / max(s_tm.n_probes, 1) + 33 * len(terms)
         s_ms = s_tm.ms_terms_kernel / max(s_tm.n_probes, 1)
         scaled = {"blocks": B * S, "steps": s_steps, "ms_per_step": s_elapsed / s_steps * 1e3,
                   "value": NQ * B * S * terms_per_query * s_steps / s_elapsed, "kernel_ms": s_ms,
-                  "eval_kernel_ms": s_tm.ms_eval_kernel / max(s_tm.n_probes, 1),
+                  "eval_kernel_ms": s_tm.ms_eval_kernel / max(s_tm.n_eval, 1),
                   "algorithmic_bytes_per_launch": s_bytes, "achieved": s_bytes / (s_ms * 1e-3) / 1e9,
                   "frac": s_bytes / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
         ctx.arena_free(big)
+    for a in arenas:
+        ctx.arena_free(a)
+    arenas = []
+
+    c4 = None
+    if args.c4_files > 0:
+        c4 = c4_leg(ctx, args, rank, world, workers, log)
 
     probes_per_step = NQ * B * terms_per_query * world
     value = probes_per_step * args.steps / elapsed
 
     if rank == 0:
-        # roofline of the dominant kernel (probe_terms): algorithmic bytes per launch (streaming
-        # regime) = every referenced bitset once + the term table; over its mean HIP-event duration.
-        alg_bytes = tm.stream_bytes / max(tm.n_probes, 1) + 33 * len(terms)
-        k1_ms = tm.ms_terms_kernel / max(tm.n_probes, 1)
-        k2_ms = tm.ms_eval_kernel / max(tm.n_probes, 1)
-        achieved = alg_bytes / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else None
+        # roofline of the dominant kernel of the timed region: algorithmic bytes per launch (streaming regime) =
+        # every referenced bitset of the launch's arenas once + the term table; over the mean of the dispatch's own
+        # start/stop timestamps, timed region and sampling passes together (same launch shape).
+        dom = "k_probe_fused" if tm.ms_fused_kernel > tm.ms_terms_kernel else "k_probe_terms"
+        k = allk.get(dom) or {}
         # HBM bytes per launch from the PMC counters: collected in separate rocprofv3 --pmc passes of this same
         # command (tools/profile.sh), corrected as MI355X_MICROARCH.md prescribes (FETCH_SIZE x2 for wide
         # coalesced reads on gfx950, + WRITE_SIZE), committed under profiles/.
-        traffic = None
+        traffic = traffic_src = None
         try:
-            rec = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-            traffic = rec["k_probe_terms"]["hbm_bytes_corrected"] if args.workload == "c2" and B == 1000 else None
+            rec = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
+            per_arena = rec[dom]["hbm_bytes_corrected_per_arena"]
+            if args.workload == "c2" and B == 1000 and k:
+                traffic = per_arena * k["arenas_per_launch"]
+                traffic_src = "profiles/r02_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py; per 1 000-block arena x arenas per launch)"
         except Exception:
             pass
         out = {
@@ -502,18 +828,32 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": "%s probe: %d rows/block x %d blocks per GPU, Q=%d %s [%s], "
-                                   "fpr %g, %d address-distinct arena replicas rotated per step"
+                                   "fpr %g, %d address-distinct arena replicas rotated per step, %d arenas (steps) per dispatch"
                                    % ("C4" if args.workload == "c4" else "C2", rows, B, NQ,
                                       "8-term Or(FieldToken)" if args.workload == "c4" else "3-term And(FieldToken)",
-                                      args.workload, args.fpr, R),
+                                      args.workload, args.fpr, R, G0),
                        "blocks_per_gpu": B, "queries": NQ, "distinct_terms": int(len(terms)),
-                       "probes_per_step": probes_per_step, "sharding": "round-robin blocks, no collective"},
-            "roofline": {"bound": "hbm", "kernel": "k_probe_terms", "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic,
-                         "traffic_source": "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py)" if traffic else None,
-                         "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": k1_ms,
-                         "eval_kernel_ms": k2_ms},
+                       "probes_per_step": probes_per_step, "sharding": "round-robin blocks, no collective",
+                       "survivors": "left on the device (host_gather: the same steps with every rank's survivors delivered to host memory)"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": k.get("achieved"), "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": k.get("frac"), "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": k.get("algorithmic_bytes_per_launch"), "kernel_ms": k.get("kernel_ms"),
+                         "samples": k.get("samples"), "arenas_per_launch": k.get("arenas_per_launch"),
+                         "timed_region": timed_region, "sampling_passes": samples, "all": allk},
+            "host_gather": {"ms_per_step": h_elapsed / args.steps * 1e3, "value": probes_per_step * args.steps / h_elapsed,
+                            "survivor_bytes_per_step_per_gpu": wps * 8, "page_locked": page_locked,
+                            "note": "same steps, every rank's survivors DMA-ed (copy stream, overlapped with the next dispatch) into one shared "
+                                    "page-locked host segment that rank 0 reads: PCIe-inclusive, never `value`"},
         }
+        if single:
+            s1 = single.get("k_probe_terms", {})
+            out["roofline_single_launch"] = dict(s1, bound="hbm", kernel="k_probe_terms", peak=HBM_PEAK_GBPS, unit="GB/s",
+                                                 eval_kernel_ms=single.get("k_eval_programs", {}).get("kernel_ms"),
+                                                 note="one 1 000-block arena (35 MB) per dispatch: ~half of such a launch is dispatch ramp + completion")
+        if q1:
+            out["q1"] = q1
+        if c4:
+            out["c4"] = c4
         out["build"] = {"workload": "C3 flush-side build: %d blocks x %d rows -> %d filters, %d distinct entries"
                                     % (B, rows, 3 * B, len(plan.off) - 1), "kernel": "k_build", "kernel_ms": build_ms,
                         "algorithmic_bytes": build_bytes, "achieved": build_bytes / max(build_ms, 1e-6) / 1e6, "unit": "GB/s",
@@ -527,15 +867,13 @@ def main():
             out["or_reduce"] = or_reduce
         if scaled:
             out["roofline_scaled"] = dict(scaled, bound="hbm", kernel="k_probe_terms", peak=HBM_PEAK_GBPS, unit="GB/s",
-                                          note="C2' of SURVEY 8d: same filters replicated x%d at distinct addresses, one launch" % args.scaled)
+                                          note="C2' of SURVEY 8d: same filters replicated x%d at distinct addresses, one arena, one launch" % args.scaled)
         if args.cpu_budget > 0 and world == 1:
             base, cpu_out, nq = cpu_baseline(words, plan.desc, cb, ops, poff, B, args.cpu_budget, log, terms_per_query)
             if not args.no_check and not np.array_equal(cpu_out, got[:nq]):
                 sys.exit("CPU baseline survivors differ from the GPU's")
             out["cpu_baseline"] = base
         print(json.dumps(out), flush=True)
-    for a in arenas:
-        ctx.arena_free(a)
     ctx.batch_free(bid)
     ctx.close()
     if world > 1:

@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(HERE, "csrc", "libbloomgpu.so")
 BSG_OK, BSG_E_INVALID, BSG_E_HIP, BSG_E_NOMEM, BSG_E_NOTFOUND, BSG_E_UNSUPPORTED, BSG_E_NODEVICE = 0, -1, -2, -3, -4, -5, -6
 KIND_FIELD, KIND_TOKEN, KIND_FIELD_TOKEN = 0, 1, 2
 OP_TERM, OP_AND, OP_OR, OP_TRUE, OP_FALSE = 0, 1, 2, 3, 4
-PROBE_ASYNC, PROBE_TIMED = 1, 2
+PROBE_ASYNC, PROBE_TIMED, PROBE_NOFUSE = 1, 2, 4
 INGEST_TRUSTED_JSON = 1
 
 TERM_DTYPE = np.dtype([("h", "<u8", (4,)), ("kind", "<u4"), ("reserved", "<u4")])
@@ -28,7 +28,9 @@ MATCH_COND_DTYPE = np.dtype([("hf", "<u8", (4,)), ("ht", "<u8", (4,)), ("kind", 
 
 class Timing(C.Structure):
     _fields_ = [("n_probes", C.c_uint64), ("ms_terms_kernel", C.c_double), ("ms_eval_kernel", C.c_double),
-                ("stream_bytes", C.c_uint64)]
+                ("stream_bytes", C.c_uint64), ("n_probe_arenas", C.c_uint64), ("n_eval", C.c_uint64),
+                ("n_fused", C.c_uint64), ("ms_fused_kernel", C.c_double), ("fused_stream_bytes", C.c_uint64),
+                ("n_fused_arenas", C.c_uint64)]
 
 
 class IngestStats(C.Structure):
@@ -49,14 +51,15 @@ def op(opcode: int, arg: int = 0) -> int:
 
 # every symbol include/bloomgpu.h declares (tests assert the .so exports all of them)
 EXPORTS = [
-    "bsg_device_count", "bsg_open", "bsg_close", "bsg_last_error", "bsg_sync", "bsg_estimate_parameters",
+    "bsg_device_count", "bsg_open", "bsg_open_err", "bsg_close", "bsg_last_error", "bsg_last_error_copy", "bsg_scope_open",
+    "bsg_sync", "bsg_estimate_parameters", "bsg_probe_many_dev", "bsg_set_probe_group", "bsg_set_gather_cost", "bsg_set_fuse_limit", "bsg_set_spin_wait",
     "bsg_hash_entries", "bsg_build", "bsg_build_hashed", "bsg_arena_load", "bsg_arena_load_sections", "bsg_arena_free",
     "bsg_batch_create", "bsg_batch_free", "bsg_probe_batch", "bsg_probe_many", "bsg_probe", "bsg_timing_read", "bsg_set_timed_stride", "bsg_last_kernel_ms",
     "bsg_or_reduce", "bsg_or_words_dev", "bsg_or_reduce_dev", "bsg_last_or_ms",
     "bsg_ingest_rows", "bsg_ingest_fallback_rows", "bsg_ingest_add_entries", "bsg_ingest_finish", "bsg_ingest_build",
     "bsg_ingest_stats_read", "bsg_ingest_free", "bsg_ingest_build_sections",
     "bsg_sections_size", "bsg_build_sections", "bsg_last_encode_ms",
-    "bsg_match_rows", "bsg_last_match_ms", "bsg_pinned_alloc", "bsg_pinned_free",
+    "bsg_match_rows", "bsg_last_match_ms", "bsg_pinned_alloc", "bsg_pinned_free", "bsg_host_register", "bsg_host_unregister",
 ]
 
 _lib = None
@@ -74,6 +77,14 @@ def load():
     vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int32
     L.bsg_device_count.restype = i32
     L.bsg_open.argtypes = [C.POINTER(i32), i32, C.POINTER(vp)]
+    L.bsg_open_err.argtypes = [C.POINTER(i32), i32, C.POINTER(vp), C.c_char_p, u64]
+    L.bsg_last_error_copy.argtypes = [vp, C.c_char_p, u64]
+    L.bsg_scope_open.argtypes = [vp, C.POINTER(vp)]
+    L.bsg_probe_many_dev.argtypes = [vp, vp, u32, u64, u32, vp]
+    L.bsg_set_probe_group.argtypes = [vp, u32]
+    L.bsg_set_gather_cost.argtypes = [vp, u32]
+    L.bsg_set_fuse_limit.argtypes = [vp, u32]
+    L.bsg_set_spin_wait.argtypes = [vp, u32]
     L.bsg_close.argtypes = [vp]
     L.bsg_last_error.argtypes = [vp]
     L.bsg_last_error.restype = C.c_char_p
@@ -112,6 +123,8 @@ def load():
     L.bsg_last_match_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.bsg_pinned_alloc.argtypes = [vp, u64, C.POINTER(vp)]
     L.bsg_pinned_free.argtypes = [vp, vp]
+    L.bsg_host_register.argtypes = [vp, vp, u64]
+    L.bsg_host_unregister.argtypes = [vp, vp]
     for name in EXPORTS:
         if name != "bsg_last_error":
             getattr(L, name).restype = i32

@@ -13,6 +13,7 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -27,7 +28,14 @@ namespace {
 
 using bsg::DevDesc;
 
+// Error reporting that survives a caller migrating between OS threads (a goroutine between two cgo calls):
+// every failure is recorded (1) in the slot of the scope / context the failing call was made on — guarded by a
+// mutex, read back with bsg_last_error(scope) or bsg_last_error_copy from ANY thread — and (2) in a thread-local
+// string that only serves calls which have no context yet (bsg_open, bsg_estimate_parameters, bsg_sections_size).
 thread_local std::string g_err;
+thread_local std::string g_ret;          // what bsg_last_error hands out: a private copy, valid until this thread's next call
+thread_local bsg_ctx *tl_scope = nullptr;
+void record_error(bsg_ctx *scope, const char *msg);   // defined after bsg_ctx
 
 int32_t fail(int32_t code, const char *fmt, ...)
 {
@@ -37,8 +45,22 @@ int32_t fail(int32_t code, const char *fmt, ...)
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
     g_err = buf;
+    if (tl_scope) record_error(tl_scope, buf);
     return code;
 }
+
+// First line of every entry point that takes a context: remembers the scope the call was made on for fail(),
+// rejects NULL, and rebinds `ctx` to the root context a scope aliases.  Nested API calls keep the outermost scope.
+struct ScopeGuard {
+    bool owner;
+    explicit ScopeGuard(bsg_ctx *s) : owner(tl_scope == nullptr && s != nullptr) { if (owner) tl_scope = s; }
+    ~ScopeGuard() { if (owner) tl_scope = nullptr; }
+};
+bsg_ctx *root_of(bsg_ctx *c);
+#define BSG_ENTER(ctx)                                            \
+    ScopeGuard scope_guard_(ctx);                                 \
+    if (!(ctx)) return fail(BSG_E_INVALID, "ctx is null");        \
+    (ctx) = root_of(ctx)
 
 #define HIP_TRY(expr)                                                                      \
     do {                                                                                   \
@@ -70,7 +92,9 @@ struct DevBuf {
     {
         if (n <= cap) return hipSuccess;
         if (p) (void)hipFree(p);
-        p = nullptr; cap = 0;
+        p = nullptr;
+        n = std::max<size_t>(n, cap + cap / 2);   // growing scratch: do not reallocate on every slightly larger call
+        cap = 0;
         hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), std::max<size_t>(n, 1) * sizeof(T));
         if (e == hipSuccess) cap = n;
         return e;
@@ -80,7 +104,7 @@ struct DevBuf {
 
 // start/stop timestamps of the two dispatches themselves (hipExtLaunchKernel), i.e. the same
 // begin/end a rocprofv3 kernel trace reports — not events bracketing the launches.
-struct EventTriple { hipEvent_t k1s, k1e, k2s, k2e; uint64_t bytes; bool has_k2; };
+struct EventTriple { hipEvent_t k1s, k1e, k2s, k2e; uint64_t bytes; uint32_t n_arenas; bool has_k1, has_k2, fused; };
 
 // Short-lived device buffers of the ingest / match / encode calls come from a per-device cache instead of
 // hipMalloc / hipFree (a flush of 1 000 rows made ~16 of each: 0.8 ms of fixed cost, 2/3 of the call).  Blocks are kept
@@ -141,6 +165,10 @@ struct Device {
     int id = 0;
     DevPool pool;
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;          // survivors leave here so the D2H of group i overlaps the kernels of group i+1
+    hipEvent_t ev_eval[2] = {nullptr, nullptr}; // out[slot] written (compute stream)
+    hipEvent_t ev_copy[2] = {nullptr, nullptr}; // out[slot] copied out (copy stream)
+    bool copy_busy[2] = {false, false};
     std::mutex mu;                 // serialises enqueue + scratch reuse on this device
     DevBuf<uint64_t> V[2];         // verdict scratch (two slots: bsg_probe_many software-pipelines launches)
     DevBuf<uint64_t> out[2];       // survivors scratch
@@ -206,6 +234,9 @@ struct Ingest;   // ingest_api.inc
 }  // namespace
 
 struct bsg_ctx {
+    bsg_ctx *parent = nullptr;   // non-null: this object is an error scope aliasing `parent` (bsg_scope_open)
+    std::mutex err_mu;
+    std::string err;             // last failure recorded on this scope / context
     std::vector<std::unique_ptr<Device>> devs;
     std::mutex mu;  // handle tables
     std::map<uint64_t, std::shared_ptr<Arena>> arenas;
@@ -213,11 +244,22 @@ struct bsg_ctx {
     std::map<uint64_t, std::shared_ptr<Ingest>> ingests;
     uint64_t next_id = 1;
     bsg_timing timing{};
-    uint32_t timed_stride = 1;   // with BSG_PROBE_TIMED, timestamp every timed_stride-th probe
+    uint32_t timed_stride = 1;   // with BSG_PROBE_TIMED, timestamp every timed_stride-th launch
     uint64_t timed_counter = 0;
+    uint32_t group_limit = bsg::kMaxGroupArenas;   // arenas one probe dispatch may cover (bsg_set_probe_group)
+    uint32_t gather_cost = 256;  // a filter is gathered instead of staged when terms * k * gather_cost < its bytes
+    uint32_t spin_wait_us = 0;   // synchronous probes poll the stream this long before blocking (bsg_set_spin_wait)
+    uint32_t fuse_max_arenas = 4; // groups up to this many arenas ride fused (probe of group i + eval of group i-1)
 };
 
 namespace {
+
+void record_error(bsg_ctx *scope, const char *msg)
+{
+    std::lock_guard<std::mutex> lk(scope->err_mu);
+    scope->err = msg;
+}
+bsg_ctx *root_of(bsg_ctx *c) { return c->parent ? c->parent : c; }
 
 void free_all_ingests(bsg_ctx *ctx);   // ingest_api.inc
 int32_t ensure_lower_table(Device &d);   // ingest_api.inc: the unicode.ToLower table the walkers fold with
@@ -259,13 +301,21 @@ int32_t drain_timing(bsg_ctx *ctx, Device &d)
     HIP_TRY(hipStreamSynchronize(d.stream));
     for (auto &t : d.pending) {
         float a = 0, b = 0;
-        HIP_TRY(hipEventElapsedTime(&a, t.k1s, t.k1e));
-        if (t.has_k2) HIP_TRY(hipEventElapsedTime(&b, t.k2s, t.k2e));   // fused launches carry K2 inside K1's dispatch
+        if (t.has_k1) HIP_TRY(hipEventElapsedTime(&a, t.k1s, t.k1e));
+        if (t.has_k2) HIP_TRY(hipEventElapsedTime(&b, t.k2s, t.k2e));
         std::lock_guard<std::mutex> lk(ctx->mu);
-        ctx->timing.n_probes += 1;
-        ctx->timing.ms_terms_kernel += a;
-        ctx->timing.ms_eval_kernel += b;
-        ctx->timing.stream_bytes += t.bytes;
+        if (t.has_k1 && t.fused) {
+            ctx->timing.n_fused += 1;
+            ctx->timing.ms_fused_kernel += a;
+            ctx->timing.fused_stream_bytes += t.bytes;
+            ctx->timing.n_fused_arenas += t.n_arenas;
+        } else if (t.has_k1) {
+            ctx->timing.n_probes += 1;
+            ctx->timing.ms_terms_kernel += a;
+            ctx->timing.stream_bytes += t.bytes;
+            ctx->timing.n_probe_arenas += t.n_arenas;
+        }
+        if (t.has_k2) { ctx->timing.n_eval += 1; ctx->timing.ms_eval_kernel += b; }
         d.free_events.push_back(t);
     }
     d.pending.clear();
@@ -414,13 +464,37 @@ int32_t bsg_open(const int32_t *device_ids, int32_t n_devices, bsg_ctx **out_ctx
 
         ctx->devs.push_back(std::move(d));
     }
+    // shards exchange partial bitsets device-to-device (bsg_or_reduce): enable xGMI peer access where the pair allows it
+    for (auto &a : ctx->devs)
+        for (auto &b : ctx->devs) {
+            if (a->id == b->id) continue;
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, a->id, b->id) == hipSuccess && can) {
+                (void)hipSetDevice(a->id);
+                const hipError_t e = hipDeviceEnablePeerAccess(b->id, 0);
+                if (e != hipSuccess) (void)hipGetLastError();   // already enabled
+            }
+        }
     *out_ctx = ctx.release();
     return BSG_OK;
+}
+
+int32_t bsg_open_err(const int32_t *device_ids, int32_t n_devices, bsg_ctx **out_ctx, char *errbuf, uint64_t cap)
+{
+    const int32_t rc = bsg_open(device_ids, n_devices, out_ctx);
+    if (errbuf && cap) {
+        const std::string &m = rc ? g_err : std::string();
+        const size_t n = std::min<size_t>(m.size(), cap - 1);
+        memcpy(errbuf, m.data(), n);
+        errbuf[n] = 0;
+    }
+    return rc;
 }
 
 int32_t bsg_close(bsg_ctx *ctx)
 {
     if (!ctx) return BSG_OK;
+    if (ctx->parent) { delete ctx; return BSG_OK; }   // an error scope owns nothing but its message
     for (auto &kv : ctx->arenas) free_arena(ctx, *kv.second);
     for (auto &kv : ctx->batches) free_batch(ctx, *kv.second);
     free_all_ingests(ctx);
@@ -428,6 +502,11 @@ int32_t bsg_close(bsg_ctx *ctx)
         Device &d = *dp;
         (void)hipSetDevice(d.id);
         if (d.stream) (void)hipStreamSynchronize(d.stream);
+        if (d.copy_stream) {
+            (void)hipStreamSynchronize(d.copy_stream);
+            for (int i = 0; i < 2; ++i) { (void)hipEventDestroy(d.ev_eval[i]); (void)hipEventDestroy(d.ev_copy[i]); }
+            (void)hipStreamDestroy(d.copy_stream);
+        }
         if (d.kb0) { (void)hipEventDestroy(d.kb0); (void)hipEventDestroy(d.kb1); }
         d.pool.trim(0);
         if (d.d_crc) (void)hipFree(d.d_crc);
@@ -445,15 +524,47 @@ int32_t bsg_close(bsg_ctx *ctx)
     return BSG_OK;
 }
 
-const char *bsg_last_error(bsg_ctx *) { return g_err.c_str(); }
+const char *bsg_last_error(bsg_ctx *ctx)
+{
+    if (!ctx) return g_err.c_str();
+    {
+        std::lock_guard<std::mutex> lk(ctx->err_mu);
+        g_ret = ctx->err;
+    }
+    return g_ret.c_str();
+}
+
+int32_t bsg_last_error_copy(bsg_ctx *ctx, char *buf, uint64_t cap)
+{
+    if (!buf || cap == 0) return BSG_E_INVALID;
+    std::string m;
+    if (ctx) { std::lock_guard<std::mutex> lk(ctx->err_mu); m = ctx->err; }
+    else m = g_err;
+    const size_t n = std::min<size_t>(m.size(), cap - 1);
+    memcpy(buf, m.data(), n);
+    buf[n] = 0;
+    return BSG_OK;
+}
+
+int32_t bsg_scope_open(bsg_ctx *ctx, bsg_ctx **out_scope)
+{
+    if (!ctx || !out_scope) return fail(BSG_E_INVALID, "null argument");
+    auto *s = new bsg_ctx();
+    s->parent = root_of(ctx);
+    *out_scope = s;
+    return BSG_OK;
+}
 
 int32_t bsg_sync(bsg_ctx *ctx)
 {
+    BSG_ENTER(ctx);
     if (!ctx) return fail(BSG_E_INVALID, "ctx is null");
     for (auto &dp : ctx->devs) {
         std::lock_guard<std::mutex> lk(dp->mu);
         if (int32_t rc = use_device(*dp)) return rc;
         HIP_TRY(hipStreamSynchronize(dp->stream));
+        if (dp->copy_stream) HIP_TRY(hipStreamSynchronize(dp->copy_stream));
+        dp->copy_busy[0] = dp->copy_busy[1] = false;
     }
     return BSG_OK;
 }
@@ -473,6 +584,7 @@ int32_t bsg_estimate_parameters(uint64_t n, double p, uint64_t *m, uint64_t *k)
 int32_t bsg_hash_entries(bsg_ctx *ctx, const uint8_t *bytes, const uint32_t *offsets, uint32_t n_entries,
                          uint64_t *out_h)
 {
+    BSG_ENTER(ctx);
     if (!ctx) return fail(BSG_E_INVALID, "ctx is null");
     if (n_entries == 0) return BSG_OK;
     if (!offsets || !out_h) return fail(BSG_E_INVALID, "null argument");
@@ -502,6 +614,7 @@ static int32_t build_common(bsg_ctx *ctx, const uint8_t *bytes, const uint32_t *
                             uint32_t n_entries, const uint32_t *fstart, const bsg_filter_desc *desc,
                             uint32_t n_filters, uint64_t *out_words, uint64_t n_words, const SectionsOut *sections = nullptr)
 {
+    BSG_ENTER(ctx);
     if (!ctx) return fail(BSG_E_INVALID, "ctx is null");
     if (n_filters == 0) { if (sections) sections->sec_off[0] = 0; return BSG_OK; }
     if (!fstart || !desc || (!out_words && !sections)) return fail(BSG_E_INVALID, "null argument");
@@ -599,6 +712,7 @@ int32_t bsg_build_hashed(bsg_ctx *ctx, const uint64_t *h, uint32_t n_entries, co
 int32_t bsg_arena_load(bsg_ctx *ctx, const uint64_t *words, uint64_t n_words, const bsg_filter_desc *desc,
                        uint32_t n_blocks, uint64_t *out_arena_id)
 {
+    BSG_ENTER(ctx);
     if (!ctx || !out_arena_id) return fail(BSG_E_INVALID, "null argument");
     if (n_blocks && !desc) return fail(BSG_E_INVALID, "desc is null");
     if (n_words && !words) return fail(BSG_E_INVALID, "words is null");
@@ -697,6 +811,7 @@ extern "C" {
 int32_t bsg_arena_load_sections(bsg_ctx *ctx, const uint8_t *region, uint64_t region_len, const uint64_t *sec_off,
                                 uint32_t n_blocks, int32_t *out_status, uint64_t *out_arena_id)
 {
+    BSG_ENTER(ctx);
     if (!ctx || !out_arena_id || (n_blocks && (!sec_off || !out_status))) return fail(BSG_E_INVALID, "null argument");
     if (ctx->devs.size() != 1) return fail(BSG_E_UNSUPPORTED, "bsg_arena_load_sections needs a single-device context");
     if (region_len && !region) return fail(BSG_E_INVALID, "region is null");
@@ -816,6 +931,7 @@ int32_t bsg_arena_load_sections(bsg_ctx *ctx, const uint8_t *region, uint64_t re
 
 int32_t bsg_arena_free(bsg_ctx *ctx, uint64_t arena_id)
 {
+    BSG_ENTER(ctx);
     if (!ctx) return fail(BSG_E_INVALID, "ctx is null");
     std::shared_ptr<Arena> a;
     {
@@ -837,6 +953,7 @@ int32_t bsg_arena_free(bsg_ctx *ctx, uint64_t arena_id)
 int32_t bsg_batch_create(bsg_ctx *ctx, const bsg_term *terms, uint32_t n_terms, const uint32_t *prog_ops,
                          const uint32_t *prog_off, uint32_t n_queries, uint64_t *out_batch_id)
 {
+    BSG_ENTER(ctx);
     if (!ctx || !out_batch_id) return fail(BSG_E_INVALID, "null argument");
     if (n_terms && !terms) return fail(BSG_E_INVALID, "terms is null");
     if (n_queries && !prog_off) return fail(BSG_E_INVALID, "prog_off is null");
@@ -966,6 +1083,7 @@ int32_t bsg_batch_create(bsg_ctx *ctx, const bsg_term *terms, uint32_t n_terms, 
 
 int32_t bsg_batch_free(bsg_ctx *ctx, uint64_t batch_id)
 {
+    BSG_ENTER(ctx);
     if (!ctx) return fail(BSG_E_INVALID, "ctx is null");
     std::shared_ptr<Batch> b;
     {
@@ -997,19 +1115,55 @@ int32_t take_events(bsg_ctx *ctx, Device &d, EventTriple &ev)
         HIP_TRY(hipEventCreate(&ev.k2s)); HIP_TRY(hipEventCreate(&ev.k2e));
     }
     ev.bytes = 0;
-    ev.has_k2 = false;
+    ev.has_k1 = ev.has_k2 = ev.fused = false;
+    ev.n_arenas = 0;
     return BSG_OK;
 }
 
-// K1 arguments: stream every referenced bitset once, one verdict word per (block, 64 terms) into V[slot].
-int32_t make_probe_args(Device &d, const ArenaShard &s, const BatchDev &bd, const Batch &B, uint32_t slot, EventTriple *ev,
-                        bsg::ProbeArgs &a, uint32_t &lds_bytes)
+// A launch group: the shards (on one device) of up to kMaxGroupArenas arenas, probed by ONE dispatch.
+struct Group {
+    std::vector<const ArenaShard *> shards;
+    std::vector<uint32_t> index;     // position of each shard's arena in the caller's list
+    uint64_t v_words = 0;            // verdict scratch the group needs (u64)
+    uint64_t out_words = 0;          // survivors the group produces (u64)
+    uint32_t max_blocks = 0, max_G = 0;
+};
+
+void fill_refs(const Group &g, const Batch &B, bsg::ArenaRef *refs)
+{
+    uint64_t v = 0, o = 0;
+    for (size_t i = 0; i < g.shards.size(); ++i) {
+        const ArenaShard &s = *g.shards[i];
+        const uint32_t G = (s.n_blocks + 63) / 64;
+        refs[i] = bsg::ArenaRef{s.d_words, s.d_desc, v, o, s.n_blocks, G};
+        v += (uint64_t)G * std::max(B.Wt, 1u) * 64;
+        o += (uint64_t)B.n_queries * G;
+    }
+}
+
+void group_add(Group &g, const Batch &B, const ArenaShard &s, uint32_t idx)
 {
     const uint32_t G = (s.n_blocks + 63) / 64;
-    HIP_TRY(d.V[slot].reserve((size_t)G * std::max(B.Wt, 1u) * 64));
+    g.shards.push_back(&s);
+    g.index.push_back(idx);
+    g.v_words += (uint64_t)G * std::max(B.Wt, 1u) * 64;
+    g.out_words += (uint64_t)B.n_queries * G;
+    g.max_blocks = std::max(g.max_blocks, s.n_blocks);
+    g.max_G = std::max(g.max_G, G);
+}
+
+// K1 arguments: stream every referenced bitset of the group once, one verdict word per (block, 64 terms) into V[slot].
+int32_t make_probe_args(bsg_ctx *ctx, Device &d, const Group &g, const BatchDev &bd, const Batch &B, uint32_t slot, EventTriple *ev,
+                        bsg::ProbeArgs &a, uint32_t &lds_bytes)
+{
+    HIP_TRY(d.V[slot].reserve(std::max<uint64_t>(g.v_words, 1)));
     a = bsg::ProbeArgs{};
-    a.words = s.d_words; a.desc = s.d_desc; a.th = bd.d_th; a.V = d.V[slot].p;
-    a.Tp = B.Tp; a.Wt = B.Wt; a.n_blocks = s.n_blocks;
+    a.th = bd.d_th; a.V = d.V[slot].p;
+    a.Tp = B.Tp; a.Wt = B.Wt;
+    a.n_arenas = (uint32_t)g.shards.size();
+    a.max_blocks = g.max_blocks;
+    a.gather_cost = ctx->gather_cost;
+    fill_refs(g, B, a.ar);
     uint32_t max_tw = 0;
     for (uint32_t y = 0; y < B.n_kinds; ++y) max_tw = std::max(max_tw, (B.term_count[y] + 63) / 64);
     const size_t head = bsg::probe_lds_head_bytes(max_tw);
@@ -1019,48 +1173,54 @@ int32_t make_probe_args(Device &d, const ArenaShard &s, const BatchDev &bd, cons
     uint64_t lds_words = 2;
     for (uint32_t y = 0; y < B.n_kinds; ++y) {
         a.kind[y] = B.kind[y]; a.term_begin[y] = B.term_begin[y]; a.term_count[y] = B.term_count[y];
-        lds_words = std::max(lds_words, std::min<uint64_t>(s.max_staged_words[B.kind[y]], a.lds_cap_words));
-        if (ev) ev->bytes += s.sum_words[B.kind[y]] * 8;
+        for (const ArenaShard *s : g.shards) {
+            lds_words = std::max(lds_words, std::min<uint64_t>(s->max_staged_words[B.kind[y]], a.lds_cap_words));
+            if (ev) ev->bytes += s->sum_words[B.kind[y]] * 8;
+        }
     }
+    if (ev) ev->n_arenas = a.n_arenas;
     lds_words = (lds_words + 1) / 2 * 2;
     lds_bytes = (uint32_t)(head + lds_words * 8);
     return BSG_OK;
 }
 
-int32_t make_eval_args(Device &d, const ArenaShard &s, const BatchDev &bd, const Batch &B, uint32_t slot, bsg::EvalArgs &a)
+int32_t make_eval_args(Device &d, const Group &g, const BatchDev &bd, const Batch &B, uint32_t slot, bsg::EvalArgs &a)
 {
-    const uint32_t G = (s.n_blocks + 63) / 64;
-    HIP_TRY(d.out[slot].reserve((size_t)B.n_queries * G));
+    HIP_TRY(d.out[slot].reserve(std::max<uint64_t>(g.out_words, 1)));
     a = bsg::EvalArgs{};
     a.V = d.V[slot].p; a.prog = bd.d_prog; a.chunk_len = bd.d_chunk_len;
-    a.out = d.out[slot].p; a.Wt = B.Wt; a.n_blocks = s.n_blocks; a.G = G; a.n_queries = B.n_queries;
+    a.out = d.out[slot].p; a.Wt = B.Wt; a.n_queries = B.n_queries;
     a.cw_cnt = bd.d_cw_cnt; a.cw = bd.d_cw; a.max_cw = B.max_cw; a.Lmax = B.Lmax; a.identity_cw = B.identity_cw ? 1u : 0u;
+    a.n_arenas = (uint32_t)g.shards.size();
+    a.max_G = g.max_G;
+    fill_refs(g, B, a.ar);
     return BSG_OK;
 }
 
-// Small arenas keep one block group per eval workgroup (latency); large ones tile kEvalGroupTile groups so a
+// Small launches keep one block group per eval workgroup (latency); large ones tile kEvalGroupTile groups so a
 // query's survivor words leave as one 32-byte store instead of four strided 8-byte stores.
-uint32_t eval_tile_for(uint32_t G) { return G >= 64 ? bsg::kEvalGroupTile : 1u; }
+uint32_t eval_tile_for(const Group &g) { return g.max_G >= 64 ? bsg::kEvalGroupTile : 1u; }
 
-int32_t enqueue_terms(Device &d, const ArenaShard &s, const BatchDev &bd, const Batch &B, uint32_t slot, EventTriple *ev)
+int32_t enqueue_terms(bsg_ctx *ctx, Device &d, const Group &g, const BatchDev &bd, const Batch &B, uint32_t slot, EventTriple *ev)
 {
     bsg::ProbeArgs a;
     uint32_t lds = 0;
-    if (int32_t rc = make_probe_args(d, s, bd, B, slot, ev, a, lds)) return rc;
+    if (int32_t rc = make_probe_args(ctx, d, g, bd, B, slot, ev, a, lds)) return rc;
     if (B.n_kinds == 0) return BSG_OK;
-    hipExtLaunchKernelGGL(bsg::k_probe_terms, dim3(s.n_blocks, B.n_kinds), dim3(bsg::kProbeThreads), lds, d.stream,
+    hipExtLaunchKernelGGL(bsg::k_probe_terms, dim3(g.max_blocks, B.n_kinds, a.n_arenas), dim3(bsg::kProbeThreads), lds, d.stream,
                           ev ? ev->k1s : nullptr, ev ? ev->k1e : nullptr, 0, a);
     HIP_TRY(hipGetLastError());
+    if (ev) ev->has_k1 = true;
     return BSG_OK;
 }
 
 // K2: programs over V[slot] -> out[slot].
-int32_t enqueue_eval(Device &d, const ArenaShard &s, const BatchDev &bd, const Batch &B, uint32_t slot, EventTriple *ev)
+int32_t enqueue_eval(Device &d, const Group &g, const BatchDev &bd, const Batch &B, uint32_t slot, EventTriple *ev)
 {
     bsg::EvalArgs a;
-    if (int32_t rc = make_eval_args(d, s, bd, B, slot, a)) return rc;
-    const uint32_t tile = eval_tile_for(a.G);
-    hipExtLaunchKernelGGL(bsg::k_eval_programs, dim3((a.G + tile - 1) / tile, B.n_chunks), dim3(bsg::kEvalThreads),
+    if (int32_t rc = make_eval_args(d, g, bd, B, slot, a)) return rc;
+    const uint32_t tile = eval_tile_for(g);
+    hipExtLaunchKernelGGL(bsg::k_eval_programs, dim3((g.max_G + tile - 1) / tile, B.n_chunks, a.n_arenas), dim3(bsg::kEvalThreads),
                           bsg::eval_lds_bytes(B.max_cw, B.max_depth), d.stream, ev ? ev->k2s : nullptr,
                           ev ? ev->k2e : nullptr, 0, a, tile);
     HIP_TRY(hipGetLastError());
@@ -1068,26 +1228,193 @@ int32_t enqueue_eval(Device &d, const ArenaShard &s, const BatchDev &bd, const B
     return BSG_OK;
 }
 
-// One launch: K1 of the current arena (slot) + K2 of the previous arena (pslot).  See k_probe_fused.
-int32_t enqueue_fused(Device &d, const ArenaShard &s, uint32_t slot, const ArenaShard &ps, uint32_t pslot, const BatchDev &bd,
+// One launch: K1 of the current group (slot) + K2 of the previous group (pslot).  See k_probe_fused.
+int32_t enqueue_fused(bsg_ctx *ctx, Device &d, const Group &g, uint32_t slot, const Group &pg, uint32_t pslot, const BatchDev &bd,
                       const Batch &B, EventTriple *ev)
 {
     bsg::FusedArgs f{};
     uint32_t lds = 0;
-    if (int32_t rc = make_probe_args(d, s, bd, B, slot, ev, f.p, lds)) return rc;
-    if (int32_t rc = make_eval_args(d, ps, bd, B, pslot, f.e)) return rc;
-    f.n_probe_x = s.n_blocks;
-    f.n_probe = s.n_blocks * B.n_kinds;
+    if (int32_t rc = make_probe_args(ctx, d, g, bd, B, slot, ev, f.p, lds)) return rc;
+    if (int32_t rc = make_eval_args(d, pg, bd, B, pslot, f.e)) return rc;
+    f.n_kinds = B.n_kinds;
+    f.n_probe = g.max_blocks * B.n_kinds * f.p.n_arenas;
     f.eval_pairs = (B.n_chunks + 1) / 2;
     f.eval_lds_half = bsg::eval_lds_bytes(B.max_cw, B.max_depth);
     lds = std::max(lds, 2 * f.eval_lds_half);
-    // (4 groups per eval workgroup on small arenas was measured slower: 14.0 vs 10.8 us per fused step — the
-    // eval chain is latency-bound and running four of them back to back outlasts the streaming.)
-    f.eval_tile = eval_tile_for(f.e.G);
-    const uint32_t grid = f.n_probe + (f.e.G + f.eval_tile - 1) / f.eval_tile * f.eval_pairs;
-    hipExtLaunchKernelGGL(bsg::k_probe_fused, dim3(grid), dim3(bsg::kProbeThreads), lds, d.stream, ev ? ev->k1s : nullptr,
+    f.eval_tile = eval_tile_for(pg);
+    const uint64_t grid = (uint64_t)f.n_probe + (uint64_t)(pg.max_G + f.eval_tile - 1) / f.eval_tile * f.eval_pairs * f.e.n_arenas;
+    if (grid > 0x7FFFFFFFull) return fail(BSG_E_UNSUPPORTED, "fused launch of %llu workgroups", (unsigned long long)grid);
+    hipExtLaunchKernelGGL(bsg::k_probe_fused, dim3((uint32_t)grid), dim3(bsg::kProbeThreads), lds, d.stream, ev ? ev->k1s : nullptr,
                           ev ? ev->k1e : nullptr, 0, f);
     HIP_TRY(hipGetLastError());
+    if (ev) { ev->has_k1 = true; ev->fused = true; }
+    return BSG_OK;
+}
+
+// survivors of device di's shard (local block lb == global block lb * nd + di) -> the caller's global bitset
+void interleave_shard(const uint64_t *part, uint32_t Q, uint32_t n_local, uint32_t di, uint32_t nd, uint64_t *dst, uint64_t Gglobal)
+{
+    const uint32_t G = (n_local + 63) / 64;
+    for (uint32_t q = 0; q < Q; ++q) {
+        const uint64_t *row = part + (size_t)q * G;
+        uint64_t *o = dst + (size_t)q * Gglobal;
+        for (uint32_t g = 0; g < G; ++g) {
+            uint64_t w = row[g];
+            while (w) {
+                const uint32_t bit = (uint32_t)__builtin_ctzll(w);
+                w &= w - 1;
+                const uint64_t b = ((uint64_t)g * 64 + bit) * nd + di;
+                o[b >> 6] |= 1ULL << (b & 63);
+            }
+        }
+    }
+}
+
+// Probes batch B against every arena of the list.  Per device the launches are software-pipelined on one in-order stream
+//   K1(g0) | F(g1) = K1(g1) + K2(g0) | F(g2) = K1(g2) + K2(g1) | ... | K2(g_last)
+// where a group g_i is up to ctx->group_limit arenas probed by ONE dispatch and F = k_probe_fused: the program evaluation
+// of group i-1 rides in the grid that streams group i's bitsets.  V/out are double-buffered by group parity.  Survivors
+// leave through the device's copy stream (D2H of group i overlaps the kernels of group i+1); contexts on several devices
+// enqueue on all of them before waiting on any, then interleave the shards' bitsets on the host.
+// out_dev != nullptr (single-device contexts): survivors are left at that device pointer instead, in the same layout.
+// (Measured on MI355X in round 1: per-arena cross-stream events cost the host 3-4 us each — per group they are noise.)
+int32_t probe_arenas(bsg_ctx *ctx, const std::vector<std::shared_ptr<Arena>> &arenas, const Batch &B, uint32_t flags,
+                     uint64_t *out_survivors, uint64_t *out_dev)
+{
+    const uint32_t nd = (uint32_t)ctx->devs.size();
+    const uint32_t n_arenas = (uint32_t)arenas.size();
+    if (B.n_queries == 0 || n_arenas == 0) return BSG_OK;
+    const bool timed = flags & BSG_PROBE_TIMED;
+    // Fusing pays while a dispatch is short enough for its ramp + completion to matter (a few arenas); behind a large
+    // group the evaluation workgroups only take LDS and issue slots from the streaming (measured at 20-32 arenas of
+    // 35 MB per dispatch: fused 5.9 us per arena, k_probe_terms + k_eval_programs 5.2 + 1.0 us with the evaluation
+    // costing no HBM time of its own).
+    const bool fuse = !(flags & BSG_PROBE_NOFUSE) && B.n_kinds > 0 && 2 * bsg::eval_lds_bytes(B.max_cw, B.max_depth) <= 64 * 1024;
+    const uint32_t fuse_max_arenas = ctx->fuse_max_arenas;
+    const uint32_t limit = std::max(1u, std::min(ctx->group_limit, bsg::kMaxGroupArenas));
+    std::vector<uint64_t> out_off(n_arenas + 1, 0);   // arena i's survivors start at out_survivors + out_off[i]
+    for (uint32_t i = 0; i < n_arenas; ++i)
+        out_off[i + 1] = out_off[i] + (uint64_t)B.n_queries * (((uint64_t)arenas[i]->n_blocks + 63) / 64);
+    // multi-device: every device's shard bitsets land in a host buffer of its own and are interleaved afterwards
+    std::vector<std::vector<uint64_t>> parts(nd > 1 && out_survivors ? nd : 0);
+    std::vector<std::vector<uint64_t>> part_off(parts.size());
+    for (uint32_t di = 0; di < nd; ++di) {
+        Device &d = *ctx->devs[di];
+        const BatchDev &bd = B.dev[di];
+        std::lock_guard<std::mutex> lk(d.mu);
+        if (int32_t rc = use_device(d)) return rc;
+        // groups of this device
+        std::vector<Group> groups;
+        for (uint32_t i = 0; i < n_arenas; ++i) {
+            const ArenaShard &s = arenas[i]->shards[di];
+            if (s.n_blocks == 0) continue;
+            if (groups.empty() || groups.back().shards.size() >= limit) groups.push_back(Group{});
+            group_add(groups.back(), B, s, i);
+        }
+        if (groups.empty()) continue;
+        uint64_t *host_base = out_survivors;
+        std::vector<uint64_t> goff(groups.size() + 1, 0);   // where each group's survivors go (u64 offset)
+        if (!parts.empty()) {
+            uint64_t total = 0;
+            for (size_t gi = 0; gi < groups.size(); ++gi) { goff[gi] = total; total += groups[gi].out_words; }
+            goff[groups.size()] = total;
+            parts[di].resize(total);
+            part_off[di] = goff;
+            host_base = parts[di].data();
+        } else {
+            // single device: a group's arenas are consecutive in the caller's list unless empty arenas sit between
+            // them (those produce no words), so the group's words are contiguous at out_off[first arena of the group]
+            for (size_t gi = 0; gi < groups.size(); ++gi) goff[gi] = out_off[groups[gi].index[0]];
+        }
+        const bool want_copy = out_survivors != nullptr || out_dev != nullptr;
+        // latency path (a single interactive query): one group, a small synchronous result — the copy rides the compute
+        // stream, no cross-stream events
+        const bool inline_copy = want_copy && groups.size() == 1 && !(flags & BSG_PROBE_ASYNC) && groups[0].out_words * 8 <= (1u << 20);
+        if (want_copy && !inline_copy && !d.copy_stream) {
+            HIP_TRY(hipStreamCreateWithFlags(&d.copy_stream, hipStreamNonBlocking));
+            for (int s2 = 0; s2 < 2; ++s2) {
+                HIP_TRY(hipEventCreateWithFlags(&d.ev_eval[s2], hipEventDisableTiming));
+                HIP_TRY(hipEventCreateWithFlags(&d.ev_copy[s2], hipEventDisableTiming));
+            }
+        }
+        std::vector<EventTriple> evs(groups.size());
+        std::vector<uint8_t> tflag(groups.size(), 0);
+        auto after_eval = [&](size_t gi, uint32_t slot) -> int32_t {   // bookkeeping once K2(gi) is enqueued
+            if (tflag[gi]) d.pending.push_back(evs[gi]);
+            if (!want_copy) return BSG_OK;
+            const uint64_t bytes = groups[gi].out_words * 8;
+            if (inline_copy) {
+                HIP_TRY(hipMemcpyAsync(out_dev ? (void *)(out_dev + goff[gi]) : (void *)(host_base + goff[gi]), d.out[slot].p, bytes,
+                                       out_dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, d.stream));
+                return BSG_OK;
+            }
+            HIP_TRY(hipEventRecord(d.ev_eval[slot], d.stream));
+            HIP_TRY(hipStreamWaitEvent(d.copy_stream, d.ev_eval[slot], 0));
+            if (out_dev) HIP_TRY(hipMemcpyAsync(out_dev + goff[gi], d.out[slot].p, bytes, hipMemcpyDeviceToDevice, d.copy_stream));
+            else HIP_TRY(hipMemcpyAsync(host_base + goff[gi], d.out[slot].p, bytes, hipMemcpyDeviceToHost, d.copy_stream));
+            HIP_TRY(hipEventRecord(d.ev_copy[slot], d.copy_stream));
+            d.copy_busy[slot] = true;
+            return BSG_OK;
+        };
+        auto before_eval = [&](uint32_t slot) -> int32_t {           // out[slot] is about to be overwritten
+            if (d.copy_busy[slot]) { HIP_TRY(hipStreamWaitEvent(d.stream, d.ev_copy[slot], 0)); d.copy_busy[slot] = false; }
+            return BSG_OK;
+        };
+        for (size_t gi = 0; gi < groups.size(); ++gi) {
+            const uint32_t slot = (uint32_t)(gi & 1);
+            tflag[gi] = timed && (ctx->timed_stride <= 1 || (ctx->timed_counter++ % ctx->timed_stride) == ctx->timed_stride / 2);
+            if (tflag[gi]) if (int32_t rc = take_events(ctx, d, evs[gi])) return rc;
+            EventTriple *ev = tflag[gi] ? &evs[gi] : nullptr;
+            if (gi > 0 && fuse && groups[gi].shards.size() <= fuse_max_arenas && groups[gi - 1].shards.size() <= fuse_max_arenas) {
+                // a fused launch's own timestamps cover the streaming of group gi AND the evaluation of group gi-1
+                if (int32_t rc = before_eval(slot ^ 1)) return rc;
+                if (int32_t rc = enqueue_fused(ctx, d, groups[gi], slot, groups[gi - 1], slot ^ 1, bd, B, ev)) return rc;
+                if (int32_t rc = after_eval(gi - 1, slot ^ 1)) return rc;
+            } else {
+                if (gi > 0) {
+                    if (int32_t rc = before_eval(slot ^ 1)) return rc;
+                    if (int32_t rc = enqueue_eval(d, groups[gi - 1], bd, B, slot ^ 1, tflag[gi - 1] ? &evs[gi - 1] : nullptr)) return rc;
+                    if (int32_t rc = after_eval(gi - 1, slot ^ 1)) return rc;
+                }
+                if (int32_t rc = enqueue_terms(ctx, d, groups[gi], bd, B, slot, ev)) return rc;
+            }
+        }
+        {
+            const size_t gl = groups.size() - 1;
+            const uint32_t slot = (uint32_t)(gl & 1);
+            if (int32_t rc = before_eval(slot)) return rc;
+            if (int32_t rc = enqueue_eval(d, groups[gl], bd, B, slot, tflag[gl] ? &evs[gl] : nullptr)) return rc;
+            if (int32_t rc = after_eval(gl, slot)) return rc;
+        }
+    }
+    if (flags & BSG_PROBE_ASYNC) return BSG_OK;
+    for (uint32_t di = 0; di < nd; ++di) {
+        Device &d = *ctx->devs[di];
+        std::lock_guard<std::mutex> lk(d.mu);
+        if (int32_t rc = use_device(d)) return rc;
+        if (ctx->spin_wait_us) {   // a short busy-wait first: waking from a blocking wait costs more than a single query's kernels run
+            const auto t0 = std::chrono::steady_clock::now();
+            while (hipStreamQuery(d.stream) == hipErrorNotReady &&
+                   std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(ctx->spin_wait_us)) {}
+        }
+        HIP_TRY(hipStreamSynchronize(d.stream));
+        if (d.copy_stream) HIP_TRY(hipStreamSynchronize(d.copy_stream));
+        d.copy_busy[0] = d.copy_busy[1] = false;
+    }
+    if (!parts.empty()) {
+        memset(out_survivors, 0, out_off[n_arenas] * 8);
+        for (uint32_t di = 0; di < nd; ++di) {
+            uint64_t o = 0;
+            for (uint32_t i = 0; i < n_arenas; ++i) {
+                const ArenaShard &s = arenas[i]->shards[di];
+                if (s.n_blocks == 0) continue;
+                const uint32_t G = (s.n_blocks + 63) / 64;
+                interleave_shard(parts[di].data() + o, B.n_queries, s.n_blocks, di, nd, out_survivors + out_off[i],
+                                 ((uint64_t)arenas[i]->n_blocks + 63) / 64);
+                o += (uint64_t)B.n_queries * G;
+            }
+        }
+    }
     return BSG_OK;
 }
 
@@ -1095,159 +1422,78 @@ int32_t enqueue_fused(Device &d, const ArenaShard &s, uint32_t slot, const Arena
 
 extern "C" int32_t bsg_set_timed_stride(bsg_ctx *ctx, uint32_t stride)
 {
-    if (!ctx) return fail(BSG_E_INVALID, "ctx is null");
+    BSG_ENTER(ctx);
     ctx->timed_stride = stride ? stride : 1;
     ctx->timed_counter = 0;
     return BSG_OK;
 }
 
-extern "C" int32_t bsg_probe_batch(bsg_ctx *ctx, uint64_t arena_id, uint64_t batch_id, uint32_t flags, uint64_t *out_survivors)
+extern "C" int32_t bsg_set_probe_group(bsg_ctx *ctx, uint32_t max_arenas_per_launch)
 {
-    if (!ctx) return fail(BSG_E_INVALID, "ctx is null");
-    std::shared_ptr<Arena> arena;
-    std::shared_ptr<Batch> batch;
-    if (int32_t rc = get_arena(ctx, arena_id, arena)) return rc;
-    if (int32_t rc = get_batch(ctx, batch_id, batch)) return rc;
-    if ((flags & BSG_PROBE_ASYNC) && out_survivors)
-        return fail(BSG_E_INVALID, "BSG_PROBE_ASYNC cannot return survivors to the host");
-    const Batch &B = *batch;
-    const uint32_t nd = (uint32_t)ctx->devs.size();
-    const uint32_t Q = B.n_queries;
-    const uint64_t Gglobal = ((uint64_t)arena->n_blocks + 63) / 64;
-    if (Q == 0 || arena->n_blocks == 0) return BSG_OK;
-    const bool timed = flags & BSG_PROBE_TIMED;
-
-    std::vector<std::vector<uint64_t>> host_parts(nd > 1 && out_survivors ? nd : 0);
-    for (uint32_t di = 0; di < nd; ++di) {
-        Device &d = *ctx->devs[di];
-        const ArenaShard &s = arena->shards[di];
-        const BatchDev &bd = B.dev[di];
-        if (s.n_blocks == 0) continue;
-        std::lock_guard<std::mutex> lk(d.mu);
-        if (int32_t rc = use_device(d)) return rc;
-        const uint32_t G = (s.n_blocks + 63) / 64;
-        EventTriple ev{};
-        if (timed) if (int32_t rc = take_events(ctx, d, ev)) return rc;
-        if (int32_t rc = enqueue_terms(d, s, bd, B, 0, timed ? &ev : nullptr)) return rc;
-        if (int32_t rc = enqueue_eval(d, s, bd, B, 0, timed ? &ev : nullptr)) return rc;
-        if (timed) {
-            if (B.n_kinds > 0) d.pending.push_back(ev); else d.free_events.push_back(ev);
-        }
-        if (out_survivors) {
-            if (nd == 1) {
-                HIP_TRY(hipMemcpyAsync(out_survivors, d.out[0].p, (size_t)Q * G * 8, hipMemcpyDeviceToHost, d.stream));
-            } else {
-                host_parts[di].resize((size_t)Q * G);
-                HIP_TRY(hipMemcpyAsync(host_parts[di].data(), d.out[0].p, (size_t)Q * G * 8, hipMemcpyDeviceToHost, d.stream));
-            }
-        }
-    }
-    if (!(flags & BSG_PROBE_ASYNC)) {
-        for (uint32_t di = 0; di < nd; ++di) {
-            Device &d = *ctx->devs[di];
-            std::lock_guard<std::mutex> lk(d.mu);
-            if (int32_t rc = use_device(d)) return rc;
-            HIP_TRY(hipStreamSynchronize(d.stream));
-        }
-    }
-    if (out_survivors && nd > 1) {
-        // host-side gather: local block lb of device di is global block lb * nd + di
-        memset(out_survivors, 0, (size_t)Q * Gglobal * 8);
-        for (uint32_t di = 0; di < nd; ++di) {
-            const ArenaShard &s = arena->shards[di];
-            if (s.n_blocks == 0) continue;
-            const uint32_t G = (s.n_blocks + 63) / 64;
-            for (uint32_t q = 0; q < Q; ++q) {
-                const uint64_t *row = host_parts[di].data() + (size_t)q * G;
-                uint64_t *dst = out_survivors + (size_t)q * Gglobal;
-                for (uint32_t g = 0; g < G; ++g) {
-                    uint64_t w = row[g];
-                    while (w) {
-                        const uint32_t bit = (uint32_t)__builtin_ctzll(w);
-                        w &= w - 1;
-                        const uint64_t b = ((uint64_t)g * 64 + bit) * nd + di;
-                        dst[b >> 6] |= 1ULL << (b & 63);
-                    }
-                }
-            }
-        }
-    }
+    BSG_ENTER(ctx);
+    ctx->group_limit = max_arenas_per_launch ? std::min(max_arenas_per_launch, bsg::kMaxGroupArenas) : bsg::kMaxGroupArenas;
     return BSG_OK;
 }
 
-// Software-pipelined enqueue on one in-order stream; per device the launches are
-//   K1(0) | F(1) = K1(1) + K2(0) | F(2) = K1(2) + K2(1) | ... | K2(n-1)
-// F = k_probe_fused: the program evaluation of arena i-1 rides in the tail of the grid that streams
-// arena i's bitsets, so a step costs one dispatch ramp instead of two.  V/out are double-buffered by
-// step parity (K1(i) writes slot i&1 while K2(i-1) reads slot (i-1)&1).
-// (Measured alternatives on MI355X: a second stream with cross-stream events is slower — every
-// hipEventRecord / hipStreamWaitEvent costs the host 3-4 us; hipExtAnyOrderLaunch on K2 gave no overlap.)
+extern "C" int32_t bsg_set_spin_wait(bsg_ctx *ctx, uint32_t microseconds)
+{
+    BSG_ENTER(ctx);
+    ctx->spin_wait_us = microseconds;
+    return BSG_OK;
+}
+
+extern "C" int32_t bsg_set_fuse_limit(bsg_ctx *ctx, uint32_t max_arenas)
+{
+    BSG_ENTER(ctx);
+    ctx->fuse_max_arenas = max_arenas;
+    return BSG_OK;
+}
+
+extern "C" int32_t bsg_set_gather_cost(bsg_ctx *ctx, uint32_t bytes_per_probe)
+{
+    BSG_ENTER(ctx);
+    ctx->gather_cost = bytes_per_probe;
+    return BSG_OK;
+}
+
+extern "C" int32_t bsg_probe_batch(bsg_ctx *ctx, uint64_t arena_id, uint64_t batch_id, uint32_t flags, uint64_t *out_survivors)
+{
+    BSG_ENTER(ctx);
+    std::vector<std::shared_ptr<Arena>> arenas(1);
+    std::shared_ptr<Batch> batch;
+    if (int32_t rc = get_arena(ctx, arena_id, arenas[0])) return rc;
+    if (int32_t rc = get_batch(ctx, batch_id, batch)) return rc;
+    if ((flags & BSG_PROBE_ASYNC) && out_survivors)
+        return fail(BSG_E_INVALID, "BSG_PROBE_ASYNC cannot return survivors to the host");
+    return probe_arenas(ctx, arenas, *batch, flags, out_survivors, nullptr);
+}
+
 extern "C" int32_t bsg_probe_many(bsg_ctx *ctx, const uint64_t *arena_ids, uint32_t n_arenas, uint64_t batch_id, uint32_t flags,
                                   uint64_t *out_survivors)
 {
-    if (!ctx || (n_arenas && !arena_ids)) return fail(BSG_E_INVALID, "null argument");
-    if (out_survivors && ctx->devs.size() != 1)
-        return fail(BSG_E_UNSUPPORTED, "bsg_probe_many returns survivors only on single-device contexts");
+    BSG_ENTER(ctx);
+    if (n_arenas && !arena_ids) return fail(BSG_E_INVALID, "null argument");
+    if ((flags & BSG_PROBE_ASYNC) && out_survivors && ctx->devs.size() != 1)
+        return fail(BSG_E_INVALID, "BSG_PROBE_ASYNC with a host output needs a single-device context (shards are interleaved on the host)");
     std::shared_ptr<Batch> batch;
     if (int32_t rc = get_batch(ctx, batch_id, batch)) return rc;
-    const Batch &B = *batch;
     std::vector<std::shared_ptr<Arena>> arenas(n_arenas);
     for (uint32_t i = 0; i < n_arenas; ++i) if (int32_t rc = get_arena(ctx, arena_ids[i], arenas[i])) return rc;
-    if (B.n_queries == 0 || n_arenas == 0) return BSG_OK;
-    const bool timed = flags & BSG_PROBE_TIMED;
-    const bool fuse = B.n_kinds > 0 && 2 * bsg::eval_lds_bytes(B.max_cw, B.max_depth) <= 64 * 1024;
-    for (uint32_t di = 0; di < ctx->devs.size(); ++di) {
-        Device &d = *ctx->devs[di];
-        const BatchDev &bd = B.dev[di];
-        std::lock_guard<std::mutex> lk(d.mu);
-        if (int32_t rc = use_device(d)) return rc;
-        std::vector<EventTriple> evs(n_arenas);
-        std::vector<uint8_t> tflag(n_arenas, 0);
-        std::vector<uint64_t> out_off(n_arenas + 1, 0);   // arena i's survivors start at out_survivors + out_off[i]
-        for (uint32_t i = 0; i < n_arenas; ++i)
-            out_off[i + 1] = out_off[i] + (uint64_t)B.n_queries * (((uint64_t)arenas[i]->n_blocks + 63) / 64);
-        const ArenaShard *prev = nullptr;
-        uint32_t prev_i = 0, prev_slot = 0, n_done = 0;
-        auto after_eval = [&](uint32_t pi, uint32_t slot) -> int32_t {   // bookkeeping once K2(pi) is enqueued
-            if (tflag[pi]) { if (B.n_kinds > 0) d.pending.push_back(evs[pi]); else d.free_events.push_back(evs[pi]); }
-            if (out_survivors)
-                HIP_TRY(hipMemcpyAsync(out_survivors + out_off[pi], d.out[slot].p, (out_off[pi + 1] - out_off[pi]) * 8,
-                                       hipMemcpyDeviceToHost, d.stream));
-            return BSG_OK;
-        };
-        for (uint32_t i = 0; i < n_arenas; ++i) {
-            const ArenaShard &s = arenas[i]->shards[di];
-            if (s.n_blocks == 0) continue;
-            const uint32_t slot = n_done & 1;
-            // the sampled probe sits in the MIDDLE of each stride: the first probe of a bsg_probe_many call follows a host
-            // round trip (the GPU may have gone idle for a moment), which is launch jitter, not the kernel
-            tflag[i] = timed && (ctx->timed_stride <= 1 || (ctx->timed_counter++ % ctx->timed_stride) == ctx->timed_stride / 2);
-            if (tflag[i]) if (int32_t rc = take_events(ctx, d, evs[i])) return rc;
-            EventTriple *ev = tflag[i] ? &evs[i] : nullptr;
-            // timestamped probes are never fused: each of their two kernels keeps its own dispatch, so its own
-            // start/stop timestamps (what bsg_timing_read and a rocprofv3 kernel trace report) stay observable
-            if (prev && fuse && !tflag[i] && !tflag[prev_i]) {
-                if (int32_t rc = enqueue_fused(d, s, slot, *prev, prev_slot, bd, B, ev)) return rc;
-                if (int32_t rc = after_eval(prev_i, prev_slot)) return rc;
-            } else {
-                if (prev) {
-                    if (int32_t rc = enqueue_eval(d, *prev, bd, B, prev_slot, tflag[prev_i] ? &evs[prev_i] : nullptr)) return rc;
-                    if (int32_t rc = after_eval(prev_i, prev_slot)) return rc;
-                }
-                // (Draining the queue before a timestamped probe was tried and rejected: after even a short idle gap
-                // the next streaming kernel measures 12-14 us instead of 8-9.5 us — the GPU leaves its busy state.)
-                if (int32_t rc = enqueue_terms(d, s, bd, B, slot, ev)) return rc;
-            }
-            prev = &s; prev_i = i; prev_slot = slot;
-            ++n_done;
-        }
-        if (prev) {
-            if (int32_t rc = enqueue_eval(d, *prev, bd, B, prev_slot, tflag[prev_i] ? &evs[prev_i] : nullptr)) return rc;
-            if (int32_t rc = after_eval(prev_i, prev_slot)) return rc;
-        }
-        if (out_survivors) HIP_TRY(hipStreamSynchronize(d.stream));
-    }
-    return BSG_OK;
+    // without an output pointer the call only enqueues (round-1 contract: pair with bsg_sync)
+    return probe_arenas(ctx, arenas, *batch, out_survivors ? flags : (flags | BSG_PROBE_ASYNC), out_survivors, nullptr);
+}
+
+extern "C" int32_t bsg_probe_many_dev(bsg_ctx *ctx, const uint64_t *arena_ids, uint32_t n_arenas, uint64_t batch_id, uint32_t flags,
+                                      void *d_out_survivors)
+{
+    BSG_ENTER(ctx);
+    if ((n_arenas && !arena_ids) || !d_out_survivors) return fail(BSG_E_INVALID, "null argument");
+    if (ctx->devs.size() != 1) return fail(BSG_E_UNSUPPORTED, "bsg_probe_many_dev needs a single-device context");
+    std::shared_ptr<Batch> batch;
+    if (int32_t rc = get_batch(ctx, batch_id, batch)) return rc;
+    std::vector<std::shared_ptr<Arena>> arenas(n_arenas);
+    for (uint32_t i = 0; i < n_arenas; ++i) if (int32_t rc = get_arena(ctx, arena_ids[i], arenas[i])) return rc;
+    return probe_arenas(ctx, arenas, *batch, flags, nullptr, static_cast<uint64_t *>(d_out_survivors));
 }
 
 extern "C" {
@@ -1255,18 +1501,20 @@ extern "C" {
 int32_t bsg_probe(bsg_ctx *ctx, uint64_t arena_id, const bsg_term *terms, uint32_t n_terms, const uint32_t *prog_ops,
                   const uint32_t *prog_off, uint32_t n_queries, uint64_t *out_survivors)
 {
+    BSG_ENTER(ctx);
     if (n_queries && !out_survivors) return fail(BSG_E_INVALID, "out_survivors is null");
     uint64_t bid = 0;
     if (int32_t rc = bsg_batch_create(ctx, terms, n_terms, prog_ops, prog_off, n_queries, &bid)) return rc;
     const int32_t rc = bsg_probe_batch(ctx, arena_id, bid, 0, out_survivors);
-    const std::string saved = g_err;
+    const std::string saved = rc ? g_err : std::string();
     (void)bsg_batch_free(ctx, bid);
-    if (rc) g_err = saved;
+    if (rc) fail(rc, "%s", saved.c_str());   // the probe's message, not the free's
     return rc;
 }
 
 int32_t bsg_last_kernel_ms(bsg_ctx *ctx, float *build_ms, float *hash_ms, float *decode_ms)
 {
+    BSG_ENTER(ctx);
     if (!ctx) return fail(BSG_E_INVALID, "ctx is null");
     Device &d = *ctx->devs[0];
     std::lock_guard<std::mutex> lk(d.mu);
@@ -1278,6 +1526,7 @@ int32_t bsg_last_kernel_ms(bsg_ctx *ctx, float *build_ms, float *hash_ms, float 
 
 int32_t bsg_last_or_ms(bsg_ctx *ctx, float *or_ms)
 {
+    BSG_ENTER(ctx);
     if (!ctx || !or_ms) return fail(BSG_E_INVALID, "null argument");
     Device &d = *ctx->devs[0];
     std::lock_guard<std::mutex> lk(d.mu);
@@ -1287,6 +1536,7 @@ int32_t bsg_last_or_ms(bsg_ctx *ctx, float *or_ms)
 
 int32_t bsg_timing_read(bsg_ctx *ctx, bsg_timing *out, int32_t reset)
 {
+    BSG_ENTER(ctx);
     if (!ctx || !out) return fail(BSG_E_INVALID, "null argument");
     for (auto &dp : ctx->devs) {
         std::lock_guard<std::mutex> lk(dp->mu);
@@ -1322,6 +1572,7 @@ static int32_t or_reduce_shard(bsg_ctx *ctx, Arena &arena, uint32_t di, uint32_t
 
 int32_t bsg_or_reduce_dev(bsg_ctx *ctx, uint64_t arena_id, uint32_t kind, void *d_out, uint64_t n_words)
 {
+    BSG_ENTER(ctx);
     if (!ctx || !d_out) return fail(BSG_E_INVALID, "null argument");
     if (kind > 2) return fail(BSG_E_INVALID, "unknown kind %u", kind);
     if (ctx->devs.size() != 1) return fail(BSG_E_UNSUPPORTED, "bsg_or_reduce_dev needs a single-device context");
@@ -1338,6 +1589,7 @@ int32_t bsg_or_reduce_dev(bsg_ctx *ctx, uint64_t arena_id, uint32_t kind, void *
 
 int32_t bsg_or_words_dev(bsg_ctx *ctx, void *d_dst, const void *d_src, uint64_t n_words, uint32_t n_src)
 {
+    BSG_ENTER(ctx);
     if (!ctx || !d_dst || (n_src && !d_src)) return fail(BSG_E_INVALID, "null argument");
     Device &d = *ctx->devs[0];
     std::lock_guard<std::mutex> lk(d.mu);
@@ -1354,6 +1606,7 @@ int32_t bsg_or_words_dev(bsg_ctx *ctx, void *d_dst, const void *d_src, uint64_t 
 
 int32_t bsg_or_reduce(bsg_ctx *ctx, uint64_t arena_id, uint32_t kind, uint64_t *out_words, uint64_t n_words)
 {
+    BSG_ENTER(ctx);
     if (!ctx || !out_words) return fail(BSG_E_INVALID, "null argument");
     if (kind > 2) return fail(BSG_E_INVALID, "unknown kind %u", kind);
     std::shared_ptr<Arena> arena;
@@ -1368,20 +1621,71 @@ int32_t bsg_or_reduce(bsg_ctx *ctx, uint64_t arena_id, uint32_t kind, uint64_t *
         else if (m != s.fixed_m[kind] || k != s.fixed_k[kind])
             return fail(BSG_E_INVALID, "filters of kind %u do not share (m, k) across devices", kind);
     }
-    std::vector<uint64_t> part(n_words);
-    memset(out_words, 0, n_words * 8);
-    for (uint32_t di = 0; di < nd; ++di) {
+    // Every device ORs its own shard into a partial bitset; the partials travel device-to-device (xGMI peer copies)
+    // onto the first device, one k_or_words folds them, and only the result crosses PCIe.  All device locks are held
+    // (taken in index order) — the reduce is a merge-time operation, not a hot concurrent one.
+    std::vector<std::unique_lock<std::mutex>> locks;
+    for (uint32_t di = 0; di < nd; ++di) locks.emplace_back(ctx->devs[di]->mu);
+    Device &d0 = *ctx->devs[0];
+    std::vector<void *> partial(nd, nullptr);
+    std::vector<hipEvent_t> done(nd, nullptr);
+    void *gathered = nullptr;
+    auto cleanup = [&]() {
+        for (uint32_t di = 0; di < nd; ++di) {
+            (void)hipSetDevice(ctx->devs[di]->id);
+            if (done[di]) (void)hipEventDestroy(done[di]);
+            if (partial[di]) ctx->devs[di]->pool.free(partial[di]);
+        }
+        (void)hipSetDevice(d0.id);
+        if (gathered) d0.pool.free(gathered);
+    };
+    int32_t rc = BSG_OK;
+    for (uint32_t di = 0; di < nd && rc == BSG_OK; ++di) {
         Device &d = *ctx->devs[di];
-        std::lock_guard<std::mutex> lk(d.mu);
-        if (int32_t rc = use_device(d)) return rc;
-        HIP_TRY(d.stage_words.reserve(n_words));
-        if (int32_t rc = or_reduce_shard(ctx, *arena, di, kind, n_words, d.stage_words.p)) return rc;
-        HIP_TRY(hipMemcpyAsync(part.data(), d.stage_words.p, n_words * 8, hipMemcpyDeviceToHost, d.stream));
-        HIP_TRY(hipStreamSynchronize(d.stream));
-        if (d.or_pending) { HIP_TRY(hipEventElapsedTime(&d.last_or_ms, d.kb0, d.kb1)); d.or_pending = false; }
-        for (uint64_t i = 0; i < n_words; ++i) out_words[i] |= part[i];
+        if ((rc = use_device(d))) break;
+        hipError_t e = d.pool.alloc(&partial[di], std::max<uint64_t>(n_words, 1) * 8);
+        if (e == hipSuccess && nd > 1) e = hipEventCreateWithFlags(&done[di], hipEventDisableTiming);
+        if (e != hipSuccess) { rc = fail(e == hipErrorOutOfMemory ? BSG_E_NOMEM : BSG_E_HIP, "or_reduce scratch: %s", hipGetErrorString(e)); break; }
+        if (arena->shards[di].n_blocks == 0) {
+            if (hipMemsetAsync(partial[di], 0, n_words * 8, d.stream) != hipSuccess) { rc = fail(BSG_E_HIP, "memset failed"); break; }
+        } else if ((rc = or_reduce_shard(ctx, *arena, di, kind, n_words, static_cast<uint64_t *>(partial[di])))) break;
+        if (nd > 1 && hipEventRecord(done[di], d.stream) != hipSuccess) { rc = fail(BSG_E_HIP, "event record failed"); break; }
     }
-    return BSG_OK;
+    if (rc == BSG_OK) rc = use_device(d0);
+    if (rc == BSG_OK && nd > 1) {
+        hipError_t e = d0.pool.alloc(&gathered, (uint64_t)(nd - 1) * std::max<uint64_t>(n_words, 1) * 8);
+        for (uint32_t di = 1; di < nd && e == hipSuccess; ++di) {
+            e = hipStreamWaitEvent(d0.stream, done[di], 0);
+            if (e == hipSuccess)
+                e = hipMemcpyPeerAsync(static_cast<uint64_t *>(gathered) + (uint64_t)(di - 1) * n_words, d0.id, partial[di],
+                                       ctx->devs[di]->id, n_words * 8, d0.stream);
+        }
+        if (e == hipSuccess && n_words) {
+            const uint32_t grid = (uint32_t)std::min<uint64_t>((n_words + 255) / 256, 4096);
+            hipLaunchKernelGGL(bsg::k_or_words, dim3(grid), dim3(256), 0, d0.stream, static_cast<uint64_t *>(partial[0]),
+                               static_cast<const uint64_t *>(gathered), n_words, nd - 1, 0);
+            e = hipGetLastError();
+        }
+        if (e != hipSuccess) rc = fail(e == hipErrorOutOfMemory ? BSG_E_NOMEM : BSG_E_HIP, "or_reduce gather: %s", hipGetErrorString(e));
+    }
+    if (rc == BSG_OK) {
+        hipError_t e = hipMemcpyAsync(out_words, partial[0], n_words * 8, hipMemcpyDeviceToHost, d0.stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(d0.stream);
+        if (e != hipSuccess) rc = fail(BSG_E_HIP, "or_reduce copy out: %s", hipGetErrorString(e));
+    }
+    if (rc == BSG_OK)
+        for (uint32_t di = 0; di < nd; ++di) {
+            Device &d = *ctx->devs[di];
+            if (!d.or_pending) continue;
+            (void)hipSetDevice(d.id);
+            (void)hipStreamSynchronize(d.stream);
+            (void)hipEventElapsedTime(&d.last_or_ms, d.kb0, d.kb1);
+            d.or_pending = false;
+        }
+    else
+        for (uint32_t di = 0; di < nd; ++di) { (void)hipSetDevice(ctx->devs[di]->id); (void)hipStreamSynchronize(ctx->devs[di]->stream); }
+    cleanup();
+    return rc;
 }
 
 }  // extern "C"

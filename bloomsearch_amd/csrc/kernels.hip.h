@@ -238,18 +238,33 @@ __device__ __forceinline__ uint64_t wave_transpose64(uint64_t x, int lane)
 // early-out, __ballot folds 64 verdicts into one u64 that lane 0 stores.
 // Verdict layout: V[((b >> 6) * Wt + w) * 64 + (b & 63)], w = 64-term word.
 // ---------------------------------------------------------------------------
-struct ProbeArgs {
+// One launch probes a GROUP of arenas (the candidate files of one query stage, bsg_probe_many): the per-arena
+// pointers ride in the kernel arguments, so a group costs one dispatch ramp instead of one per arena — at 35 MB
+// per arena the ~3-4 us ramp + completion of a dispatch is as long as the streaming itself.
+constexpr uint32_t kMaxGroupArenas = 32;
+
+struct ArenaRef {
     const uint64_t *words;
     const DevDesc *desc;          // [n_blocks * 3]
+    uint64_t v_off;               // u64 offset of this arena's verdict words inside V
+    uint64_t out_off;             // u64 offset of this arena's survivors inside out ([n_queries][G])
+    uint32_t n_blocks;
+    uint32_t G;                   // ceil(n_blocks / 64)
+};
+
+struct ProbeArgs {
     const uint64_t *th;           // SoA term hashes: th[j * Tp + t], j < 4
     uint64_t *V;
     uint32_t Tp;                  // padded term count (multiple of 64)
     uint32_t Wt;                  // Tp / 64
-    uint32_t n_blocks;
     uint32_t lds_cap_words;       // filters with more words take the gather path
+    uint32_t gather_cost;         // a filter is gathered (not staged) when terms * k * gather_cost < its bytes
+    uint32_t n_arenas;
+    uint32_t max_blocks;          // most blocks of any arena of the group (grid x)
     uint32_t kind[3];             // referenced kinds, blockIdx.y indexes this
     uint32_t term_begin[3];       // first term (multiple of 64) of that kind
     uint32_t term_count[3];       // real terms of that kind
+    ArenaRef ar[kMaxGroupArenas];
 };
 
 // x mod m for m < 2^31: the remainder candidate x - q*m lies in [0, 2m) so only
@@ -495,17 +510,19 @@ __host__ __device__ inline uint32_t probe_lds_head_bytes(uint32_t n_tw)
     return (n_tw * 8u + n_tw * 128u + 15u) & ~15u;
 }
 
-__device__ __forceinline__ void probe_role(const ProbeArgs &a, uint32_t b, uint32_t y, uint64_t *lds64)
+__device__ __forceinline__ void probe_role(const ProbeArgs &a, uint32_t ai, uint32_t b, uint32_t y, uint64_t *lds64)
 {
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & (kWave - 1);
     const uint32_t wave = tid / kWave;
 
-    const DevDesc d = a.desc[(uint64_t)b * 3 + a.kind[y]];
+    const ArenaRef &ar = a.ar[ai];
+    if (b >= ar.n_blocks) return;   // arenas of a group may differ in size
+    const DevDesc d = ar.desc[(uint64_t)b * 3 + a.kind[y]];
     const uint32_t t0 = a.term_begin[y];
     const uint32_t n_real = a.term_count[y];
     const uint32_t n_tw = (n_real + 63) >> 6;
-    uint64_t *vout = a.V + ((uint64_t)(b >> 6) * a.Wt + (t0 >> 6)) * 64 + (b & 63);
+    uint64_t *vout = a.V + ar.v_off + ((uint64_t)(b >> 6) * a.Wt + (t0 >> 6)) * 64 + (b & 63);
 
     if (d.m == 0) {  // nil filter: cannot disqualify (query_exec.go:137-151)
         for (uint32_t w = tid; w < n_tw; w += kProbeThreads) vout[(uint64_t)w * 64] = ~0ULL;
@@ -516,9 +533,12 @@ __device__ __forceinline__ void probe_role(const ProbeArgs &a, uint32_t b, uint3
     char *image = reinterpret_cast<char *>(lds64) + probe_lds_head_bytes(n_tw);
 
     const uint64_t nw = (d.m + 63) >> 6;
-    const uint64_t *src = a.words + d.word_off;
+    const uint64_t *src = ar.words + d.word_off;
     const bool m32 = d.m < (1ull << 31);
-    if (nw <= a.lds_cap_words) {
+    // Few probes against a large bitset (a single query, Q = 1): touching <= terms * k sectors straight from L2 / HBM
+    // beats streaming the whole bitset into LDS (the "gather regime" of SURVEY 8d).
+    const bool gather = (uint64_t)n_real * d.k * a.gather_cost < nw * 8;
+    if (nw <= a.lds_cap_words && !gather) {
         // HBM -> LDS by LDS-DMA: every wave issues all of its 1 KiB pieces back to back
         // (64 lanes x 16 B, no VGPR round trip); the single wait sits in probe_block.
         const uint32_t nbytes = (uint32_t)(((nw + 1) >> 1) << 4);
@@ -536,10 +556,11 @@ __device__ __forceinline__ void probe_role(const ProbeArgs &a, uint32_t b, uint3
     }
 }
 
+// grid = (max_blocks, referenced kinds, arenas of the group)
 __global__ __launch_bounds__(kProbeThreads) void k_probe_terms(const ProbeArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
-    probe_role(a, blockIdx.x, blockIdx.y, lds64);
+    probe_role(a, blockIdx.z, blockIdx.x, blockIdx.y, lds64);
 }
 
 // ---------------------------------------------------------------------------
@@ -557,14 +578,15 @@ struct EvalArgs {
     const uint32_t *chunk_len;   // ops actually used by chunk c (<= Lmax; the rest is NOP padding)
     const uint32_t *cw;          // chunk c needs verdict words cw[c * max_cw .. + cw_cnt[c])  (padding entries are 0)
     const uint32_t *cw_cnt;
-    uint64_t *out;               // [n_queries][G]
+    uint64_t *out;               // arena i: [n_queries][G_i] at out + ar[i].out_off
     uint32_t Wt;
-    uint32_t n_blocks;
-    uint32_t G;
     uint32_t n_queries;
     uint32_t max_cw;             // max words of any chunk (LDS carve + cw stride)
     uint32_t Lmax;               // max program length of any chunk (prog stride)
     uint32_t identity_cw;        // 1: every chunk uses words 0..max_cw-1 in order (small batches): no list to load
+    uint32_t n_arenas;
+    uint32_t max_G;              // most 64-block groups of any arena of the launch
+    ArenaRef ar[kMaxGroupArenas];
 };
 
 // LDS bytes one 256-query half needs: transposed verdict words + per-lane stack
@@ -579,9 +601,10 @@ constexpr uint32_t kEvalGroupTile = 4;   // block groups one eval "half" handles
 // of one "half" (a whole k_eval_programs workgroup, or half of a fused workgroup).  The program words
 // are fetched once and reused for every group; the gt survivor words of a query are stored together.
 // `active` = false halves only take part in the barriers.
-__device__ __forceinline__ void eval_role(const EvalArgs &a, uint32_t g0, uint32_t gt, uint32_t c, uint32_t htid, uint64_t *lds,
-                                          bool active)
+__device__ __forceinline__ void eval_role(const EvalArgs &a, const ArenaRef &ar, uint32_t g0, uint32_t gt, uint32_t c, uint32_t htid,
+                                          uint64_t *lds, bool active)
 {
+    const uint64_t *V = a.V + ar.v_off;
     const int lane = htid & (kWave - 1);
     const uint32_t wave = htid / kWave;
     constexpr uint32_t n_waves = kEvalThreads / kWave;
@@ -610,10 +633,10 @@ __device__ __forceinline__ void eval_role(const EvalArgs &a, uint32_t g0, uint32
             const uint32_t g = g0 + t;
             if (t > 0) __syncthreads();   // everyone is done reading VT of the previous group
             if (active) {
-                const bool row_valid = (g * 64 + (uint32_t)lane) < a.n_blocks;
+                const bool row_valid = (g * 64 + (uint32_t)lane) < ar.n_blocks;
                 for (uint32_t s = wave; s < ncw; s += n_waves) {
                     const uint32_t w = a.identity_cw ? s : a.cw[cw0 + s];
-                    uint64_t x = row_valid ? a.V[((uint64_t)g * a.Wt + w) * 64 + lane] : 0ULL;
+                    uint64_t x = row_valid ? V[((uint64_t)g * a.Wt + w) * 64 + lane] : 0ULL;
                     VT[s * 64 + lane] = wave_transpose64(x, lane);
                 }
             }
@@ -638,23 +661,25 @@ __device__ __forceinline__ void eval_role(const EvalArgs &a, uint32_t g0, uint32
                 for (uint32_t j = 0; j < kPre; ++j) if (j < len) step(pre[j]);
                 for (uint32_t j = kPre; j < len; ++j) step(P[(uint64_t)j * kEvalThreads]);
             }
-            const uint32_t nvalid = a.n_blocks - g * 64;
+            const uint32_t nvalid = ar.n_blocks - g * 64;
             res[t] = top & (nvalid >= 64 ? ~0ULL : ((1ULL << nvalid) - 1));
         }
     }
     if (active && q < a.n_queries) {
-        uint64_t *dst = a.out + (uint64_t)q * a.G + g0;
+        uint64_t *dst = a.out + ar.out_off + (uint64_t)q * ar.G + g0;
 #pragma unroll
         for (uint32_t t = 0; t < kEvalGroupTile; ++t) if (t < gt) dst[t] = res[t];
     }
 }
 
-// grid = (ceil(G / tile), n_chunks); tile (1 or kEvalGroupTile) is chosen by the host
+// grid = (ceil(max_G / tile), n_chunks, arenas); tile (1 or kEvalGroupTile) is chosen by the host
 __global__ __launch_bounds__(kEvalThreads) void k_eval_programs(const EvalArgs a, const uint32_t tile)
 {
     extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
+    const ArenaRef &ar = a.ar[blockIdx.z];
     const uint32_t g0 = blockIdx.x * tile;
-    eval_role(a, g0, min(tile, a.G - g0), blockIdx.y, threadIdx.x, lds64, true);
+    if (g0 >= ar.G) return;
+    eval_role(a, ar, g0, min(tile, ar.G - g0), blockIdx.y, threadIdx.x, lds64, true);
 }
 
 // ---------------------------------------------------------------------------
@@ -668,29 +693,35 @@ __global__ __launch_bounds__(kEvalThreads) void k_eval_programs(const EvalArgs a
 struct FusedArgs {
     ProbeArgs p;
     EvalArgs e;
-    uint32_t n_probe_x;      // probe role: blocks of arena i (grid x of k_probe_terms)
-    uint32_t n_probe;        // = n_probe_x * number of referenced kinds
+    uint32_t n_probe;        // probe role workgroups = p.max_blocks * referenced kinds * p.n_arenas
     uint32_t eval_pairs;     // ceil(n_chunks / 2) of the eval role
     uint32_t eval_lds_half;  // bytes of LDS per 256-query half
     uint32_t eval_tile;      // block groups per eval half (1 or kEvalGroupTile)
+    uint32_t n_kinds;
 };
 
 __global__ __launch_bounds__(kProbeThreads) void k_probe_fused(const FusedArgs f)
 {
     extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
     const uint32_t id = blockIdx.x;
-    const uint32_t g_tiles = (f.e.G + f.eval_tile - 1) / f.eval_tile;
-    const uint32_t n_eval = g_tiles * f.eval_pairs;
+    const uint32_t g_tiles = (f.e.max_G + f.eval_tile - 1) / f.eval_tile;
+    const uint32_t per_arena = g_tiles * f.eval_pairs;
+    const uint32_t n_eval = per_arena * f.e.n_arenas;
     if (id >= n_eval) {
         const uint32_t j = id - n_eval;
-        probe_role(f.p, j % f.n_probe_x, j / f.n_probe_x, lds64);
+        const uint32_t per_probe_arena = f.p.max_blocks * f.n_kinds;
+        const uint32_t ai = j / per_probe_arena, r = j - ai * per_probe_arena;
+        probe_role(f.p, ai, r % f.p.max_blocks, r / f.p.max_blocks, lds64);
     } else {
-        const uint32_t gtile = id / f.eval_pairs, pair = id - gtile * f.eval_pairs;
+        const uint32_t ai = id / per_arena, r = id - ai * per_arena;
+        const uint32_t gtile = r / f.eval_pairs, pair = r - gtile * f.eval_pairs;
+        const ArenaRef &ar = f.e.ar[ai];
+        const uint32_t g0 = gtile * f.eval_tile;
+        if (g0 >= ar.G) return;
         const uint32_t half = threadIdx.x >> 8, htid = threadIdx.x & 255u;
         const uint32_t c = pair * 2 + half;
         const uint32_t n_chunks = (f.e.n_queries + kEvalThreads - 1) / kEvalThreads;
-        const uint32_t g0 = gtile * f.eval_tile;
-        eval_role(f.e, g0, min(f.eval_tile, f.e.G - g0), c, htid, lds64 + (uint64_t)half * (f.eval_lds_half / 8), c < n_chunks);
+        eval_role(f.e, ar, g0, min(f.eval_tile, ar.G - g0), c, htid, lds64 + (uint64_t)half * (f.eval_lds_half / 8), c < n_chunks);
     }
 }
 

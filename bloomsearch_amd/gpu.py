@@ -147,6 +147,36 @@ class Context:
             o += sz
         return res
 
+    def probe_many_dev(self, arena_ids, batch_id: int, d_out_ptr: int, flags: int = 0):
+        """Survivors of every arena, back to back, at a device pointer (single-device contexts)."""
+        ids = np.ascontiguousarray(arena_ids, dtype=np.uint64)
+        self._check(self.L.bsg_probe_many_dev(self.h, _lib._ptr(ids), len(ids), batch_id, flags, C.c_void_p(d_out_ptr)))
+
+    def probe_many_into(self, arena_ids, batch_id: int, out: np.ndarray, flags: int = 0):
+        """Synchronous probe of every arena; survivors written back to back into `out` (u64, e.g. pinned memory)."""
+        ids = np.ascontiguousarray(arena_ids, dtype=np.uint64)
+        self._check(self.L.bsg_probe_many(self.h, _lib._ptr(ids), len(ids), batch_id, flags, C.c_void_p(out.ctypes.data)))
+
+    def set_probe_group(self, max_arenas_per_launch: int):
+        self._check(self.L.bsg_set_probe_group(self.h, max_arenas_per_launch))
+
+    def set_spin_wait(self, microseconds: int):
+        self._check(self.L.bsg_set_spin_wait(self.h, microseconds))
+
+    def set_fuse_limit(self, max_arenas: int):
+        self._check(self.L.bsg_set_fuse_limit(self.h, max_arenas))
+
+    def set_gather_cost(self, bytes_per_probe: int):
+        self._check(self.L.bsg_set_gather_cost(self.h, bytes_per_probe))
+
+    def scope(self):
+        """An error scope: an alias of this context with its own last-error slot (bsg_scope_open)."""
+        h = C.c_void_p()
+        self._check(self.L.bsg_scope_open(self.h, C.byref(h)))
+        sc = Context.__new__(Context)
+        sc.L, sc.h, sc.n_devices = self.L, h, self.n_devices
+        return sc
+
     def probe(self, arena_id: int, n_blocks: int, terms: np.ndarray, prog_ops, prog_off) -> np.ndarray:
         assert terms.dtype == TERM_DTYPE
         ops = np.ascontiguousarray(prog_ops, dtype=np.uint32)
@@ -284,6 +314,12 @@ class Context:
 
     def pinned_free(self, arr: np.ndarray):
         self._check(self.L.bsg_pinned_free(self.h, C.c_void_p(arr.ctypes.data)))
+
+    def host_register(self, arr: np.ndarray):
+        self._check(self.L.bsg_host_register(self.h, C.c_void_p(arr.ctypes.data), arr.nbytes))
+
+    def host_unregister(self, arr: np.ndarray):
+        self._check(self.L.bsg_host_unregister(self.h, C.c_void_p(arr.ctypes.data)))
 
     # ---- final row test on the device ----
     def match_rows(self, rows, matcher):

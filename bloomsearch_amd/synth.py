@@ -115,3 +115,37 @@ def lengths_to_offsets(lengths: np.ndarray) -> np.ndarray:
     np.cumsum(lengths, out=off[1:])
     assert off[-1] < 2 ** 32, "entry blob exceeds the u32 offset range of one bsg_build call"
     return off.astype(np.uint32)
+
+
+def make_queries(n_queries, workload, seed):
+    """C2 query batch.  'needle': And(FT(level), FT(service), FT(user_id)) — a log search for one
+    user's events; 'lowcard': SURVEY C2's And(FT(level), FT(service), FT(nested.region)).
+    Every position draws an absent value with probability 1/4."""
+    from . import query as Q
+    rng = np.random.default_rng(seed)
+    exprs = []
+    if workload == "c4":
+        # BASELINE configs[3] / SURVEY C4: 8-term Or(FieldToken...) over the low-cardinality fields,
+        # every position absent with probability 1/2 (an Or of present values alone would keep every block).
+        def pick(field, present, absent):
+            return Q.FieldToken(field, present() if rng.random() >= 0.5 else absent())
+        for _ in range(n_queries):
+            w = lambda: WORDS[rng.integers(0, len(WORDS))]
+            nw = lambda: "absent-word-%d" % rng.integers(0, 8)
+            exprs.append(Q.Or(
+                pick("level", lambda: LEVELS[rng.integers(0, 4)], lambda: "absent-level-%d" % rng.integers(0, 4)),
+                pick("service", lambda: SERVICES[rng.integers(0, 5)], lambda: "absent-svc-%d" % rng.integers(0, 4)),
+                pick("nested.region", lambda: "region-%d" % rng.integers(0, 8), lambda: "region-%d" % rng.integers(8, 12)),
+                pick("nested.az", lambda: "az-%d" % rng.integers(0, 3), lambda: "az-%d" % rng.integers(3, 6)),
+                pick("tags", w, nw), pick("tags", w, nw), pick("message", w, nw), pick("message", w, nw)))
+        return exprs
+    for _ in range(n_queries):
+        lv = LEVELS[rng.integers(0, 4)] if rng.random() >= 0.25 else "absent-level-%d" % rng.integers(0, 4)
+        sv = SERVICES[rng.integers(0, 5)] if rng.random() >= 0.25 else "absent-svc-%d" % rng.integers(0, 4)
+        if workload == "needle":
+            third = Q.FieldToken("user_id", str(int(rng.integers(0, N_USERS * 4 // 3))))
+        else:
+            rg = "region-%d" % rng.integers(0, 8) if rng.random() >= 0.25 else "region-%d" % rng.integers(8, 12)
+            third = Q.FieldToken("nested.region", rg)
+        exprs.append(Q.And(Q.FieldToken("level", lv), Q.FieldToken("service", sv), third))
+    return exprs

@@ -89,14 +89,21 @@ typedef struct bsg_filter_desc {
 /* Device-side timing of probes issued with BSG_PROBE_TIMED (HIP events on the
  * library's own stream; accumulated until read). */
 typedef struct bsg_timing {
-    uint64_t n_probes;        /* probes accumulated                                  */
-    double   ms_terms_kernel; /* sum of probe_terms kernel durations (the HBM stream) */
-    double   ms_eval_kernel;  /* sum of eval_programs kernel durations               */
-    uint64_t stream_bytes;    /* sum over probes of bitset bytes streamed by probe_terms */
+    uint64_t n_probes;           /* timestamped k_probe_terms dispatches                                    */
+    double   ms_terms_kernel;    /* sum of their durations (the HBM stream)                                 */
+    double   ms_eval_kernel;     /* sum of the timestamped k_eval_programs durations (n_eval of them)       */
+    uint64_t stream_bytes;       /* bitset bytes streamed by those k_probe_terms dispatches                 */
+    uint64_t n_probe_arenas;     /* arenas those dispatches covered (one dispatch probes a group of arenas) */
+    uint64_t n_eval;
+    uint64_t n_fused;            /* timestamped k_probe_fused dispatches (probe of group i + eval of i-1)   */
+    double   ms_fused_kernel;
+    uint64_t fused_stream_bytes; /* bitset bytes streamed by their probe role                               */
+    uint64_t n_fused_arenas;
 } bsg_timing;
 
 #define BSG_PROBE_ASYNC  1u  /* enqueue only; caller later calls bsg_sync                    */
-#define BSG_PROBE_TIMED  2u  /* bracket the kernels with HIP events (see bsg_timing_read)    */
+#define BSG_PROBE_TIMED  2u  /* timestamp the dispatches (see bsg_timing_read)               */
+#define BSG_PROBE_NOFUSE 4u  /* never fuse: every group runs as k_probe_terms + k_eval_programs */
 
 typedef struct bsg_ctx bsg_ctx;
 
@@ -104,8 +111,20 @@ typedef struct bsg_ctx bsg_ctx;
 BSG_API int32_t bsg_device_count(void);
 BSG_API int32_t bsg_open(const int32_t *device_ids, int32_t n_devices, bsg_ctx **out_ctx);
 BSG_API int32_t bsg_close(bsg_ctx *ctx);
-/* Message of the calling thread's most recent failure (valid until its next call). */
+/* ---- errors ----
+ * Every failing call records its message on the handle it was made on; bsg_last_error(handle) returns a private copy of
+ * it (valid until the calling thread's next bsg_last_error) and may run on ANY OS thread — nothing here depends on the
+ * caller staying on one thread between the failing call and the read (a goroutine may migrate between two cgo calls,
+ * SURVEY 7 hard part 6: no runtime.LockOSThread).  A context shared by concurrent callers has ONE slot, so a Go host
+ * gives every goroutine-confined caller (flush worker, merge, each query's file worker) a SCOPE of its own:
+ * bsg_scope_open returns a lightweight alias of the context — valid wherever a bsg_ctx* is — that owns nothing but its
+ * own error slot; close it with bsg_close before the context.  bsg_last_error(NULL) serves only the context-free entry
+ * points (bsg_open, bsg_estimate_parameters, bsg_sections_size) and is thread-local; bsg_open_err returns bsg_open's
+ * message in the same call instead. */
 BSG_API const char *bsg_last_error(bsg_ctx *ctx);
+BSG_API int32_t bsg_last_error_copy(bsg_ctx *ctx, char *buf, uint64_t cap);
+BSG_API int32_t bsg_scope_open(bsg_ctx *ctx, bsg_ctx **out_scope);
+BSG_API int32_t bsg_open_err(const int32_t *device_ids, int32_t n_devices, bsg_ctx **out_ctx, char *errbuf, uint64_t cap);
 BSG_API int32_t bsg_sync(bsg_ctx *ctx);
 
 /* ---- sizing: bloom/v3 EstimateParameters + New's clamps, as called by
@@ -168,14 +187,31 @@ BSG_API int32_t bsg_probe_batch(bsg_ctx *ctx, uint64_t arena_id, uint64_t batch_
                                 uint64_t *out_survivors);
 
 /* Probe the same batch against each of n_arenas arenas (e.g. the candidate files of one query
- * stage) in one call.  Launches are software-pipelined: the program evaluation of arena i rides inside
- * the launch that streams arena i+1's bitsets (k_probe_fused); probes selected for timestamping
- * (BSG_PROBE_TIMED, bsg_set_timed_stride) run as two separate launches instead.  out_survivors == NULL: enqueue only
- * (results stay on the device; pair with bsg_sync).  Otherwise the call is synchronous and arena
- * i's survivors ([n_queries][ceil(n_blocks_i / 64)] u64) are written back to back in arena order
- * (single-device contexts). */
+ * stage) in one call.  Up to 32 arenas (bsg_set_probe_group) are covered by ONE dispatch — a 35 MB arena streams in
+ * about the time a dispatch takes to ramp up and complete, so per-arena launches cap the HBM roofline fraction near
+ * one half — and dispatches are software-pipelined: the program evaluation of group i rides inside the launch that
+ * streams group i+1's bitsets (k_probe_fused).  out_survivors == NULL: enqueue only (results stay on the device; pair
+ * with bsg_sync).  Otherwise the call is synchronous (unless BSG_PROBE_ASYNC is set on a single-device context: then
+ * out_survivors must be C memory that stays valid until the next bsg_sync) and arena i's survivors ([n_queries][ceil(n_blocks_i / 64)] u64)
+ * are written back to back in arena order; they leave the device on a copy stream while the next group is being
+ * probed (pass memory from bsg_pinned_alloc for a plain DMA).  Contexts opened on several devices probe their shards
+ * concurrently and interleave the shards' bitsets on the host. */
 BSG_API int32_t bsg_probe_many(bsg_ctx *ctx, const uint64_t *arena_ids, uint32_t n_arenas, uint64_t batch_id,
                                uint32_t flags, uint64_t *out_survivors);
+/* Same, survivors left at a DEVICE pointer (single-device contexts; one-process-per-GPU layers that forward them). */
+BSG_API int32_t bsg_probe_many_dev(bsg_ctx *ctx, const uint64_t *arena_ids, uint32_t n_arenas, uint64_t batch_id,
+                                   uint32_t flags, void *d_out_survivors);
+/* Arenas one probe dispatch may cover (1..32; 0 = default 32). */
+BSG_API int32_t bsg_set_probe_group(bsg_ctx *ctx, uint32_t max_arenas_per_launch);
+/* Synchronous probes poll their stream for up to this long before they block (default 0: block at once).  A single
+ * query's kernels finish in ~10 us; being woken from a blocking wait costs more than that. */
+BSG_API int32_t bsg_set_spin_wait(bsg_ctx *ctx, uint32_t microseconds);
+/* Groups of up to this many arenas ride fused (k_probe_fused: the probe of group i and the program evaluation of group
+ * i-1 in one dispatch; default 4, 0 = never).  Larger groups run as k_probe_terms + k_eval_programs. */
+BSG_API int32_t bsg_set_fuse_limit(bsg_ctx *ctx, uint32_t max_arenas);
+/* Gather regime: a filter is read by <= terms * k sector gathers instead of being streamed into LDS when
+ * terms * k * bytes_per_probe < its size (default 256; 0 = always stream). */
+BSG_API int32_t bsg_set_gather_cost(bsg_ctx *ctx, uint32_t bytes_per_probe);
 
 /* One-shot convenience: batch_create + probe_batch + batch_free. */
 BSG_API int32_t bsg_probe(bsg_ctx *ctx, uint64_t arena_id, const bsg_term *terms, uint32_t n_terms,
@@ -183,7 +219,7 @@ BSG_API int32_t bsg_probe(bsg_ctx *ctx, uint64_t arena_id, const bsg_term *terms
                           uint64_t *out_survivors);
 
 BSG_API int32_t bsg_timing_read(bsg_ctx *ctx, bsg_timing *out, int32_t reset);
-/* With BSG_PROBE_TIMED, bsg_probe_many timestamps only every stride-th probe (default 1 = all). */
+/* With BSG_PROBE_TIMED, only every stride-th dispatch group is timestamped (default 1 = all). */
 BSG_API int32_t bsg_set_timed_stride(bsg_ctx *ctx, uint32_t stride);
 /* Device time (the dispatch's own start/stop timestamps) of the most recent k_build / k_hash_entries /
  * k_decode_sections launch made through bsg_build* / bsg_hash_entries / bsg_arena_load_sections on the
@@ -225,6 +261,9 @@ BSG_API int32_t bsg_last_encode_ms(bsg_ctx *ctx, float *encode_ms);
  * 23 -> 11 ms). */
 BSG_API int32_t bsg_pinned_alloc(bsg_ctx *ctx, uint64_t n_bytes, void **out_ptr);
 BSG_API int32_t bsg_pinned_free(bsg_ctx *ctx, void *ptr);
+/* Page-lock memory the caller already owns (C memory, an mmap of a file or of shared memory; never Go-heap memory). */
+BSG_API int32_t bsg_host_register(bsg_ctx *ctx, void *ptr, uint64_t n_bytes);
+BSG_API int32_t bsg_host_unregister(bsg_ctx *ctx, void *ptr);
 
 /* ---- device ingest: rows -> distinct bloom entries -> exact counts -> bitsets ----
  * Replaces, on the flush / merge worker, the reference's per-row host loop

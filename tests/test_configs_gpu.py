@@ -1,0 +1,263 @@
+"""BASELINE configs[3] (C4) and configs[4] (C5) on the GPU against the oracle, and the launch-grouping machinery they
+ride on: one dispatch per group of arenas, survivors leaving on a copy stream, multi-device contexts interleaving
+their shards on the host.  Block COUNTS are the configs' (1 250 per GPU at 8-way, 10 000 in total); rows per block are
+kept small so the CPU side of the test (generator + oracle) runs in seconds."""
+import multiprocessing as mp
+import os
+
+import numpy as np
+import pytest
+
+from bloomsearch_amd import _lib, query as Q, synth
+from bloomsearch_amd._lib import DESC_DTYPE, BloomGpuError
+from bloomsearch_amd.arena import plan_blocks
+from bloomsearch_amd.gpu import Context, pack_entries
+from oracle import oracle as O
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+ROWS = 5              # rows per block in these tests: few enough that a block lacks most low-cardinality values, so an Or of 8 leaves prunes
+
+
+def _gen(args):
+    b, rows = args
+    return synth.block_entry_sets(b * rows, rows)
+
+
+def gen_blocks(ids, rows=ROWS):
+    jobs = [(int(b), rows) for b in ids]
+    if len(jobs) < 64:
+        return [_gen(j) for j in jobs]
+    with mp.get_context("fork").Pool(min(32, os.cpu_count() or 1)) as pool:
+        return pool.map(_gen, jobs, chunksize=64)
+
+
+def c4_batch(ctx, nq, seed=99):
+    cb = Q.compile_queries(synth.make_queries(nq, "c4", seed))
+    ops, poff, _ = cb.arrays()
+    terms = H.gpu_terms(ctx, cb)
+    return cb, terms, ops, poff
+
+
+def test_c4_query_shape_over_a_1250_block_shard(ctx):
+    """configs[3] as one of 8 ranks sees it: blocks b = 8 j + 3 of a 10 000-block set, Q 8-term Or(FieldToken) queries."""
+    ids = np.arange(3, 10000, 8)
+    assert len(ids) == 1250
+    plan = plan_blocks(gen_blocks(ids), 0.001)
+    words = ctx.build(plan.blob, plan.off, plan.fstart, plan.desc, plan.n_words)
+    assert np.array_equal(words, H.oracle_words(plan))
+    cb, terms, ops, poff = c4_batch(ctx, 64)
+    aid = ctx.arena_load(words, plan.desc)
+    got = ctx.probe(aid, 1250, terms, ops, poff)
+    want = O.probe_batch(words, plan.desc.view(O.DESC_DTYPE), terms.view(O.TERM_DTYPE), ops, poff)
+    assert np.array_equal(got, want)
+    # the Or of 8 leaves must actually prune somewhere and keep somewhere, or the test shows nothing
+    ones = sum(bin(int(x)).count("1") for x in got.ravel())
+    assert 0 < ones < 64 * 1250
+    ctx.arena_free(aid)
+
+
+def test_c4_10000_blocks_on_an_8_entry_multi_device_context():
+    """The whole configs[3] set behind ONE context that lists 8 devices (device 0 eight times: eight streams, eight
+    shards, block b on entry b % 8) as 10 files of 1 000 blocks probed by one bsg_probe_many; the host-interleaved
+    survivors must equal the oracle's over every file, and a single-device context's."""
+    n_files, per_file, nq = 10, 1000, 48
+    with Context((0,) * 8) as mctx, Context((0,)) as sctx:
+        cb, terms, ops, poff = c4_batch(sctx, nq, seed=7)
+        mb = mctx.batch_create(terms, ops, poff)
+        sb = sctx.batch_create(terms, ops, poff)
+        m_ids, s_ids, wants = [], [], []
+        for f in range(n_files):
+            plan = plan_blocks(gen_blocks(range(f * per_file, (f + 1) * per_file)), 0.001)
+            words = sctx.build(plan.blob, plan.off, plan.fstart, plan.desc, plan.n_words)
+            m_ids.append(mctx.arena_load(words, plan.desc))
+            s_ids.append(sctx.arena_load(words, plan.desc))
+            wants.append(O.probe_batch(words, plan.desc.view(O.DESC_DTYPE), terms.view(O.TERM_DTYPE), ops, poff))
+        got_m = mctx.probe_many(m_ids, mb, 0, nq, [per_file] * n_files)
+        got_s = sctx.probe_many(s_ids, sb, 0, nq, [per_file] * n_files)
+        for f in range(n_files):
+            assert np.array_equal(got_m[f], wants[f]), f
+            assert np.array_equal(got_s[f], wants[f]), f
+        # one arena through bsg_probe_batch on the sharded context: same interleave
+        assert np.array_equal(mctx.probe_batch(m_ids[3], mb, nq, per_file), wants[3])
+
+
+def test_c5_or_reduce_of_1250_fixed_geometry_blocks_equals_oracle_build_of_the_union(ctx):
+    """configs[4] as one rank sees it: 1 250 token filters built at the FILE-level geometry (m, k) =
+    EstimateParameters(n_union, p); their OR must equal the oracle's build of the union's entries at that geometry
+    (the only condition under which OR == rebuild)."""
+    n_blocks = 1250
+    blocks = gen_blocks(np.arange(5, 10000, 8))
+    union = set()
+    per_block = []
+    for sets in blocks:
+        blob, lens = sets[1]
+        off = np.zeros(len(lens) + 1, dtype=np.int64)
+        np.cumsum(lens, out=off[1:])
+        raw = blob.tobytes()
+        toks = [raw[off[i]: off[i + 1]] for i in range(len(lens))]
+        per_block.append(toks)
+        union.update(toks)
+    m, k = O.estimate_parameters(len(union), 0.001)
+    nw = O.words_for(m)
+    stride = (nw + 15) // 16 * 16
+    desc = np.zeros(n_blocks * 3, dtype=DESC_DTYPE)
+    fstart, ents = [0], []
+    for b in range(n_blocks):
+        fstart.append(len(ents))                 # field: absent
+        desc[b * 3 + 1] = (b * stride, m, k, 0)
+        ents += per_block[b]
+        fstart += [len(ents), len(ents)]         # field::token: absent
+    blob, off = pack_entries(ents)
+    words = ctx.build(blob, off, np.asarray(fstart, dtype=np.uint32), desc, n_blocks * stride)
+    aid = ctx.arena_load(words, desc)
+    got = ctx.or_reduce(aid, 1, nw)
+    ctx.arena_free(aid)
+    want = O.Filter(m, k)
+    for t in union:
+        want.add(t)
+    assert np.array_equal(got, want.words)
+    # and on a context that shards the same arena over 8 entries (partials combined inside the library)
+    with Context((0,) * 8) as mctx:
+        aid = mctx.arena_load(words, desc)
+        assert np.array_equal(mctx.or_reduce(aid, 1, nw), want.words)
+
+
+def test_grouped_launches_equal_one_launch_per_arena(ctx):
+    """A dispatch covers a GROUP of arenas (per-arena pointers in the kernel arguments): any grouping — one arena per
+    launch, 3, 32, more arenas than one group holds, arenas of different sizes, an arena without blocks, fused or not —
+    must return what one probe per arena returns."""
+    rng = np.random.default_rng(5)
+    plans, vocab = [], None
+    for n_blocks in (70, 3, 129, 64, 200, 1, 65):
+        plan, _, vocab = H.make_random_arena(rng, n_blocks, absent_frac=0.02)
+        plans.append((plan, ctx.build(plan.blob, plan.off, plan.fstart, plan.desc, plan.n_words)))
+    cb = Q.compile_queries([None] + [H.random_expression(rng, vocab, None) for _ in range(520)])
+    ops, poff, _ = cb.arrays()
+    terms = H.gpu_terms(ctx, cb)
+    bid = ctx.batch_create(terms, ops, poff)
+    arenas, nbs, wants = [], [], []
+    for plan, words in plans:
+        arenas.append(ctx.arena_load(words, plan.desc))
+        nbs.append(plan.n_blocks)
+        wants.append(O.probe_batch(words, plan.desc.view(O.DESC_DTYPE), terms.view(O.TERM_DTYPE), ops, poff))
+    empty = ctx.arena_load(np.zeros(2, dtype=np.uint64), np.zeros(0, dtype=DESC_DTYPE))
+    arenas.append(empty); nbs.append(0); wants.append(np.zeros((cb.n_queries, 0), dtype=np.uint64))
+    order = [int(i) for i in rng.integers(0, len(arenas), size=75)] + [7, 0, 7]
+    try:
+        for limit in (1, 3, 32):
+            ctx.set_probe_group(limit)
+            for flags in (0, _lib.PROBE_NOFUSE, _lib.PROBE_TIMED):
+                got = ctx.probe_many([arenas[i] for i in order], bid, flags, cb.n_queries, [nbs[i] for i in order])
+                for g, i in zip(got, order):
+                    assert np.array_equal(g, wants[i]), (limit, flags, i)
+    finally:
+        ctx.set_probe_group(0)
+    t = ctx.timing_read()
+    assert t.n_fused > 0 and t.n_probes > 0 and t.n_eval > 0 and t.n_fused_arenas >= t.n_fused
+    for a in arenas:
+        ctx.arena_free(a)
+    ctx.batch_free(bid)
+
+
+class HipMem:
+    """Raw device memory for the test (hipMalloc through ctypes on the HIP runtime the library itself links)."""
+
+    def __init__(self, n_bytes):
+        import ctypes as C
+        self.C = C
+        self.hip = C.CDLL("libamdhip64.so")
+        self.ptr = C.c_void_p()
+        assert self.hip.hipMalloc(C.byref(self.ptr), C.c_size_t(n_bytes)) == 0
+        self.n = n_bytes
+
+    def read(self):
+        out = np.zeros(self.n // 8, dtype=np.uint64)
+        assert self.hip.hipMemcpy(self.C.c_void_p(out.ctypes.data), self.ptr, self.C.c_size_t(self.n), 2) == 0   # hipMemcpyDeviceToHost
+        return out
+
+    def free(self):
+        self.hip.hipFree(self.ptr)
+
+
+def test_survivors_to_device_pointer_and_async_host_output(ctx):
+    rng = np.random.default_rng(6)
+    plan, _, vocab = H.make_random_arena(rng, 150, absent_frac=0.0)
+    words = ctx.build(plan.blob, plan.off, plan.fstart, plan.desc, plan.n_words)
+    cb = Q.compile_queries([H.random_expression(rng, vocab, None) for _ in range(300)])
+    ops, poff, _ = cb.arrays()
+    terms = H.gpu_terms(ctx, cb)
+    bid = ctx.batch_create(terms, ops, poff)
+    aid = ctx.arena_load(words, plan.desc)
+    want = O.probe_batch(words, plan.desc.view(O.DESC_DTYPE), terms.view(O.TERM_DTYPE), ops, poff)
+    n = 40                                                     # two groups
+    G = want.shape[1]
+    dmem = HipMem(n * cb.n_queries * G * 8)
+    ctx.probe_many_dev([aid] * n, bid, dmem.ptr.value)
+    got = dmem.read().reshape(n, cb.n_queries, G)
+    dmem.free()
+    assert all(np.array_equal(got[i], want) for i in range(n))
+    pinned = ctx.pinned_array(n * cb.n_queries * G * 8).view(np.uint64)
+    pinned[:] = 0
+    ctx.probe_many_into([aid] * n, bid, pinned, _lib.PROBE_ASYNC)
+    ctx.sync()
+    got = pinned.reshape(n, cb.n_queries, G)
+    assert all(np.array_equal(got[i], want) for i in range(n))
+    # the latency path (one group, small synchronous result, optional spin wait) returns the same bits
+    small = np.zeros(cb.n_queries * G, dtype=np.uint64)
+    for spin in (0, 50):
+        ctx.set_spin_wait(spin)
+        small[:] = 0
+        ctx.probe_many_into([aid], bid, small)
+        assert np.array_equal(small.reshape(cb.n_queries, G), want)
+    ctx.set_spin_wait(0)
+    ctx.pinned_free(pinned.view(np.uint8))
+    ctx.arena_free(aid)
+    ctx.batch_free(bid)
+
+
+def test_gather_regime_equals_streamed_probe(ctx):
+    """Q = 1: few probes against large bitsets read <= terms x k sectors instead of streaming the bitset into LDS
+    (bsg_set_gather_cost); the verdicts cannot depend on which way the bits were fetched."""
+    blocks = gen_blocks(range(40), rows=4000)
+    plan = plan_blocks(blocks, 0.001)
+    words = ctx.build(plan.blob, plan.off, plan.fstart, plan.desc, plan.n_words)
+    aid = ctx.arena_load(words, plan.desc)
+    d = synth.draws(0, 4000)
+    for exprs in ([Q.And(Q.FieldToken("level", "error"), Q.FieldToken("user_id", str(int(d["user_id"][17]))))],
+                  [Q.FieldToken("user_id", str(int(u))) for u in d["user_id"][:5]] + [Q.Token("absent"), Q.Field("nested.az")]):
+        cb = Q.compile_queries(exprs)
+        ops, poff, _ = cb.arrays()
+        terms = H.gpu_terms(ctx, cb)
+        want = O.probe_batch(words, plan.desc.view(O.DESC_DTYPE), terms.view(O.TERM_DTYPE), ops, poff)
+        try:
+            for cost in (0, 256, 1 << 20):
+                ctx.set_gather_cost(cost)
+                assert np.array_equal(ctx.probe(aid, 40, terms, ops, poff), want), cost
+        finally:
+            ctx.set_gather_cost(256)
+    ctx.arena_free(aid)
+
+
+def test_error_scopes_keep_their_own_message(ctx):
+    """bsg_scope_open: every scope owns its error slot, readable from any thread (a goroutine may change OS thread
+    between the failing cgo call and bsg_last_error)."""
+    import threading
+    a, b = ctx.scope(), ctx.scope()
+    with pytest.raises(BloomGpuError) as ea:
+        a.arena_free(0xDEAD)
+    with pytest.raises(BloomGpuError) as eb:
+        b.batch_free(0xBEEF)
+    assert "arena" in str(ea.value) and "batch" in str(eb.value)
+    seen = {}
+
+    def reader():                      # another OS thread reads both slots
+        seen["a"] = a.L.bsg_last_error(a.h).decode()
+        seen["b"] = b.L.bsg_last_error(b.h).decode()
+    th = threading.Thread(target=reader)
+    th.start(); th.join()
+    assert "arena" in seen["a"] and "57005" in seen["a"] and "batch" in seen["b"]
+    # scopes are full aliases of the context: compute calls work through them
+    assert a.hash_strings(["hello"]).shape == (1, 4)
+    a.close(); b.close()
