@@ -194,21 +194,33 @@ def or_reduce_leg(ctx, plan, B, fpr, n_union, world, log):
            "check": "equals bsg_build(union of the blocks' entries, m, k) bit for bit"}
     res["frac"] = res["achieved"] / HBM_PEAK_GBPS
     if world > 1:
-        # the exchange half; a failure here must not take the probe measurement down with it
+        # the exchange half, inside the library (bsg_or_allreduce: ncclAllGather over xGMI + k_or_words); the unique id
+        # travels over the harness' own channel.  A failure here must not take the probe measurement down with it.
         try:
             import torch.distributed as dist
+            from bloomsearch_amd.gpu import Context
+            box = [Context.comm_unique_id() if dist.get_rank() == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            ctx.comm_init(box[0], dist.get_rank(), world)
             ts = []
             for _ in range(6):
                 part = out.clone()
                 dist.barrier()
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
-                P.or_allreduce_(part, ctx)
-                torch.cuda.synchronize()
+                ctx.or_allreduce_dev([part.data_ptr()], nw)
                 ts.append(time.perf_counter() - t1)
+            full = ctx.or_allreduce(aid, 1, nw)            # the whole operation: local OR + exchange + copy out
+            if not np.array_equal(full, part.cpu().numpy().view(np.uint64)):
+                sys.exit("bsg_or_allreduce and bsg_or_allreduce_dev disagree")
+            # every rank must hold every rank's bits: the local partial is a subset of the result
+            if np.any(got & ~full):
+                sys.exit("OR all-reduce lost bits of this rank's partial")
+            ctx.comm_destroy()
             res["allreduce_ms"] = float(np.median(ts[1:])) * 1e3
             res["allreduce_wire_bytes_in_per_gpu"] = (world - 1) * nw * 8
-            res["allreduce"] = "all_gather (RCCL) of %d partials + k_or_words" % world
+            res["allreduce_gbps_in_per_gpu"] = (world - 1) * nw * 8 / max(res["allreduce_ms"], 1e-9) / 1e6
+            res["allreduce"] = "bsg_or_allreduce_dev: ncclAllGather (RCCL over xGMI) of %d partials + k_or_words, inside libbloomgpu" % world
         except Exception as exc:  # noqa: BLE001 - reported, not swallowed
             res["allreduce_error"] = repr(exc)
             log("OR all-reduce failed: %r" % (exc,))
@@ -217,6 +229,37 @@ def or_reduce_leg(ctx, plan, B, fpr, n_union, world, log):
         % (B, nw * 8 / 1e3, local_ms * 1e3, res["achieved"], 100 * res["frac"],
            ("; all-reduce over %d ranks %.2f ms" % (world, res["allreduce_ms"])) if "allreduce_ms" in res else "", t_setup))
     return res
+
+
+def go_reference_baseline(rows, n_blocks_sample, log):
+    """The reference's own Go CPU path (go/overlay/bench_reference_test.go::BenchmarkReferenceProbeLoop) when this box has
+    a Go toolchain and BLOOMSEARCH_REFERENCE points at a checkout whose modules resolve; None otherwise (the usual case:
+    neither the build image nor the GPU box has Go, and /root/reference does not travel)."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    go, ref = shutil.which("go"), os.environ.get("BLOOMSEARCH_REFERENCE")
+    if not go or not ref or not os.path.isdir(ref):
+        log("cpu_baseline: no Go toolchain / BLOOMSEARCH_REFERENCE here (go=%s): timing the oracle's restatement instead" % go)
+        return None
+    from bloomsearch_amd import synth
+    with tempfile.NamedTemporaryFile("wb", suffix=".ndjson", delete=False) as f:
+        for b in range(n_blocks_sample):
+            f.write(b"\n".join(synth.rows_json(b * rows, rows)) + b"\n")
+        path = f.name
+    try:
+        out = subprocess.run([os.path.join(ROOT, "go", "run_bench_reference.sh"), ref, path, str(rows)],
+                             capture_output=True, text=True, timeout=900)
+        m = re.search(r"BenchmarkReferenceProbeLoop\S*\s+\d+\s+.*?([0-9.e+]+) cores\s+([0-9.e+]+) probes/s", out.stdout)
+        if out.returncode != 0 or not m:
+            log("cpu_baseline: go harness failed (rc %d): %s" % (out.returncode, (out.stderr or out.stdout)[-400:]))
+            return None
+        return {"value": float(m.group(2)), "unit": "probes/s", "cores": int(float(m.group(1))), "kind": "reference",
+                "sample": "BenchmarkReferenceProbeLoop: 256 C2-shaped queries x %d blocks of %d rows (parseFilterSection + "
+                          "evaluateBloomFilters per (query, block)), real bloom/v3" % (n_blocks_sample, rows)}
+    finally:
+        os.unlink(path)
 
 
 def cpu_baseline(words, desc, cb, ops, poff, n_blocks, budget_s, log, terms_per_query=3):
@@ -872,7 +915,9 @@ def main():
             base, cpu_out, nq = cpu_baseline(words, plan.desc, cb, ops, poff, B, args.cpu_budget, log, terms_per_query)
             if not args.no_check and not np.array_equal(cpu_out, got[:nq]):
                 sys.exit("CPU baseline survivors differ from the GPU's")
-            out["cpu_baseline"] = base
+            out["cpu_baseline"] = go_reference_baseline(rows, min(B, 100), log) or base
+            if out["cpu_baseline"] is not base:
+                out["cpu_baseline_port"] = base
         print(json.dumps(out), flush=True)
     ctx.batch_free(bid)
     ctx.close()

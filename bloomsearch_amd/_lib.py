@@ -56,6 +56,7 @@ EXPORTS = [
     "bsg_hash_entries", "bsg_build", "bsg_build_hashed", "bsg_arena_load", "bsg_arena_load_sections", "bsg_arena_free",
     "bsg_batch_create", "bsg_batch_free", "bsg_probe_batch", "bsg_probe_many", "bsg_probe", "bsg_timing_read", "bsg_set_timed_stride", "bsg_last_kernel_ms",
     "bsg_or_reduce", "bsg_or_words_dev", "bsg_or_reduce_dev", "bsg_last_or_ms",
+    "bsg_comm_unique_id", "bsg_comm_init", "bsg_comm_destroy", "bsg_or_allreduce", "bsg_or_allreduce_dev",
     "bsg_ingest_rows", "bsg_ingest_fallback_rows", "bsg_ingest_add_entries", "bsg_ingest_finish", "bsg_ingest_build",
     "bsg_ingest_stats_read", "bsg_ingest_free", "bsg_ingest_build_sections",
     "bsg_sections_size", "bsg_build_sections", "bsg_last_encode_ms",
@@ -108,6 +109,11 @@ def load():
     L.bsg_or_words_dev.argtypes = [vp, vp, vp, u64, u32]
     L.bsg_or_reduce_dev.argtypes = [vp, u64, u32, vp, u64]
     L.bsg_last_or_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    L.bsg_comm_unique_id.argtypes = [vp]
+    L.bsg_comm_init.argtypes = [vp, vp, i32, i32]
+    L.bsg_comm_destroy.argtypes = [vp]
+    L.bsg_or_allreduce.argtypes = [vp, u64, u32, vp, u64]
+    L.bsg_or_allreduce_dev.argtypes = [vp, vp, u64]
     L.bsg_ingest_rows.argtypes = [vp, vp, vp, u32, vp, u32, vp, u32, vp, u32, C.POINTER(u64)]
     L.bsg_ingest_fallback_rows.argtypes = [vp, u64, vp, u32, C.POINTER(u32)]
     L.bsg_ingest_add_entries.argtypes = [vp, u64, vp, vp, u32, vp, vp]

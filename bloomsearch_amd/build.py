@@ -49,7 +49,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return LIB
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
            "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
-           "-I", INCLUDE, "-I", CSRC, "-I", os.path.join(CSRC, "host"), "-o", LIB + ".tmp"] + sources() + ["-lpthread"]
+           "-I", INCLUDE, "-I", CSRC, "-I", os.path.join(CSRC, "host"), "-o", LIB + ".tmp"] + sources() + ["-lpthread", "-ldl"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

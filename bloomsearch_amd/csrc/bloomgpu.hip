@@ -74,6 +74,7 @@ constexpr uint32_t kLdsBudget = 144 * 1024;   // dynamic LDS a workgroup may req
 constexpr uint32_t kLdsCapWords = kLdsBudget / 8;  // staged-filter cap before the per-launch head is taken off
 constexpr uint64_t kAlignWords = 16;          // filters start on 128-byte boundaries in HBM
 constexpr uint32_t kBuildSliceEntries = 8192; // entries per workgroup for non-staged builds
+constexpr uint64_t kMaxHashCount = 1024;      // k above this is rejected (EstimateParameters: 30 at p = 1e-9, 100 at 1e-30)
 
 uint64_t barrett_magic(uint64_t m)
 {
@@ -248,6 +249,8 @@ struct bsg_ctx {
     uint64_t timed_counter = 0;
     uint32_t group_limit = bsg::kMaxGroupArenas;   // arenas one probe dispatch may cover (bsg_set_probe_group)
     uint32_t gather_cost = 256;  // a filter is gathered instead of staged when terms * k * gather_cost < its bytes
+    std::vector<void *> comms;   // ncclComm_t per device (bsg_comm_init)
+    uint32_t comm_world = 0, comm_rank = 0;
     uint32_t spin_wait_us = 0;   // synchronous probes poll the stream this long before blocking (bsg_set_spin_wait)
     uint32_t fuse_max_arenas = 4; // groups up to this many arenas ride fused (probe of group i + eval of group i-1)
 };
@@ -262,6 +265,7 @@ void record_error(bsg_ctx *scope, const char *msg)
 bsg_ctx *root_of(bsg_ctx *c) { return c->parent ? c->parent : c; }
 
 void free_all_ingests(bsg_ctx *ctx);   // ingest_api.inc
+void destroy_comms(bsg_ctx *ctx);      // comm_api.inc
 int32_t ensure_lower_table(Device &d);   // ingest_api.inc: the unicode.ToLower table the walkers fold with
 
 struct SectionsOut { uint8_t *region; uint64_t cap; uint64_t *sec_off; };   // encode_api.inc
@@ -416,7 +420,8 @@ int32_t validate_descs(const bsg_filter_desc *desc, size_t n, uint64_t n_words)
     for (size_t i = 0; i < n; ++i) {
         if (desc[i].m == 0) continue;
         const uint64_t nw = (desc[i].m + 63) / 64;
-        if (desc[i].k == 0) return fail(BSG_E_INVALID, "descriptor %zu: k == 0", i);
+        if (desc[i].k == 0 || desc[i].k > kMaxHashCount)
+            return fail(BSG_E_INVALID, "descriptor %zu: k = %u outside [1, %llu]", i, desc[i].k, (unsigned long long)kMaxHashCount);
         if (desc[i].word_off > n_words || nw > n_words - desc[i].word_off)
             return fail(BSG_E_INVALID, "descriptor %zu: words [%llu, +%llu) outside arena of %llu words", i,
                         (unsigned long long)desc[i].word_off, (unsigned long long)nw, (unsigned long long)n_words);
@@ -498,6 +503,7 @@ int32_t bsg_close(bsg_ctx *ctx)
     for (auto &kv : ctx->arenas) free_arena(ctx, *kv.second);
     for (auto &kv : ctx->batches) free_batch(ctx, *kv.second);
     free_all_ingests(ctx);
+    destroy_comms(ctx);
     for (auto &dp : ctx->devs) {
         Device &d = *dp;
         (void)hipSetDevice(d.id);
@@ -851,8 +857,12 @@ int32_t bsg_arena_load_sections(bsg_ctx *ctx, const uint8_t *region, uint64_t re
             if (flen > plen - pos) { st = -4; break; }
             if (flen < 24) { st = -5; break; }
             const uint64_t m = rd_be64(sec + pos), k = rd_be64(sec + pos + 8), bl = rd_be64(sec + pos + 16);
+            // k is bounded (kMaxHashCount): a corrupt section with a valid CRC must not make k_probe_terms loop 2^32 times
+            // per term.  (bloom/v3 ReadFrom accepts m and the bitset length independently; a filter whose bitset is
+            // shorter than m is a bad filter here — nil, i.e. it cannot prune — see INTEGRATION.md.)
+            if (bl > ~0ull - 63 || m == 0 || k == 0 || k > kMaxHashCount) { st = -5; break; }
             const uint64_t nw = (bl + 63) / 64;
-            if (24 + 8 * nw > flen || m == 0 || k == 0 || k > 0xFFFFFFFFull || (m + 63) / 64 > nw) { st = -5; break; }
+            if (nw > (flen - 24) / 8 || (m + 63) / 64 > nw) { st = -5; break; }
             tmp[c] = DevDesc{0, m, barrett_magic(m), (uint32_t)k, 0};
             woff[c] = (uint32_t)(pos + 24);
             nwv[c] = (uint32_t)((m + 63) / 64);
@@ -1693,3 +1703,4 @@ int32_t bsg_or_reduce(bsg_ctx *ctx, uint64_t arena_id, uint32_t kind, uint64_t *
 #include "encode_api.inc"
 #include "ingest_api.inc"
 #include "match_api.inc"
+#include "comm_api.inc"

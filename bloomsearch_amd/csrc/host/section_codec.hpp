@@ -103,6 +103,8 @@ inline std::vector<uint8_t> encode_filter_section(const FilterView filters[3])
 }
 
 // parseFilterSection (file_format.go:392-448): CRC first, then flags, then each present filter.
+constexpr uint64_t kMaxHashCount = 1024;   // bloom/v3 EstimateParameters gives k = 30 at p = 1e-9, 100 at 1e-30
+
 inline int32_t parse_filter_section(const uint8_t *section, size_t len, ParsedFilter out[3])
 {
     if (len < 5) return kSectionTooSmall;
@@ -120,8 +122,11 @@ inline int32_t parse_filter_section(const uint8_t *section, size_t len, ParsedFi
         if (flen > plen - pos) return kSectionTruncated;
         if (flen < 24) return kSectionBadFilter;
         const uint64_t m = get_be64(section + pos), k = get_be64(section + pos + 8), blen = get_be64(section + pos + 16);
+        // same checks as the device path (bsg_arena_load_sections): the bitset must cover m, and (blen + 63) / 64 must
+        // not wrap; k is bounded so that a corrupt section with a valid CRC cannot make a probe loop for minutes
+        if (blen > ~0ull - 63 || m == 0 || k == 0 || k > kMaxHashCount) return kSectionBadFilter;
         const uint64_t nw = (blen + 63) / 64;
-        if (24 + 8 * nw > flen) return kSectionBadFilter;
+        if (nw > (flen - 24) / 8 || (m + 63) / 64 > nw) return kSectionBadFilter;
         out[c].present = true; out[c].m = m; out[c].k = k;
         out[c].words.resize(nw);
         for (uint64_t i = 0; i < nw; ++i) out[c].words[i] = get_be64(section + pos + 24 + 8 * i);

@@ -82,6 +82,23 @@ inline const LowerPair kLowerTable[] = {
 #include "unicode_lower.inc"
 };
 
+// Code points this build's tables know nothing about (unassigned in the Unicode version they were generated from): a
+// newer Unicode may have made them cased letters.  The device walker never folds them itself — it hands the row to the
+// host, whose own unicode.ToLower then decides (a Go host: its toolchain's tables; this mirror: identity).
+struct RuneRange { uint32_t from, to; };
+inline const RuneRange kUnknownRanges[] = {
+#include "unicode_unknown.inc"
+};
+inline bool is_unknown_rune(uint32_t r)
+{
+    size_t lo = 0, hi = sizeof(kUnknownRanges) / sizeof(kUnknownRanges[0]);
+    while (lo < hi) {
+        const size_t mid = (lo + hi) / 2;
+        if (kUnknownRanges[mid].to < r) lo = mid + 1; else hi = mid;
+    }
+    return lo < sizeof(kUnknownRanges) / sizeof(kUnknownRanges[0]) && kUnknownRanges[lo].from <= r;
+}
+
 // unicode.ToLower: simple case mapping (one rune -> one rune)
 inline uint32_t to_lower(uint32_t r)
 {

@@ -180,7 +180,7 @@ __device__ __forceinline__ void insert_begin(InsertState &x, const IngestTable t
     x.fresh = false;
     x.done = !active;
     if (active && (h[0] == 0 || h[1] == 0 || h[2] == 0 || h[3] == 0)) {
-        __hip_atomic_store(status, kTableExotic, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_max(status, kTableExotic, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         x.done = true;
     }
 }
@@ -225,7 +225,7 @@ __device__ __forceinline__ void set_insert2(const IngestTable ta, const uint64_t
                     else if (c1 == 0 || c2 == 0 || c3 == 0) {      /* the claimer's h1..h3 are still in flight */           \
                         advance = false;                                                                                 \
                         if (++X.spins > kSpinLimit) {              /* never a duplicate slot: give the set to the host */ \
-                            __hip_atomic_store(status, kTableExotic, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);        \
+                            __hip_atomic_fetch_max(status, kTableExotic, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);        \
                             X.done = true;                                                                               \
                         }                                                                                                \
                     }                                                                                                    \
@@ -234,7 +234,7 @@ __device__ __forceinline__ void set_insert2(const IngestTable ta, const uint64_t
                     X.idx = (X.idx + 1) & tab.mask;                                                                      \
                     X.probes += 1;                                                                                       \
                     if (X.probes > kMaxProbe) {                                                                          \
-                        __hip_atomic_store(status, kTableOverflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          \
+                        __hip_atomic_fetch_max(status, kTableOverflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          \
                         X.done = true;                                                                                   \
                     } else if ((X.probes & 15u) == 0u &&                                                                 \
                                __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != kTableOk) {      \
@@ -281,7 +281,7 @@ struct IngestArgs {
     uint32_t *status;               // per table
     uint32_t *fallback_rows;        // rows the host walker must finish
     uint32_t *n_fallback;
-    const uint32_t *lower;          // [0x20000]: unicode.ToLower(cp) where it differs from cp, else 0 (no cased rune lies above)
+    const uint32_t *lower;          // [0x20000]: unicode.ToLower(cp) where it differs from cp, 0 = unchanged, 0xFFFFFFFF = unknown code point (host)
     uint32_t n_rows;
     uint32_t n_sets;
     uint32_t validate;              // 1: run the validation pass first (rows of unknown provenance)
@@ -435,11 +435,12 @@ __device__ __forceinline__ uint32_t rune_utf8(uint32_t r, uint32_t &n)
 __device__ __forceinline__ uint32_t str_rune(Walker &w, uint32_t r)
 {
     if (rune_space(r)) return word_end(w) ? R_CONTINUE : 0xFFu;
+    // (the validation pass looks the rune up too: a code point these tables do not know sends the row to the host, whose
+    // own unicode.ToLower decides — a newer Unicode may have made it a cased letter)
+    const uint32_t lo = r < 0x20000u ? w.lower[r] : 0u;
+    if (lo == 0xFFFFFFFFu) return R_FAIL;
     if (!w.quiet) {
-        if (r < 0x20000u) {
-            const uint32_t lo = w.lower[r];
-            if (lo != 0u) r = lo;
-        }
+        if (lo != 0u) r = lo;
         uint32_t n = 1, bytes = r;
         if (r >= 0x80u) bytes = rune_utf8(r, n);
         if (!w.in_token) { hs_init(w.tok); w.ft = w.ps; w.in_token = true; }

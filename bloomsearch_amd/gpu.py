@@ -209,6 +209,36 @@ class Context:
     def or_reduce_dev(self, arena_id: int, kind: int, d_out_ptr: int, n_words: int):
         self._check(self.L.bsg_or_reduce_dev(self.h, arena_id, kind, C.c_void_p(d_out_ptr), n_words))
 
+    # ---- RCCL OR all-reduce inside the library ----
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        L = _lib.load()
+        buf = (C.c_uint8 * 128)()
+        rc = L.bsg_comm_unique_id(buf)
+        if rc:
+            raise BloomGpuError(rc, L.bsg_last_error(None).decode())
+        return bytes(buf)
+
+    def comm_init(self, unique_id=None, rank: int = 0, world: int = 0):
+        """unique_id None: every device of this (multi-device) context becomes a rank; else join as `rank` of `world`."""
+        if unique_id is None:
+            self._check(self.L.bsg_comm_init(self.h, None, 0, 0))
+        else:
+            buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+            self._check(self.L.bsg_comm_init(self.h, buf, rank, world))
+
+    def comm_destroy(self):
+        self._check(self.L.bsg_comm_destroy(self.h))
+
+    def or_allreduce(self, arena_id: int, kind: int, n_words: int) -> np.ndarray:
+        out = np.zeros(n_words, dtype=np.uint64)
+        self._check(self.L.bsg_or_allreduce(self.h, arena_id, kind, _lib._ptr(out), n_words))
+        return out
+
+    def or_allreduce_dev(self, d_ptrs, n_words: int):
+        arr = (C.c_void_p * len(d_ptrs))(*d_ptrs)
+        self._check(self.L.bsg_or_allreduce_dev(self.h, arr, n_words))
+
     def last_or_ms(self) -> float:
         v = C.c_float()
         self._check(self.L.bsg_last_or_ms(self.h, C.byref(v)))

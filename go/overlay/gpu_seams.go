@@ -1,0 +1,348 @@
+//go:build bloomgpu
+
+// gpu_seams.go — the reference engine's side of the libbloomgpu binding.  Drop this file (and oracle_parity_test.go,
+// bench_reference_test.go) into a checkout of github.com/danthegoodman1/bloomsearch (package bloomsearch) and build with
+// -tags bloomgpu; go/run_parity.sh does it in a scratch copy.  Everything here calls the engine's own unexported
+// pieces (bloomEntrySets, BloomFilters, makeFieldTokenKey, indexRow ...) and the cgo package ../bloomgpu.
+//
+// Seams (reference file:line):
+//   buildFiltersGPU ........... entries.buildFilters per partition + file level, flush.go:204,253; merge.go:771,516
+//   buildFiltersFromRowsGPU ... indexRow per row + buildFilters (ingest.go:450, merge.go:746) for the default tokenizer
+//   loadArena / loadArenaSections ... cursor.filtersFor + parseFilterSection per block, file_format.go:392-448,575
+//   probeBlocks ............... evaluateBlockFilters' per-block loop, query_exec.go:572-615
+//   matchRowsGPU .............. matchRowBytes per row of the surviving blocks, query_exec.go:729-764
+package bloomsearch
+
+import (
+	"errors"
+	"sort"
+	"time"
+
+	"github.com/bits-and-blooms/bloom/v3"
+
+	"bloomsearch_amd/go/bloomgpu"
+)
+
+var errGPUSetUnrepresentable = errors.New("bloomgpu: a distinct-entry set cannot be represented on the device; use the host path for this flush")
+
+// gpuFilter wraps device-built words as a real *bloom.BloomFilter (FileMetadata.BloomFilters exports concrete library
+// objects that external MetaStores consume, file_format.go:61,328-332).  bloom.FromWithM does not re-insert.
+func gpuFilter(words []uint64, d bloomgpu.FilterDesc) *bloom.BloomFilter {
+	nw := (d.M + 63) / 64
+	return bloom.FromWithM(words[d.WordOff:d.WordOff+nw], uint(d.M), uint(d.K))
+}
+
+func sizeFor(n int, fpr float64) (uint64, uint32) {
+	m, k := bloom.EstimateParameters(uint(max(n, 1)), fpr) // sizing stays in Go: (m, k) are the library's own
+	return uint64(max(m, 1)), uint32(max(k, 1))             // bloom.New clamps both to >= 1
+}
+
+// buildFiltersGPU replaces the AddString loops of buildSizedBloomFilter (ingest.go:139-145) for a whole flush: sets[i]
+// are the entry sets of block i; callers append the file-level union (flush.go:253) as the last element.
+func buildFiltersGPU(g *bloomgpu.Context, sets []*bloomEntrySets, fpr float64) ([]BloomFilters, error) {
+	var bytes []byte
+	offsets := []uint32{0}
+	fstart := []uint32{0}
+	desc := make([]bloomgpu.FilterDesc, 0, 3*len(sets))
+	var cursor uint64
+	for _, s := range sets {
+		for _, set := range []map[string]struct{}{s.fields, s.tokens, s.fieldTokens} {
+			m, k := sizeFor(len(set), fpr)
+			desc = append(desc, bloomgpu.FilterDesc{WordOff: cursor, M: m, K: k})
+			cursor += (m + 63) / 64
+			for entry := range set {
+				bytes = append(bytes, entry...)
+				offsets = append(offsets, uint32(len(bytes)))
+			}
+			fstart = append(fstart, uint32(len(offsets)-1))
+		}
+	}
+	words, err := g.Build(bytes, offsets, fstart, desc, cursor)
+	if err != nil {
+		return nil, err
+	}
+	out := make([]BloomFilters, len(sets))
+	for i := range sets {
+		out[i] = BloomFilters{
+			FieldBloomFilter:      gpuFilter(words, desc[3*i]),
+			TokenBloomFilter:      gpuFilter(words, desc[3*i+1]),
+			FieldTokenBloomFilter: gpuFilter(words, desc[3*i+2]),
+		}
+	}
+	return out, nil
+}
+
+// buildFiltersFromRowsGPU is the device-ingest variant of the flush / merge build: the marshaled rows of every
+// partition buffer go to the device as they are, which walks, tokenizes, deduplicates and counts them —
+// bloomEntrySets.indexRow never runs on the host for rows inside the device walker's envelope.  Only valid for the
+// default tokenizer (isBasicWhitespaceLowerTokenizer, row_matcher.go:37-40).  rows[b] = marshaled rows of partition
+// buffer b.  Returns per-buffer filters + counts, then the file-level ones (last element).
+func buildFiltersFromRowsGPU(g *bloomgpu.Context, rows [][][]byte, fpr float64) ([]BloomFilters, []BloomEntryCounts, error) {
+	var blob []byte
+	rowOff := []uint64{0}
+	first := []uint32{0}
+	parent := make([]uint32, len(rows)) // every buffer's parent is file-level set 0 (flush.go:221)
+	for _, buf := range rows {
+		for _, r := range buf {
+			blob = append(blob, r...)
+			rowOff = append(rowOff, uint64(len(blob)))
+		}
+		first = append(first, uint32(len(rowOff)-1))
+	}
+	ing, err := g.IngestRows(blob, rowOff, first, parent, 1, bloomgpu.IngestTrustedJSON /* json.Marshal output */)
+	if err != nil {
+		return nil, nil, err
+	}
+	defer ing.Free()
+	fb, err := ing.FallbackRows()
+	if err != nil {
+		return nil, nil, err
+	}
+	if len(fb) > 0 {
+		// rows outside the device walker's envelope (invalid UTF-8, lone surrogate escapes, raw control bytes, code
+		// points newer than the library's Unicode tables, very deep nesting): the engine's own indexRow, entries handed over
+		perSet := map[uint32]*bloomEntrySets{}
+		for _, r := range fb {
+			b := uint32(sort.Search(len(first), func(i int) bool { return first[i] > r }) - 1)
+			if perSet[b] == nil {
+				perSet[b] = newBloomEntrySets()
+			}
+			perSet[b].indexRow(rows[b][r-first[b]], BasicWhitespaceLowerTokenizer)
+		}
+		var eb []byte
+		eo, es, ek := []uint32{0}, []uint32{}, []uint32{}
+		for b, s := range perSet {
+			for kind, set := range []map[string]struct{}{s.fields, s.tokens, s.fieldTokens} {
+				for e := range set {
+					eb = append(eb, e...)
+					eo, es, ek = append(eo, uint32(len(eb))), append(es, b), append(ek, uint32(kind))
+				}
+			}
+		}
+		if err := ing.AddEntries(eb, eo, es, ek); err != nil {
+			return nil, nil, err
+		}
+	}
+	counts, status, err := ing.Finish()
+	if err != nil {
+		return nil, nil, err
+	}
+	for _, st := range status {
+		if st != 0 { // 2^-62 per entry: a set the tables cannot represent -> the stock host path for this flush
+			return nil, nil, errGPUSetUnrepresentable
+		}
+	}
+	n := len(rows) + 1
+	desc := make([]bloomgpu.FilterDesc, 3*n)
+	var cursor uint64
+	for i, c := range counts {
+		m, k := sizeFor(int(c), fpr)
+		desc[i] = bloomgpu.FilterDesc{WordOff: cursor, M: m, K: k}
+		cursor += (m + 63) / 64
+	}
+	words, err := ing.Build(desc, cursor)
+	if err != nil {
+		return nil, nil, err
+	}
+	filters := make([]BloomFilters, n)
+	entryCounts := make([]BloomEntryCounts, n)
+	for i := 0; i < n; i++ {
+		filters[i] = BloomFilters{
+			FieldBloomFilter:      gpuFilter(words, desc[3*i]),
+			TokenBloomFilter:      gpuFilter(words, desc[3*i+1]),
+			FieldTokenBloomFilter: gpuFilter(words, desc[3*i+2]),
+		}
+		entryCounts[i] = BloomEntryCounts{Fields: int(counts[3*i]), Tokens: int(counts[3*i+1]), FieldTokens: int(counts[3*i+2])}
+	}
+	return filters, entryCounts, nil
+}
+
+// loadArena uploads already-decoded block filters (what blockFilterCursor.filtersFor + parseFilterSection yield per
+// block).  A nil filter becomes m == 0: it cannot disqualify (query_exec.go:137-151).
+func loadArena(g *bloomgpu.Context, blocks []*BloomFilters) (bloomgpu.Arena, error) {
+	var words []uint64
+	desc := make([]bloomgpu.FilterDesc, 0, 3*len(blocks))
+	for _, b := range blocks {
+		for _, f := range []*bloom.BloomFilter{b.FieldBloomFilter, b.TokenBloomFilter, b.FieldTokenBloomFilter} {
+			if f == nil {
+				desc = append(desc, bloomgpu.FilterDesc{})
+				continue
+			}
+			desc = append(desc, bloomgpu.FilterDesc{WordOff: uint64(len(words)), M: uint64(f.Cap()), K: uint32(f.K())})
+			words = append(words, f.BitSet().Bytes()...) // native []uint64, no byte swap
+		}
+	}
+	return g.ArenaLoad(words, desc)
+}
+
+// loweredQuery is a *BloomQuery flattened into distinct terms + a postfix program, case by case after
+// evaluateBloomExpression / evaluateBloomCondition (query_exec.go:89-159).
+type loweredQuery struct {
+	index map[string]uint32 // kind byte + key -> term index
+	keys  []string
+	kinds []uint32
+	ops   []uint32
+}
+
+func (l *loweredQuery) term(kind uint32, key string) uint32 {
+	if l.index == nil {
+		l.index = map[string]uint32{}
+	}
+	k := string(rune('0'+kind)) + key
+	if i, ok := l.index[k]; ok {
+		return i
+	}
+	i := uint32(len(l.keys))
+	l.index[k] = i
+	l.keys = append(l.keys, key)
+	l.kinds = append(l.kinds, kind)
+	return i
+}
+
+func (l *loweredQuery) emit(e *BloomExpression) {
+	if e == nil {
+		l.ops = append(l.ops, bloomgpu.Op(bloomgpu.OpTrue, 0))
+		return
+	}
+	switch e.ExpressionType {
+	case BloomExpressionCondition:
+		switch {
+		case e.Condition == nil:
+			l.ops = append(l.ops, bloomgpu.Op(bloomgpu.OpTrue, 0))
+		case e.Condition.Type == BloomField:
+			l.ops = append(l.ops, bloomgpu.Op(bloomgpu.OpTerm, l.term(bloomgpu.KindField, e.Condition.Field)))
+		case e.Condition.Type == BloomToken:
+			l.ops = append(l.ops, bloomgpu.Op(bloomgpu.OpTerm, l.term(bloomgpu.KindToken, e.Condition.Token)))
+		case e.Condition.Type == BloomFieldToken:
+			l.ops = append(l.ops, bloomgpu.Op(bloomgpu.OpTerm, l.term(bloomgpu.KindFieldToken, makeFieldTokenKey(e.Condition.Field, e.Condition.Token))))
+		default:
+			l.ops = append(l.ops, bloomgpu.Op(bloomgpu.OpFalse, 0))
+		}
+	case BloomExpressionAnd, BloomExpressionOr:
+		for i := range e.Children {
+			l.emit(&e.Children[i])
+		}
+		op := bloomgpu.OpAnd
+		if e.ExpressionType == BloomExpressionOr {
+			op = bloomgpu.OpOr
+		}
+		l.ops = append(l.ops, bloomgpu.Op(op, uint32(len(e.Children))))
+	default:
+		l.ops = append(l.ops, bloomgpu.Op(bloomgpu.OpFalse, 0))
+	}
+}
+
+// compileBloomQueries lowers a batch of queries (nil query / nil expression = no ops = every block survives,
+// query_exec.go:81-83) and hashes every distinct term ONCE on the device.
+func compileBloomQueries(g *bloomgpu.Context, queries []*BloomQuery) (bloomgpu.Batch, error) {
+	var l loweredQuery
+	progOff := []uint32{0}
+	for _, q := range queries {
+		if q != nil && q.Expression != nil {
+			l.emit(q.Expression)
+		}
+		progOff = append(progOff, uint32(len(l.ops)))
+	}
+	bytes, offsets := bloomgpu.PackEntries(l.keys)
+	h, err := g.HashEntries(bytes, offsets)
+	if err != nil {
+		return bloomgpu.Batch{}, err
+	}
+	terms := make([]bloomgpu.Term, len(l.keys))
+	for i := range terms {
+		terms[i] = bloomgpu.Term{H: h[i], Kind: l.kinds[i]}
+	}
+	return g.BatchCreate(terms, l.ops, progOff)
+}
+
+// probeBlocks replaces the per-block loop of evaluateBlockFilters (query_exec.go:572-615) for the candidate files of one
+// query stage: survivors[f][b>>6] bit b&63 == evaluateBloomFilters(block b of file f, pruneBloomQuery).  perBlock is
+// the synthesised BlockStats.Duration share of one block (batch time / blocks; asserted > 0 at
+// query_handles_test.go:1062).
+func probeBlocks(g *bloomgpu.Context, arenas []bloomgpu.Arena, q *BloomQuery) (survivors [][]uint64, perBlock time.Duration, err error) {
+	start := time.Now()
+	batch, err := compileBloomQueries(g, []*BloomQuery{q})
+	if err != nil {
+		return nil, 0, err
+	}
+	defer g.BatchFree(batch)
+	survivors, err = g.ProbeMany(arenas, batch)
+	blocks := 0
+	for _, a := range arenas {
+		blocks += int(a.Blocks)
+	}
+	return survivors, blockDuration(time.Since(start), blocks), err
+}
+
+// blockDuration spreads a batch's wall time over its blocks, never returning zero for a block that was evaluated.
+func blockDuration(batch time.Duration, blocks int) time.Duration {
+	if blocks <= 0 {
+		return 0
+	}
+	return max(batch/time.Duration(blocks), time.Nanosecond)
+}
+
+// matchRowsGPU is the final row test of the surviving blocks' rows for a Field / Token / FieldToken expression (regex
+// conditions keep matchRowBytes).  FieldToken is the (path, token) PAIR at one leaf, not the joined key
+// (row_matcher.go:587).  Rows in hostRows must be decided by the stock matcher.
+func matchRowsGPU(g *bloomgpu.Context, rows [][]byte, expr *BloomExpression) (bits []uint64, hostRows []uint32, err error) {
+	var blob []byte
+	rowOff := []uint64{0}
+	for _, r := range rows {
+		blob = append(blob, r...)
+		rowOff = append(rowOff, uint64(len(blob)))
+	}
+	var fields, tokens []string
+	var kinds []uint32
+	var ops []uint32
+	var walk func(e *BloomExpression)
+	walk = func(e *BloomExpression) {
+		if e == nil {
+			ops = append(ops, bloomgpu.Op(bloomgpu.OpTrue, 0))
+			return
+		}
+		switch e.ExpressionType {
+		case BloomExpressionCondition:
+			c := e.Condition
+			switch {
+			case c == nil:
+				ops = append(ops, bloomgpu.Op(bloomgpu.OpTrue, 0))
+			case c.Type == BloomField || c.Type == BloomToken || c.Type == BloomFieldToken:
+				kind := map[BloomConditionType]uint32{BloomField: bloomgpu.KindField, BloomToken: bloomgpu.KindToken, BloomFieldToken: bloomgpu.KindFieldToken}[c.Type]
+				ops = append(ops, bloomgpu.Op(bloomgpu.OpTerm, uint32(len(kinds))))
+				fields, tokens, kinds = append(fields, c.Field), append(tokens, c.Token), append(kinds, kind)
+			default:
+				ops = append(ops, bloomgpu.Op(bloomgpu.OpFalse, 0))
+			}
+		case BloomExpressionAnd, BloomExpressionOr:
+			for i := range e.Children {
+				walk(&e.Children[i])
+			}
+			op := bloomgpu.OpAnd
+			if e.ExpressionType == BloomExpressionOr {
+				op = bloomgpu.OpOr
+			}
+			ops = append(ops, bloomgpu.Op(op, uint32(len(e.Children))))
+		default:
+			ops = append(ops, bloomgpu.Op(bloomgpu.OpFalse, 0))
+		}
+	}
+	if expr != nil {
+		walk(expr)
+	}
+	fb, fo := bloomgpu.PackEntries(fields)
+	hf, err := g.HashEntries(fb, fo)
+	if err != nil {
+		return nil, nil, err
+	}
+	tb, to := bloomgpu.PackEntries(tokens)
+	ht, err := g.HashEntries(tb, to)
+	if err != nil {
+		return nil, nil, err
+	}
+	conds := make([]bloomgpu.MatchCond, len(kinds))
+	for i := range conds {
+		conds[i] = bloomgpu.MatchCond{HF: hf[i], HT: ht[i], Kind: kinds[i]}
+	}
+	return g.MatchRows(blob, rowOff, conds, ops)
+}

@@ -240,6 +240,22 @@ BSG_API int32_t bsg_or_reduce_dev(bsg_ctx *ctx, uint64_t arena_id, uint32_t kind
 /* Device time of the most recent k_or_reduce_blocks dispatch on the context's first device. */
 BSG_API int32_t bsg_last_or_ms(bsg_ctx *ctx, float *or_ms);
 
+/* ---- the OR-reduce across GPUs: RCCL over xGMI inside the library (a Go host cannot call torch.distributed) ----
+ * RCCL has no bitwise-OR reduction: the all-reduce is ncclAllGather of the ranks' partial bitsets (each GPU receives
+ * (world - 1) / world of the result over its point-to-point links in parallel) + one local OR kernel.  librccl is bound
+ * at run time; without it these calls fail with BSG_E_UNSUPPORTED and everything else keeps working.
+ *   one process per GPU : rank 0 calls bsg_comm_unique_id and hands the 128 bytes to the other ranks (any channel);
+ *                         every rank calls bsg_comm_init(ctx, id, rank, world) on its single-device context.
+ *   one process, N GPUs : bsg_comm_init(ctx, NULL, 0, 0) makes every device of the context a rank (ncclCommInitAll).
+ * bsg_or_allreduce = bsg_or_reduce over the whole communicator: every rank's out_words receives the same bitset. */
+#define BSG_COMM_ID_BYTES 128
+BSG_API int32_t bsg_comm_unique_id(uint8_t *out_id);
+BSG_API int32_t bsg_comm_init(bsg_ctx *ctx, const uint8_t *id, int32_t rank, int32_t world);
+BSG_API int32_t bsg_comm_destroy(bsg_ctx *ctx);
+BSG_API int32_t bsg_or_allreduce(bsg_ctx *ctx, uint64_t arena_id, uint32_t kind, uint64_t *out_words, uint64_t n_words);
+/* In place on device memory: d_words[i] = n_words u64 on the context's device i (one pointer for a single-device context). */
+BSG_API int32_t bsg_or_allreduce_dev(bsg_ctx *ctx, void *const *d_words, uint64_t n_words);
+
 /* ---- filter sections written on the device (encodeFilterSection, file_format.go:343-384) ----
  * Section b = the three filters desc[3b .. 3b+2] (m == 0 => absent, flag bit clear):
  *   [u8 flags] { [u32 LE 24 + 8 nw] [u64 BE m] [u64 BE k] [u64 BE m] [nw x u64 BE words] }* [u32 LE CRC32C of all before]

@@ -98,11 +98,24 @@ def leaf_token_input(value):
     return None
 
 
+# Simple lowercase mappings Unicode 14.0 added (UnicodeData.txt 14.0.0, field 13), which this interpreter's Unicode 13.0
+# data lacks and every Go >= 1.21 (Unicode 15.0) has.  Transcribed independently of tools/gen_unicode_tables.py:
+#   2C2F -> 2C5F (Glagolitic caudate chrivi); A7C0 -> A7C1, A7D0 -> A7D1, A7D6 -> A7D7, A7D8 -> A7D9 (Latin Extended-D);
+#   Vithkuqi capitals 10570-1057A, 1057C-1058A, 1058C-10592, 10594-10595 -> +0x27.
+_UNICODE_14_LOWER = {0x2C2F: 0x2C5F, 0xA7C0: 0xA7C1, 0xA7D0: 0xA7D1, 0xA7D6: 0xA7D7, 0xA7D8: 0xA7D9}
+for _a, _b in ((0x10570, 0x1057A), (0x1057C, 0x1058A), (0x1058C, 0x10592), (0x10594, 0x10595)):
+    for _cp in range(_a, _b + 1):
+        _UNICODE_14_LOWER[_cp] = _cp + 0x27
+
+
 def _to_lower_rune(ch: str) -> str:
     """Go unicode.ToLower: SIMPLE case mapping (one rune -> one rune).  Python's str.lower() is the
     full mapping; for a single character they differ only for U+0130 (full: 'i' + U+0307)."""
     if ch == "\u0130":
         return "i"
+    d = _UNICODE_14_LOWER.get(ord(ch))
+    if d is not None:
+        return chr(d)
     lo = ch.lower()
     return lo if len(lo) == 1 else ch
 

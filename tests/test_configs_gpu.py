@@ -33,6 +33,26 @@ def gen_blocks(ids, rows=ROWS):
         return pool.map(_gen, jobs, chunksize=64)
 
 
+class HipMem:
+    """Raw device memory for the test (hipMalloc through ctypes on the HIP runtime the library itself links)."""
+
+    def __init__(self, n_bytes):
+        import ctypes as C
+        self.C = C
+        self.hip = C.CDLL("libamdhip64.so")
+        self.ptr = C.c_void_p()
+        assert self.hip.hipMalloc(C.byref(self.ptr), C.c_size_t(n_bytes)) == 0
+        self.n = n_bytes
+
+    def read(self):
+        out = np.zeros(self.n // 8, dtype=np.uint64)
+        assert self.hip.hipMemcpy(self.C.c_void_p(out.ctypes.data), self.ptr, self.C.c_size_t(self.n), 2) == 0   # hipMemcpyDeviceToHost
+        return out
+
+    def free(self):
+        self.hip.hipFree(self.ptr)
+
+
 def c4_batch(ctx, nq, seed=99):
     cb = Q.compile_queries(synth.make_queries(nq, "c4", seed))
     ops, poff, _ = cb.arrays()
@@ -124,6 +144,41 @@ def test_c5_or_reduce_of_1250_fixed_geometry_blocks_equals_oracle_build_of_the_u
         assert np.array_equal(mctx.or_reduce(aid, 1, nw), want.words)
 
 
+def test_rccl_or_allreduce_inside_the_library_world_of_one(ctx):
+    """bsg_comm_init / bsg_or_allreduce: librccl bound at run time, a communicator of one rank on this box's single GPU
+    (the N > 1 exchange runs in bench.py under torchrun): all-gather + OR must reproduce bsg_or_reduce, and the
+    in-place device form must leave the partial unchanged."""
+    from bloomsearch_amd.gpu import Context as Cx
+    rng = np.random.default_rng(41)
+    universe = ["tok%d" % i for i in range(5000)]
+    m, k = O.estimate_parameters(len(universe), 0.001)
+    nw = O.words_for(m)
+    stride = (nw + 15) // 16 * 16
+    n_blocks = 9
+    desc = np.zeros(n_blocks * 3, dtype=DESC_DTYPE)
+    fstart, ents = [0], []
+    for b in range(n_blocks):
+        fstart.append(len(ents))
+        desc[b * 3 + 1] = (b * stride, m, k, 0)
+        ents += [t for t in universe if rng.random() < 0.2]
+        fstart += [len(ents), len(ents)]
+    blob, off = pack_entries(ents)
+    words = ctx.build(blob, off, np.asarray(fstart, dtype=np.uint32), desc, n_blocks * stride)
+    aid = ctx.arena_load(words, desc)
+    want = ctx.or_reduce(aid, 1, nw)
+    with pytest.raises(BloomGpuError):
+        ctx.or_allreduce(aid, 1, nw)                        # no communicator yet
+    ctx.comm_init(Cx.comm_unique_id(), 0, 1)
+    assert np.array_equal(ctx.or_allreduce(aid, 1, nw), want)
+    dmem = HipMem(nw * 8)
+    assert dmem.hip.hipMemcpy(dmem.ptr, dmem.C.c_void_p(want.ctypes.data), dmem.C.c_size_t(nw * 8), 1) == 0   # HostToDevice
+    ctx.or_allreduce_dev([dmem.ptr.value], nw)
+    assert np.array_equal(dmem.read(), want)
+    dmem.free()
+    ctx.comm_destroy()
+    ctx.arena_free(aid)
+
+
 def test_grouped_launches_equal_one_launch_per_arena(ctx):
     """A dispatch covers a GROUP of arenas (per-arena pointers in the kernel arguments): any grouping — one arena per
     launch, 3, 32, more arenas than one group holds, arenas of different sizes, an arena without blocks, fused or not —
@@ -159,26 +214,6 @@ def test_grouped_launches_equal_one_launch_per_arena(ctx):
     for a in arenas:
         ctx.arena_free(a)
     ctx.batch_free(bid)
-
-
-class HipMem:
-    """Raw device memory for the test (hipMalloc through ctypes on the HIP runtime the library itself links)."""
-
-    def __init__(self, n_bytes):
-        import ctypes as C
-        self.C = C
-        self.hip = C.CDLL("libamdhip64.so")
-        self.ptr = C.c_void_p()
-        assert self.hip.hipMalloc(C.byref(self.ptr), C.c_size_t(n_bytes)) == 0
-        self.n = n_bytes
-
-    def read(self):
-        out = np.zeros(self.n // 8, dtype=np.uint64)
-        assert self.hip.hipMemcpy(self.C.c_void_p(out.ctypes.data), self.ptr, self.C.c_size_t(self.n), 2) == 0   # hipMemcpyDeviceToHost
-        return out
-
-    def free(self):
-        self.hip.hipFree(self.ptr)
 
 
 def test_survivors_to_device_pointer_and_async_host_output(ctx):

@@ -37,6 +37,24 @@ def test_basic_whitespace_tokenizer_table(text, expected):
     assert W.basic_whitespace_lower_tokenizer(text) == expected
 
 
+def test_unicode_14_case_pairs_fold_like_go_1_21_and_later():
+    """Cased letters added in Unicode 14.0 (Python 3.10's tables stop at 13.0): one row per added range, host twin
+    against the oracle's independently transcribed list (Go >= 1.21 ships Unicode 15.0; the reference needs Go 1.26)."""
+    cases = [("\u2c2f", "\u2c5f"),                              # Glagolitic
+             ("\ua7c0", "\ua7c1"), ("\ua7d0", "\ua7d1"), ("\ua7d6", "\ua7d7"), ("\ua7d8", "\ua7d9"),   # Latin Extended-D
+             ("\U00010570", "\U00010597"), ("\U0001057a", "\U000105a1"), ("\U0001057c", "\U000105a3"),
+             ("\U0001058a", "\U000105b1"), ("\U0001058c", "\U000105b3"), ("\U00010592", "\U000105b9"),
+             ("\U00010594", "\U000105bb"), ("\U00010595", "\U000105bc")]                                 # Vithkuqi, every sub-range's ends
+    for up, lo in cases:
+        text = "x%sy %s" % (up, up)
+        want = ["x%sy" % lo, lo]
+        assert Hst.tokenize(text) == want, hex(ord(up))
+        assert W.basic_whitespace_lower_tokenizer(text) == want
+    # the gaps inside the Vithkuqi block stay as they are
+    for cp in (0x1057B, 0x1058B, 0x10593):
+        assert Hst.tokenize(chr(cp)) == [chr(cp)]
+
+
 def test_tokenizer_unicode_folding_and_spaces():
     # row_matcher_test.go:38-41: Kelvin sign folds to 'k' (3 bytes -> 1), U+0130 folds to 'i', NBSP splits
     assert Hst.tokenize("Kelvin") == ["kelvin"]

@@ -11,7 +11,7 @@ import json
 import numpy as np
 import pytest
 
-from bloomsearch_amd import host as Hst, ingest as I, synth
+from bloomsearch_amd import host as Hst, ingest as I, query as Q, synth
 from oracle import oracle as O
 from oracle import walker_oracle as W
 from tests.test_host_tables import JSON_MATCHING, KEYS, _random_value, go_marshal
@@ -222,6 +222,28 @@ def test_unicode_fuzz_device_and_host_agree_with_the_oracle(ctx, flags):
         for u, x in zip(union, sets):
             u |= x
     check_against_sets(res, 8, union, "file")
+
+
+def test_unicode_14_case_pairs_fold_on_the_device_and_unknown_code_points_go_to_the_host(ctx, flags):
+    """Rows with cased letters Unicode 14.0 added fold on the device exactly as the oracle's list says (what Go >= 1.21
+    does); a code point the tables do not know (unassigned in the Unicode they were generated from: here U+A7CB and
+    U+10D50, both cased letters since Unicode 16.0) sends the row to the host, whose own unicode.ToLower decides."""
+    ups = ["\u2c2f", "\ua7c0", "\ua7d0", "\ua7d6", "\ua7d8", "\U00010570", "\U0001057c", "\U0001058c", "\U00010595"]
+    rows = [json.dumps({"msg": "Tok%s %s END" % (u, u), "k%s" % u: "v"}, ensure_ascii=bool(i & 1), separators=(",", ":")).encode()
+            for i, u in enumerate(ups)]
+    res = I.device_ingest(ctx, [rows], FPR, flags=flags)
+    assert len(res.fallback_rows) == 0
+    sets = oracle_sets(rows)
+    assert "tok\u2c5f" in sets[1] and "\U00010597" in sets[1]
+    check_against_sets(res, 0, sets, "unicode 14")
+    unknown = [json.dumps({"msg": "a%sb" % u}, ensure_ascii=bool(i & 1), separators=(",", ":")).encode()
+               for i, u in enumerate(["\ua7cb", "\U00010d50", "\ua7cb"])]
+    res = I.device_ingest(ctx, [rows[:2] + unknown], FPR, flags=flags)
+    assert list(res.fallback_rows) == [2, 3, 4]
+    # the host walker of this mirror finishes them (identity fold): nothing is lost
+    assert int(res.counts[0, 1]) == len(oracle_sets(rows[:2] + unknown)[1])
+    hits, handed_back = ctx.match_rows(unknown + rows[:1], Q.CompiledMatcher(Q.Token("tok\u2c5f")))
+    assert list(handed_back) == [0, 1, 2] and list(hits) == [False, False, False, True]
 
 
 def test_tables_grow_from_a_tiny_hint(ctx, flags):
