@@ -52,8 +52,9 @@ def op(opcode: int, arg: int = 0) -> int:
 # every symbol include/bloomgpu.h declares (tests assert the .so exports all of them)
 EXPORTS = [
     "bsg_device_count", "bsg_open", "bsg_open_err", "bsg_close", "bsg_last_error", "bsg_last_error_copy", "bsg_scope_open",
-    "bsg_sync", "bsg_estimate_parameters", "bsg_probe_many_dev", "bsg_set_probe_group", "bsg_set_gather_cost", "bsg_set_fuse_limit", "bsg_set_spin_wait",
+    "bsg_sync", "bsg_estimate_parameters", "bsg_probe_many_dev", "bsg_set_probe_group", "bsg_set_gather_cost", "bsg_set_fuse_limit", "bsg_set_spin_wait", "bsg_set_ingest_chunk",
     "bsg_hash_entries", "bsg_build", "bsg_build_hashed", "bsg_arena_load", "bsg_arena_load_sections", "bsg_arena_free",
+    "bsg_arena_stream_begin", "bsg_arena_stream_append", "bsg_arena_stream_finish", "bsg_arena_stream_abort",
     "bsg_batch_create", "bsg_batch_free", "bsg_probe_batch", "bsg_probe_many", "bsg_probe", "bsg_timing_read", "bsg_set_timed_stride", "bsg_last_kernel_ms",
     "bsg_or_reduce", "bsg_or_words_dev", "bsg_or_reduce_dev", "bsg_last_or_ms",
     "bsg_comm_unique_id", "bsg_comm_init", "bsg_comm_destroy", "bsg_or_allreduce", "bsg_or_allreduce_dev",
@@ -86,6 +87,7 @@ def load():
     L.bsg_set_gather_cost.argtypes = [vp, u32]
     L.bsg_set_fuse_limit.argtypes = [vp, u32]
     L.bsg_set_spin_wait.argtypes = [vp, u32]
+    L.bsg_set_ingest_chunk.argtypes = [vp, u64]
     L.bsg_close.argtypes = [vp]
     L.bsg_last_error.argtypes = [vp]
     L.bsg_last_error.restype = C.c_char_p
@@ -97,6 +99,10 @@ def load():
     L.bsg_arena_load.argtypes = [vp, vp, u64, vp, u32, C.POINTER(u64)]
     L.bsg_arena_load_sections.argtypes = [vp, vp, u64, vp, u32, vp, C.POINTER(u64)]
     L.bsg_arena_free.argtypes = [vp, u64]
+    L.bsg_arena_stream_begin.argtypes = [vp, vp, vp, u32, C.POINTER(u64)]
+    L.bsg_arena_stream_append.argtypes = [vp, u64, u64, vp, u64]
+    L.bsg_arena_stream_finish.argtypes = [vp, u64, vp, C.POINTER(u64)]
+    L.bsg_arena_stream_abort.argtypes = [vp, u64]
     L.bsg_batch_create.argtypes = [vp, vp, u32, vp, vp, u32, C.POINTER(u64)]
     L.bsg_batch_free.argtypes = [vp, u64]
     L.bsg_probe_batch.argtypes = [vp, u64, u64, u32, vp]

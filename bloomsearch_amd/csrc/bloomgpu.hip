@@ -114,7 +114,7 @@ struct DevPool {
     std::multimap<size_t, void *> idle;            // size class -> block
     std::map<void *, size_t> live;                 // block -> size class
     size_t idle_bytes = 0;
-    static constexpr size_t kMaxIdleBytes = 6ull << 30;
+    static constexpr size_t kMaxIdleBytes = 48ull << 30;   // of 288 GB: a 10 M-row flush holds ~10 GB of tables + rows, and hipMalloc of that costs 0.2-0.5 s
     static size_t size_class(size_t n)
     {
         n = std::max<size_t>(n, 256);
@@ -181,6 +181,7 @@ struct Device {
     DevBuf<bsg::BuildItem> stage_items;
     DevBuf<uint64_t> stage_words;
     DevBuf<uint8_t> stage_region;  // encoded filter sections
+    std::vector<uint8_t *> idle_staging;   // pinned 4 MiB chunk buffers of finished arena streams
     std::vector<EventTriple> pending;
     std::vector<EventTriple> free_events;
     uint32_t *d_lower = nullptr;              // unicode.ToLower table for k_ingest_rows (512 KB)
@@ -231,6 +232,7 @@ struct Batch {
 };
 
 struct Ingest;   // ingest_api.inc
+struct ArenaStream;   // stream_api.inc
 
 }  // namespace
 
@@ -243,6 +245,7 @@ struct bsg_ctx {
     std::map<uint64_t, std::shared_ptr<Arena>> arenas;
     std::map<uint64_t, std::shared_ptr<Batch>> batches;
     std::map<uint64_t, std::shared_ptr<Ingest>> ingests;
+    std::map<uint64_t, std::shared_ptr<ArenaStream>> streams;
     uint64_t next_id = 1;
     bsg_timing timing{};
     uint32_t timed_stride = 1;   // with BSG_PROBE_TIMED, timestamp every timed_stride-th launch
@@ -251,6 +254,7 @@ struct bsg_ctx {
     uint32_t gather_cost = 256;  // a filter is gathered instead of staged when terms * k * gather_cost < its bytes
     std::vector<void *> comms;   // ncclComm_t per device (bsg_comm_init)
     uint32_t comm_world = 0, comm_rank = 0;
+    uint64_t ingest_chunk_bytes = 64ull << 20;   // rows per upload chunk of bsg_ingest_rows (bsg_set_ingest_chunk)
     uint32_t spin_wait_us = 0;   // synchronous probes poll the stream this long before blocking (bsg_set_spin_wait)
     uint32_t fuse_max_arenas = 4; // groups up to this many arenas ride fused (probe of group i + eval of group i-1)
 };
@@ -266,6 +270,7 @@ bsg_ctx *root_of(bsg_ctx *c) { return c->parent ? c->parent : c; }
 
 void free_all_ingests(bsg_ctx *ctx);   // ingest_api.inc
 void destroy_comms(bsg_ctx *ctx);      // comm_api.inc
+void free_all_streams(bsg_ctx *ctx);   // stream_api.inc
 int32_t ensure_lower_table(Device &d);   // ingest_api.inc: the unicode.ToLower table the walkers fold with
 
 struct SectionsOut { uint8_t *region; uint64_t cap; uint64_t *sec_off; };   // encode_api.inc
@@ -503,6 +508,7 @@ int32_t bsg_close(bsg_ctx *ctx)
     for (auto &kv : ctx->arenas) free_arena(ctx, *kv.second);
     for (auto &kv : ctx->batches) free_batch(ctx, *kv.second);
     free_all_ingests(ctx);
+    free_all_streams(ctx);
     destroy_comms(ctx);
     for (auto &dp : ctx->devs) {
         Device &d = *dp;
@@ -515,6 +521,7 @@ int32_t bsg_close(bsg_ctx *ctx)
         }
         if (d.kb0) { (void)hipEventDestroy(d.kb0); (void)hipEventDestroy(d.kb1); }
         d.pool.trim(0);
+        for (uint8_t *p : d.idle_staging) (void)hipHostFree(p);
         if (d.d_crc) (void)hipFree(d.d_crc);
         if (d.d_lower) (void)hipFree(d.d_lower);
         for (auto *v : {&d.pending, &d.free_events})
@@ -811,134 +818,6 @@ inline uint32_t rd_le32(const uint8_t *p) { uint32_t v; memcpy(&v, p, 4); return
 
 extern "C" {
 
-// Arena straight from the on-disk bytes: the host only walks the section HEADERS (flags, lengths, m, k —
-// a few dozen bytes per block) to lay the arena out; CRC32C and the big-endian -> native word decode of
-// every filter run on the device (k_decode_sections).
-int32_t bsg_arena_load_sections(bsg_ctx *ctx, const uint8_t *region, uint64_t region_len, const uint64_t *sec_off,
-                                uint32_t n_blocks, int32_t *out_status, uint64_t *out_arena_id)
-{
-    BSG_ENTER(ctx);
-    if (!ctx || !out_arena_id || (n_blocks && (!sec_off || !out_status))) return fail(BSG_E_INVALID, "null argument");
-    if (ctx->devs.size() != 1) return fail(BSG_E_UNSUPPORTED, "bsg_arena_load_sections needs a single-device context");
-    if (region_len && !region) return fail(BSG_E_INVALID, "region is null");
-    for (uint32_t b = 0; b < n_blocks; ++b)
-        if (sec_off[b + 1] < sec_off[b] || sec_off[b + 1] > region_len) return fail(BSG_E_INVALID, "sec_off not monotone / outside region at %u", b);
-    auto arena = std::make_shared<Arena>();
-    arena->n_blocks = n_blocks;
-    arena->shards.resize(1);
-    ArenaShard &s = arena->shards[0];
-    s.n_blocks = n_blocks;
-    std::vector<bsg::SectionInfo> info(n_blocks);
-    std::vector<DevDesc> dd((size_t)n_blocks * 3);
-    uint64_t cursor = 0;
-    for (uint32_t b = 0; b < n_blocks; ++b) {
-        bsg::SectionInfo &si = info[b];
-        si = bsg::SectionInfo{};
-        const uint8_t *sec = region + sec_off[b];
-        const uint64_t len = sec_off[b + 1] - sec_off[b];
-        for (uint32_t c = 0; c < 3; ++c) dd[(size_t)b * 3 + c] = DevDesc{0, 0, 0, 0, 0};
-        out_status[b] = 0;
-        if (len == 0) continue;                                   // block without a section: all filters nil
-        if (len < 5 || len > 0xFFFFFFFFull) { out_status[b] = -1; continue; }   // parseFilterSection: too small
-        si.begin = sec_off[b];
-        si.len = (uint32_t)len;                                   // the device checks the CRC even if the structure is bad
-        const uint64_t plen = len - 4;
-        const uint8_t flags = sec[0];
-        if (flags & ~7u) { out_status[b] = -3; continue; }
-        uint64_t pos = 1;
-        int32_t st = 0;
-        DevDesc tmp[3] = {};
-        uint32_t woff[3] = {0, 0, 0}, nwv[3] = {0, 0, 0};
-        for (uint32_t c = 0; c < 3 && st == 0; ++c) {
-            if (!((flags >> c) & 1)) continue;
-            if (plen - pos < 4) { st = -4; break; }
-            const uint64_t flen = rd_le32(sec + pos);
-            pos += 4;
-            if (flen > plen - pos) { st = -4; break; }
-            if (flen < 24) { st = -5; break; }
-            const uint64_t m = rd_be64(sec + pos), k = rd_be64(sec + pos + 8), bl = rd_be64(sec + pos + 16);
-            // k is bounded (kMaxHashCount): a corrupt section with a valid CRC must not make k_probe_terms loop 2^32 times
-            // per term.  (bloom/v3 ReadFrom accepts m and the bitset length independently; a filter whose bitset is
-            // shorter than m is a bad filter here — nil, i.e. it cannot prune — see INTEGRATION.md.)
-            if (bl > ~0ull - 63 || m == 0 || k == 0 || k > kMaxHashCount) { st = -5; break; }
-            const uint64_t nw = (bl + 63) / 64;
-            if (nw > (flen - 24) / 8 || (m + 63) / 64 > nw) { st = -5; break; }
-            tmp[c] = DevDesc{0, m, barrett_magic(m), (uint32_t)k, 0};
-            woff[c] = (uint32_t)(pos + 24);
-            nwv[c] = (uint32_t)((m + 63) / 64);
-            pos += flen;
-        }
-        if (st == 0 && pos != plen) st = -6;
-        if (st) { out_status[b] = st; continue; }
-        for (uint32_t c = 0; c < 3; ++c) {
-            if (!tmp[c].m) continue;
-            tmp[c].word_off = cursor;
-            cursor += ((uint64_t)nwv[c] + kAlignWords - 1) / kAlignWords * kAlignWords;
-            dd[(size_t)b * 3 + c] = tmp[c];
-            si.present |= 1u << c;
-            si.woff[c] = woff[c]; si.nw[c] = nwv[c]; si.dst[c] = tmp[c].word_off;
-            s.sum_words[c] += nwv[c];
-            if (nwv[c] <= kLdsCapWords) s.max_staged_words[c] = std::max<uint64_t>(s.max_staged_words[c], nwv[c]);
-            if (s.fixed_m[c] == 0 && s.geometry_uniform[c]) { s.fixed_m[c] = tmp[c].m; s.fixed_k[c] = tmp[c].k; }
-            else if (s.fixed_m[c] != tmp[c].m || s.fixed_k[c] != tmp[c].k) s.geometry_uniform[c] = false;
-        }
-    }
-    s.n_words = cursor + kAlignWords;
-    Device &d = *ctx->devs[0];
-    std::lock_guard<std::mutex> lk(d.mu);
-    if (int32_t rc = use_device(d)) return rc;
-    uint8_t *d_region = nullptr;
-    bsg::SectionInfo *d_info = nullptr;
-    int32_t *d_status = nullptr;
-    auto cleanup = [&]() {
-        if (d_region) (void)hipFree(d_region);
-        if (d_info) (void)hipFree(d_info);
-        if (d_status) (void)hipFree(d_status);
-    };
-    hipError_t e = hipSuccess;
-    bool timed_decode = false;
-    if (!d.d_crc) {
-        e = hipMalloc(reinterpret_cast<void **>(&d.d_crc), sizeof(bsg::CrcConsts));
-        if (e == hipSuccess) e = hipMemcpyAsync(d.d_crc, &crc_consts(), sizeof(bsg::CrcConsts), hipMemcpyHostToDevice, d.stream);
-    }
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&s.d_words), s.n_words * 8);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&s.d_desc), std::max<size_t>(dd.size(), 1) * sizeof(DevDesc));
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_region), region_len + 64);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_info), std::max<size_t>(info.size(), 1) * sizeof(bsg::SectionInfo));
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_status), std::max<size_t>(n_blocks, 1) * 4);
-    if (e == hipSuccess) e = hipMemsetAsync(s.d_words, 0, s.n_words * 8, d.stream);
-    if (e == hipSuccess && region_len) e = hipMemcpyAsync(d_region, region, region_len, hipMemcpyHostToDevice, d.stream);
-    if (e == hipSuccess && n_blocks) {
-        e = hipMemcpyAsync(s.d_desc, dd.data(), dd.size() * sizeof(DevDesc), hipMemcpyHostToDevice, d.stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(d_info, info.data(), info.size() * sizeof(bsg::SectionInfo), hipMemcpyHostToDevice, d.stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(d_status, out_status, (size_t)n_blocks * 4, hipMemcpyHostToDevice, d.stream);
-        if (e == hipSuccess) {
-            if (!d.kb0) { e = hipEventCreate(&d.kb0); if (e == hipSuccess) e = hipEventCreate(&d.kb1); }
-            if (e == hipSuccess) {
-                hipExtLaunchKernelGGL(bsg::k_decode_sections, dim3(n_blocks), dim3(bsg::kDecodeThreads), 0, d.stream, d.kb0, d.kb1, 0,
-                                      (const uint8_t *)d_region, (const bsg::SectionInfo *)d_info, (const bsg::CrcConsts *)d.d_crc,
-                                      s.d_words, s.d_desc, d_status);
-                e = hipGetLastError();
-                timed_decode = e == hipSuccess;
-            }
-        }
-        if (e == hipSuccess) e = hipMemcpyAsync(out_status, d_status, (size_t)n_blocks * 4, hipMemcpyDeviceToHost, d.stream);
-    }
-    if (e == hipSuccess) e = hipStreamSynchronize(d.stream);
-    d.last_decode_ms = 0.f;
-    if (e == hipSuccess && timed_decode) e = hipEventElapsedTime(&d.last_decode_ms, d.kb0, d.kb1);
-    cleanup();
-    if (e != hipSuccess) {
-        free_arena(ctx, *arena);
-        return fail(e == hipErrorOutOfMemory ? BSG_E_NOMEM : BSG_E_HIP, "section upload/decode failed: %s", hipGetErrorString(e));
-    }
-    std::lock_guard<std::mutex> lk2(ctx->mu);
-    const uint64_t id = ctx->next_id++;
-    ctx->arenas[id] = arena;
-    *out_arena_id = id;
-    return BSG_OK;
-}
-
 int32_t bsg_arena_free(bsg_ctx *ctx, uint64_t arena_id)
 {
     BSG_ENTER(ctx);
@@ -1136,7 +1015,7 @@ struct Group {
     std::vector<uint32_t> index;     // position of each shard's arena in the caller's list
     uint64_t v_words = 0;            // verdict scratch the group needs (u64)
     uint64_t out_words = 0;          // survivors the group produces (u64)
-    uint32_t max_blocks = 0, max_G = 0;
+    uint32_t max_blocks = 0, max_G = 0, total_G = 0;
 };
 
 void fill_refs(const Group &g, const Batch &B, bsg::ArenaRef *refs)
@@ -1160,6 +1039,7 @@ void group_add(Group &g, const Batch &B, const ArenaShard &s, uint32_t idx)
     g.out_words += (uint64_t)B.n_queries * G;
     g.max_blocks = std::max(g.max_blocks, s.n_blocks);
     g.max_G = std::max(g.max_G, G);
+    g.total_G += G;
 }
 
 // K1 arguments: stream every referenced bitset of the group once, one verdict word per (block, 64 terms) into V[slot].
@@ -1209,7 +1089,14 @@ int32_t make_eval_args(Device &d, const Group &g, const BatchDev &bd, const Batc
 
 // Small launches keep one block group per eval workgroup (latency); large ones tile kEvalGroupTile groups so a
 // query's survivor words leave as one 32-byte store instead of four strided 8-byte stores.
-uint32_t eval_tile_for(const Group &g) { return g.max_G >= 64 ? bsg::kEvalGroupTile : 1u; }
+// (A 32-arena group of 1 000-block arenas with one group per workgroup wrote 66.7 MB for 16.8 MB of survivors: 8-byte
+// stores at a 128-byte stride cost a 32-byte sector each.)
+uint32_t eval_tile_for(const Group &g)
+{
+    static const char *force = getenv("BSG_LAB_EVAL_TILE");   // lab only
+    if (force) return std::max(1, atoi(force));
+    return (g.max_G >= 64 || g.total_G >= 64) ? bsg::kEvalGroupTile : 1u;
+}
 
 int32_t enqueue_terms(bsg_ctx *ctx, Device &d, const Group &g, const BatchDev &bd, const Batch &B, uint32_t slot, EventTriple *ev)
 {
@@ -1442,6 +1329,13 @@ extern "C" int32_t bsg_set_probe_group(bsg_ctx *ctx, uint32_t max_arenas_per_lau
 {
     BSG_ENTER(ctx);
     ctx->group_limit = max_arenas_per_launch ? std::min(max_arenas_per_launch, bsg::kMaxGroupArenas) : bsg::kMaxGroupArenas;
+    return BSG_OK;
+}
+
+extern "C" int32_t bsg_set_ingest_chunk(bsg_ctx *ctx, uint64_t bytes)
+{
+    BSG_ENTER(ctx);
+    ctx->ingest_chunk_bytes = bytes ? std::max<uint64_t>(bytes, 1u << 16) : (64ull << 20);
     return BSG_OK;
 }
 
@@ -1704,3 +1598,4 @@ int32_t bsg_or_reduce(bsg_ctx *ctx, uint64_t arena_id, uint32_t kind, uint64_t *
 #include "ingest_api.inc"
 #include "match_api.inc"
 #include "comm_api.inc"
+#include "stream_api.inc"

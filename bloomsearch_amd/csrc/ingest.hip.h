@@ -285,6 +285,7 @@ struct IngestArgs {
     uint32_t n_rows;
     uint32_t n_sets;
     uint32_t validate;              // 1: run the validation pass first (rows of unknown provenance)
+    uint32_t row_first, row_end;    // this launch walks rows [row_first, row_end): a chunk whose bytes have landed
 };
 
 typedef __attribute__((address_space(3))) uint8_t lds_u8;
@@ -764,8 +765,8 @@ __global__ __launch_bounds__(kIngestThreads, BSG_INGEST_WPE) void k_ingest_rows(
     lds_u64i *cache = (lds_u64i *)lds_raw;
     for (uint32_t i = threadIdx.x; i < kCacheEntries * 4; i += kIngestThreads) cache[i] = 0;
     __syncthreads();
-    const uint32_t r = blockIdx.x * kIngestThreads + threadIdx.x;
-    const bool live = r < a.n_rows;
+    const uint32_t r = a.row_first + blockIdx.x * kIngestThreads + threadIdx.x;
+    const bool live = r < a.row_end;
     // the set this row belongs to: last s with set_first_row[s] <= r
     uint32_t lo = 0, hi = a.n_sets;
     while (live && hi - lo > 1) {

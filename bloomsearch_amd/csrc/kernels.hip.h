@@ -930,48 +930,110 @@ __device__ __forceinline__ uint32_t crc32c_payload(const uint8_t *sec, uint32_t 
     return part[0];
 }
 
-struct SectionInfo {
-    uint64_t begin;          // byte offset of the section in the uploaded region
-    uint32_t len;            // section bytes incl. the 4-byte CRC trailer (0 => nothing to do)
-    uint32_t present;        // bit c set: filter c is decoded
-    uint32_t woff[3];        // byte offset of filter c's first big-endian word inside the section
-    uint32_t nw[3];          // words of filter c
-    uint64_t dst[3];         // word offset of filter c in the arena
+// One on-disk section as the region cursor knows it before any byte of it has been read: where it lies and where its
+// filters will go.  Everything else — flags, lengths, (m, k), the word counts — is parsed ON THE DEVICE from the bytes
+// themselves (k_decode_sections), so the host never looks inside a section on the read path.
+struct SectionSlot {
+    uint64_t begin;          // byte offset of the section inside the uploaded region image
+    uint64_t slot_words;     // word offset of the section's slot in the arena (128-byte aligned)
+    uint32_t len;            // section bytes incl. the 4-byte CRC trailer (0 => block without a section)
+    uint32_t slot_cap_words; // words the slot holds (section bytes + room for the per-filter alignment)
+    uint32_t block;          // local block index: where desc / status of this section live
+    uint32_t pad;
 };
 
+constexpr uint32_t kMaxHashCountDev = 1024;   // same bound as the host side (kMaxHashCount)
 
-__global__ __launch_bounds__(kDecodeThreads) void k_decode_sections(const uint8_t *region, const SectionInfo *info,
+__device__ __forceinline__ uint64_t rd_be64_dev(const uint8_t *p) { return __builtin_bswap64(load_u64_unaligned(p)); }
+__device__ __forceinline__ uint32_t rd_le32_dev(const uint8_t *p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
+
+// parseFilterSection's structural checks (file_format.go:392-448), after the CRC has passed.  Returns 0 or the status the
+// host-side parser would give (-3 unknown flags, -4 truncated, -5 bad filter, -6 trailing bytes); fills woff / nw / m / k.
+__device__ inline int32_t parse_section_header(const uint8_t *sec, uint32_t plen, uint32_t &present, uint32_t woff[3], uint32_t nw[3],
+                                               uint64_t m[3], uint32_t k[3])
+{
+    present = 0;
+    const uint32_t flags = sec[0];
+    if (flags & ~7u) return -3;
+    uint64_t pos = 1;
+    for (uint32_t c = 0; c < 3; ++c) {
+        woff[c] = nw[c] = 0; m[c] = 0; k[c] = 0;
+        if (!((flags >> c) & 1u)) continue;
+        if (plen - pos < 4) return -4;
+        const uint64_t flen = rd_le32_dev(sec + pos);
+        pos += 4;
+        if (flen > plen - pos) return -4;
+        if (flen < 24) return -5;
+        const uint64_t mm = rd_be64_dev(sec + pos), kk = rd_be64_dev(sec + pos + 8), bl = rd_be64_dev(sec + pos + 16);
+        if (bl > ~0ull - 63 || mm == 0 || kk == 0 || kk > kMaxHashCountDev) return -5;
+        const uint64_t words = (bl + 63) / 64;
+        if (words > (flen - 24) / 8 || (mm + 63) / 64 > words) return -5;
+        m[c] = mm; k[c] = (uint32_t)kk;
+        woff[c] = (uint32_t)(pos + 24);
+        nw[c] = (uint32_t)((mm + 63) / 64);
+        present |= 1u << c;
+        pos += flen;
+    }
+    return pos == plen ? 0 : -6;
+}
+
+// grid.x = sections [first, first + gridDim.x) of the slot table.  CRC32C of the payload (crc32c_payload), then — in one
+// thread — the header chain, then every present filter's big-endian words byte-swapped into the section's slot and its
+// DevDesc (word offset, m, k, Barrett magic) written.  A CRC mismatch (-2 = ErrInvalidHash) or a structural error marks
+// the block and leaves its filters nil (m = 0): a corrupt section cannot poison the batch (query_exec.go:580-590).
+__global__ __launch_bounds__(kDecodeThreads) void k_decode_sections(const uint8_t *region, const SectionSlot *slots, uint32_t first,
                                                                    const CrcConsts *consts, uint64_t *arena, DevDesc *desc,
                                                                    int32_t *status)
 {
     __shared__ uint32_t tab[8][256];
     __shared__ uint32_t part[kDecodeThreads];
-    __shared__ uint32_t bad;
-    const uint32_t b = blockIdx.x, tid = threadIdx.x;
-    const SectionInfo si = info[b];
-    if (si.len < 5) return;
+    __shared__ int32_t st;
+    __shared__ uint32_t s_present, s_woff[3], s_nw[3];
+    __shared__ uint64_t s_dst[3];
+    const uint32_t tid = threadIdx.x;
+    const SectionSlot sl = slots[first + blockIdx.x];
+    const uint32_t b = sl.block;
+    if (sl.len == 0) return;                                       // block without a section: filters stay nil, status 0
+    if (sl.len < 5) { if (tid == 0) status[b] = -1; return; }      // parseFilterSection: too small
     for (uint32_t i = tid; i < 8 * 256; i += kDecodeThreads) (&tab[0][0])[i] = (&consts->table[0][0])[i];
     __syncthreads();
-    const uint8_t *sec = region + si.begin;
-    const uint32_t P = si.len - 4;
+    const uint8_t *sec = region + sl.begin;
+    const uint32_t P = sl.len - 4;
     const uint32_t raw = crc32c_payload(sec, P, tab, consts, part, tid);
     if (tid == 0) {
         // fold in the 0xFFFFFFFF initial value (shifted over the whole payload) and the final xor
         const uint32_t total = raw ^ crc_multmodp(crc_x2nmodp(P, 3, consts->x2n), 0xFFFFFFFFu) ^ 0xFFFFFFFFu;
-        const uint32_t want = (uint32_t)sec[P] | (uint32_t)sec[P + 1] << 8 | (uint32_t)sec[P + 2] << 16 | (uint32_t)sec[P + 3] << 24;
-        bad = total != want;
-        if (bad) {
-            status[b] = -2;
-            for (uint32_t c = 0; c < 3; ++c) desc[(uint64_t)b * 3 + c].m = 0;
+        int32_t r = total != rd_le32_dev(sec + P) ? -2 : 0;
+        uint64_t m[3];
+        uint32_t k[3];
+        if (r == 0) r = parse_section_header(sec, P, s_present, s_woff, s_nw, m, k);
+        if (r == 0) {
+            uint64_t cursor = sl.slot_words;
+            for (uint32_t c = 0; c < 3; ++c) {
+                if (!((s_present >> c) & 1u)) continue;
+                s_dst[c] = cursor;
+                cursor += ((uint64_t)s_nw[c] + 15) / 16 * 16;
+            }
+            if (cursor - sl.slot_words > sl.slot_cap_words) r = -5;   // cannot happen for a slot sized from the section length
         }
+        if (r == 0) {
+            for (uint32_t c = 0; c < 3; ++c) {
+                if (!((s_present >> c) & 1u)) continue;
+                uint64_t magic = m[c] <= 1 ? ~0ULL : ~0ULL / m[c];
+                if (m[c] > 1 && (m[c] & (m[c] - 1)) == 0) magic += 1;
+                desc[(uint64_t)b * 3 + c] = DevDesc{s_dst[c], m[c], magic, k[c], 0};
+            }
+        }
+        status[b] = r;
+        st = r;
     }
     __syncthreads();
-    if (bad) return;
+    if (st != 0) return;
     for (uint32_t c = 0; c < 3; ++c) {
-        if (!((si.present >> c) & 1u)) continue;
-        const uint8_t *src = sec + si.woff[c];
-        uint64_t *dst = arena + si.dst[c];
-        for (uint32_t w = tid; w < si.nw[c]; w += kDecodeThreads) dst[w] = __builtin_bswap64(load_u64_unaligned(src + 8ull * w));
+        if (!((s_present >> c) & 1u)) continue;
+        const uint8_t *src = sec + s_woff[c];
+        uint64_t *dst = arena + s_dst[c];
+        for (uint32_t w = tid; w < s_nw[c]; w += kDecodeThreads) dst[w] = __builtin_bswap64(load_u64_unaligned(src + 8ull * w));
     }
 }
 

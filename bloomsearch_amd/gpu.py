@@ -111,6 +111,26 @@ class Context:
                                                    _lib._ptr(status), C.byref(aid)))
         return int(aid.value), status[: len(sections)]
 
+    def arena_stream_begin(self, sec_begin, sec_end) -> int:
+        sb = np.ascontiguousarray(sec_begin, dtype=np.uint64)
+        se = np.ascontiguousarray(sec_end, dtype=np.uint64)
+        sid = C.c_uint64()
+        self._check(self.L.bsg_arena_stream_begin(self.h, _lib._ptr(sb), _lib._ptr(se), len(sb), C.byref(sid)))
+        return int(sid.value)
+
+    def arena_stream_append(self, stream_id: int, file_offset: int, data: bytes):
+        buf = np.frombuffer(data, dtype=np.uint8)
+        self._check(self.L.bsg_arena_stream_append(self.h, stream_id, file_offset, _lib._ptr(buf), len(buf)))
+
+    def arena_stream_finish(self, stream_id: int, n_blocks: int):
+        status = np.zeros(max(n_blocks, 1), dtype=np.int32)
+        aid = C.c_uint64()
+        self._check(self.L.bsg_arena_stream_finish(self.h, stream_id, _lib._ptr(status), C.byref(aid)))
+        return int(aid.value), status[:n_blocks]
+
+    def arena_stream_abort(self, stream_id: int):
+        self._check(self.L.bsg_arena_stream_abort(self.h, stream_id))
+
     def arena_free(self, arena_id: int):
         self._check(self.L.bsg_arena_free(self.h, arena_id))
 
@@ -159,6 +179,9 @@ class Context:
 
     def set_probe_group(self, max_arenas_per_launch: int):
         self._check(self.L.bsg_set_probe_group(self.h, max_arenas_per_launch))
+
+    def set_ingest_chunk(self, n_bytes: int):
+        self._check(self.L.bsg_set_ingest_chunk(self.h, n_bytes))
 
     def set_spin_wait(self, microseconds: int):
         self._check(self.L.bsg_set_spin_wait(self.h, microseconds))

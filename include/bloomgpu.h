@@ -163,13 +163,27 @@ BSG_API int32_t bsg_arena_load(bsg_ctx *ctx, const uint64_t *words, uint64_t n_w
                                const bsg_filter_desc *desc, uint32_t n_blocks, uint64_t *out_arena_id);
 /* Same, straight from the on-disk bytes: section b = region[sec_off[b] .. sec_off[b+1]) exactly as
  * encodeFilterSection wrote it (file_format.go:343-384; an empty range = block without filters).
- * CRC32C verification and the big-endian -> native decode run on the device; the host only reads the
- * section headers.  out_status[b]: 0 ok, else parseFilterSection's failure for that block (-1 too small,
- * -2 CRC mismatch = ErrInvalidHash, -3 unknown flags, -4 truncated, -5 bad filter, -6 trailing bytes);
- * a failed block gets nil filters and never poisons the others (query_exec.go:580-590).  Single-device
- * contexts. */
+ * Everything inside a section — CRC32C, flags, lengths, (m, k), the big-endian words — is parsed and decoded on the
+ * device; the host never looks inside.  out_status[b]: 0 ok, else parseFilterSection's failure for that block (-1 too
+ * small, -2 CRC mismatch = ErrInvalidHash, -3 unknown flags, -4 truncated, -5 bad filter, -6 trailing bytes, -7 the
+ * section's bytes were never completely handed over); a failed block gets nil filters and never poisons the others
+ * (query_exec.go:580-590).  Deviations from bloom/v3 ReadFrom, both "bad filter": a bitset shorter than m, and
+ * k > 1024 (a corrupt section with a valid CRC must not make a probe loop 2^32 times).  Contexts on several devices
+ * shard the blocks round-robin as bsg_arena_load does. */
 BSG_API int32_t bsg_arena_load_sections(bsg_ctx *ctx, const uint8_t *region, uint64_t region_len, const uint64_t *sec_off,
                                         uint32_t n_blocks, int32_t *out_status, uint64_t *out_arena_id);
+/* The same load as the reference's region cursor performs it (blockFilterCursor / planBlockFilterReads,
+ * file_format.go:511-662): the host hands the file's filter region over in the chunks it reads (<= 4 MiB each in the
+ * reference), in any order, skipping what it does not need; a section is decoded as soon as its last byte has
+ * arrived, while the next chunk is still being copied.
+ *   begin : sec_begin[b] / sec_end[b] = FILE offsets of candidate block b's section (equal = no section)
+ *   append: bytes[0 .. len) = file bytes [file_offset, file_offset + len); copied out before the call returns
+ *   finish: out_status[n_blocks] as above, the arena id; the stream id is consumed (abort discards it instead) */
+BSG_API int32_t bsg_arena_stream_begin(bsg_ctx *ctx, const uint64_t *sec_begin, const uint64_t *sec_end, uint32_t n_blocks,
+                                       uint64_t *out_stream_id);
+BSG_API int32_t bsg_arena_stream_append(bsg_ctx *ctx, uint64_t stream_id, uint64_t file_offset, const uint8_t *bytes, uint64_t len);
+BSG_API int32_t bsg_arena_stream_finish(bsg_ctx *ctx, uint64_t stream_id, int32_t *out_status, uint64_t *out_arena_id);
+BSG_API int32_t bsg_arena_stream_abort(bsg_ctx *ctx, uint64_t stream_id);
 BSG_API int32_t bsg_arena_free(bsg_ctx *ctx, uint64_t arena_id);
 
 /* Compile + upload a batch of queries: n_terms distinct terms and, per query q,
@@ -323,6 +337,9 @@ typedef struct bsg_ingest_stats {
 BSG_API int32_t bsg_ingest_rows(bsg_ctx *ctx, const uint8_t *rows, const uint64_t *row_off, uint32_t n_rows,
                                 const uint32_t *set_first_row, uint32_t n_sets, const uint32_t *parent_of_set,
                                 uint32_t n_parents, const uint32_t *slots_hint, uint32_t flags, uint64_t *out_ingest_id);
+/* bsg_ingest_rows uploads the rows in chunks of about this many bytes (default 64 MiB, 0 restores it): the copy of chunk
+ * i+1 overlaps the walk of chunk i. */
+BSG_API int32_t bsg_set_ingest_chunk(bsg_ctx *ctx, uint64_t bytes);
 /* Row indices (ascending) the host walker must finish; rows_out may be NULL to query the count. */
 BSG_API int32_t bsg_ingest_fallback_rows(bsg_ctx *ctx, uint64_t ingest_id, uint32_t *rows_out, uint32_t cap,
                                          uint32_t *n_out);

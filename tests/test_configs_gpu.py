@@ -296,3 +296,94 @@ def test_error_scopes_keep_their_own_message(ctx):
     # scopes are full aliases of the context: compute calls work through them
     assert a.hash_strings(["hello"]).shape == (1, 4)
     a.close(); b.close()
+
+
+def _sections_of(ctx, rng, n_blocks, max_tokens=2500):
+    plan, _, vocab = H.make_random_arena(rng, n_blocks, absent_frac=0.05, max_tokens=max_tokens)
+    words = ctx.build(plan.blob, plan.off, plan.fstart, plan.desc, plan.n_words)
+    sections = []
+    for b in range(n_blocks):
+        fl = []
+        for c in range(3):
+            d = plan.desc[b * 3 + c]
+            nw = O.words_for(int(d["m"])) if d["m"] else 0
+            fl.append(O.Filter(int(d["m"]), int(d["k"]), words[int(d["word_off"]): int(d["word_off"]) + nw]) if d["m"] else None)
+        sections.append(O.encode_filter_section(fl))
+    return plan, words, vocab, sections
+
+
+def test_region_cursor_streams_chunks_like_blockFilterCursor():
+    """a9 (file_format.go:511-662): a file's filter region handed over in chunks — in order with sections straddling the
+    chunk boundaries, out of order, with a gap that is never read, with a corrupt section — on a single-device context
+    and on one that shards over three entries.  Decoded arenas must probe exactly like the oracle over the same filters;
+    unread sections report -7 and behave as nil filters; a corrupt one is isolated."""
+    rng = np.random.default_rng(123)
+    n_blocks = 61
+    with Context((0,)) as c1, Context((0,) * 3) as c3:
+        plan, words, vocab, sections = _sections_of(c1, rng, n_blocks)
+        cb = Q.compile_queries([None] + [H.random_expression(rng, vocab, None) for _ in range(300)])
+        ops, poff, _ = cb.arrays()
+        terms = H.gpu_terms(c1, cb)
+        # a "file": 1 000 bytes of row data, then the sections back to back, except a 70-byte hole before block 30
+        file_bytes = bytearray(rng.integers(0, 256, size=1000, dtype=np.uint8).tobytes())
+        begin, end = [], []
+        for b, s in enumerate(sections):
+            if b == 30:
+                file_bytes += b"\xAA" * 70
+            begin.append(len(file_bytes))
+            file_bytes += s
+            end.append(len(file_bytes))
+        file_bytes += b"footer"
+        file_bytes = bytes(file_bytes)
+        want_all = O.probe_batch(words, plan.desc.view(O.DESC_DTYPE), terms.view(O.TERM_DTYPE), ops, poff)
+
+        def expect(nil_blocks):
+            d2 = plan.desc.copy()
+            for b in nil_blocks:
+                d2["m"][b * 3: b * 3 + 3] = 0
+            return O.probe_batch(words, d2.view(O.DESC_DTYPE), terms.view(O.TERM_DTYPE), ops, poff)
+
+        for ctx in (c1, c3):
+            # (1) in order, chunk sizes that never line up with section boundaries (incl. chunks smaller than a header)
+            sid = ctx.arena_stream_begin(begin, end)
+            o = 900
+            sizes = [7, 1, 33, 5000, 11, 40000, 3, 100000]
+            i = 0
+            while o < len(file_bytes):
+                n = sizes[i % len(sizes)]; i += 1
+                ctx.arena_stream_append(sid, o, file_bytes[o: o + n])
+                o += n
+            aid, status = ctx.arena_stream_finish(sid, n_blocks)
+            assert not status.any()
+            assert np.array_equal(ctx.probe(aid, n_blocks, terms, ops, poff), want_all)
+            ctx.arena_free(aid)
+            # (2) out of order + a range that is never read (blocks 10..14) + a chunk appended twice
+            sid = ctx.arena_stream_begin(begin, end)
+            ranges = [(begin[40], len(file_bytes)), (begin[15], begin[40] + 9), (0, begin[10] + 5), (begin[15], begin[20])]
+            for lo, hi in ranges:
+                ctx.arena_stream_append(sid, lo, file_bytes[lo:hi])
+            aid, status = ctx.arena_stream_finish(sid, n_blocks)
+            unread = {b for b in range(10, 15) if len(sections[b]) > 0}
+            assert {b for b in range(n_blocks) if status[b] == -7} == unread
+            assert not any(status[b] for b in range(n_blocks) if b not in unread)
+            assert np.array_equal(ctx.probe(aid, n_blocks, terms, ops, poff), expect(unread))
+            ctx.arena_free(aid)
+            # (3) a flipped bit inside block 22's section: ErrInvalidHash for that block only
+            bad = bytearray(file_bytes); bad[(begin[22] + end[22]) // 2] ^= 4; bad = bytes(bad)
+            sid = ctx.arena_stream_begin(begin, end)
+            for o in range(0, len(bad), 65536):
+                ctx.arena_stream_append(sid, o, bad[o: o + 65536])
+            aid, status = ctx.arena_stream_finish(sid, n_blocks)
+            assert status[22] == -2 and not any(status[b] for b in range(n_blocks) if b != 22)
+            assert np.array_equal(ctx.probe(aid, n_blocks, terms, ops, poff), expect({22}))
+            ctx.arena_free(aid)
+            # (4) abort releases everything; the whole-region form on the sharded context equals the single-device one
+            sid = ctx.arena_stream_begin(begin, end)
+            ctx.arena_stream_append(sid, begin[0], file_bytes[begin[0]: begin[5]])
+            ctx.arena_stream_abort(sid)
+            with pytest.raises(BloomGpuError):
+                ctx.arena_stream_finish(sid, n_blocks)
+            aid, status = ctx.arena_load_sections(sections)
+            assert not status.any()
+            assert np.array_equal(ctx.probe(aid, n_blocks, terms, ops, poff), want_all)
+            ctx.arena_free(aid)

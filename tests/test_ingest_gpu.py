@@ -246,6 +246,31 @@ def test_unicode_14_case_pairs_fold_on_the_device_and_unknown_code_points_go_to_
     assert list(handed_back) == [0, 1, 2] and list(hits) == [False, False, False, True]
 
 
+def test_chunked_upload_overlapping_the_walk(ctx, flags):
+    """bsg_ingest_rows uploads the rows in chunks and walks chunk i while chunk i+1 is in flight: with a 64 KiB chunk
+    a few thousand rows become dozens of chunks — sets spanning chunk boundaries, tables that must grow in the middle
+    (tiny hint => re-runs of single chunks), rows for the host in several chunks.  Counts, bitsets and the fallback list
+    must be exactly those of the one-chunk run."""
+    rng = np.random.default_rng(99)
+    row_sets = []
+    for s_ in range(5):
+        rows = synth.rows_json(s_ * 700, 700)
+        for j in range(0, 700, 97):                       # rows the device hands back (nested deeper than it follows), spread over the chunks
+            rows[j] = b'{"d":' * 20 + b'"deep%d"' % j + b"}" * 20
+        row_sets.append(rows)
+    try:
+        ctx.set_ingest_chunk(1 << 16)
+        small = I.device_ingest(ctx, row_sets, FPR, parent_of_set=[0] * 5, n_parents=1, flags=flags, slots_hint=[64] * 15)
+    finally:
+        ctx.set_ingest_chunk(0)
+    whole = I.device_ingest(ctx, row_sets, FPR, parent_of_set=[0] * 5, n_parents=1, flags=flags)
+    assert small.stats.table_grows > 0
+    assert list(small.fallback_rows) == list(whole.fallback_rows) and len(whole.fallback_rows) == 5 * 8
+    assert np.array_equal(small.counts, whole.counts)
+    for s_, rows in enumerate(row_sets):
+        check_against_sets(small, s_, oracle_sets(rows), "set %d" % s_)
+
+
 def test_tables_grow_from_a_tiny_hint(ctx, flags):
     rows = synth.rows_json(0, 1500)
     res = I.device_ingest(ctx, [rows], FPR, parent_of_set=[0], n_parents=1, slots_hint=[64, 64, 64], flags=flags)
