@@ -637,6 +637,7 @@ def main():
     ap.add_argument("--samples", type=int, default=16, help="timestamped dispatches of each kernel beyond the timed region")
     ap.add_argument("--c4-files", type=int, default=10, help="files of the c4 leg (0 = skip the leg)")
     ap.add_argument("--c4-blocks-per-file", type=int, default=1000)
+    ap.add_argument("--compact-rounds", type=int, default=-1, help="lab: compaction rounds of the many-term probe mode (bsg_set_lab key 1)")
     ap.add_argument("--no-q1", action="store_true", help="skip the Q = 1 latency leg")
     ap.add_argument("--no-single", action="store_true", help="skip the one-arena-per-launch sampling pass")
     args = ap.parse_args()
@@ -663,6 +664,8 @@ def main():
 
     ctx = Context((local_rank,))
     ctx.set_probe_group(args.group)
+    if args.compact_rounds >= 0:
+        ctx.set_lab(1, args.compact_rounds)
     B, rows, NQ = args.blocks, args.rows_per_block, args.queries
 
     # ---- untimed setup: this rank's shard = global blocks rank, rank + world, ... (round-robin) ----

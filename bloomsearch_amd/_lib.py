@@ -52,7 +52,7 @@ def op(opcode: int, arg: int = 0) -> int:
 # every symbol include/bloomgpu.h declares (tests assert the .so exports all of them)
 EXPORTS = [
     "bsg_device_count", "bsg_open", "bsg_open_err", "bsg_close", "bsg_last_error", "bsg_last_error_copy", "bsg_scope_open",
-    "bsg_sync", "bsg_estimate_parameters", "bsg_probe_many_dev", "bsg_set_probe_group", "bsg_set_gather_cost", "bsg_set_fuse_limit", "bsg_set_spin_wait", "bsg_set_ingest_chunk",
+    "bsg_sync", "bsg_estimate_parameters", "bsg_probe_many_dev", "bsg_set_probe_group", "bsg_set_gather_cost", "bsg_set_fuse_limit", "bsg_set_spin_wait", "bsg_set_ingest_chunk", "bsg_set_lab",
     "bsg_hash_entries", "bsg_build", "bsg_build_hashed", "bsg_arena_load", "bsg_arena_load_sections", "bsg_arena_free",
     "bsg_arena_stream_begin", "bsg_arena_stream_append", "bsg_arena_stream_finish", "bsg_arena_stream_abort",
     "bsg_batch_create", "bsg_batch_free", "bsg_probe_batch", "bsg_probe_many", "bsg_probe", "bsg_timing_read", "bsg_set_timed_stride", "bsg_last_kernel_ms",
@@ -88,6 +88,7 @@ def load():
     L.bsg_set_fuse_limit.argtypes = [vp, u32]
     L.bsg_set_spin_wait.argtypes = [vp, u32]
     L.bsg_set_ingest_chunk.argtypes = [vp, u64]
+    L.bsg_set_lab.argtypes = [vp, u32, u64]
     L.bsg_close.argtypes = [vp]
     L.bsg_last_error.argtypes = [vp]
     L.bsg_last_error.restype = C.c_char_p

@@ -256,6 +256,7 @@ struct bsg_ctx {
     uint32_t comm_world = 0, comm_rank = 0;
     uint64_t ingest_chunk_bytes = 64ull << 20;   // rows per upload chunk of bsg_ingest_rows (bsg_set_ingest_chunk)
     uint32_t spin_wait_us = 0;   // synchronous probes poll the stream this long before blocking (bsg_set_spin_wait)
+    uint32_t compact_rounds = BSG_COMPACT_ROUNDS;   // many-term probe mode (bsg_set_lab)
     uint32_t fuse_max_arenas = 4; // groups up to this many arenas ride fused (probe of group i + eval of group i-1)
 };
 
@@ -1070,6 +1071,8 @@ int32_t make_probe_args(bsg_ctx *ctx, Device &d, const Group &g, const BatchDev 
     }
     if (ev) ev->n_arenas = a.n_arenas;
     lds_words = (lds_words + 1) / 2 * 2;
+    a.lds_image_bytes = (uint32_t)(lds_words * 8);
+    a.compact_rounds = ctx->compact_rounds;
     lds_bytes = (uint32_t)(head + lds_words * 8);
     return BSG_OK;
 }
@@ -1330,6 +1333,14 @@ extern "C" int32_t bsg_set_probe_group(bsg_ctx *ctx, uint32_t max_arenas_per_lau
     BSG_ENTER(ctx);
     ctx->group_limit = max_arenas_per_launch ? std::min(max_arenas_per_launch, bsg::kMaxGroupArenas) : bsg::kMaxGroupArenas;
     return BSG_OK;
+}
+
+// lab knobs (tools/, bench sweeps): key 1 = compaction rounds of the many-term probe mode
+extern "C" int32_t bsg_set_lab(bsg_ctx *ctx, uint32_t key, uint64_t value)
+{
+    BSG_ENTER(ctx);
+    if (key == 1) { ctx->compact_rounds = (uint32_t)std::min<uint64_t>(value, 16); return BSG_OK; }
+    return fail(BSG_E_INVALID, "unknown lab key %u", key);
 }
 
 extern "C" int32_t bsg_set_ingest_chunk(bsg_ctx *ctx, uint64_t bytes)

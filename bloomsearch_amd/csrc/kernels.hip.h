@@ -259,6 +259,8 @@ struct ProbeArgs {
     uint32_t Wt;                  // Tp / 64
     uint32_t lds_cap_words;       // filters with more words take the gather path
     uint32_t gather_cost;         // a filter is gathered (not staged) when terms * k * gather_cost < its bytes
+    uint32_t lds_image_bytes;     // LDS reserved for the bitset image (the verdict words and wave queues follow it)
+    uint32_t compact_rounds;      // many-term mode: locations 1..R run as compaction rounds, the rest from registers
     uint32_t n_arenas;
     uint32_t max_blocks;          // most blocks of any arena of the group (grid x)
     uint32_t kind[3];             // referenced kinds, blockIdx.y indexes this
@@ -335,129 +337,198 @@ __device__ __forceinline__ void par_task_finish(const ParTask &p, BITS32 bits, l
 // Mode C (many terms).  Each wave owns a contiguous range of term words and runs
 //   round 0 : location 0 of every term (8 B/term, coalesced), survivors compacted into the wave's
 //             private LDS queue (ballot + mbcnt; no atomics, no barriers);
-//   rounds 1..kCompactRounds : one location per round for the survivors (two gathered hash rows),
-//             compacted in place;
+//   rounds 1..R : one location per round for the survivors (two gathered hash rows), compacted in place;
 //   tail    : what is left keeps all four hashes in registers and runs the remaining locations with a
 //             wave-level early-out (no further table loads).
-// Loads are issued kGroup chunks at a time so a wave pays one L2 round trip per stage, not per
-// 64-term chunk.  Absent terms die geometrically: ~2 probes per absent term.
+// Absent terms die geometrically (~2 probes each); a present term costs all k.  The mode is bound by VALU issue — at
+// 4 054 terms over 1 000 blocks of 282 kbit the round-1 version spent 39 VALU instructions per 64-lane probe, of which the
+// Barrett reduction is 12 (tools/ubench_mod.hip: 18 ns per wave-probe per SIMD; an FP64 quotient estimate is slower, 22 ns) —
+// so this version is written for instruction count: the wave index is made scalar (readfirstlane) so that chunk bounds,
+// loop trips and the queue length live in SGPRs and every "is this chunk in range" test is a scalar branch; the
+// padded tail of the last term word is probed like real terms (its verdict bits are never referenced) instead of being
+// masked per lane; the bitset image sits at LDS offset 0 so a bit address is two shifts; the 64x64 mul-high is spelled
+// out in 32-bit pieces.
 constexpr uint32_t kGroup = 4;
-constexpr uint32_t kCompactRounds = 1;   // locations 1..kCompactRounds run as compaction rounds, the rest from registers
-// (measured on MI355X: 1 and 3 rounds tie at ~4k terms — the extra gathers cost what the saved VALU buys — and 1 is
-// faster at 256-1024 terms; the many-term mode is bound by L2 gather latency, VALU is ~40% busy)
+constexpr uint32_t kTailBatch = 4;
+#ifndef BSG_COMPACT_ROUNDS
+#define BSG_COMPACT_ROUNDS 2
+#endif
 
-template <bool M32, typename BITS32>
+// x mod m for m < 2^31 from the halves of x and of magic = floor(2^64 / m): only the low 32 bits of the quotient matter.
+__device__ __forceinline__ uint32_t mod_m32_parts(uint32_t xl, uint32_t xh, uint32_t m, uint32_t ml, uint32_t mh)
+{
+    const uint32_t t1 = __umulhi(xl, ml);
+    const uint64_t c = (uint64_t)xh * ml + t1;
+    const uint64_t dd = (uint64_t)xl * mh + (uint32_t)c;
+    const uint32_t qlo = xh * mh + (uint32_t)(c >> 32) + (uint32_t)(dd >> 32);
+    const uint32_t r = xl - qlo * m;
+    return min(r, r - m);   // r in [0, 2m): r - m wraps far above r exactly when r < m
+}
+template <bool M32>
+__device__ __forceinline__ uint64_t locate_c(const DevDesc &d, uint64_t x)
+{
+    if (M32) return mod_m32_parts((uint32_t)x, (uint32_t)(x >> 32), (uint32_t)d.m, (uint32_t)d.magic, (uint32_t)(d.magic >> 32));
+    return mod_m(x, d.m, d.magic);
+}
+// One bit of the filter as 0 / 1.  The staged image sits at LDS offset 0, so its words are addressed by plain integers
+// (a pointer derived from the dynamic-LDS symbol costs a v_add of the link-time base, which is 0, per access).
+__device__ __forceinline__ uint32_t bit_at(const lds_u32 *, uint64_t loc)
+{
+    const lds_u32 *w = (const lds_u32 *)(uintptr_t)(((uint32_t)loc >> 3) & ~3u);
+    return __builtin_amdgcn_ubfe(*w, (uint32_t)loc, 1u);   // v_bfe_u32 takes the offset from bits [4:0]
+}
+__device__ __forceinline__ uint32_t bit_at(const uint32_t *bits, uint64_t loc)
+{
+    return (bits[loc >> 5] >> ((uint32_t)loc & 31u)) & 1u;
+}
+// global load with a uniform base and a 32-bit per-lane byte offset: selects the saddr + voffset form (no 64-bit address math)
+__device__ __forceinline__ uint64_t load_u64_at(const uint64_t *base, uint32_t byte_off)
+{
+    return *reinterpret_cast<const uint64_t *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+__device__ __forceinline__ uint32_t lane_rank(uint64_t mask)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+template <bool M32, uint32_t NW, typename BITS32>
 __device__ __forceinline__ void probe_rounds(const ProbeArgs &a, const DevDesc &d, BITS32 bits, uint32_t t0,
-                                             uint32_t n_real, uint32_t n_tw, lds_u16 *queues, lds_u32 *vbits,
+                                             uint32_t n_tw, lds_u16 *queues, lds_u32 *vbits,
                                              uint32_t wave, uint32_t lane, const uint64_t (&loc_first)[kGroup])
 {
-    const uint32_t wpw = (n_tw + kProbeWaves - 1) / kProbeWaves;
+    // wave, n_tw, t0 are wave-uniform (scalar registers): so is everything derived from them
+    const uint32_t wpw = (n_tw + NW - 1) / NW;
     const uint32_t w0 = wave * wpw;
     if (w0 >= n_tw) return;
     const uint32_t w1 = min(n_tw, w0 + wpw);
+    const uint32_t nw = w1 - w0;                 // term words of this wave
     lds_u16 *q = queues + (uint32_t)w0 * 64;
     const uint32_t base = w0 * 64;
-#ifdef BSG_LAB_FAKE_TERM_LOADS   // lab only: synthesize the hashes from the index to isolate VALU+LDS from term-table loads
-    struct FakeRow { uint64_t salt; __device__ uint64_t operator[](uint32_t i) const { return (i + salt) * 0x9E3779B97F4A7C15ULL; } };
-    struct FakeTable {
-        uint64_t salt;
-        __device__ uint64_t operator[](uint32_t i) const { return (i + salt) * 0x9E3779B97F4A7C15ULL; }
-        __device__ FakeRow operator+(uint64_t off) const { return FakeRow{salt + off}; }
-    };
-    const FakeTable th{t0 + base};
-#else
-    const uint64_t *th = a.th + t0 + base;   // this wave's slice of hash row 0
-#endif
-    uint32_t qn = 0;
+    const uint64_t *th = a.th + t0 + base;       // this wave's slice of hash row 0
+    uint32_t qn = 0;                             // queue length (scalar)
+    const uint32_t compact_rounds = a.compact_rounds;
+    const uint32_t lane8 = lane * 8u;
 
-    auto compact = [&](bool hit, uint32_t value, uint32_t &count) {
-        const uint64_t mask = __ballot(hit);
-        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-        if (hit) q[count + rank] = (uint16_t)value;
-        count += (uint32_t)__builtin_popcountll(mask);
-    };
-
-    // ---- round 0 ----
-    for (uint32_t w = w0; w < w1; w += kGroup) {
+    // ---- round 0: groups of kGroup chunks; the hashes of group g + 1 are requested before group g is worked on, so the
+    // wave sees one L2 round trip for the whole round instead of one per group ----
+    uint64_t hn[kGroup];
+#pragma unroll
+    for (uint32_t u = 0; u < kGroup; ++u) hn[u] = (kGroup + u < nw) ? load_u64_at(th + (kGroup + u) * 64, lane8) : 0;
+    for (uint32_t c0 = 0; c0 < nw; c0 += kGroup) {
         uint64_t loc[kGroup];
-        if (w == w0) {
+        if (c0 == 0) {
 #pragma unroll
             for (uint32_t u = 0; u < kGroup; ++u) loc[u] = loc_first[u];   // computed before the DMA wait
         } else {
             uint64_t h[kGroup];
 #pragma unroll
-            for (uint32_t u = 0; u < kGroup; ++u) h[u] = (w + u < w1) ? th[(w + u - w0) * 64 + lane] : 0;
+            for (uint32_t u = 0; u < kGroup; ++u) h[u] = hn[u];
 #pragma unroll
-            for (uint32_t u = 0; u < kGroup; ++u) loc[u] = locate<M32>(d, h[u]);
+            for (uint32_t u = 0; u < kGroup; ++u) hn[u] = (c0 + kGroup + u < nw) ? load_u64_at(th + (c0 + kGroup + u) * 64, lane8) : 0;
+#pragma unroll
+            for (uint32_t u = 0; u < kGroup; ++u) loc[u] = locate_c<M32>(d, h[u]);
         }
-        // all kGroup bit tests first (independent LDS reads in flight together), then the compactions: the queue
-        // writes may alias the bitset image as far as the compiler knows, so it will not hoist the reads itself
-        bool hit[kGroup];
+        uint32_t hit[kGroup];
 #pragma unroll
-        for (uint32_t u = 0; u < kGroup; ++u)
-            hit[u] = (w + u < w1) & (base + (w + u - w0) * 64 + lane < n_real) & test_bit(bits, loc[u]);   // branch-free: loc is always in range
+        for (uint32_t u = 0; u < kGroup; ++u) hit[u] = bit_at(bits, loc[u]);     // loc is always in range; chunks past nw are dropped below
 #pragma unroll
-        for (uint32_t u = 0; u < kGroup; ++u)
-            if (w + u < w1) compact(hit[u], (w + u - w0) * 64 + lane, qn);   // wave-uniform condition
-    }
-    // ---- rounds 1..kCompactRounds: one location per round, survivors compacted in place ----
-    {
-        uint32_t i = 1;
-        for (; i < d.k && i <= kCompactRounds && qn != 0; ++i) {
-            const auto ra = th + (uint64_t)ha_row(i) * a.Tp, rb = th + (uint64_t)hb_row(i) * a.Tp;
-            uint32_t out = 0;
-            for (uint32_t j = 0; j < qn; j += 64 * kGroup) {
-                uint32_t li[kGroup];
-                uint64_t x[kGroup];
-#pragma unroll
-                for (uint32_t u = 0; u < kGroup; ++u) li[u] = (j + u * 64 + lane < qn) ? (uint32_t)q[j + u * 64 + lane] : 0u;
-#pragma unroll
-                for (uint32_t u = 0; u < kGroup; ++u) x[u] = (j + u * 64 < qn) ? ra[li[u]] + (uint64_t)i * rb[li[u]] : 0;
-                bool hit[kGroup];
-#pragma unroll
-                for (uint32_t u = 0; u < kGroup; ++u)
-                    hit[u] = (j + u * 64 + lane < qn) & test_bit(bits, locate<M32>(d, x[u]));
-#pragma unroll
-                for (uint32_t u = 0; u < kGroup; ++u)
-                    if (j + u * 64 < qn) compact(hit[u], li[u], out);   // wave-uniform; out <= j: in place is safe
+        for (uint32_t u = 0; u < kGroup; ++u) {
+            if (c0 + u < nw) {                                                    // scalar branch
+                const uint64_t mask = __ballot(hit[u] != 0u);
+                if (hit[u] != 0u) q[qn + lane_rank(mask)] = (uint16_t)((c0 + u) * 64 + lane);
+                qn += (uint32_t)__builtin_popcountll(mask);
             }
-            qn = out;
         }
-        // ---- tail: remaining locations from registers, two chunks interleaved, wave-level early-out ----
-        if (i < d.k && qn != 0) {
-            const auto r1 = th + (uint64_t)a.Tp, r2 = th + 2ull * a.Tp, r3 = th + 3ull * a.Tp;
-            const uint32_t i0 = i;
-            for (uint32_t j = 0; j < qn; j += 128) {
-                const bool two = j + 64 < qn;
-                bool aliveA = j + lane < qn, aliveB = two && (j + 64 + lane < qn);
-                const uint32_t liA = aliveA ? (uint32_t)q[j + lane] : 0u, liB = aliveB ? (uint32_t)q[j + 64 + lane] : 0u;
-                const uint64_t a0 = th[liA], a1 = r1[liA], a2 = r2[liA], a3 = r3[liA];
-                uint64_t b0 = 0, b1 = 0, b2 = 0, b3 = 0;
-                if (two) { b0 = th[liB]; b1 = r1[liB]; b2 = r2[liB]; b3 = r3[liB]; }
-                for (uint32_t ii = i0; ii < d.k; ++ii) {
-                    if ((__ballot(aliveA) | __ballot(aliveB)) == 0) break;
-                    if (aliveA) aliveA = test_bit(bits, locate<M32>(d, location(a0, a1, a2, a3, ii)));
-                    if (aliveB) aliveB = test_bit(bits, locate<M32>(d, location(b0, b1, b2, b3, ii)));
+    }
+    // ---- rounds 1..R: one location per round, survivors compacted in place ----
+    uint32_t i = 1;
+    for (; i < d.k && i <= compact_rounds && qn != 0; ++i) {
+        const uint64_t *ra = th + (uint64_t)ha_row(i) * a.Tp, *rb = th + (uint64_t)hb_row(i) * a.Tp;
+        uint32_t out = 0;
+        for (uint32_t j = 0; j < qn; j += 64 * kGroup) {
+            uint32_t li[kGroup];
+            uint64_t x[kGroup];
+            bool live[kGroup];
+            uint32_t hit[kGroup];
+#pragma unroll
+            for (uint32_t u = 0; u < kGroup; ++u) {
+                live[u] = j + u * 64 + lane < qn;
+                li[u] = live[u] ? (uint32_t)q[j + u * 64 + lane] : 0u;
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < kGroup; ++u)
+                x[u] = (j + u * 64 < qn) ? load_u64_at(ra, li[u] * 8u) + (uint64_t)i * load_u64_at(rb, li[u] * 8u) : 0;
+#pragma unroll
+            for (uint32_t u = 0; u < kGroup; ++u) hit[u] = live[u] ? bit_at(bits, locate_c<M32>(d, x[u])) : 0u;
+#pragma unroll
+            for (uint32_t u = 0; u < kGroup; ++u) {
+                if (j + u * 64 < qn) {                                            // scalar; out <= j: in place is safe
+                    const uint64_t mask = __ballot(hit[u] != 0u);
+                    if (hit[u] != 0u) q[out + lane_rank(mask)] = (uint16_t)li[u];
+                    out += (uint32_t)__builtin_popcountll(mask);
                 }
-                if (aliveA) __hip_atomic_fetch_or(&vbits[(base + liA) >> 5], 1u << ((base + liA) & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (aliveB) __hip_atomic_fetch_or(&vbits[(base + liB) >> 5], 1u << ((base + liB) & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
-            return;
         }
+        qn = out;
     }
-    // every location passed during the compaction rounds (k <= kCompactRounds + 1): the queue holds the accepted terms
+    // ---- tail: remaining locations from registers, two chunks interleaved, wave-level early-out ----
+    if (i < d.k && qn != 0) {
+        const uint64_t *r1 = th + (uint64_t)a.Tp, *r2 = th + 2ull * a.Tp, *r3 = th + 3ull * a.Tp;
+        const uint32_t i0 = i;
+        for (uint32_t j = 0; j < qn; j += 128) {
+            const bool two = j + 64 < qn;                                         // scalar
+            bool aliveA = j + lane < qn, aliveB = two && (j + 64 + lane < qn);
+            const uint32_t liA = aliveA ? (uint32_t)q[j + lane] : 0u, liB = aliveB ? (uint32_t)q[j + 64 + lane] : 0u;
+            const uint64_t a0 = load_u64_at(th, liA * 8u), a1 = load_u64_at(r1, liA * 8u), a2 = load_u64_at(r2, liA * 8u), a3 = load_u64_at(r3, liA * 8u);
+            uint64_t b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+            if (two) { b0 = load_u64_at(th, liB * 8u); b1 = load_u64_at(r1, liB * 8u); b2 = load_u64_at(r2, liB * 8u); b3 = load_u64_at(r3, liB * 8u); }
+            // the remaining locations in batches of kTailBatch: all reductions first, then all LDS reads in flight together,
+            // then one AND — a wave pays one LDS round trip per batch instead of one per location.  (A present term — about
+            // two in five lanes here — keeps its wave alive through every location anyway; the wave-level early-out only
+            // fires between batches.)
+            for (uint32_t ii = i0; ii < d.k; ii += kTailBatch) {
+                if ((__ballot(aliveA) | __ballot(aliveB)) == 0) break;
+                uint32_t ba[kTailBatch], bb[kTailBatch];
+#pragma unroll
+                for (uint32_t v = 0; v < kTailBatch; ++v) {
+                    const uint32_t iv = ii + v;                                   // uniform
+                    ba[v] = bb[v] = 1u;
+                    if (iv < d.k) {
+                        const bool odd = iv & 1u, use3 = ((iv & 3u) == 1u) | ((iv & 3u) == 2u);
+                        const uint64_t xa = (odd ? a1 : a0) + (uint64_t)iv * (use3 ? a3 : a2);
+                        ba[v] = bit_at(bits, locate_c<M32>(d, xa));
+                        if (two) {
+                            const uint64_t xb = (odd ? b1 : b0) + (uint64_t)iv * (use3 ? b3 : b2);
+                            bb[v] = bit_at(bits, locate_c<M32>(d, xb));
+                        }
+                    }
+                }
+                uint32_t alla = 1u, allb = 1u;
+#pragma unroll
+                for (uint32_t v = 0; v < kTailBatch; ++v) { alla &= ba[v]; allb &= bb[v]; }
+                aliveA = aliveA & (alla != 0u);
+                aliveB = aliveB & (allb != 0u);
+            }
+            if (aliveA) __hip_atomic_fetch_or(&vbits[(base + liA) >> 5], 1u << ((base + liA) & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (aliveB) __hip_atomic_fetch_or(&vbits[(base + liB) >> 5], 1u << ((base + liB) & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        return;
+    }
+    // every location passed during the compaction rounds (k <= R + 1): the queue holds the accepted terms
     for (uint32_t j = lane; j < qn; j += 64) {
         const uint32_t idx = base + q[j];
         __hip_atomic_fetch_or(&vbits[idx >> 5], 1u << (idx & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
 }
 
-template <bool M32, bool STAGED>
+template <bool M32, bool STAGED, uint32_t NT>
 __device__ __forceinline__ void probe_block(const ProbeArgs &a, const DevDesc &d, const uint64_t *src, char *image,
                                             uint32_t t0, uint32_t n_real, uint32_t n_tw, lds_u64 *vw, lds_u16 *queues,
                                             uint64_t *vout, uint32_t tid)
 {
-    const uint32_t lane = tid & (kWave - 1), wave = tid / kWave;
+    constexpr uint32_t kProbeThreads = NT, kProbeWaves = NT / kWave;   // shadow the 512-thread defaults
+    const uint32_t lane = tid & (kWave - 1);
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid / kWave);   // scalar: chunk bounds and loop trips stay in SGPRs
     const bool par = n_tw <= kParallelKMaxWords;
     const uint32_t n_tasks = n_tw * d.k;
     // ---- work that does not need the bitset: runs while the DMA is in flight ----
@@ -476,7 +547,7 @@ __device__ __forceinline__ void probe_block(const ProbeArgs &a, const DevDesc &d
 #pragma unroll
         for (uint32_t u = 0; u < kGroup; ++u) h[u] = (w0 + u < w1) ? a.th[t0 + (w0 + u) * 64 + lane] : 0;
 #pragma unroll
-        for (uint32_t u = 0; u < kGroup; ++u) loc_first[u] = locate<M32>(d, h[u]);
+        for (uint32_t u = 0; u < kGroup; ++u) loc_first[u] = locate_c<M32>(d, h[u]);
     }
     if (STAGED) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -488,7 +559,7 @@ __device__ __forceinline__ void probe_block(const ProbeArgs &a, const DevDesc &d
             for (uint32_t task = wave + kProbeWaves; task < n_tasks; task += kProbeWaves)
                 par_task_finish(par_task_prepare<M32>(a, d, t0, n_real, n_tw, task, lane), bits, vw, lane);
         } else {
-            probe_rounds<M32>(a, d, bits, t0, n_real, n_tw, queues, (lds_u32 *)vw, wave, lane, loc_first);
+            probe_rounds<M32, kProbeWaves>(a, d, bits, t0, n_tw, queues, (lds_u32 *)vw, wave, lane, loc_first);
         }
     } else {
         const uint32_t *bits = reinterpret_cast<const uint32_t *>(src);
@@ -497,21 +568,24 @@ __device__ __forceinline__ void probe_block(const ProbeArgs &a, const DevDesc &d
             for (uint32_t task = wave + kProbeWaves; task < n_tasks; task += kProbeWaves)
                 par_task_finish(par_task_prepare<M32>(a, d, t0, n_real, n_tw, task, lane), bits, vw, lane);
         } else {
-            probe_rounds<M32>(a, d, bits, t0, n_real, n_tw, queues, (lds_u32 *)vw, wave, lane, loc_first);
+            probe_rounds<M32, kProbeWaves>(a, d, bits, t0, n_tw, queues, (lds_u32 *)vw, wave, lane, loc_first);
         }
     }
     __syncthreads();
     for (uint32_t w = tid; w < n_tw; w += kProbeThreads) vout[(uint64_t)w * 64] = vw[w];
 }
 
-// LDS carve of k_probe_terms: [verdict words n_tw x 8 B][wave queues n_tw x 64 x 2 B][pad to 16 B][bitset image]
+// LDS carve of k_probe_terms: [bitset image: a.lds_image_bytes, at offset 0 so a bit address needs no base add]
+//                             [verdict words n_tw x 8 B][wave queues n_tw x 64 x 2 B]
 __host__ __device__ inline uint32_t probe_lds_head_bytes(uint32_t n_tw)
 {
     return (n_tw * 8u + n_tw * 128u + 15u) & ~15u;
 }
 
+template <uint32_t NT = kProbeThreads>
 __device__ __forceinline__ void probe_role(const ProbeArgs &a, uint32_t ai, uint32_t b, uint32_t y, uint64_t *lds64)
 {
+    constexpr uint32_t kProbeThreads = NT, kProbeWaves = NT / kWave;   // shadow the 512-thread defaults
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & (kWave - 1);
     const uint32_t wave = tid / kWave;
@@ -528,9 +602,9 @@ __device__ __forceinline__ void probe_role(const ProbeArgs &a, uint32_t ai, uint
         for (uint32_t w = tid; w < n_tw; w += kProbeThreads) vout[(uint64_t)w * 64] = ~0ULL;
         return;
     }
-    lds_u64 *vw = (lds_u64 *)lds64;
+    char *image = reinterpret_cast<char *>(lds64);
+    lds_u64 *vw = (lds_u64 *)(lds64 + (a.lds_image_bytes >> 3));
     lds_u16 *queues = (lds_u16 *)(vw + n_tw);
-    char *image = reinterpret_cast<char *>(lds64) + probe_lds_head_bytes(n_tw);
 
     const uint64_t nw = (d.m + 63) >> 6;
     const uint64_t *src = ar.words + d.word_off;
@@ -548,11 +622,11 @@ __device__ __forceinline__ void probe_role(const ProbeArgs &a, uint32_t ai, uint
             if (boff < nbytes)
                 __builtin_amdgcn_global_load_lds((glb_void *)(g + boff), (lds_void *)(image + c), 16, 0, BSG_DMA_AUX);
         }
-        if (m32) probe_block<true, true>(a, d, src, image, t0, n_real, n_tw, vw, queues, vout, tid);
-        else     probe_block<false, true>(a, d, src, image, t0, n_real, n_tw, vw, queues, vout, tid);
+        if (m32) probe_block<true, true, NT>(a, d, src, image, t0, n_real, n_tw, vw, queues, vout, tid);
+        else     probe_block<false, true, NT>(a, d, src, image, t0, n_real, n_tw, vw, queues, vout, tid);
     } else {
-        if (m32) probe_block<true, false>(a, d, src, image, t0, n_real, n_tw, vw, queues, vout, tid);
-        else     probe_block<false, false>(a, d, src, image, t0, n_real, n_tw, vw, queues, vout, tid);
+        if (m32) probe_block<true, false, NT>(a, d, src, image, t0, n_real, n_tw, vw, queues, vout, tid);
+        else     probe_block<false, false, NT>(a, d, src, image, t0, n_real, n_tw, vw, queues, vout, tid);
     }
 }
 
@@ -562,6 +636,10 @@ __global__ __launch_bounds__(kProbeThreads) void k_probe_terms(const ProbeArgs a
     extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
     probe_role(a, blockIdx.z, blockIdx.x, blockIdx.y, lds64);
 }
+
+// (Measured and dropped, twice now: the same kernel with 1 024 threads per block — 16 waves sharing one block's image, 32
+// waves per CU instead of 24 — runs the 4 054-term batch in 28.6 us per 1 000 blocks against 19.0 us: each wave then owns
+// half as many term words, and its fixed per-round costs and queue traffic stay.)
 
 // ---------------------------------------------------------------------------
 // K2  eval_programs: workgroup = (group of 64 blocks, chunk of 256 queries).

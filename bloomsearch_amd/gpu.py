@@ -183,6 +183,9 @@ class Context:
     def set_ingest_chunk(self, n_bytes: int):
         self._check(self.L.bsg_set_ingest_chunk(self.h, n_bytes))
 
+    def set_lab(self, key: int, value: int):
+        self._check(self.L.bsg_set_lab(self.h, key, value))
+
     def set_spin_wait(self, microseconds: int):
         self._check(self.L.bsg_set_spin_wait(self.h, microseconds))
 

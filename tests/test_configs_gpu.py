@@ -387,3 +387,36 @@ def test_region_cursor_streams_chunks_like_blockFilterCursor():
             assert not status.any()
             assert np.array_equal(ctx.probe(aid, n_blocks, terms, ops, poff), want_all)
             ctx.arena_free(aid)
+
+
+@pytest.mark.parametrize("n_terms", [129, 191, 192, 193, 700, 4100])
+def test_many_term_mode_every_compaction_depth(ctx, n_terms):
+    """The many-term probe mode (> 128 distinct terms of one kind: per-wave rounds with ballot compaction, padded tail of
+    the last term word probed like real terms) against the oracle at term counts around the 64-term word boundaries, for
+    filters with k = 1, 2, 7, 10, 14 and for 0..3 compaction rounds, staged and gathered."""
+    rng = np.random.default_rng(n_terms)
+    vocab = ["tok%d" % i for i in range(6000)]
+    blocks = []
+    for b in range(13):
+        toks = sorted({vocab[i] for i in rng.integers(0, len(vocab), size=int(rng.integers(1, 2500)))})
+        blocks.append(H.entry_sets_from_strings(["f"], toks, ["f::" + t for t in toks]))
+    for fpr in (0.5, 0.3, 0.01, 0.001, 0.0001):          # k = 1, 2, 7, 10, 14
+        plan = plan_blocks(blocks, fpr)
+        words = ctx.build(plan.blob, plan.off, plan.fstart, plan.desc, plan.n_words)
+        picks = rng.choice(len(vocab), size=n_terms, replace=False)
+        exprs = [Q.Token(vocab[i]) for i in picks] + [Q.And(Q.Token(vocab[picks[0]]), Q.FieldToken("f", vocab[picks[1]]))]
+        cb = Q.compile_queries(exprs)
+        ops, poff, _ = cb.arrays()
+        terms = H.gpu_terms(ctx, cb)
+        want = O.probe_batch(words, plan.desc.view(O.DESC_DTYPE), terms.view(O.TERM_DTYPE), ops, poff)
+        aid = ctx.arena_load(words, plan.desc)
+        try:
+            for rounds in (0, 1, 2, 3):
+                ctx.set_lab(1, rounds)
+                for cost in (256, 1 << 24):               # staged, then everything gathered from global memory
+                    ctx.set_gather_cost(cost)
+                    assert np.array_equal(ctx.probe(aid, 13, terms, ops, poff), want), (fpr, rounds, cost)
+        finally:
+            ctx.set_lab(1, 2)
+            ctx.set_gather_cost(256)
+            ctx.arena_free(aid)
