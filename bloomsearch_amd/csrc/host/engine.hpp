@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstring>
+#include <chrono>
 #include <map>
 #include <memory>
 #include <string>
@@ -79,6 +80,10 @@ struct DataFile {
 struct BlockStats {                      // query_exec.go:63-72
     uint64_t file_id = 0, block_offset = 0;
     int64_t rows_processed = 0, bytes_processed = 0, total_rows = 0, total_bytes = 0;
+    // query_exec.go:578,598-600: the reference timestamps every block; a batched probe has one wall time for all of them,
+    // so every candidate block gets batch time / blocks (plus its share of the scan), never zero
+    // (query_handles_test.go:1062 asserts Duration > 0)
+    int64_t duration_ns = 0;
     bool bloom_filter_skipped = false;
 };
 
@@ -252,9 +257,16 @@ public:
     }
 
     // Query: nil expression => no bloom conditions => no filter reads, every block scanned (query_exec.go:503-508).
-    int32_t query(const BloomExpression *expr, QueryResult &out)
+    // regex: the field-scoped regex tree of the query; files and blocks are pruned by
+    // pruneBloomQuery = AndBloomQueries(bloom, RegexFieldGuardBloomQuery(regex)) (query_exec.go:220), rows are matched by the
+    // bloom tree AND the regex tree (row_matcher.go:353-368).
+    int32_t query(const BloomExpression *row_expr, QueryResult &out, const RegexExpression *regex = nullptr)
     {
         out = QueryResult{};
+        const auto t_begin = std::chrono::steady_clock::now();
+        BloomExpression guard, prune_storage;
+        const bool has_guard = regex_field_guard(regex, guard);
+        const BloomExpression *expr = and_bloom_queries(row_expr, has_guard ? &guard : nullptr, prune_storage) ? &prune_storage : nullptr;
         std::vector<uint8_t> file_ok(files_.size(), 1);
         std::vector<std::vector<uint8_t>> block_ok(files_.size());
         for (size_t f = 0; f < files_.size(); ++f) block_ok[f].assign(files_[f].blocks.size(), 1);
@@ -295,9 +307,17 @@ public:
                 o += (files_[f].blocks.size() + 63) / 64;
             }
         }
-        RowMatcher matcher(expr);
+        const int64_t probe_ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_begin).count();
+        size_t candidate_blocks = 0;
+        for (size_t f = 0; f < files_.size(); ++f) if (file_ok[f]) candidate_blocks += files_[f].blocks.size();
+        const int64_t probe_share = candidate_blocks ? std::max<int64_t>(1, probe_ns / (int64_t)candidate_blocks) : 0;
+        RowMatcher matcher(row_expr);
+        RegexRowMatcher regex_matcher(regex);
+        if (!regex_matcher.valid()) return fail(kErrInvalidQuery, "regex pattern does not compile");
         // the scan list: every row of every block that survived both stages, in file / block order
         std::vector<const std::string *> scan;
+        std::vector<size_t> scanned_stats;          // block_stats entries of the scanned blocks (for the scan's time share)
+        const auto t_scan = std::chrono::steady_clock::now();
         for (size_t f = 0; f < files_.size(); ++f) {
             out.files_considered++;
             if (!file_ok[f]) { out.files_bloom_skipped++; continue; }   // file stage prune: no BlockStats for its blocks
@@ -307,6 +327,7 @@ public:
                 st.file_id = files_[f].file_id; st.block_offset = blk.block_offset;
                 st.total_rows = (int64_t)blk.rows.size();
                 st.total_bytes = (int64_t)(blk.row_bytes + blk.filter_section.size());
+                st.duration_ns = probe_share;
                 if (block_ok[f][b] == 2) {        // recordUnreadBlocks (query_exec.go:625-639): totals only, error surfaced
                     out.errors.push_back("failed to read data block bloom filters: file " + std::to_string(files_[f].file_id) +
                                          " block offset " + std::to_string(blk.block_offset) + ": invalid hash");
@@ -323,18 +344,36 @@ public:
                     st.bytes_processed += (int64_t)row.size() + 4;
                     scan.push_back(&row);
                 }
+                scanned_stats.push_back(out.block_stats.size());
                 out.block_stats.push_back(st);
             }
         }
         std::vector<uint8_t> hit(scan.size(), 0);
         bool on_device = false;
-        if (cfg_.device_match && expr && !scan.empty()) {
-            if (int32_t rc = match_rows_device(expr, scan, matcher, hit, on_device)) return rc;
+        if (cfg_.device_match && row_expr && !scan.empty()) {
+            if (int32_t rc = match_rows_device(row_expr, scan, matcher, hit, on_device)) return rc;
         }
         if (!on_device)
             for (size_t i = 0; i < scan.size(); ++i) hit[i] = matcher.match(*scan[i]);
+        if (regex) {
+            // the regex patterns only run on rows the bloom tree kept AND — when the device matcher is on — on rows whose
+            // guard fields exist: the field guard the probe already used, evaluated per row by k_match_rows
+            std::vector<uint8_t> cand(scan.size(), 1);
+            bool guard_on_device = false;
+            if (cfg_.device_match && has_guard && !scan.empty()) {
+                RowMatcher guard_host(&guard);
+                if (int32_t rc = match_rows_device(&guard, scan, guard_host, cand, guard_on_device)) return rc;
+                if (!guard_on_device) std::fill(cand.begin(), cand.end(), 1);
+            }
+            for (size_t i = 0; i < scan.size(); ++i)
+                if (hit[i]) hit[i] = cand[i] && regex_matcher.match(*scan[i]);
+        }
         for (size_t i = 0; i < scan.size(); ++i)
             if (hit[i]) out.rows.push_back(*scan[i]);
+        if (!scanned_stats.empty()) {
+            const int64_t scan_ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_scan).count();
+            for (size_t i : scanned_stats) out.block_stats[i].duration_ns += std::max<int64_t>(1, scan_ns / (int64_t)scanned_stats.size());
+        }
         return kEngineOk;
     }
 

@@ -11,6 +11,7 @@
 #pragma once
 #include <cstdint>
 #include <map>
+#include <regex>
 #include <memory>
 #include <string>
 #include <string_view>
@@ -113,6 +114,143 @@ inline bool expression_from_json(const JNode &n, BloomExpression &out)
     }
     return true;
 }
+
+// ---- regex query tree and its bloom field guard (query.go:520-538, :612-718) ----
+// RegexExpression mirrors the reference's exported struct; RegexFieldGuardBloomQuery turns every regex condition into
+// Field(cond.Field) — a row can only match FieldRegex(f, ..) if path f exists, so files / blocks whose field filter lacks f
+// are pruned before any row is scanned (query_exec.go:220: pruneBloomQuery = AndBloomQueries(rowBloom, guard)).
+enum class RegexType : uint8_t { Condition, And, Or, Unknown };
+struct RegexExpression {
+    RegexType type = RegexType::Unknown;
+    bool has_condition = false;
+    std::string field, pattern;
+    std::vector<RegexExpression> children;
+};
+inline RegexExpression FieldRegex(std::string field, std::string pattern)
+{
+    RegexExpression e; e.type = RegexType::Condition; e.has_condition = true; e.field = std::move(field); e.pattern = std::move(pattern);
+    return e;
+}
+inline bool regex_expression_from_json(const JNode &n, RegexExpression &out)
+{
+    if (n.type != JType::Object) return false;
+    const JNode *t = n.get("ExpressionType");
+    const std::string ts = (t && t->type == JType::String) ? t->text : "";
+    out.type = ts == "CONDITION" ? RegexType::Condition : ts == "AND" ? RegexType::And : ts == "OR" ? RegexType::Or : RegexType::Unknown;
+    const JNode *c = n.get("Condition");
+    out.has_condition = c && c->type == JType::Object;
+    if (out.has_condition) {
+        const JNode *f = c->get("Field"), *pt = c->get("Pattern");
+        out.field = (f && f->type == JType::String) ? f->text : "";
+        out.pattern = (pt && pt->type == JType::String) ? pt->text : "";
+    }
+    const JNode *kids = n.get("Children");
+    if (kids && kids->type == JType::Array) {
+        out.children.resize(kids->items.size());
+        for (size_t i = 0; i < kids->items.size(); ++i)
+            if (!regex_expression_from_json(kids->items[i], out.children[i])) return false;
+    }
+    return true;
+}
+// regexExpressionToBloomFieldExpression (query.go:651-696): false = nil.  And / Or keep their node even when every child
+// was dropped (the reference builds the node from whatever children survive; no flattening here).
+inline bool regex_to_bloom_field_expression(const RegexExpression &e, BloomExpression &out)
+{
+    switch (e.type) {
+    case RegexType::Condition:
+        if (!e.has_condition) return false;
+        out = Field(e.field);
+        return true;
+    case RegexType::And:
+    case RegexType::Or: {
+        out = BloomExpression{};
+        out.type = e.type == RegexType::And ? ExprType::And : ExprType::Or;
+        for (const RegexExpression &c : e.children) {
+            BloomExpression child;
+            if (regex_to_bloom_field_expression(c, child)) out.children.push_back(std::move(child));
+        }
+        return true;
+    }
+    default:
+        return false;
+    }
+}
+// RegexFieldGuardBloomQuery (query.go:698-707): nil query / nil expression / untranslatable => no guard
+inline bool regex_field_guard(const RegexExpression *regex, BloomExpression &out)
+{
+    return regex && regex_to_bloom_field_expression(*regex, out);
+}
+// AndBloomQueries (query.go:709-718): a nil side yields the other; otherwise And(left, right) WITH flattening
+inline bool and_bloom_queries(const BloomExpression *left, const BloomExpression *right, BloomExpression &out)
+{
+    if (!left && !right) return false;
+    if (!left) { out = *right; return true; }
+    if (!right) { out = *left; return true; }
+    out = And({*left, *right});
+    return true;
+}
+
+// The regex half of the final row test (row_matcher.go:548-573): a condition holds when its pattern matches the text of any
+// primitive at or beneath the field path (decoded text for strings, the raw literal for numbers and booleans; null never).
+// Patterns are compiled with std::regex (ECMAScript): the mirror covers the common subset it shares with Go's RE2 syntax.
+class RegexRowMatcher {
+public:
+    explicit RegexRowMatcher(const RegexExpression *e)
+    {
+        if (!e) return;
+        root_ = *e; has_root_ = true;
+        collect(root_);
+    }
+    bool valid() const { return valid_; }
+    bool match(std::string_view row)
+    {
+        if (!has_root_) return true;
+        sat_.assign(conds_.size(), 0);
+        walker_.walk(row, [&](const Emission &em) {
+            if (!em.is_leaf || !em.has_text) return true;
+            for (size_t i = 0; i < conds_.size(); ++i) {
+                if (sat_[i]) continue;
+                const std::string &f = conds_[i]->field;
+                const bool under = em.path == f || (em.path.size() > f.size() && em.path.compare(0, f.size(), f) == 0 && em.path[f.size()] == '.');
+                if (under && std::regex_search(em.text.begin(), em.text.end(), res_[i])) sat_[i] = 1;
+            }
+            return true;
+        });
+        size_t next = 0;
+        return eval(root_, next);
+    }
+
+private:
+    RegexExpression root_;
+    bool has_root_ = false, valid_ = true;
+    std::vector<const RegexExpression *> conds_;
+    std::vector<std::regex> res_;
+    std::vector<uint8_t> sat_;
+    PathWalker walker_;
+    void collect(const RegexExpression &e)
+    {
+        if (e.type == RegexType::Condition) {
+            if (!e.has_condition || e.field.empty()) return;   // nil condition: true; empty field: constant false (row_matcher.go:446-451)
+            conds_.push_back(&e);
+            // the one RE2 idiom the mirror translates: a leading (?i) becomes the icase flag
+            const bool icase = e.pattern.rfind("(?i)", 0) == 0;
+            try { res_.emplace_back(icase ? e.pattern.substr(4) : e.pattern,
+                                    std::regex::ECMAScript | std::regex::optimize | (icase ? std::regex::icase : std::regex::ECMAScript)); }
+            catch (const std::regex_error &) { res_.emplace_back(); valid_ = false; }
+            return;
+        }
+        for (auto &c : e.children) collect(c);
+    }
+    bool eval(const RegexExpression &e, size_t &next) const
+    {
+        switch (e.type) {
+        case RegexType::Condition: return !e.has_condition ? true : (e.field.empty() ? false : (bool)sat_[next++]);
+        case RegexType::And: { bool r = true; for (auto &c : e.children) r = eval(c, next) && r; return r; }
+        case RegexType::Or: { bool r = false; for (auto &c : e.children) r = eval(c, next) || r; return !e.children.empty() && r; }
+        default: return false;
+        }
+    }
+};
 
 // ---- lowering to the C-ABI ----
 class QueryBatch {

@@ -184,6 +184,68 @@ int32_t bsh_match_row(const char *expr_json, uint64_t expr_len, const uint8_t *r
     return m.match(std::string_view(reinterpret_cast<const char *>(row), row_len)) ? 1 : 0;
 }
 
+namespace {
+void expression_to_json(const BloomExpression &e, std::string &out)
+{
+    out += "{\"ExpressionType\":";
+    out += e.type == ExprType::Condition ? "\"CONDITION\"" : e.type == ExprType::And ? "\"AND\"" : e.type == ExprType::Or ? "\"OR\"" : "\"?\"";
+    if (e.type == ExprType::Condition) {
+        out += ",\"Condition\":";
+        if (!e.has_condition) out += "null";
+        else {
+            const char *t = e.condition.type == CondType::Field ? "FIELD" : e.condition.type == CondType::Token ? "TOKEN"
+                          : e.condition.type == CondType::FieldToken ? "FIELD_TOKEN" : "?";
+            out += std::string("{\"Type\":\"") + t + "\",\"Field\":";
+            json_escape(out, e.condition.field);
+            out += ",\"Token\":";
+            json_escape(out, e.condition.token);
+            out += "}";
+        }
+    } else {
+        out += ",\"Children\":[";
+        for (size_t i = 0; i < e.children.size(); ++i) { if (i) out.push_back(','); expression_to_json(e.children[i], out); }
+        out += "]";
+    }
+    out += "}";
+}
+bool parse_regex_json(const char *json, uint64_t len, RegexExpression &e, bool &nil)
+{
+    nil = true;
+    std::string_view sv(json ? json : "", json ? len : 0);
+    if (sv.empty()) return true;
+    JNode dom;
+    if (!parse_dom(sv, dom)) return false;
+    if (dom.type == JType::Null) return true;
+    if (!regex_expression_from_json(dom, e)) return false;
+    nil = false;
+    return true;
+}
+}  // namespace
+
+// pruneBloomQuery (query_exec.go:220): AndBloomQueries(bloom, RegexFieldGuardBloomQuery(regex)) as JSON ("null" = nil query)
+int32_t bsh_prune_query(const char *bloom_json, uint64_t bloom_len, const char *regex_json, uint64_t regex_len, char **out, uint64_t *out_len)
+{
+    BloomExpression b, guard, pruned;
+    RegexExpression r;
+    bool bnil = true, rnil = true;
+    if (!parse_expression_json(bloom_json, bloom_len, b, bnil) || !parse_regex_json(regex_json, regex_len, r, rnil)) return BSH_E_INVALID;
+    const bool has_guard = regex_field_guard(rnil ? nullptr : &r, guard);
+    std::string s = "null";
+    if (and_bloom_queries(bnil ? nullptr : &b, has_guard ? &guard : nullptr, pruned)) { s.clear(); expression_to_json(pruned, s); }
+    return give(s, out, out_len);
+}
+
+// the regex half of matchRowBytes (row_matcher.go:548-573): 1 match, 0 no match, < 0 invalid arguments / pattern
+int32_t bsh_match_row_regex(const char *regex_json, uint64_t regex_len, const uint8_t *row, uint64_t row_len)
+{
+    RegexExpression r;
+    bool nil = true;
+    if (!parse_regex_json(regex_json, regex_len, r, nil)) return BSH_E_INVALID;
+    RegexRowMatcher m(nil ? nullptr : &r);
+    if (!m.valid()) return BSH_E_INVALID;
+    return m.match(std::string_view(reinterpret_cast<const char *>(row), row_len)) ? 1 : 0;
+}
+
 int32_t bsh_section_encode(const uint64_t *const words[3], const uint64_t m[3], const uint64_t k[3], uint8_t **out, uint64_t *out_len)
 {
     FilterView fv[3];
@@ -269,7 +331,8 @@ int32_t bse_query(bse_engine *e, const char *query_json, uint64_t len, char **ou
 {
     if (!e || !out_json) return BSH_E_INVALID;
     BloomExpression expr;
-    bool nil = true;
+    RegexExpression regex;
+    bool nil = true, has_regex = false;
     std::string_view sv(query_json ? query_json : "", query_json ? len : 0);
     if (!sv.empty()) {
         JNode dom;
@@ -283,12 +346,20 @@ int32_t bse_query(bse_engine *e, const char *query_json, uint64_t len, char **ou
                     nil = false;
                 }
             }
+            const JNode *rx = dom.get("Regex");
+            if (rx && rx->type == JType::Object) {
+                const JNode *ex = rx->get("Expression");
+                if (ex && ex->type == JType::Object) {
+                    if (!regex_expression_from_json(*ex, regex)) return BSE_E_INVALID_QUERY;
+                    has_regex = true;
+                }
+            }
         } else if (dom.type != JType::Null) {
             return BSE_E_INVALID_QUERY;
         }
     }
     QueryResult res;
-    if (int32_t rc = e->eng->query(nil ? nullptr : &expr, res)) return rc;
+    if (int32_t rc = e->eng->query(nil ? nullptr : &expr, res, has_regex ? &regex : nullptr)) return rc;
     std::string out = "{\"rows\":[";
     for (size_t i = 0; i < res.rows.size(); ++i) { if (i) out.push_back(','); out += res.rows[i]; }
     out += "],\"stats\":{\"BlockStats\":[";
@@ -298,6 +369,7 @@ int32_t bse_query(bse_engine *e, const char *query_json, uint64_t len, char **ou
         out += "{\"FileID\":" + std::to_string(s.file_id) + ",\"BlockOffset\":" + std::to_string(s.block_offset) +
                ",\"RowsProcessed\":" + std::to_string(s.rows_processed) + ",\"BytesProcessed\":" + std::to_string(s.bytes_processed) +
                ",\"TotalRows\":" + std::to_string(s.total_rows) + ",\"TotalBytes\":" + std::to_string(s.total_bytes) +
+               ",\"Duration\":" + std::to_string(s.duration_ns) +
                ",\"BloomFilterSkipped\":" + (s.bloom_filter_skipped ? "true" : "false") + "}";
     }
     out += "],\"Errors\":[";

@@ -14,7 +14,7 @@ from ._lib import TERM_DTYPE
 HOST_EXPORTS = [
     "bsh_free", "bsh_tokenize", "bsh_entry_sets_new", "bsh_entry_sets_free", "bsh_entry_sets_index_row",
     "bsh_entry_sets_union_into", "bsh_entry_sets_counts", "bsh_entry_sets_export_sizes", "bsh_entry_sets_export",
-    "bsh_batch_new", "bsh_batch_free", "bsh_batch_add_query", "bsh_batch_sizes", "bsh_batch_export", "bsh_match_row",
+    "bsh_batch_new", "bsh_batch_free", "bsh_batch_add_query", "bsh_batch_sizes", "bsh_batch_export", "bsh_match_row", "bsh_prune_query", "bsh_match_row_regex",
     "bsh_section_encode", "bsh_section_parse", "bsh_crc32c",
     "bse_open", "bse_close", "bse_last_error", "bse_stop", "bse_ingest_rows", "bse_flush", "bse_merge", "bse_query",
     "bse_describe", "bse_corrupt_section_byte", "bse_section_bytes",
@@ -51,6 +51,8 @@ def lib():
     L.bsh_batch_sizes.argtypes = [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), pu64]; L.bsh_batch_sizes.restype = None
     L.bsh_batch_export.argtypes = [vp, vp, vp, vp, vp, vp]
     L.bsh_match_row.argtypes = [C.c_char_p, u64, C.c_char_p, u64]
+    L.bsh_prune_query.argtypes = [C.c_char_p, u64, C.c_char_p, u64, pp, pu64]
+    L.bsh_match_row_regex.argtypes = [C.c_char_p, u64, C.c_char_p, u64]
     L.bsh_section_encode.argtypes = [C.POINTER(vp), pu64, pu64, pp, pu64]
     L.bsh_section_parse.argtypes = [C.c_char_p, u64, pu64, pu64, C.POINTER(vp)]
     L.bsh_crc32c.argtypes = [C.c_char_p, u64]; L.bsh_crc32c.restype = u32
@@ -177,6 +179,27 @@ def match_row(expression, row: bytes) -> bool:
     return bool(rc)
 
 
+def prune_query(bloom_expression, regex_expression):
+    """pruneBloomQuery of the host mirror -> expression dict or None."""
+    L = lib()
+    b = json.dumps(bloom_expression).encode()
+    r = json.dumps(regex_expression).encode()
+    p, n = C.c_void_p(), C.c_uint64()
+    rc = L.bsh_prune_query(b, len(b), r, len(r), C.byref(p), C.byref(n))
+    if rc:
+        raise HostError(rc)
+    return json.loads(_take(L, p, n))
+
+
+def match_row_regex(regex_expression, row: bytes) -> bool:
+    L = lib()
+    r = json.dumps(regex_expression).encode()
+    rc = L.bsh_match_row_regex(r, len(r), row, len(row))
+    if rc < 0:
+        raise HostError(rc)
+    return bool(rc)
+
+
 def crc32c(data: bytes) -> int:
     return int(lib().bsh_crc32c(data, len(data)))
 
@@ -252,8 +275,9 @@ class Engine:
     def stop(self):
         self._check(self.L.bse_stop(self.h))
 
-    def query(self, bloom_expression=None):
-        q = json.dumps({"Bloom": {"Expression": bloom_expression} if bloom_expression is not None else None}).encode()
+    def query(self, bloom_expression=None, regex_expression=None):
+        q = json.dumps({"Bloom": {"Expression": bloom_expression} if bloom_expression is not None else None,
+                        "Regex": {"Expression": regex_expression} if regex_expression is not None else None}).encode()
         p, n = C.c_void_p(), C.c_uint64()
         self._check(self.L.bse_query(self.h, q, len(q), C.byref(p), C.byref(n)))
         return json.loads(_take(self.L, p, n))

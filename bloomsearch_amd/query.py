@@ -62,6 +62,49 @@ def and_bloom_queries(left, right):
     return And(left, right)
 
 
+# ---- regex query tree (query.go:520-538, :612-649) and its bloom field guard (:651-707) ----
+def FieldRegex(field: str, pattern: str) -> dict:
+    return {"ExpressionType": "CONDITION", "Condition": {"Field": field, "Pattern": pattern}}
+
+
+def _flatten_regex(expressions, expression_type):
+    out = []
+    for e in expressions:
+        if e.get("ExpressionType") == expression_type and e.get("Condition") is None:
+            out.extend(e.get("Children") or [])
+        else:
+            out.append(e)
+    return out
+
+
+def RegexAnd(*expressions) -> dict:
+    return {"ExpressionType": "AND", "Children": _flatten_regex(expressions, "AND")}
+
+
+def RegexOr(*expressions) -> dict:
+    return {"ExpressionType": "OR", "Children": _flatten_regex(expressions, "OR")}
+
+
+def regex_field_guard_bloom_query(regex_expression):
+    """RegexFieldGuardBloomQuery (query.go:698-707) on bare expressions: every regex condition becomes Field(cond.Field);
+    And / Or keep their node around whatever children translate (no flattening); anything else is nil."""
+    if regex_expression is None:
+        return None
+    t = regex_expression.get("ExpressionType")
+    if t == "CONDITION":
+        c = regex_expression.get("Condition")
+        return None if c is None else Field(c.get("Field", ""))
+    if t in ("AND", "OR"):
+        kids = [g for g in (regex_field_guard_bloom_query(c) for c in regex_expression.get("Children") or []) if g is not None]
+        return {"ExpressionType": EXPR_AND if t == "AND" else EXPR_OR, "Children": kids}
+    return None
+
+
+def prune_bloom_query(bloom_expression, regex_expression):
+    """pruneBloomQuery (query_exec.go:220)."""
+    return and_bloom_queries(bloom_expression, regex_field_guard_bloom_query(regex_expression))
+
+
 def make_field_token_key(field: str, token: str) -> str:
     """makeFieldTokenKey (tokenizer.go:509-511): plain concatenation, no escaping."""
     return field + "::" + token

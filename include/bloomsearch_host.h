@@ -63,6 +63,12 @@ BSG_API int32_t bsh_batch_export(const bsh_batch *b, uint8_t *term_bytes, uint32
 
 /* final exact test of one row against one expression: 1 match, 0 no match, negative error */
 BSG_API int32_t bsh_match_row(const char *expr_json, uint64_t expr_len, const uint8_t *row, uint64_t row_len);
+/* pruneBloomQuery = AndBloomQueries(bloom, RegexFieldGuardBloomQuery(regex)) (query_exec.go:220, query.go:651-718) as JSON in the
+ * reference's struct shape; "null" when both sides are nil.  regex_json: {"ExpressionType": "CONDITION"|"AND"|"OR",
+ * "Condition": {"Field", "Pattern"}, "Children": [...]}. */
+BSG_API int32_t bsh_prune_query(const char *bloom_json, uint64_t bloom_len, const char *regex_json, uint64_t regex_len, char **out, uint64_t *out_len);
+/* The regex half of the final row test (row_matcher.go:548-573; std::regex ECMAScript stands in for RE2): 1 / 0 / < 0. */
+BSG_API int32_t bsh_match_row_regex(const char *regex_json, uint64_t regex_len, const uint8_t *row, uint64_t row_len);
 
 /* filter section codec; filters[c].m == 0 => absent */
 BSG_API int32_t bsh_section_encode(const uint64_t *const words[3], const uint64_t m[3], const uint64_t k[3],

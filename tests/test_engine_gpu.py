@@ -65,6 +65,34 @@ def test_block_stats_accuracy(ctx):
     assert skipped[0]["RowsProcessed"] == 0 and skipped[0]["BytesProcessed"] == 0
     assert skipped[0]["TotalRows"] == 3 and skipped[0]["TotalBytes"] > 0
     assert scanned[0]["RowsProcessed"] == 2 == scanned[0]["TotalRows"] and scanned[0]["BytesProcessed"] > 0
+    # BlockStats.Duration: the batched probe has one wall time for all blocks; every candidate block gets its share and none
+    # reports zero (query_exec.go:578,598-600; asserted > 0 at query_handles_test.go:1062)
+    assert all(b["Duration"] > 0 for b in stats)
+    assert scanned[0]["Duration"] > skipped[0]["Duration"]      # the scanned block also carries the scan's time
+
+
+def test_regex_query_is_pruned_by_its_field_guard(ctx):
+    """Query.Regex: files / blocks are pruned by AndBloomQueries(bloom, RegexFieldGuardBloomQuery(regex)) (query_exec.go:220) —
+    a block none of whose rows has the field cannot match FieldRegex on it — and rows are matched by bloom AND regex
+    (row_matcher.go:353-368); with the device matcher on, the patterns only run on rows the guard's Field conditions keep."""
+    e = new_engine(ctx, PartitionField="partition", BloomFalsePositiveRate=1e-6)
+    ingest_and_flush(e, [
+        {"id": 1.0, "partition": "a", "message": "timeout talking to db", "level": "error"},
+        {"id": 2.0, "partition": "a", "message": "retry scheduled", "level": "info"},
+        {"id": 3.0, "partition": "b", "note": "timeout in a field the regex does not name"},
+        {"id": 4.0, "partition": "b", "note": "nothing"},
+        {"id": 5.0, "partition": "c", "message": "all good", "level": "error", "svc": {"name": "payments"}},
+    ])
+    regex = Q.RegexAnd(Q.FieldRegex("message", "timeout|retry"), Q.FieldRegex("level", "^err"))
+    res = e.query(None, regex)
+    assert result_ids(res) == {1.0}
+    stats = {b["BlockOffset"]: b for b in res["stats"]["BlockStats"]}
+    assert sum(b["BloomFilterSkipped"] for b in stats.values()) == 1       # partition b has neither message nor level
+    # bloom AND regex; regex alone beneath a path; a guard that keeps everything
+    assert result_ids(e.query(Q.Token("retry"), Q.FieldRegex("level", "^(info|error)$"))) == {2.0}
+    assert result_ids(e.query(None, Q.FieldRegex("svc", "^pay"))) == {5.0}
+    assert result_ids(e.query(None, Q.RegexOr(Q.FieldRegex("note", "^nothing$"), Q.FieldRegex("id", "^1\\.0$")))) == {1.0, 4.0}
+    assert result_ids(e.query(Q.Field("partition"), {"ExpressionType": "CONDITION", "Condition": None})) == {1.0, 2.0, 3.0, 4.0, 5.0}
 
 
 def test_measured_filter_sizing(ctx):

@@ -191,6 +191,50 @@ def go_marshal(obj) -> bytes:
     return s.encode()
 
 
+def test_regex_field_guard_keeps_the_boolean_shape():
+    """RegexFieldGuardBloomQuery (query.go:651-707) and pruneBloomQuery = AndBloomQueries(bloom, guard) (query_exec.go:220),
+    host mirror against the Python restatement; shape test after query_builder_test.go:214-260."""
+    regex = Q.RegexOr(Q.FieldRegex("service", "^pay"), Q.RegexAnd(Q.FieldRegex("level", "^error$"), Q.FieldRegex("message", "timeout")))
+    guard = Hst.prune_query(None, regex)
+    assert guard == Q.regex_field_guard_bloom_query(regex)
+    assert guard["ExpressionType"] == "OR" and len(guard["Children"]) == 2
+    assert guard["Children"][0]["Condition"] == {"Type": "FIELD", "Field": "service", "Token": ""}
+    assert [c["Condition"]["Field"] for c in guard["Children"][1]["Children"]] == ["level", "message"]
+    # AndBloomQueries: nil sides pass through, two real sides are And-ed WITH same-type flattening (query.go:709-718, :600-610)
+    bloom = Q.And(Q.Field("user.name"), Q.Token("timeout"))
+    both = Hst.prune_query(bloom, Q.RegexAnd(Q.FieldRegex("a", "x"), Q.FieldRegex("b", "y")))
+    want = Q.prune_bloom_query(bloom, Q.RegexAnd(Q.FieldRegex("a", "x"), Q.FieldRegex("b", "y")))
+    strip = lambda e: ({"ExpressionType": e["ExpressionType"], "Children": [strip(c) for c in e.get("Children", [])]} if e["ExpressionType"] != "CONDITION"
+                       else {"ExpressionType": "CONDITION", "Condition": {k: v for k, v in (e["Condition"] or {}).items() if v != ""}})
+    assert strip(both) == strip(want)
+    assert [c["Condition"]["Type"] for c in both["Children"]] == ["FIELD", "TOKEN", "FIELD", "FIELD"]      # flattened into one AND
+    assert Hst.prune_query(bloom, None) is not None and Hst.prune_query(None, None) is None
+    # a nil regex condition contributes nothing; an unknown node type makes the whole guard nil
+    assert Hst.prune_query(None, {"ExpressionType": "AND", "Children": [{"ExpressionType": "CONDITION", "Condition": None}]}) == \
+        {"ExpressionType": "AND", "Children": []}
+    assert Hst.prune_query(None, {"ExpressionType": "XOR", "Children": []}) is None
+
+
+def test_regex_row_matching_tables():
+    """FieldRegex semantics (row_matcher.go:440-476, :519-573): the pattern sees the text of every primitive at or beneath
+    the field path.  Rows and verdicts of query_test.go:119-128 and tokenizer_test.go:192-215."""
+    regex = Q.RegexOr(Q.RegexAnd(Q.FieldRegex("message", "timeout|retry"), Q.FieldRegex("level", "^err")), Q.FieldRegex("service", "^pay"))
+    for row, want in [(b'{"message":"retry now","level":"error"}', True), (b'{"service":"payments"}', True),
+                      (b'{"message":"retry now","level":"info"}', False)]:
+        assert Hst.match_row_regex(regex, row) == want, row
+    nested = Q.RegexAnd(Q.FieldRegex("users.name", "(?i)^jo"), Q.RegexOr(Q.FieldRegex("users.active", "^true$"), Q.FieldRegex("users.id", "^2$")))
+    assert Hst.match_row_regex(nested, b'{"users":[{"id":1,"name":"John","active":true},{"id":2,"name":"Jane","active":false}]}')
+    assert not Hst.match_row_regex(nested, b'{"users":[{"id":3,"name":"Alice","active":false}]}')
+    # beneath the path, raw number literals, null never, empty field constant-false, nil condition true, empty Or false
+    assert Hst.match_row_regex(Q.FieldRegex("a", "^1500000$"), b'{"a":{"b":[1500000]}}')
+    assert not Hst.match_row_regex(Q.FieldRegex("a", "."), b'{"a":null,"ab":"x"}')
+    assert not Hst.match_row_regex(Q.FieldRegex("", "."), b'{"a":"x"}')
+    assert Hst.match_row_regex({"ExpressionType": "CONDITION", "Condition": None}, b'{"a":"x"}')
+    assert not Hst.match_row_regex({"ExpressionType": "OR", "Children": []}, b'{"a":"x"}')
+    with pytest.raises(Hst.HostError):
+        Hst.match_row_regex(Q.FieldRegex("message", "[unterminated("), b'{"message":"x"}')
+
+
 def test_index_row_matches_walker_oracle_on_random_rows():
     # the property generator of no_false_negatives_test.go:398-459, re-seeded (any seeded RNG does)
     rng = np.random.default_rng(7)
