@@ -23,7 +23,6 @@ INGEST_TRUSTED_JSON = 1
 
 TERM_DTYPE = np.dtype([("h", "<u8", (4,)), ("kind", "<u4"), ("reserved", "<u4")])
 DESC_DTYPE = np.dtype([("word_off", "<u8"), ("m", "<u8"), ("k", "<u4"), ("reserved", "<u4")])
-MATCH_COND_DTYPE = np.dtype([("hf", "<u8", (4,)), ("ht", "<u8", (4,)), ("kind", "<u4"), ("reserved", "<u4")])
 
 
 class Timing(C.Structure):
@@ -132,7 +131,7 @@ def load():
     L.bsg_sections_size.argtypes = [vp, u32, C.POINTER(u64)]
     L.bsg_build_sections.argtypes = [vp, vp, vp, u32, vp, vp, u32, u64, vp, u64, vp]
     L.bsg_last_encode_ms.argtypes = [vp, C.POINTER(C.c_float)]
-    L.bsg_match_rows.argtypes = [vp, vp, vp, u32, vp, u32, vp, u32, vp, vp, u32, C.POINTER(u32)]
+    L.bsg_match_rows.argtypes = [vp, vp, vp, u32, vp, vp, vp, u32, vp, u32, vp, vp, u32, C.POINTER(u32)]
     L.bsg_last_match_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.bsg_pinned_alloc.argtypes = [vp, u64, C.POINTER(vp)]
     L.bsg_pinned_free.argtypes = [vp, vp]

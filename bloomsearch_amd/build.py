@@ -48,7 +48,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-           "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
+           "-fvisibility=hidden", "-Wall", "-Wno-unused-function", *os.environ.get("BSG_EXTRA_CXXFLAGS", "").split(),
            "-I", INCLUDE, "-I", CSRC, "-I", os.path.join(CSRC, "host"), "-o", LIB + ".tmp"] + sources() + ["-lpthread", "-ldl"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)

@@ -21,6 +21,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <random>
 #include <string>
 #include <vector>
 
@@ -252,6 +253,7 @@ struct bsg_ctx {
     uint64_t timed_counter = 0;
     uint32_t group_limit = bsg::kMaxGroupArenas;   // arenas one probe dispatch may cover (bsg_set_probe_group)
     uint32_t gather_cost = 256;  // a filter is gathered instead of staged when terms * k * gather_cost < its bytes
+    bsg::FpKey fp_key{};         // secret key of the entries' fingerprints (drawn at bsg_open; never leaves the process)
     std::vector<void *> comms;   // ncclComm_t per device (bsg_comm_init)
     uint32_t comm_world = 0, comm_rank = 0;
     uint64_t ingest_chunk_bytes = 64ull << 20;   // rows per upload chunk of bsg_ingest_rows (bsg_set_ingest_chunk)
@@ -455,6 +457,12 @@ int32_t bsg_open(const int32_t *device_ids, int32_t n_devices, bsg_ctx **out_ctx
     if (hipGetDeviceCount(&count) != hipSuccess || count == 0)
         return fail(BSG_E_NODEVICE, "no HIP device visible (libbloomgpu has no CPU fallback)");
     auto ctx = std::make_unique<bsg_ctx>();
+    {
+        std::random_device rd;
+        auto r64 = [&]() { return ((uint64_t)rd() << 32) ^ (uint64_t)rd() ^ ((uint64_t)(uintptr_t)ctx.get() << 7) ^
+                                  (uint64_t)std::chrono::steady_clock::now().time_since_epoch().count(); };
+        ctx->fp_key = bsg::FpKey{r64(), r64() | 1, r64() | 1};
+    }
     for (int32_t i = 0; i < n_devices; ++i) {
         if (device_ids[i] < 0 || device_ids[i] >= count)
             return fail(BSG_E_INVALID, "device id %d out of range [0,%d)", device_ids[i], count);

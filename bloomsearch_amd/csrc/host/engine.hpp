@@ -554,20 +554,12 @@ private:
     {
         MatcherProgram mp(expr);
         if (mp.kinds.size() > 64) return kEngineOk;
-        std::vector<bsg_match_cond> conds(mp.kinds.size());
-        if (!conds.empty()) {
-            std::vector<uint8_t> bytes;
-            std::vector<uint32_t> offsets{0};
-            for (auto &f : mp.fields) { bytes.insert(bytes.end(), f.begin(), f.end()); offsets.push_back((uint32_t)bytes.size()); }
-            for (auto &t : mp.tokens) { bytes.insert(bytes.end(), t.begin(), t.end()); offsets.push_back((uint32_t)bytes.size()); }
-            std::vector<uint64_t> h(conds.size() * 8);
-            if (bsg_hash_entries(ctx_, bytes.data(), offsets.data(), (uint32_t)conds.size() * 2, h.data())) return fail(kErrGpu, bsg_last_error(ctx_));
-            for (size_t c = 0; c < conds.size(); ++c) {
-                memcpy(conds[c].hf, &h[c * 4], 32);
-                memcpy(conds[c].ht, &h[(conds.size() + c) * 4], 32);
-                conds[c].kind = mp.kinds[c];
-                conds[c].reserved = 0;
-            }
+        // condition strings as the C-ABI takes them: field i, token i, ... (hashed and fingerprinted on the device)
+        std::vector<uint8_t> cbytes;
+        std::vector<uint32_t> coff{0};
+        for (size_t c = 0; c < mp.kinds.size(); ++c) {
+            cbytes.insert(cbytes.end(), mp.fields[c].begin(), mp.fields[c].end()); coff.push_back((uint32_t)cbytes.size());
+            cbytes.insert(cbytes.end(), mp.tokens[c].begin(), mp.tokens[c].end()); coff.push_back((uint32_t)cbytes.size());
         }
         std::vector<uint8_t> bytes;
         std::vector<uint64_t> row_off{0};
@@ -575,8 +567,9 @@ private:
         std::vector<uint64_t> bits((scan.size() + 63) / 64);
         std::vector<uint32_t> fb(scan.size());
         uint32_t n_fb = 0;
-        const int32_t rc = bsg_match_rows(ctx_, bytes.data(), row_off.data(), (uint32_t)scan.size(), conds.data(), (uint32_t)conds.size(),
-                                          mp.prog_ops.data(), (uint32_t)mp.prog_ops.size(), bits.data(), fb.data(), (uint32_t)fb.size(), &n_fb);
+        const int32_t rc = bsg_match_rows(ctx_, bytes.data(), row_off.data(), (uint32_t)scan.size(), cbytes.data(), coff.data(), mp.kinds.data(),
+                                          (uint32_t)mp.kinds.size(), mp.prog_ops.data(), (uint32_t)mp.prog_ops.size(), bits.data(), fb.data(),
+                                          (uint32_t)fb.size(), &n_fb);
         if (rc == BSG_E_UNSUPPORTED) return kEngineOk;      // expression too deep / long: host matcher
         if (rc) return fail(kErrGpu, bsg_last_error(ctx_));
         for (size_t i = 0; i < scan.size(); ++i) hit[i] = (bits[i >> 6] >> (i & 63)) & 1;

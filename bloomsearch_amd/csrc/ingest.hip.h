@@ -41,32 +41,62 @@ constexpr uint32_t kTableOk = 0, kTableOverflow = 1, kTableExotic = 2;
 
 struct IngestTable {
     uint64_t *slots;   // [mask + 1][4]
+    uint64_t *fps;     // [mask + 1]: keyed fingerprint of the entry stored in the slot (0 while its claimer is still writing)
     uint32_t mask;     // capacity - 1 (capacity is a power of two)
     uint32_t pad;
 };
 
+// Exactness where the reference is exact.  Go's map compares BYTES; the tables compare the 256 bits of bloom/v3's sum256,
+// and MurmurHash3_x64_128 has seed-independent internal-state collisions: for any entry of >= 24 bytes an attacker can
+// write a second one with the same four base hashes (tests/test_collisions.py constructs such pairs).  The device would
+// count them once where the reference counts twice (a different m, different bytes on disk), and the row matcher would
+// accept a row matchRowBytes rejects.  So every entry also carries a 64-bit fingerprint under a per-context SECRET key
+// (multiply-xor over the same 8-byte words murmur consumes, keys drawn at bsg_open): equal hashes with different
+// fingerprints cannot be crafted without the key.  The device never resolves such a pair itself — the table is flagged
+// (status 2: the caller rebuilds that set on its host path), the matcher hands the row to the host matcher.
+struct FpKey { uint64_t k0, k1, k2; };   // k1, k2 odd
+
+__device__ __forceinline__ uint64_t fp_word(uint64_t f, uint64_t w, uint64_t k) { return (f ^ w) * k; }
+__device__ __forceinline__ uint64_t fp_final(uint64_t f, uint64_t len, const FpKey &key)
+{
+    f = (f ^ len) * key.k1;
+    f ^= f >> 31;
+    return f ? f : 1;     // 0 is the "still being written" mark of a table slot
+}
+
 // ---------------- streaming murmur3_x64_128 pair (bloom/v3 sum256) ----------------
 struct HashStream {
     uint64_t h1, h2, lo, hi;
+    uint64_t f;        // running keyed fingerprint over the completed 16-byte blocks
     uint32_t n;
 };
 
-__device__ __forceinline__ void hs_init(HashStream &s) { s.h1 = s.h2 = s.lo = s.hi = 0; s.n = 0; }
+__device__ __forceinline__ void hs_init(HashStream &s, const FpKey &key) { s.h1 = s.h2 = s.lo = s.hi = 0; s.f = key.k0; s.n = 0; }
+__device__ __forceinline__ void hs_block(HashStream &s, const FpKey &key)
+{
+    bmix(s.h1, s.h2, s.lo, s.hi);
+    s.f = fp_word(fp_word(s.f, s.lo, key.k1), s.hi, key.k2);
+}
 
-__device__ __forceinline__ void hs_absorb(HashStream &s, uint32_t byte)
+__device__ __forceinline__ void hs_absorb(HashStream &s, uint32_t byte, const FpKey &key)
 {
     const uint32_t t = s.n & 15u;
     const uint64_t v = (uint64_t)byte << ((t & 7u) * 8u);
     if (t < 8u) s.lo |= v; else s.hi |= v;
     s.n += 1;
-    if (t == 15u) { bmix(s.h1, s.h2, s.lo, s.hi); s.lo = 0; s.hi = 0; }
+    if (t == 15u) { hs_block(s, key); s.lo = 0; s.hi = 0; }
 }
 
 // (h0,h1) = murmur(d), (h2,h3) = murmur(d || 0x01): same tail handling as base_hashes (kernels.hip.h)
-__device__ __forceinline__ void hs_finish(const HashStream &s, uint64_t h[4])
+// ... and the entry's keyed fingerprint: the blocks' running value, the tail words, the length
+__device__ __forceinline__ uint64_t hs_finish(const HashStream &s, uint64_t h[4], const FpKey &key)
 {
     const uint32_t t = s.n & 15u;
     uint64_t k1 = s.lo, k2 = s.hi;
+    uint64_t f = s.f;
+    if (t > 0) f = fp_word(f, k1, key.k1);
+    if (t > 8) f = fp_word(f, k2, key.k2);
+    f = fp_final(f, s.n, key);
     {
         uint64_t a1 = s.h1, a2 = s.h2;
         if (t > 8) mix_k2(a2, k2);
@@ -85,10 +115,27 @@ __device__ __forceinline__ void hs_finish(const HashStream &s, uint64_t h[4])
         }
         murmur_finalize(b1, b2, (uint64_t)s.n + 1, h[2], h[3]);
     }
+    return f;
+}
+
+// The same fingerprint straight from an entry's bytes (host-walked entries, condition strings): blob with >= 16 readable
+// bytes after the last entry, as base_hashes_words.
+__device__ __forceinline__ uint64_t entry_fp(const uint8_t *p, uint32_t len, const FpKey &key)
+{
+    uint64_t f = key.k0;
+    const uint32_t nb = len >> 4;
+    for (uint32_t i = 0; i < nb; ++i) f = fp_word(fp_word(f, load_u64_unaligned(p + 16 * i), key.k1), load_u64_unaligned(p + 16 * i + 8), key.k2);
+    const uint32_t t = len & 15u;
+    uint64_t k1 = load_u64_unaligned(p + 16 * nb), k2 = load_u64_unaligned(p + 16 * nb + 8);
+    if (t < 8) { k1 = t ? (k1 & (~0ULL >> (64 - 8 * t))) : 0; k2 = 0; }
+    else       { k2 = t > 8 ? (k2 & (~0ULL >> (64 - 8 * (t - 8)))) : 0; }
+    if (t > 0) f = fp_word(f, k1, key.k1);
+    if (t > 8) f = fp_word(f, k2, key.k2);
+    return fp_final(f, len, key);
 }
 
 // Absorbs n (1..8) bytes held little-endian in the low bytes of v (bytes above n must be zero).
-__device__ __forceinline__ void hs_absorb_n(HashStream &s, uint64_t v, uint32_t n)
+__device__ __forceinline__ void hs_absorb_n(HashStream &s, uint64_t v, uint32_t n, const FpKey &key)
 {
     const uint32_t t = s.n & 15u;
     s.n += n;
@@ -98,7 +145,7 @@ __device__ __forceinline__ void hs_absorb_n(HashStream &s, uint64_t v, uint32_t 
     } else {
         s.hi |= v << ((t - 8u) * 8u);
         if (t + n >= 16u) {
-            bmix(s.h1, s.h2, s.lo, s.hi);
+            hs_block(s, key);
             s.lo = (t + n > 16u) ? v >> ((16u - t) * 8u) : 0;   // t > 8 here, so the shift is < 64
             s.hi = 0;
         }
@@ -194,10 +241,13 @@ __device__ __forceinline__ void insert_begin(InsertState &x, const IngestTable t
 // entry never see h1..h3 and insert duplicates (measured: 64 equal rows -> 64 "distinct").  Every trip does a
 // bounded amount of work (no inner wait).
 // COUNT = false leaves the distinct counters alone and reports through fresh_x instead (the caller aggregates).
+// fa / fb: the entries' keyed fingerprints.  The winner of a slot stores it after h1..h3; a reader that finds all four hash
+// words equal waits for the fingerprint like it waits for h1..h3, and a DIFFERENT fingerprint under equal hashes — a
+// murmur3 state collision, i.e. an adversarial entry — flags the table (status 2: the caller rebuilds the set on the host).
 template <bool COUNT = true>
-__device__ __forceinline__ void set_insert2(const IngestTable ta, const uint64_t ha[4], bool active_a, uint32_t *count_a, uint32_t *status_a,
+__device__ __forceinline__ void set_insert2(const IngestTable ta, const uint64_t ha[4], uint64_t fa, bool active_a, uint32_t *count_a, uint32_t *status_a,
                                             bool &present_a,
-                                            const IngestTable tb, const uint64_t hb[4], bool active_b, uint32_t *count_b, uint32_t *status_b,
+                                            const IngestTable tb, const uint64_t hb[4], uint64_t fb, bool active_b, uint32_t *count_b, uint32_t *status_b,
                                             bool &present_b, bool *fresh_a = nullptr, bool *fresh_b = nullptr)
 {
     InsertState A, B;
@@ -205,24 +255,29 @@ __device__ __forceinline__ void set_insert2(const IngestTable ta, const uint64_t
     insert_begin(B, tb, hb, active_b, status_b);
     do {
         glb_u64 *sa = (glb_u64 *)ta.slots + (uint64_t)A.idx * 4, *sb = (glb_u64 *)tb.slots + (uint64_t)B.idx * 4;
-        uint64_t a0 = 0, a1 = 0, a2 = 0, a3 = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0;
-        if (!A.done) { a0 = ld_agent(sa); a1 = ld_agent(sa + 1); a2 = ld_agent(sa + 2); a3 = ld_agent(sa + 3); }
-        if (!B.done) { b0 = ld_agent(sb); b1 = ld_agent(sb + 1); b2 = ld_agent(sb + 2); b3 = ld_agent(sb + 3); }
+        glb_u64 *pa = (glb_u64 *)ta.fps + A.idx, *pb = (glb_u64 *)tb.fps + B.idx;
+        uint64_t a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0, b4 = 0;
+        if (!A.done) { a0 = ld_agent(sa); a1 = ld_agent(sa + 1); a2 = ld_agent(sa + 2); a3 = ld_agent(sa + 3); a4 = ld_agent(pa); }
+        if (!B.done) { b0 = ld_agent(sb); b1 = ld_agent(sb + 1); b2 = ld_agent(sb + 2); b3 = ld_agent(sb + 3); b4 = ld_agent(pb); }
         const bool cas_a = !A.done && a0 == 0, cas_b = !B.done && b0 == 0;
         uint64_t old_a = 0, old_b = 0;
         bool won_a = false, won_b = false;
         if (cas_a) won_a = __hip_atomic_compare_exchange_strong(sa, &old_a, ha[0], __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (cas_b) won_b = __hip_atomic_compare_exchange_strong(sb, &old_b, hb[0], __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#define BSG_SETTLE(X, won, cas, s, h, c0, c1, c2, c3, tab, status)                                              \
+#define BSG_SETTLE(X, won, cas, s, pf, h, f, c0, c1, c2, c3, c4, tab, status)                                   \
         if (!X.done) {                                                                                                   \
             if (won) {                                                                                                   \
-                st_agent(s + 1, h[1]); st_agent(s + 2, h[2]); st_agent(s + 3, h[3]);                                     \
+                st_agent(s + 1, h[1]); st_agent(s + 2, h[2]); st_agent(s + 3, h[3]); st_agent(pf, f);                    \
                 X.done = true; X.fresh = true;   /* a first insert: present stays false, see the cache policy */         \
             } else if (!cas) {            /* (a lost claim looks at the same slot again on the next trip) */             \
                 bool advance = true;                                                                                     \
                 if (c0 == h[0]) {                                                                                        \
-                    if (c1 == h[1] && c2 == h[2] && c3 == h[3]) { X.done = true; X.present = true; advance = false; }    \
-                    else if (c1 == 0 || c2 == 0 || c3 == 0) {      /* the claimer's h1..h3 are still in flight */           \
+                    if (c1 == h[1] && c2 == h[2] && c3 == h[3] && c4 == f) { X.done = true; X.present = true; advance = false; } \
+                    else if (c1 == h[1] && c2 == h[2] && c3 == h[3] && c4 != 0) {   /* equal hashes, another entry */       \
+                        __hip_atomic_fetch_max(status, kTableExotic, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);        \
+                        X.done = true; advance = false;                                                                  \
+                    }                                                                                                    \
+                    else if (c1 == 0 || c2 == 0 || c3 == 0 || (c1 == h[1] && c2 == h[2] && c3 == h[3])) {  /* the claimer's words are still in flight */ \
                         advance = false;                                                                                 \
                         if (++X.spins > kSpinLimit) {              /* never a duplicate slot: give the set to the host */ \
                             __hip_atomic_fetch_max(status, kTableExotic, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);        \
@@ -243,8 +298,8 @@ __device__ __forceinline__ void set_insert2(const IngestTable ta, const uint64_t
                 }                                                                                                        \
             }                                                                                                            \
         }
-        BSG_SETTLE(A, won_a, cas_a, sa, ha, a0, a1, a2, a3, ta, status_a)
-        BSG_SETTLE(B, won_b, cas_b, sb, hb, b0, b1, b2, b3, tb, status_b)
+        BSG_SETTLE(A, won_a, cas_a, sa, pa, ha, fa, a0, a1, a2, a3, a4, ta, status_a)
+        BSG_SETTLE(B, won_b, cas_b, sb, pb, hb, fb, b0, b1, b2, b3, b4, tb, status_b)
 #undef BSG_SETTLE
     } while (__ballot(!A.done || !B.done) != 0ull);
     if (COUNT) {
@@ -258,10 +313,10 @@ __device__ __forceinline__ void set_insert2(const IngestTable ta, const uint64_t
     present_b = B.present;
 }
 
-__device__ __forceinline__ void set_insert(const IngestTable t, const uint64_t h[4], uint32_t *count, uint32_t *status)
+__device__ __forceinline__ void set_insert(const IngestTable t, const uint64_t h[4], uint64_t f, uint32_t *count, uint32_t *status)
 {
     bool pa, pb;
-    set_insert2(t, h, true, count, status, pa, t, h, false, count, status, pb);
+    set_insert2(t, h, f, true, count, status, pa, t, h, f, false, count, status, pb);
 }
 
 // ---------------- row walker ----------------
@@ -286,6 +341,7 @@ struct IngestArgs {
     uint32_t n_sets;
     uint32_t validate;              // 1: run the validation pass first (rows of unknown provenance)
     uint32_t row_first, row_end;    // this launch walks rows [row_first, row_end): a chunk whose bytes have landed
+    FpKey key;                      // the context's fingerprint key
 };
 
 typedef __attribute__((address_space(3))) uint8_t lds_u8;
@@ -317,6 +373,7 @@ struct Walker {
     uint32_t lit;            // S_LIT: 0 true, 1 false, 2 null; S_*_U: hex digits seen << 16 | value so far
     uint32_t req, req_len;   // pending request
     const uint32_t *lower;   // IngestArgs::lower
+    FpKey key;               // fingerprint key of the context (uniform)
     bool quiet;              // leaf without a path (scalars at the root): nothing is emitted
     bool in_token;
     bool ft_on;              // keep the path::word stream (the ingest walker); the row matcher only needs the word's own hash
@@ -337,20 +394,20 @@ __device__ __forceinline__ void leaf_start(Walker &w)
 __device__ __forceinline__ void word_byte(Walker &w, uint32_t c)
 {
     if (w.quiet) return;
-    if (!w.in_token) { hs_init(w.tok); w.ft = w.ps; w.in_token = true; }
+    if (!w.in_token) { hs_init(w.tok, w.key); w.ft = w.ps; w.in_token = true; }
     if (c - 'A' < 26u) c += 32;                    // ASCII fold (appendFoldedWord fast path, row_matcher.go:187-202)
-    hs_absorb(w.tok, c);
-    if (w.ft_on) hs_absorb(w.ft, c);
+    hs_absorb(w.tok, c, w.key);
+    if (w.ft_on) hs_absorb(w.ft, c, w.key);
 }
 
 // n (1..8) word bytes, little-endian in v, upper bytes zero
 __device__ __forceinline__ void word_run(Walker &w, uint64_t v, uint32_t n)
 {
     if (w.quiet) return;
-    if (!w.in_token) { hs_init(w.tok); w.ft = w.ps; w.in_token = true; }
+    if (!w.in_token) { hs_init(w.tok, w.key); w.ft = w.ps; w.in_token = true; }
     v = swar_lower(v);                             // ASCII fold (appendFoldedWord fast path, row_matcher.go:187-202)
-    hs_absorb_n(w.tok, v, n);
-    if (w.ft_on) hs_absorb_n(w.ft, v, n);
+    hs_absorb_n(w.tok, v, n, w.key);
+    if (w.ft_on) hs_absorb_n(w.ft, v, n, w.key);
 }
 
 __device__ __forceinline__ uint32_t c_at(uint64_t v, uint32_t i) { return (uint32_t)(v >> (i * 8u)) & 0xFFu; }
@@ -444,9 +501,9 @@ __device__ __forceinline__ uint32_t str_rune(Walker &w, uint32_t r)
         if (lo != 0u) r = lo;
         uint32_t n = 1, bytes = r;
         if (r >= 0x80u) bytes = rune_utf8(r, n);
-        if (!w.in_token) { hs_init(w.tok); w.ft = w.ps; w.in_token = true; }
-        hs_absorb_n(w.tok, bytes, n);
-        if (w.ft_on) hs_absorb_n(w.ft, bytes, n);
+        if (!w.in_token) { hs_init(w.tok, w.key); w.ft = w.ps; w.in_token = true; }
+        hs_absorb_n(w.tok, bytes, n, w.key);
+        if (w.ft_on) hs_absorb_n(w.ft, bytes, n, w.key);
     }
     return 0xFFu;
 }
@@ -702,20 +759,21 @@ __device__ __forceinline__ uint32_t walker_step(Walker &w)
 #define BSG_INGEST_WPE 3
 #endif
 constexpr uint32_t kCacheEntries = BSG_INGEST_CACHE;   // lab: -DBSG_INGEST_CACHE / -DBSG_INGEST_WPE (waves per SIMD the kernel is compiled for)
-constexpr uint32_t kIngestLdsBytes = kCacheEntries * 32 + kIngestThreads * kLaneLds;   // cache, then the lanes' path buffers
+constexpr uint32_t kCacheEntryWords = 5;               // tag ^ h0, h1, h2, h3, fingerprint
+constexpr uint32_t kIngestLdsBytes = kCacheEntries * kCacheEntryWords * 8 + kIngestThreads * kLaneLds;   // cache, then the lanes' path buffers
 typedef __attribute__((address_space(3))) uint64_t lds_u64i;
 
-__device__ __forceinline__ bool cache_hit(const lds_u64i *cache, uint32_t table_id, const uint64_t h[4])
+__device__ __forceinline__ bool cache_hit(const lds_u64i *cache, uint32_t table_id, const uint64_t h[4], uint64_t fp)
 {
     const uint64_t tag = h[0] ^ ((uint64_t)(table_id + 1) * 0x9E3779B97F4A7C15ULL);
-    const lds_u64i *e = cache + (size_t)((uint32_t)(h[1] >> 8) & (kCacheEntries - 1)) * 4;
-    return e[0] == tag && e[1] == h[1] && e[2] == h[2] && e[3] == h[3];
+    const lds_u64i *e = cache + (size_t)((uint32_t)(h[1] >> 8) & (kCacheEntries - 1)) * kCacheEntryWords;
+    return e[0] == tag && e[1] == h[1] && e[2] == h[2] && e[3] == h[3] && e[4] == fp;   // a hash-equal entry with another fingerprint goes to the table, which flags it
 }
-__device__ __forceinline__ void cache_put(lds_u64i *cache, uint32_t table_id, const uint64_t h[4])
+__device__ __forceinline__ void cache_put(lds_u64i *cache, uint32_t table_id, const uint64_t h[4], uint64_t fp)
 {
-    lds_u64i *e = cache + (size_t)((uint32_t)(h[1] >> 8) & (kCacheEntries - 1)) * 4;
+    lds_u64i *e = cache + (size_t)((uint32_t)(h[1] >> 8) & (kCacheEntries - 1)) * kCacheEntryWords;
     e[0] = h[0] ^ ((uint64_t)(table_id + 1) * 0x9E3779B97F4A7C15ULL);
-    e[1] = h[1]; e[2] = h[2]; e[3] = h[3];
+    e[1] = h[1]; e[2] = h[2]; e[3] = h[3]; e[4] = fp;
 }
 
 
@@ -763,7 +821,7 @@ __global__ __launch_bounds__(kIngestThreads, BSG_INGEST_WPE) void k_ingest_rows(
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     lds_u64i *cache = (lds_u64i *)lds_raw;
-    for (uint32_t i = threadIdx.x; i < kCacheEntries * 4; i += kIngestThreads) cache[i] = 0;
+    for (uint32_t i = threadIdx.x; i < kCacheEntries * kCacheEntryWords; i += kIngestThreads) cache[i] = 0;
     __syncthreads();
     const uint32_t r = a.row_first + blockIdx.x * kIngestThreads + threadIdx.x;
     const bool live = r < a.row_end;
@@ -778,10 +836,11 @@ __global__ __launch_bounds__(kIngestThreads, BSG_INGEST_WPE) void k_ingest_rows(
     Walker w;
     ChunkCursor cc;
     cc.chunks = reinterpret_cast<const uint64_t *>(a.rows);
-    w.path = (lds_u8 *)lds_raw + kCacheEntries * 32 + threadIdx.x * kLaneLds;
+    w.path = (lds_u8 *)lds_raw + kCacheEntries * kCacheEntryWords * 8 + threadIdx.x * kLaneLds;
     w.lower = a.lower;
+    w.key = a.key;
     w.ft_on = true;
-    hs_init(w.ps); hs_init(w.tok); hs_init(w.ft);
+    hs_init(w.ps, w.key); hs_init(w.tok, w.key); hs_init(w.ft, w.key);
 
     // pass 1: validate.  A row the device walker cannot finish contributes NOTHING here; it goes to the host walker whole.
     BSG_PROF_T(p0);
@@ -815,32 +874,32 @@ __global__ __launch_bounds__(kIngestThreads, BSG_INGEST_WPE) void k_ingest_rows(
         w.req = Q_NONE;
         // (B1) path hashes for Q_FIELD / Q_LEAF
         HashStream s;
-        hs_init(s);
+        hs_init(s, w.key);
         const uint32_t plen = (q == Q_FIELD || q == Q_LEAF) ? w.req_len : 0u;
         for (uint32_t i = 0; __ballot(i < plen) != 0ull; ++i)
-            if (i < plen) hs_absorb(s, w.path[i]);
+            if (i < plen) hs_absorb(s, w.path[i], w.key);
         if (q == Q_WORD) s = w.tok;
-        uint64_t ha[4], hb[4];
-        if (q != Q_NONE) hs_finish(s, ha);
+        uint64_t ha[4], hb[4], fa = 0, fb = 0;
+        if (q != Q_NONE) fa = hs_finish(s, ha, w.key);
         if (q == Q_LEAF) {                          // the leaf's words continue from path + "::" (makeFieldTokenKey, tokenizer.go:509-511)
             w.ps = s;
-            hs_absorb(w.ps, ':');
-            hs_absorb(w.ps, ':');
+            hs_absorb(w.ps, ':', w.key);
+            hs_absorb(w.ps, ':', w.key);
         }
-        if (q == Q_WORD) hs_finish(w.ft, hb);
+        if (q == Q_WORD) fb = hs_finish(w.ft, hb, w.key);
         BSG_PROF_T(tb1);
         BSG_PROF_ADD(3, ta1, tb1);
         // (B2) inserts.  Only entries met as duplicates are cached: a first insert is usually a row-unique value
         // (timestamp, id) that would only push hot entries out of the cache.
         const uint32_t ta = t0 + (q == Q_WORD ? 1u : 0u), tb = t0 + 2u;
-        const bool need_a = q != Q_NONE && !cache_hit(cache, ta, ha);
-        const bool need_b = q == Q_WORD && !cache_hit(cache, tb, hb);
+        const bool need_a = q != Q_NONE && !cache_hit(cache, ta, ha, fa);
+        const bool need_b = q == Q_WORD && !cache_hit(cache, tb, hb, fb);
         if (__ballot(need_a || need_b) != 0ull) {
             bool pa, pb;
-            set_insert2(a.tables[ta], ha, need_a, a.counts + ta, a.status + ta, pa,
-                        a.tables[tb], hb, need_b, a.counts + tb, a.status + tb, pb);
-            if (pa) cache_put(cache, ta, ha);
-            if (pb) cache_put(cache, tb, hb);
+            set_insert2(a.tables[ta], ha, fa, need_a, a.counts + ta, a.status + ta, pa,
+                        a.tables[tb], hb, fb, need_b, a.counts + tb, a.status + tb, pb);
+            if (pa) cache_put(cache, ta, ha, fa);
+            if (pb) cache_put(cache, tb, hb, fb);
             BSG_PROF_ADD(6, 0, 1);
         }
         BSG_PROF_T(tb2);
@@ -857,14 +916,27 @@ __global__ __launch_bounds__(kIngestThreads, BSG_INGEST_WPE) void k_ingest_rows(
 
 // ---------------- host-walked entries (fallback rows) ----------------
 __global__ __launch_bounds__(256) void k_ingest_add(const uint8_t *bytes, const uint32_t *off, const uint32_t *table_of_entry,
-                                                    uint32_t n, const IngestTable *tables, uint32_t *counts, uint32_t *status)
+                                                    uint32_t n, const IngestTable *tables, uint32_t *counts, uint32_t *status, const FpKey key)
 {
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n) return;
     uint64_t h[4];
     base_hashes_words(bytes + off[e], off[e + 1] - off[e], h);
+    const uint64_t f = entry_fp(bytes + off[e], off[e + 1] - off[e], key);
     const uint32_t t = table_of_entry[e];
-    set_insert(tables[t], h, counts + t, status + t);
+    set_insert(tables[t], h, f, counts + t, status + t);
+}
+
+// hashes + fingerprints of packed strings (the row matcher's condition strings)
+__global__ __launch_bounds__(256) void k_hash_fp_entries(const uint8_t *bytes, const uint32_t *off, uint32_t n, uint64_t *out_h, uint64_t *out_fp,
+                                                         const FpKey key)
+{
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    uint64_t h[4];
+    base_hashes_words(bytes + off[e], off[e + 1] - off[e], h);
+    for (int j = 0; j < 4; ++j) out_h[(uint64_t)e * 4 + j] = h[j];
+    out_fp[e] = entry_fp(bytes + off[e], off[e + 1] - off[e], key);
 }
 
 // ---------------- union / rehash: every occupied slot of src[item] is inserted into dst[item] ----------------
@@ -894,9 +966,10 @@ __global__ __launch_bounds__(256) void k_ingest_union(const IngestTable *src_tab
         }
         const uint64_t ha[4] = {x0.x, x0.y, y0.x, y0.y}, hb[4] = {x1.x, x1.y, y1.x, y1.y};
         const bool act_a = x0.x != 0, act_b = x1.x != 0;
+        const uint64_t fpa = act_a ? s.fps[i] : 0, fpb = act_b ? s.fps[j] : 0;
         if (__ballot(act_a || act_b) != 0ull) {
             bool pa, pb, fa, fb;
-            set_insert2<false>(d, ha, act_a, nullptr, dst_status + it.dst, pa, d, hb, act_b, nullptr, dst_status + it.dst, pb, &fa, &fb);
+            set_insert2<false>(d, ha, fpa, act_a, nullptr, dst_status + it.dst, pa, d, hb, fpb, act_b, nullptr, dst_status + it.dst, pb, &fa, &fb);
             fresh += (uint32_t)fa + (uint32_t)fb;
         }
     }

@@ -390,17 +390,15 @@ class Context:
                 off[1:] = np.cumsum([len(r) for r in rows], dtype=np.uint64)
             blob = np.frombuffer(b"".join(rows), dtype=np.uint8)
         n = len(off) - 1
-        conds = np.zeros(len(matcher.kinds), dtype=_lib.MATCH_COND_DTYPE)
-        if len(conds):
-            conds["hf"] = self.hash_strings(matcher.fields)
-            conds["ht"] = self.hash_strings(matcher.tokens)
-            conds["kind"] = np.asarray(matcher.kinds, dtype=np.uint32)
+        strings = [s for pair in zip(matcher.fields, matcher.tokens) for s in pair]      # field 0, token 0, field 1, ...
+        cblob, coff = pack_entries(strings)
+        kinds = np.asarray(matcher.kinds, dtype=np.uint32)
         ops = np.asarray(matcher.prog_ops, dtype=np.uint32)
         bits = np.zeros((n + 63) // 64, dtype=np.uint64)
         fb = np.zeros(max(n, 1), dtype=np.uint32)
         nfb = C.c_uint32()
-        self._check(self.L.bsg_match_rows(self.h, _lib._ptr(blob), _lib._ptr(off), n, _lib._ptr(conds), len(conds), _lib._ptr(ops), len(ops),
-                                          _lib._ptr(bits), _lib._ptr(fb), len(fb), C.byref(nfb)))
+        self._check(self.L.bsg_match_rows(self.h, _lib._ptr(blob), _lib._ptr(off), n, _lib._ptr(cblob), _lib._ptr(coff), _lib._ptr(kinds), len(kinds),
+                                          _lib._ptr(ops), len(ops), _lib._ptr(bits), _lib._ptr(fb), len(fb), C.byref(nfb)))
         match = np.unpackbits(bits.view(np.uint8), bitorder="little")[:n].astype(bool)
         return match, fb[: nfb.value].copy()
 

@@ -71,12 +71,12 @@ type Term struct {
 	Reserved uint32
 }
 
-// MatchCond mirrors bsg_match_cond (72 bytes).
+// MatchCond is one condition of the device row matcher: kind + the field and token strings (empty where the kind has
+// none).  The library hashes and fingerprints them itself.
 type MatchCond struct {
-	HF       [4]uint64
-	HT       [4]uint64
-	Kind     uint32
-	Reserved uint32
+	Kind  uint32
+	Field string
+	Token string
 }
 
 // IngestStats mirrors bsg_ingest_stats.
@@ -90,7 +90,6 @@ type IngestStats struct {
 func init() {
 	if unsafe.Sizeof(FilterDesc{}) != unsafe.Sizeof(C.bsg_filter_desc{}) ||
 		unsafe.Sizeof(Term{}) != unsafe.Sizeof(C.bsg_term{}) ||
-		unsafe.Sizeof(MatchCond{}) != unsafe.Sizeof(C.bsg_match_cond{}) ||
 		unsafe.Sizeof(IngestStats{}) != unsafe.Sizeof(C.bsg_ingest_stats{}) {
 		panic("bloomgpu: struct layout differs from bloomgpu.h")
 	}
@@ -484,7 +483,8 @@ func (in *Ingest) Stats() (IngestStats, error) {
 func (in *Ingest) Free() error { return in.g.err(C.bsg_ingest_free(in.g.c, in.id)) }
 
 // MatchRows is the final row test on the device (bsg_match_rows): bits[r>>6] bit r&63 <=> row r matches; rows listed
-// in hostRows are outside the device walker's envelope and must be decided by matchRowBytes.
+// in hostRows must be decided by matchRowBytes (outside the device walker's envelope, or a hash collision with a
+// condition string that only a byte compare can settle).
 func (g *Context) MatchRows(rows []byte, rowOff []uint64, conds []MatchCond, progOps []uint32) (bits []uint64, hostRows []uint32, err error) {
 	n := len(rowOff) - 1
 	if n <= 0 {
@@ -492,12 +492,18 @@ func (g *Context) MatchRows(rows []byte, rowOff []uint64, conds []MatchCond, pro
 	}
 	bits = make([]uint64, (n+63)/64)
 	hostRows = make([]uint32, n)
-	var cp *C.bsg_match_cond
-	if len(conds) > 0 {
-		cp = (*C.bsg_match_cond)(unsafe.Pointer(&conds[0]))
+	var cbytes []byte
+	coff := make([]uint32, 1, 2*len(conds)+1)
+	kinds := make([]uint32, len(conds))
+	for i, c := range conds {
+		cbytes = append(cbytes, c.Field...)
+		coff = append(coff, uint32(len(cbytes)))
+		cbytes = append(cbytes, c.Token...)
+		coff = append(coff, uint32(len(cbytes)))
+		kinds[i] = c.Kind
 	}
 	var nfb C.uint32_t
-	rc := C.bsg_match_rows(g.c, u8p(rows), u64p(rowOff), C.uint32_t(n), cp, C.uint32_t(len(conds)), u32p(progOps),
-		C.uint32_t(len(progOps)), u64p(bits), u32p(hostRows), C.uint32_t(n), &nfb)
+	rc := C.bsg_match_rows(g.c, u8p(rows), u64p(rowOff), C.uint32_t(n), u8p(cbytes), u32p(coff), u32p(kinds), C.uint32_t(len(conds)),
+		u32p(progOps), C.uint32_t(len(progOps)), u64p(bits), u32p(hostRows), C.uint32_t(n), &nfb)
 	return bits, hostRows[:nfb], g.err(rc)
 }

@@ -292,8 +292,7 @@ func matchRowsGPU(g *bloomgpu.Context, rows [][]byte, expr *BloomExpression) (bi
 		blob = append(blob, r...)
 		rowOff = append(rowOff, uint64(len(blob)))
 	}
-	var fields, tokens []string
-	var kinds []uint32
+	var conds []bloomgpu.MatchCond
 	var ops []uint32
 	var walk func(e *BloomExpression)
 	walk = func(e *BloomExpression) {
@@ -309,8 +308,8 @@ func matchRowsGPU(g *bloomgpu.Context, rows [][]byte, expr *BloomExpression) (bi
 				ops = append(ops, bloomgpu.Op(bloomgpu.OpTrue, 0))
 			case c.Type == BloomField || c.Type == BloomToken || c.Type == BloomFieldToken:
 				kind := map[BloomConditionType]uint32{BloomField: bloomgpu.KindField, BloomToken: bloomgpu.KindToken, BloomFieldToken: bloomgpu.KindFieldToken}[c.Type]
-				ops = append(ops, bloomgpu.Op(bloomgpu.OpTerm, uint32(len(kinds))))
-				fields, tokens, kinds = append(fields, c.Field), append(tokens, c.Token), append(kinds, kind)
+				ops = append(ops, bloomgpu.Op(bloomgpu.OpTerm, uint32(len(conds))))
+				conds = append(conds, bloomgpu.MatchCond{Kind: kind, Field: c.Field, Token: c.Token})
 			default:
 				ops = append(ops, bloomgpu.Op(bloomgpu.OpFalse, 0))
 			}
@@ -329,20 +328,6 @@ func matchRowsGPU(g *bloomgpu.Context, rows [][]byte, expr *BloomExpression) (bi
 	}
 	if expr != nil {
 		walk(expr)
-	}
-	fb, fo := bloomgpu.PackEntries(fields)
-	hf, err := g.HashEntries(fb, fo)
-	if err != nil {
-		return nil, nil, err
-	}
-	tb, to := bloomgpu.PackEntries(tokens)
-	ht, err := g.HashEntries(tb, to)
-	if err != nil {
-		return nil, nil, err
-	}
-	conds := make([]bloomgpu.MatchCond, len(kinds))
-	for i := range conds {
-		conds[i] = bloomgpu.MatchCond{HF: hf[i], HT: ht[i], Kind: kinds[i]}
 	}
 	return g.MatchRows(blob, rowOff, conds, ops)
 }

@@ -352,8 +352,10 @@ BSG_API int32_t bsg_ingest_add_entries(bsg_ctx *ctx, uint64_t ingest_id, const u
 /* Unions the sets into their parents and returns the exact distinct counts
  * out_counts[(n_sets + n_parents) * 3] (bloomEntrySets.counts).  out_status[n_sets + n_parents] (may be
  * NULL): 0 ok, 2 = the set cannot be represented and must be rebuilt on the host path: it met an entry whose
- * base hashes contain a zero word (probability 2^-62 per entry), or a slot claim that was never completed
- * (a wave context-switched out for ~seconds between its CAS and its stores). */
+ * base hashes contain a zero word (probability 2^-62 per entry), a slot claim that was never completed (a wave
+ * context-switched out for ~seconds between its CAS and its stores), or two DIFFERENT entries with the same four base hashes
+ * (a MurmurHash3 state collision, constructible for entries of >= 24 bytes: every entry also carries a 64-bit fingerprint
+ * under a per-context secret key, so the pair is noticed instead of being counted once — Go's map would count two). */
 BSG_API int32_t bsg_ingest_finish(bsg_ctx *ctx, uint64_t ingest_id, uint64_t *out_counts, uint32_t *out_status);
 /* desc[(n_sets + n_parents) * 3]: geometry and output offsets of every table's filter (m == 0 skips it);
  * out_words as bsg_build. */
@@ -374,24 +376,21 @@ BSG_API int32_t bsg_ingest_free(bsg_ctx *ctx, uint64_t ingest_id);
 
 /* ---- final row test on the device (compileRowMatcher / matchRowBytes, row_matcher.go:257-626) ----
  * One expression over Field / Token / FieldToken conditions, evaluated for every row of the surviving blocks.
- * conds[i]: kind (BSG_KIND_*), hf = base hashes of the FIELD string (Field, FieldToken), ht = base hashes of the TOKEN
- * string (Token, FieldToken) — both from bsg_hash_entries; FieldToken is the (path, token) PAIR at one leaf, not the
- * joined "path::token" key (row_matcher.go:587).  prog_ops: the public postfix program over condition indices
- * (BSG_OP_TERM i / AND n / OR n / TRUE / FALSE; n_ops == 0 = nil expression = every row matches; a nil condition
- * lowers to TRUE, an unknown condition or expression type to FALSE, as evalMatcherNode does).
- * out_bits[ceil(n_rows / 64)]: bit r & 63 of word r >> 6 set <=> row r matches.  Rows outside the device walker's
- * envelope (see bsg_ingest_rows) are listed in out_fallback_rows (ascending; their bit is 0) and must be decided by
- * the host matcher.  Target tokens are never normalised (Token("ALICE") misses, row_matcher_test.go:99-100).
+ * Condition i: cond_kinds[i] (BSG_KIND_*) and two strings packed like bsg_hash_entries' input — entry 2i = the FIELD
+ * string (Field, FieldToken; empty for Token), entry 2i + 1 = the TOKEN string (Token, FieldToken; empty for Field):
+ * cond_off[2 * n_conds + 1].  FieldToken is the (path, token) PAIR at one leaf, not the joined "path::token" key
+ * (row_matcher.go:587).  prog_ops: the public postfix program over condition indices (BSG_OP_TERM i / AND n / OR n / TRUE /
+ * FALSE; n_ops == 0 = nil expression = every row matches; a nil condition lowers to TRUE, an unknown condition or expression
+ * type to FALSE, as evalMatcherNode does).
+ * out_bits[ceil(n_rows / 64)]: bit r & 63 of word r >> 6 set <=> row r matches.  Rows the device cannot decide are listed
+ * in out_fallback_rows (ascending; their bit is 0) and must be decided by the host matcher: rows outside the device
+ * walker's envelope (see bsg_ingest_rows), and rows in which an emission has the base hashes of a condition string but
+ * not its keyed fingerprint — a MurmurHash3 state collision, where only matchRowBytes' byte compare is exact.
+ * Target tokens are never normalised (Token("ALICE") misses, row_matcher_test.go:99-100).
  * Limits: 64 conditions, expression depth 64 (BSG_E_UNSUPPORTED beyond). */
-typedef struct bsg_match_cond {
-    uint64_t hf[4];
-    uint64_t ht[4];
-    uint32_t kind;
-    uint32_t reserved;
-} bsg_match_cond;
-
 BSG_API int32_t bsg_match_rows(bsg_ctx *ctx, const uint8_t *rows, const uint64_t *row_off, uint32_t n_rows,
-                               const bsg_match_cond *conds, uint32_t n_conds, const uint32_t *prog_ops, uint32_t n_ops,
+                               const uint8_t *cond_bytes, const uint32_t *cond_off, const uint32_t *cond_kinds, uint32_t n_conds,
+                               const uint32_t *prog_ops, uint32_t n_ops,
                                uint64_t *out_bits, uint32_t *out_fallback_rows, uint32_t fallback_cap,
                                uint32_t *out_n_fallback);
 /* Device time of the most recent k_match_rows dispatch on the context's first device. */

@@ -71,16 +71,15 @@ int main(void)
     uint64_t m = 0, k = 0, total = 0;
     bsg_filter_desc d[3];
     bsg_term t;
-    bsg_match_cond c;
     bsg_ingest_stats st;
     bsg_ctx *ctx = NULL;
     int32_t ids[1] = {0};
     int32_t rc;
-    memset(d, 0, sizeof d); memset(&t, 0, sizeof t); memset(&c, 0, sizeof c); memset(&st, 0, sizeof st);
+    memset(d, 0, sizeof d); memset(&t, 0, sizeof t); memset(&st, 0, sizeof st);
     if (bsg_estimate_parameters(100, 0.01, &m, &k) != BSG_OK || m != 959 || k != 7) return 2;
     d[1].m = m; d[1].k = (uint32_t)k;
     if (bsg_sections_size(d, 1, &total) != BSG_OK || total != 1 + 4 + 24 + 8 * ((m + 63) / 64) + 4) return 3;
-    if (sizeof(bsg_term) != 40 || sizeof(bsg_filter_desc) != 24 || sizeof(bsg_match_cond) != 72) return 4;
+    if (sizeof(bsg_term) != 40 || sizeof(bsg_filter_desc) != 24) return 4;
     rc = bsg_open(ids, 1, &ctx);
     printf("devices=%d open=%d crc=%08x\n", (int)bsg_device_count(), (int)rc, (unsigned)bsh_crc32c((const uint8_t *)"123456789", 9));
     if (rc == BSG_OK) {
