@@ -361,13 +361,16 @@ class SharedHost:
                 pass
 
 
+PROBE_KERNEL = "k_probe_terms"      # "k_probe_terms_many" for batches with more than 128 distinct terms of one kind
+
+
 def kernel_stats(tm, n_terms):
     """Per-kernel roofline inputs from the library's dispatch timestamps (bsg_timing)."""
     out = {}
     if tm.n_probes:
         ms = tm.ms_terms_kernel / tm.n_probes
         by = tm.stream_bytes / tm.n_probes + 33 * n_terms
-        out["k_probe_terms"] = {"samples": int(tm.n_probes), "arenas_per_launch": tm.n_probe_arenas / tm.n_probes,
+        out[PROBE_KERNEL] = {"samples": int(tm.n_probes), "arenas_per_launch": tm.n_probe_arenas / tm.n_probes,
                                 "kernel_ms": ms, "algorithmic_bytes_per_launch": by, "achieved": by / ms / 1e6,
                                 "frac": by / ms / 1e6 / HBM_PEAK_GBPS}
     if tm.n_fused:
@@ -559,12 +562,16 @@ def c4_leg(ctx, args, rank, world, workers, log):
     per_call = max(1, 32 // max(n_files, 1))           # steps handed to one bsg_probe_many call (<= 32 arenas per dispatch)
     make = lambda i: reps[i % R]
     dt, tm = pr.measure(make, steps, max(2, min(args.warmup, 8)), per_call)
+    global PROBE_KERNEL
+    saved_kernel, PROBE_KERNEL = PROBE_KERNEL, "k_probe_terms"      # 77 distinct terms: the few-term kernel
+    c4_kernels = kernel_stats(tm, len(terms))
+    PROBE_KERNEL = saved_kernel
     probes = NQ * total_blocks * 8
     res = {"workload": "C4: %d rows/block x %d blocks in %d files, block b on rank b %% %d, Q=%d 8-term Or(FieldToken), %d distinct terms; "
                        "%d address-distinct replicas rotated per step" % (rows, total_blocks, n_files, world, NQ, len(terms), R),
            "scaling": "strong", "n_gpus": world, "steps": steps, "ms_per_step": dt / steps * 1e3, "value": probes * steps / dt,
            "unit": "probes/s", "probes_per_step": probes, "stream_bytes_per_step_per_gpu": ft_bytes,
-           "kernels": kernel_stats(tm, len(terms)),
+           "kernels": c4_kernels,
            "check": "every rank's shard of every file bit-exact vs the oracle on the first %d queries" % nchk}
     # the same steps with the host-side gather inside the timed region
     slot_words = words_per_step * per_call
@@ -710,10 +717,28 @@ def main():
         if st.any():
             sys.exit("device section decode reported failures on clean sections")
         ctx.arena_free(sid)
+        # a9: the same region through the cursor-shaped API, 4 MiB at a time as blockFilterCursor reads it
+        # (file_format.go:618): the copy of chunk i + 1 overlaps the decode of chunk i
+        blob_secs = b"".join(secs)
+        offs = np.zeros(len(secs) + 1, dtype=np.uint64)
+        offs[1:] = np.cumsum([len(x) for x in secs])
+        t3 = time.time()
+        stream = ctx.arena_stream_begin(offs[:-1], offs[1:])
+        for o in range(0, len(blob_secs), 4 << 20):
+            ctx.arena_stream_append(stream, o, blob_secs[o: o + (4 << 20)])
+        sid2, st2 = ctx.arena_stream_finish(stream, len(secs))
+        t4 = time.time()
+        stream_dec_ms = ctx.last_kernel_ms()[2]
+        if st2.any():
+            sys.exit("streamed section decode reported failures on clean sections")
+        ctx.arena_free(sid2)
         decode = {"kernel": "k_decode_sections", "kernel_ms": dec_ms, "section_bytes": sec_bytes,
                   "algorithmic_bytes": 2 * sec_bytes, "achieved": 2 * sec_bytes / max(dec_ms, 1e-6) / 1e6, "unit": "GB/s",
                   "note": "CRC32C + BE->LE decode of %d filter sections on the device; bytes = sections read + words written" % B,
                   "end_to_end_s_incl_h2d": t2 - t1,
+                  "stream": {"api": "bsg_arena_stream_begin / append (4 MiB chunks) / finish", "chunks": (len(blob_secs) + (4 << 20) - 1) // (4 << 20),
+                             "end_to_end_s_incl_h2d": t4 - t3, "decode_kernels_ms_sum": stream_dec_ms,
+                             "note": "sections are parsed (flags, lengths, m, k), CRC-checked and decoded on the device as their last byte lands"},
                   "encode": {"kernels": "k_encode_payload + k_crc_sections", "kernel_ms": enc_ms,
                              "achieved": 3 * sec_bytes / max(enc_ms, 1e-6) / 1e6, "unit": "GB/s",
                              "note": "LE->BE + framing + CRC32C of the same sections on the device (bsg_build_sections); bytes = "
@@ -739,6 +764,8 @@ def main():
     terms["h"] = ctx.hash_strings(cb.term_strings)
     terms["kind"] = kinds
     bid = ctx.batch_create(terms, ops, poff)
+    global PROBE_KERNEL
+    PROBE_KERNEL = "k_probe_terms_many" if np.bincount(np.asarray(kinds, dtype=np.int64), minlength=3).max() > 128 else "k_probe_terms"
 
     ft_bytes = int(sum((int(m) + 63) // 64 * 8 for m in plan.desc["m"][2::3]))
     R = args.replicas or max(2, int(np.ceil(2 * 256 * 2 ** 20 / max(ft_bytes, 1))))
@@ -860,7 +887,7 @@ def main():
         # roofline of the dominant kernel of the timed region: algorithmic bytes per launch (streaming regime) =
         # every referenced bitset of the launch's arenas once + the term table; over the mean of the dispatch's own
         # start/stop timestamps, timed region and sampling passes together (same launch shape).
-        dom = "k_probe_fused" if tm.ms_fused_kernel > tm.ms_terms_kernel else "k_probe_terms"
+        dom = "k_probe_fused" if tm.ms_fused_kernel > tm.ms_terms_kernel else PROBE_KERNEL
         k = allk.get(dom) or {}
         # HBM bytes per launch from the PMC counters: collected in separate rocprofv3 --pmc passes of this same
         # command (tools/profile.sh), corrected as MI355X_MICROARCH.md prescribes (FETCH_SIZE x2 for wide
@@ -897,8 +924,8 @@ def main():
                                     "page-locked host segment that rank 0 reads: PCIe-inclusive, never `value`"},
         }
         if single:
-            s1 = single.get("k_probe_terms", {})
-            out["roofline_single_launch"] = dict(s1, bound="hbm", kernel="k_probe_terms", peak=HBM_PEAK_GBPS, unit="GB/s",
+            s1 = single.get(PROBE_KERNEL, {})
+            out["roofline_single_launch"] = dict(s1, bound="hbm", kernel=PROBE_KERNEL, peak=HBM_PEAK_GBPS, unit="GB/s",
                                                  eval_kernel_ms=single.get("k_eval_programs", {}).get("kernel_ms"),
                                                  note="one 1 000-block arena (35 MB) per dispatch: ~half of such a launch is dispatch ramp + completion")
         if q1:
@@ -917,7 +944,7 @@ def main():
         if or_reduce:
             out["or_reduce"] = or_reduce
         if scaled:
-            out["roofline_scaled"] = dict(scaled, bound="hbm", kernel="k_probe_terms", peak=HBM_PEAK_GBPS, unit="GB/s",
+            out["roofline_scaled"] = dict(scaled, bound="hbm", kernel=PROBE_KERNEL, peak=HBM_PEAK_GBPS, unit="GB/s",
                                           note="C2' of SURVEY 8d: same filters replicated x%d at distinct addresses, one arena, one launch" % args.scaled)
         if args.cpu_budget > 0 and world == 1:
             base, cpu_out, nq = cpu_baseline(words, plan.desc, cb, ops, poff, B, args.cpu_budget, log, terms_per_query)

@@ -229,6 +229,7 @@ struct Batch {
     uint32_t max_cw = 1;            // most verdict words any 256-query chunk references
     uint32_t Lmax = 1;              // longest lowered program of the batch (uniform chunk stride)
     bool identity_cw = false;       // few verdict words: every chunk transposes all of them, no per-chunk list
+    bool many_terms = false;        // some kind has more than 128 distinct terms: k_probe_terms_many, never fused
     std::vector<BatchDev> dev;
 };
 
@@ -477,6 +478,7 @@ int32_t bsg_open(const int32_t *device_ids, int32_t n_devices, bsg_ctx **out_ctx
         HIP_TRY(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
         // more than 64 KiB of dynamic LDS per workgroup is opt-in per kernel
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(bsg::k_probe_terms), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(bsg::k_probe_terms_many), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(bsg::k_probe_fused), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(bsg::k_build), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(bsg::k_build_sets), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
@@ -743,12 +745,17 @@ int32_t bsg_arena_load(bsg_ctx *ctx, const uint64_t *words, uint64_t n_words, co
     auto arena = std::make_shared<Arena>();
     arena->n_blocks = n_blocks;
     arena->shards.resize(nd);
-    for (uint32_t di = 0; di < nd; ++di) {
+    // every shard is repacked and its copy ENQUEUED before any device is waited for: the devices' PCIe links run in parallel
+    std::vector<std::vector<uint64_t>> images(nd);
+    std::vector<std::vector<DevDesc>> descs(nd);
+    hipError_t e = hipSuccess;
+    for (uint32_t di = 0; di < nd && e == hipSuccess; ++di) {
         ArenaShard &s = arena->shards[di];
         Device &d = *ctx->devs[di];
         s.n_blocks = n_blocks > di ? (n_blocks - di + nd - 1) / nd : 0;
         // re-lay the shard's filters on 128-byte boundaries
-        std::vector<DevDesc> dd((size_t)s.n_blocks * 3);
+        std::vector<DevDesc> &dd = descs[di];
+        dd.resize((size_t)s.n_blocks * 3);
         uint64_t cursor = 0;
         for (uint32_t lb = 0; lb < s.n_blocks; ++lb) {
             const uint32_t b = lb * nd + di;
@@ -768,7 +775,8 @@ int32_t bsg_arena_load(bsg_ctx *ctx, const uint64_t *words, uint64_t n_words, co
         }
         s.n_words = cursor + kAlignWords;
         // one repacked host image -> one H2D copy (the caller's pointers are not retained)
-        std::vector<uint64_t> image(s.n_words, 0);
+        std::vector<uint64_t> &image = images[di];
+        image.assign(s.n_words, 0);
         for (uint32_t lb = 0; lb < s.n_blocks; ++lb) {
             const uint32_t b = lb * nd + di;
             for (uint32_t c = 0; c < 3; ++c) {
@@ -779,16 +787,22 @@ int32_t bsg_arena_load(bsg_ctx *ctx, const uint64_t *words, uint64_t n_words, co
         }
         std::lock_guard<std::mutex> lk(d.mu);
         if (int32_t rc = use_device(d)) { free_arena(ctx, *arena); return rc; }
-        hipError_t e = hipMalloc(reinterpret_cast<void **>(&s.d_words), s.n_words * 8);
+        e = hipMalloc(reinterpret_cast<void **>(&s.d_words), s.n_words * 8);
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&s.d_desc), std::max<size_t>(dd.size(), 1) * sizeof(DevDesc));
         if (e == hipSuccess && !dd.empty())
             e = hipMemcpyAsync(s.d_desc, dd.data(), dd.size() * sizeof(DevDesc), hipMemcpyHostToDevice, d.stream);
         if (e == hipSuccess) e = hipMemcpyAsync(s.d_words, image.data(), s.n_words * 8, hipMemcpyHostToDevice, d.stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(d.stream);
-        if (e != hipSuccess) {
-            free_arena(ctx, *arena);
-            return fail(e == hipErrorOutOfMemory ? BSG_E_NOMEM : BSG_E_HIP, "arena upload failed: %s", hipGetErrorString(e));
-        }
+    }
+    for (uint32_t di = 0; di < nd && e == hipSuccess; ++di) {
+        Device &d = *ctx->devs[di];
+        std::lock_guard<std::mutex> lk(d.mu);
+        (void)hipSetDevice(d.id);
+        e = hipStreamSynchronize(d.stream);
+    }
+    if (e != hipSuccess) {
+        for (auto &dp : ctx->devs) { std::lock_guard<std::mutex> lk(dp->mu); (void)hipSetDevice(dp->id); (void)hipStreamSynchronize(dp->stream); }
+        free_arena(ctx, *arena);
+        return fail(e == hipErrorOutOfMemory ? BSG_E_NOMEM : BSG_E_HIP, "arena upload failed: %s", hipGetErrorString(e));
     }
     std::lock_guard<std::mutex> lk(ctx->mu);
     const uint64_t id = ctx->next_id++;
@@ -900,6 +914,7 @@ int32_t bsg_batch_create(bsg_ctx *ctx, const bsg_term *terms, uint32_t n_terms, 
         B.Lmax = std::max<uint32_t>(B.Lmax, (uint32_t)lowered[q].size());
     }
     B.identity_cw = B.Wt >= 1 && B.Wt <= 8;
+    for (uint32_t y = 0; y < B.n_kinds; ++y) if ((B.term_count[y] + 63) / 64 > bsg::kParallelKMaxWords) B.many_terms = true;
     std::vector<uint32_t> chunk_len(std::max(B.n_chunks, 1u), 0), cw_cnt(std::max(B.n_chunks, 1u), 0);
     std::vector<std::vector<uint32_t>> chunk_words(B.n_chunks);
     for (uint32_t c = 0; c < B.n_chunks; ++c) {
@@ -1115,8 +1130,12 @@ int32_t enqueue_terms(bsg_ctx *ctx, Device &d, const Group &g, const BatchDev &b
     uint32_t lds = 0;
     if (int32_t rc = make_probe_args(ctx, d, g, bd, B, slot, ev, a, lds)) return rc;
     if (B.n_kinds == 0) return BSG_OK;
-    hipExtLaunchKernelGGL(bsg::k_probe_terms, dim3(g.max_blocks, B.n_kinds, a.n_arenas), dim3(bsg::kProbeThreads), lds, d.stream,
-                          ev ? ev->k1s : nullptr, ev ? ev->k1e : nullptr, 0, a);
+    if (B.many_terms)
+        hipExtLaunchKernelGGL(bsg::k_probe_terms_many, dim3(g.max_blocks, B.n_kinds, a.n_arenas), dim3(bsg::kProbeThreads), lds, d.stream,
+                              ev ? ev->k1s : nullptr, ev ? ev->k1e : nullptr, 0, a);
+    else
+        hipExtLaunchKernelGGL(bsg::k_probe_terms, dim3(g.max_blocks, B.n_kinds, a.n_arenas), dim3(bsg::kProbeThreads), lds, d.stream,
+                              ev ? ev->k1s : nullptr, ev ? ev->k1e : nullptr, 0, a);
     HIP_TRY(hipGetLastError());
     if (ev) ev->has_k1 = true;
     return BSG_OK;
@@ -1197,7 +1216,7 @@ int32_t probe_arenas(bsg_ctx *ctx, const std::vector<std::shared_ptr<Arena>> &ar
     // group the evaluation workgroups only take LDS and issue slots from the streaming (measured at 20-32 arenas of
     // 35 MB per dispatch: fused 5.9 us per arena, k_probe_terms + k_eval_programs 5.2 + 1.0 us with the evaluation
     // costing no HBM time of its own).
-    const bool fuse = !(flags & BSG_PROBE_NOFUSE) && B.n_kinds > 0 && 2 * bsg::eval_lds_bytes(B.max_cw, B.max_depth) <= 64 * 1024;
+    const bool fuse = !(flags & BSG_PROBE_NOFUSE) && !B.many_terms && B.n_kinds > 0 && 2 * bsg::eval_lds_bytes(B.max_cw, B.max_depth) <= 64 * 1024;
     const uint32_t fuse_max_arenas = ctx->fuse_max_arenas;
     const uint32_t limit = std::max(1u, std::min(ctx->group_limit, bsg::kMaxGroupArenas));
     std::vector<uint64_t> out_off(n_arenas + 1, 0);   // arena i's survivors start at out_survivors + out_off[i]

@@ -521,7 +521,10 @@ __device__ __forceinline__ void probe_rounds(const ProbeArgs &a, const DevDesc &
     }
 }
 
-template <bool M32, bool STAGED, uint32_t NT>
+// ONLY_PAR: the kernel for batches of <= 128 terms per kind carries no many-term code at all (k_probe_terms); sharing one
+// kernel cost the 29-term C2 probe 9% in a grouped launch and 25% in a single one (5.03 -> 5.47 us, 7.9 -> 9.9 us per
+// 1 000 blocks) through nothing but register allocation and scheduling around code it never runs.
+template <bool M32, bool STAGED, uint32_t NT, bool ONLY_PAR>
 __device__ __forceinline__ void probe_block(const ProbeArgs &a, const DevDesc &d, const uint64_t *src, char *image,
                                             uint32_t t0, uint32_t n_real, uint32_t n_tw, lds_u64 *vw, lds_u16 *queues,
                                             uint64_t *vout, uint32_t tid)
@@ -529,7 +532,7 @@ __device__ __forceinline__ void probe_block(const ProbeArgs &a, const DevDesc &d
     constexpr uint32_t kProbeThreads = NT, kProbeWaves = NT / kWave;   // shadow the 512-thread defaults
     const uint32_t lane = tid & (kWave - 1);
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid / kWave);   // scalar: chunk bounds and loop trips stay in SGPRs
-    const bool par = n_tw <= kParallelKMaxWords;
+    const bool par = ONLY_PAR || n_tw <= kParallelKMaxWords;
     const uint32_t n_tasks = n_tw * d.k;
     // ---- work that does not need the bitset: runs while the DMA is in flight ----
     for (uint32_t w = tid; w < n_tw; w += kProbeThreads) {
@@ -540,7 +543,7 @@ __device__ __forceinline__ void probe_block(const ProbeArgs &a, const DevDesc &d
     uint64_t loc_first[kGroup] = {};
     if (par) {
         if (wave < n_tasks) first = par_task_prepare<M32>(a, d, t0, n_real, n_tw, wave, lane);
-    } else {
+    } else if (!ONLY_PAR) {
         const uint32_t wpw = (n_tw + kProbeWaves - 1) / kProbeWaves;
         const uint32_t w0 = wave * wpw, w1 = min(n_tw, w0 + wpw);
         uint64_t h[kGroup];
@@ -558,7 +561,7 @@ __device__ __forceinline__ void probe_block(const ProbeArgs &a, const DevDesc &d
             if (wave < n_tasks) par_task_finish(first, bits, vw, lane);
             for (uint32_t task = wave + kProbeWaves; task < n_tasks; task += kProbeWaves)
                 par_task_finish(par_task_prepare<M32>(a, d, t0, n_real, n_tw, task, lane), bits, vw, lane);
-        } else {
+        } else if (!ONLY_PAR) {
             probe_rounds<M32, kProbeWaves>(a, d, bits, t0, n_tw, queues, (lds_u32 *)vw, wave, lane, loc_first);
         }
     } else {
@@ -567,7 +570,7 @@ __device__ __forceinline__ void probe_block(const ProbeArgs &a, const DevDesc &d
             if (wave < n_tasks) par_task_finish(first, bits, vw, lane);
             for (uint32_t task = wave + kProbeWaves; task < n_tasks; task += kProbeWaves)
                 par_task_finish(par_task_prepare<M32>(a, d, t0, n_real, n_tw, task, lane), bits, vw, lane);
-        } else {
+        } else if (!ONLY_PAR) {
             probe_rounds<M32, kProbeWaves>(a, d, bits, t0, n_tw, queues, (lds_u32 *)vw, wave, lane, loc_first);
         }
     }
@@ -582,7 +585,7 @@ __host__ __device__ inline uint32_t probe_lds_head_bytes(uint32_t n_tw)
     return (n_tw * 8u + n_tw * 128u + 15u) & ~15u;
 }
 
-template <uint32_t NT = kProbeThreads>
+template <uint32_t NT = kProbeThreads, bool ONLY_PAR = false>
 __device__ __forceinline__ void probe_role(const ProbeArgs &a, uint32_t ai, uint32_t b, uint32_t y, uint64_t *lds64)
 {
     constexpr uint32_t kProbeThreads = NT, kProbeWaves = NT / kWave;   // shadow the 512-thread defaults
@@ -622,19 +625,25 @@ __device__ __forceinline__ void probe_role(const ProbeArgs &a, uint32_t ai, uint
             if (boff < nbytes)
                 __builtin_amdgcn_global_load_lds((glb_void *)(g + boff), (lds_void *)(image + c), 16, 0, BSG_DMA_AUX);
         }
-        if (m32) probe_block<true, true, NT>(a, d, src, image, t0, n_real, n_tw, vw, queues, vout, tid);
-        else     probe_block<false, true, NT>(a, d, src, image, t0, n_real, n_tw, vw, queues, vout, tid);
+        if (m32) probe_block<true, true, NT, ONLY_PAR>(a, d, src, image, t0, n_real, n_tw, vw, queues, vout, tid);
+        else     probe_block<false, true, NT, ONLY_PAR>(a, d, src, image, t0, n_real, n_tw, vw, queues, vout, tid);
     } else {
-        if (m32) probe_block<true, false, NT>(a, d, src, image, t0, n_real, n_tw, vw, queues, vout, tid);
-        else     probe_block<false, false, NT>(a, d, src, image, t0, n_real, n_tw, vw, queues, vout, tid);
+        if (m32) probe_block<true, false, NT, ONLY_PAR>(a, d, src, image, t0, n_real, n_tw, vw, queues, vout, tid);
+        else     probe_block<false, false, NT, ONLY_PAR>(a, d, src, image, t0, n_real, n_tw, vw, queues, vout, tid);
     }
 }
 
 // grid = (max_blocks, referenced kinds, arenas of the group)
+// k_probe_terms: batches whose kinds all have <= 128 distinct terms (mode A only); k_probe_terms_many: everything else.
 __global__ __launch_bounds__(kProbeThreads) void k_probe_terms(const ProbeArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
-    probe_role(a, blockIdx.z, blockIdx.x, blockIdx.y, lds64);
+    probe_role<kProbeThreads, true>(a, blockIdx.z, blockIdx.x, blockIdx.y, lds64);
+}
+__global__ __launch_bounds__(kProbeThreads) void k_probe_terms_many(const ProbeArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
+    probe_role<kProbeThreads, false>(a, blockIdx.z, blockIdx.x, blockIdx.y, lds64);
 }
 
 // (Measured and dropped, twice now: the same kernel with 1 024 threads per block — 16 waves sharing one block's image, 32
@@ -789,7 +798,7 @@ __global__ __launch_bounds__(kProbeThreads) void k_probe_fused(const FusedArgs f
         const uint32_t j = id - n_eval;
         const uint32_t per_probe_arena = f.p.max_blocks * f.n_kinds;
         const uint32_t ai = j / per_probe_arena, r = j - ai * per_probe_arena;
-        probe_role(f.p, ai, r % f.p.max_blocks, r / f.p.max_blocks, lds64);
+        probe_role<kProbeThreads, true>(f.p, ai, r % f.p.max_blocks, r / f.p.max_blocks, lds64);   // fused launches are few-term launches
     } else {
         const uint32_t ai = id / per_arena, r = id - ai * per_arena;
         const uint32_t gtile = r / f.eval_pairs, pair = r - gtile * f.eval_pairs;
