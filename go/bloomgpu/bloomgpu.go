@@ -282,6 +282,49 @@ func (g *Context) ArenaLoadSections(region []byte, secOff []uint64) (Arena, []in
 	return Arena{uint64(id), uint32(n)}, status, g.err(rc)
 }
 
+// ArenaStream is a filter region being handed over chunk by chunk (bsg_arena_stream_*): the device-side counterpart of
+// blockFilterCursor (file_format.go:511-662).
+type ArenaStream struct {
+	g      *Context
+	id     C.uint64_t
+	blocks int
+}
+
+// ArenaStreamBegin opens a stream for the candidate blocks whose sections lie at file offsets
+// [secBegin[b], secEnd[b]) (equal = the block has no section).
+func (g *Context) ArenaStreamBegin(secBegin, secEnd []uint64) (*ArenaStream, error) {
+	if len(secBegin) != len(secEnd) {
+		return nil, errors.New("bloomgpu: secBegin and secEnd differ in length")
+	}
+	var id C.uint64_t
+	rc := C.bsg_arena_stream_begin(g.c, u64p(secBegin), u64p(secEnd), C.uint32_t(len(secBegin)), &id)
+	if err := g.err(rc); err != nil {
+		return nil, err
+	}
+	return &ArenaStream{g, id, len(secBegin)}, nil
+}
+
+// Append hands over file bytes [fileOffset, fileOffset+len(chunk)) — one read of the region cursor (<= 4 MiB in the
+// reference), in any order; the bytes are copied out before the call returns.
+func (s *ArenaStream) Append(fileOffset uint64, chunk []byte) error {
+	return s.g.err(C.bsg_arena_stream_append(s.g.c, s.id, C.uint64_t(fileOffset), u8p(chunk), C.uint64_t(len(chunk))))
+}
+
+// Finish returns the resident arena and parseFilterSection's status per block (0 ok, -2 ErrInvalidHash, -7 never read ...).
+func (s *ArenaStream) Finish() (Arena, []int32, error) {
+	status := make([]int32, s.blocks)
+	var sp *C.int32_t
+	if s.blocks > 0 {
+		sp = (*C.int32_t)(unsafe.Pointer(&status[0]))
+	}
+	var id C.uint64_t
+	rc := C.bsg_arena_stream_finish(s.g.c, s.id, sp, &id)
+	return Arena{uint64(id), uint32(s.blocks)}, status, s.g.err(rc)
+}
+
+// Abort discards the stream.
+func (s *ArenaStream) Abort() error { return s.g.err(C.bsg_arena_stream_abort(s.g.c, s.id)) }
+
 // ArenaFree is bsg_arena_free.
 func (g *Context) ArenaFree(a Arena) error { return g.err(C.bsg_arena_free(g.c, C.uint64_t(a.ID))) }
 
