@@ -645,6 +645,7 @@ def main():
     ap.add_argument("--c4-files", type=int, default=10, help="files of the c4 leg (0 = skip the leg)")
     ap.add_argument("--c4-blocks-per-file", type=int, default=1000)
     ap.add_argument("--compact-rounds", type=int, default=-1, help="lab: compaction rounds of the many-term probe mode (bsg_set_lab key 1)")
+    ap.add_argument("--untimed", action="store_true", help="lab: no dispatch timestamps inside the timed region (what they cost)")
     ap.add_argument("--no-q1", action="store_true", help="skip the Q = 1 latency leg")
     ap.add_argument("--no-single", action="store_true", help="skip the one-arena-per-launch sampling pass")
     args = ap.parse_args()
@@ -799,7 +800,7 @@ def main():
     # may be fewer than one dispatch covers)
     pr.run([make(i) for i in range(min(per_call, args.steps))], per_call, 0)
     ctx.sync()
-    elapsed, tm = pr.measure(make, args.steps, args.warmup, per_call)
+    elapsed, tm = pr.measure(make, args.steps, args.warmup, per_call, timed=not args.untimed)
     timed_region = kernel_stats(tm, len(terms))
 
     # the same steps with the host-side gather inside the timed region: survivors of every step DMA-ed into a shared,

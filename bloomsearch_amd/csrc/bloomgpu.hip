@@ -165,6 +165,7 @@ struct DevPool {
 
 struct Device {
     int id = 0;
+    uint32_t n_cus = 256;
     DevPool pool;
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;          // survivors leave here so the D2H of group i overlaps the kernels of group i+1
@@ -474,6 +475,7 @@ int32_t bsg_open(const int32_t *device_ids, int32_t n_devices, bsg_ctx **out_ctx
                         prop.gcnArchName);
         auto d = std::make_unique<Device>();
         d->id = device_ids[i];
+        d->n_cus = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 256u;
         HIP_TRY(hipSetDevice(d->id));
         HIP_TRY(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
         // more than 64 KiB of dynamic LDS per workgroup is opt-in per kernel
@@ -481,7 +483,7 @@ int32_t bsg_open(const int32_t *device_ids, int32_t n_devices, bsg_ctx **out_ctx
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(bsg::k_probe_terms_many), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(bsg::k_probe_fused), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(bsg::k_build), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(bsg::k_build_sets), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(bsg::k_build_sets), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget - bsg::kSetListBytes));
 
         ctx->devs.push_back(std::move(d));
     }

@@ -341,6 +341,7 @@ struct IngestArgs {
     uint32_t n_sets;
     uint32_t validate;              // 1: run the validation pass first (rows of unknown provenance)
     uint32_t row_first, row_end;    // this launch walks rows [row_first, row_end): a chunk whose bytes have landed
+    uint32_t rows_per_wave;         // multiple of 64: wave w of the launch walks rows [row_first + w * rows_per_wave, + rows_per_wave)
     FpKey key;                      // the context's fingerprint key
 };
 
@@ -749,41 +750,57 @@ __device__ __forceinline__ uint32_t walker_step(Walker &w)
 
 // ---------------- workgroup dedup cache ----------------
 // Most emissions repeat entries this workgroup has just inserted (field paths, levels, message words ...).
-// A direct-mapped LDS cache of confirmed inserts (all four hashes, the table folded into word 0) answers those
-// without touching the table.  Lanes update it without locking: a torn entry can only produce a false hit for
-// an entry that agrees with two unrelated entries on 128 hash bits each.
-#ifndef BSG_INGEST_CACHE
-#define BSG_INGEST_CACHE 512
+// An LDS cache of confirmed inserts answers those without touching the table.  Lanes update it without locking: a
+// torn entry can only produce a false hit for an entry that agrees with unrelated entries on 64 hash bits each AND on
+// the keyed fingerprint.
+#ifndef BSG_INGEST_CACHE_SETS
+#define BSG_INGEST_CACHE_SETS 448
 #endif
 #ifndef BSG_INGEST_WPE
 #define BSG_INGEST_WPE 3
 #endif
-constexpr uint32_t kCacheEntries = BSG_INGEST_CACHE;   // lab: -DBSG_INGEST_CACHE / -DBSG_INGEST_WPE (waves per SIMD the kernel is compiled for)
-constexpr uint32_t kCacheEntryWords = 5;               // tag ^ h0, h1, h2, h3, fingerprint
-constexpr uint32_t kIngestLdsBytes = kCacheEntries * kCacheEntryWords * 8 + kIngestThreads * kLaneLds;   // cache, then the lanes' path buffers
+// 2-way sets of (h0 ^ table, h1, fingerprint): the first murmur3 hash of the entry and its keyed fingerprint — what the
+// table itself needs to tell two entries apart once their hashes agree.  Way 0 is the most recently confirmed entry of
+// the set; a new one pushes it to way 1 (two hot entries that share a set no longer evict each other every round:
+// with ~150 hot entries a direct-mapped cache of 512 sent 16 of 32 rounds to the table, see profiles/).
+constexpr uint32_t kCacheSets = BSG_INGEST_CACHE_SETS;  // lab: -DBSG_INGEST_CACHE_SETS / -DBSG_INGEST_WPE (waves per SIMD the kernel is compiled for)
+constexpr uint32_t kCacheEntryWords = 3;
+constexpr uint32_t kCacheWords = kCacheSets * 2 * kCacheEntryWords;
+constexpr uint32_t kIngestLdsBytes = kCacheWords * 8 + kIngestThreads * kLaneLds;   // cache, then the lanes' path buffers
 typedef __attribute__((address_space(3))) uint64_t lds_u64i;
+
+__device__ __forceinline__ uint32_t cache_set(const uint64_t h[4]) { return ((((uint32_t)(h[1] >> 8)) & 0xFFFFu) * kCacheSets) >> 16; }
+__device__ __forceinline__ uint64_t cache_tag(uint32_t table_id, const uint64_t h[4]) { return h[0] ^ ((uint64_t)(table_id + 1) * 0x9E3779B97F4A7C15ULL); }
 
 __device__ __forceinline__ bool cache_hit(const lds_u64i *cache, uint32_t table_id, const uint64_t h[4], uint64_t fp)
 {
-    const uint64_t tag = h[0] ^ ((uint64_t)(table_id + 1) * 0x9E3779B97F4A7C15ULL);
-    const lds_u64i *e = cache + (size_t)((uint32_t)(h[1] >> 8) & (kCacheEntries - 1)) * kCacheEntryWords;
-    return e[0] == tag && e[1] == h[1] && e[2] == h[2] && e[3] == h[3] && e[4] == fp;   // a hash-equal entry with another fingerprint goes to the table, which flags it
+    const uint64_t tag = cache_tag(table_id, h);
+    const lds_u64i *e = cache + (size_t)cache_set(h) * 2 * kCacheEntryWords;
+    // (an entry whose hashes agree with a cached one but whose fingerprint differs goes to the table, which flags the pair)
+    return (e[0] == tag && e[1] == h[1] && e[2] == fp) || (e[3] == tag && e[4] == h[1] && e[5] == fp);
 }
 __device__ __forceinline__ void cache_put(lds_u64i *cache, uint32_t table_id, const uint64_t h[4], uint64_t fp)
 {
-    lds_u64i *e = cache + (size_t)((uint32_t)(h[1] >> 8) & (kCacheEntries - 1)) * kCacheEntryWords;
-    e[0] = h[0] ^ ((uint64_t)(table_id + 1) * 0x9E3779B97F4A7C15ULL);
-    e[1] = h[1]; e[2] = h[2]; e[3] = h[3]; e[4] = fp;
+    const uint64_t tag = cache_tag(table_id, h);
+    lds_u64i *e = cache + (size_t)cache_set(h) * 2 * kCacheEntryWords;
+    const uint64_t o0 = e[0], o1 = e[1], o2 = e[2];
+    if (o0 == tag && o1 == h[1] && o2 == fp) return;
+    e[3] = o0; e[4] = o1; e[5] = o2;
+    e[0] = tag; e[1] = h[1]; e[2] = fp;
 }
 
 
 // lab only (-DBSG_INGEST_PROF): per-phase wave cycles accumulated behind *n_fallback (slots 1..7 as u64)
 #ifdef BSG_INGEST_PROF
+#define BSG_PROF_DECL uint64_t prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
 #define BSG_PROF_T(var) const uint64_t var = __builtin_readcyclecounter()
-#define BSG_PROF_ADD(slot, t0, t1) do { if ((threadIdx.x & 63u) == 0u) atomicAdd((unsigned long long *)a.n_fallback + (slot), (unsigned long long)((t1) - (t0))); } while (0)
+#define BSG_PROF_ADD(slot, t0, t1) prof_acc[slot] += (uint64_t)((t1) - (t0))
+#define BSG_PROF_FLUSH() do { if ((threadIdx.x & 63u) == 0u) for (int pi = 1; pi < 8; ++pi) atomicAdd((unsigned long long *)a.n_fallback + pi, (unsigned long long)prof_acc[pi]); } while (0)
 #else
+#define BSG_PROF_DECL
 #define BSG_PROF_T(var)
 #define BSG_PROF_ADD(slot, t0, t1)
+#define BSG_PROF_FLUSH()
 #endif
 
 struct ChunkCursor {
@@ -817,14 +834,31 @@ __device__ __forceinline__ uint32_t advance(Walker &w, ChunkCursor &cc)
     return walker_step<EMIT>(w);
 }
 
+// One wave walks a contiguous run of rows_per_wave rows, 64 at a time (lane = row); the four waves of a workgroup take
+// neighbouring runs, so a workgroup stays inside one block (or two) and its dedup cache stays warm: a workgroup that
+// sees each lane's row only once sends ~15 of a row's 32 emission rounds to the table (every entry is new to IT), one
+// that has walked a few rows per lane only the 2-3 rounds whose entries are new to the block (timestamps, ids).
 __global__ __launch_bounds__(kIngestThreads, BSG_INGEST_WPE) void k_ingest_rows(const IngestArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     lds_u64i *cache = (lds_u64i *)lds_raw;
-    for (uint32_t i = threadIdx.x; i < kCacheEntries * kCacheEntryWords; i += kIngestThreads) cache[i] = 0;
+    for (uint32_t i = threadIdx.x; i < kCacheWords; i += kIngestThreads) cache[i] = 0;
     __syncthreads();
-    const uint32_t r = a.row_first + blockIdx.x * kIngestThreads + threadIdx.x;
-    const bool live = r < a.row_end;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t wave = (uint64_t)blockIdx.x * (kIngestThreads / 64) + (threadIdx.x >> 6);
+    const uint64_t run_begin = a.row_first + wave * a.rows_per_wave;
+    const uint32_t run_end = (uint32_t)(run_begin + a.rows_per_wave < a.row_end ? run_begin + a.rows_per_wave : a.row_end);
+    Walker w;
+    ChunkCursor cc;
+    cc.chunks = reinterpret_cast<const uint64_t *>(a.rows);
+    w.path = (lds_u8 *)lds_raw + kCacheWords * 8 + threadIdx.x * kLaneLds;
+    w.lower = a.lower;
+    w.key = a.key;
+    w.ft_on = true;
+    BSG_PROF_DECL;
+    for (uint64_t tile = run_begin; tile < run_end; tile += 64) {
+    const uint32_t r = (uint32_t)tile + lane;
+    const bool live = r < run_end;
     // the set this row belongs to: last s with set_first_row[s] <= r
     uint32_t lo = 0, hi = a.n_sets;
     while (live && hi - lo > 1) {
@@ -833,13 +867,6 @@ __global__ __launch_bounds__(kIngestThreads, BSG_INGEST_WPE) void k_ingest_rows(
     }
     const uint32_t t0 = lo * 3;
     const uint64_t row_begin = live ? a.row_off[r] : 0, row_end = live ? a.row_off[r + 1] : 0;
-    Walker w;
-    ChunkCursor cc;
-    cc.chunks = reinterpret_cast<const uint64_t *>(a.rows);
-    w.path = (lds_u8 *)lds_raw + kCacheEntries * kCacheEntryWords * 8 + threadIdx.x * kLaneLds;
-    w.lower = a.lower;
-    w.key = a.key;
-    w.ft_on = true;
     hs_init(w.ps, w.key); hs_init(w.tok, w.key); hs_init(w.ft, w.key);
 
     // pass 1: validate.  A row the device walker cannot finish contributes NOTHING here; it goes to the host walker whole.
@@ -912,6 +939,8 @@ __global__ __launch_bounds__(kIngestThreads, BSG_INGEST_WPE) void k_ingest_rows(
         const uint32_t slot = __hip_atomic_fetch_add(a.n_fallback, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         a.fallback_rows[slot] = r;
     }
+    }
+    BSG_PROF_FLUSH();
 }
 
 // ---------------- host-walked entries (fallback rows) ----------------
@@ -946,30 +975,45 @@ __global__ __launch_bounds__(256) void k_ingest_union(const IngestTable *src_tab
                                                       const UnionItem *items, uint32_t *dst_counts, uint32_t *dst_status)
 {
     __shared__ uint32_t wg_fresh;
+    __shared__ uint32_t queue[4][256];                   // per wave: the occupied slots of its 4 x 64 scanned ones
     if (threadIdx.x == 0) wg_fresh = 0;
     __syncthreads();
     const UnionItem it = items[blockIdx.y];
     const IngestTable s = src_tables[it.src];
     const IngestTable d = dst_tables[it.dst];
     const uint64_t cap = (uint64_t)s.mask + 1;
-    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t *q = queue[threadIdx.x >> 6];
+    const uint64_t wave = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (uint64_t)gridDim.x * 4;
     uint32_t fresh = 0;
-    // two source slots per trip (both halves of both loaded up front), their inserts overlapped by set_insert2
-    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < cap; i += 2 * stride) {
-        const uint64_t j = i + stride;
-        const ulonglong2 *p = reinterpret_cast<const ulonglong2 *>(s.slots + i * 4);
-        const ulonglong2 x0 = p[0], y0 = p[1];
-        ulonglong2 x1 = make_ulonglong2(0, 0), y1 = x1;
-        if (j < cap) {
-            const ulonglong2 *q = reinterpret_cast<const ulonglong2 *>(s.slots + j * 4);
-            x1 = q[0]; y1 = q[1];
+    // occupied <=> fingerprint != 0 (the walk is over): scan the 8-byte fingerprints, compact, insert densely — the source
+    // tables are ~0.2 full, so walking their 32-byte slots moves 5x the bytes and keeps 1 lane in 6 busy in set_insert2
+    for (uint64_t base = wave * 256; base < cap; base += n_waves * 256) {
+        uint64_t f[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4; ++u) {
+            const uint64_t i = base + u * 64 + lane;
+            f[u] = i < cap ? s.fps[i] : 0;
         }
-        const uint64_t ha[4] = {x0.x, x0.y, y0.x, y0.y}, hb[4] = {x1.x, x1.y, y1.x, y1.y};
-        const bool act_a = x0.x != 0, act_b = x1.x != 0;
-        const uint64_t fpa = act_a ? s.fps[i] : 0, fpb = act_b ? s.fps[j] : 0;
-        if (__ballot(act_a || act_b) != 0ull) {
+        uint32_t n = 0;
+#pragma unroll
+        for (uint32_t u = 0; u < 4; ++u) {
+            const uint64_t mask = __ballot(f[u] != 0);
+            if (f[u] != 0) q[n + lane_rank(mask)] = u * 64 + lane;
+            n += (uint32_t)__builtin_popcountll(mask);
+        }
+        __builtin_amdgcn_wave_barrier();                 // a wave's LDS writes are visible to its own later reads (program order)
+        for (uint32_t e = lane; e < n; e += 128) {
+            const uint32_t e2 = e + 64;
+            const bool act_b = e2 < n;
+            const uint64_t i = base + q[e], j = base + (act_b ? q[e2] : q[e]);
+            const ulonglong2 *p = reinterpret_cast<const ulonglong2 *>(s.slots + i * 4);
+            const ulonglong2 *r = reinterpret_cast<const ulonglong2 *>(s.slots + j * 4);
+            const ulonglong2 x0 = p[0], y0 = p[1], x1 = r[0], y1 = r[1];
+            const uint64_t ha[4] = {x0.x, x0.y, y0.x, y0.y}, hb[4] = {x1.x, x1.y, y1.x, y1.y};
+            const uint64_t fpa = s.fps[i], fpb = s.fps[j];
             bool pa, pb, fa, fb;
-            set_insert2<false>(d, ha, fpa, act_a, nullptr, dst_status + it.dst, pa, d, hb, fpb, act_b, nullptr, dst_status + it.dst, pb, &fa, &fb);
+            set_insert2<false>(d, ha, fpa, true, nullptr, dst_status + it.dst, pa, d, hb, fpb, act_b, nullptr, dst_status + it.dst, pb, &fa, &fb);
             fresh += (uint32_t)fa + (uint32_t)fb;
         }
     }
@@ -996,33 +1040,65 @@ struct SetBuildArgs {
 
 constexpr uint32_t kBuildSetsThreads = 1024;   // one workgroup per table: 16 waves keep more slot loads in flight than 8 (1.16 -> see profiles)
 
+// A table is mostly empty slots (sized for 4 entries per row, filled to ~0.2): walking the 32-byte slots themselves
+// moves 5x the bytes that matter and leaves 5 of 6 lanes idle in the Barrett / atomic part.  So a tile of slots is
+// scanned through the 8-byte fingerprints (non-zero <=> occupied once the walk has ended), the occupied indices are
+// compacted into an LDS list (ballot + mbcnt, one LDS add per wave), and the list is worked off densely.
+constexpr uint32_t kSetTile = 4 * kBuildSetsThreads;            // slots scanned per trip
+constexpr uint32_t kSetListBytes = kSetTile * 4 + 16;            // static LDS of k_build_sets beside the staged bitset
+
 template <bool M32, typename BITS32>
-__device__ __forceinline__ void build_from_slots(const IngestTable t, const SetBuildItem &it, const DevDesc &d, BITS32 bits, uint32_t tid)
+__device__ __forceinline__ void build_from_slots(const IngestTable t, const SetBuildItem &it, const DevDesc &d, BITS32 bits, uint32_t tid,
+                                                 uint32_t *list, uint32_t *n_list)
 {
-    // two slots per trip, all four 16-byte halves loaded before the first is used
-    for (uint64_t i = it.slot_begin + tid; i < it.slot_end; i += 2 * kBuildSetsThreads) {
-        const uint64_t j = i + kBuildSetsThreads;
-        const ulonglong2 *p = reinterpret_cast<const ulonglong2 *>(t.slots + i * 4);
-        const ulonglong2 x0 = p[0], y0 = p[1];
-        ulonglong2 x1 = make_ulonglong2(0, 0), y1 = x1;
-        if (j < it.slot_end) {
-            const ulonglong2 *q = reinterpret_cast<const ulonglong2 *>(t.slots + j * 4);
-            x1 = q[0]; y1 = q[1];
+    for (uint64_t base = it.slot_begin; base < it.slot_end; base += kSetTile) {
+        if (tid == 0) *n_list = 0;
+        __syncthreads();
+        uint64_t f[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4; ++u) {
+            const uint64_t i = base + u * kBuildSetsThreads + tid;
+            f[u] = i < it.slot_end ? t.fps[i] : 0;
         }
-        if (x0.x != 0) {
-            const uint64_t h[4] = {x0.x, x0.y, y0.x, y0.y};
-            set_entry_bits<M32>(bits, d, h);
+#pragma unroll
+        for (uint32_t u = 0; u < 4; ++u) {
+            const uint64_t mask = __ballot(f[u] != 0);
+            if (mask == 0) continue;
+            uint32_t at = 0;
+            if ((tid & 63u) == 0u) at = atomicAdd(n_list, (uint32_t)__builtin_popcountll(mask));
+            at = __builtin_amdgcn_readfirstlane(at);
+            if (f[u] != 0) list[at + lane_rank(mask)] = u * kBuildSetsThreads + tid;
         }
-        if (x1.x != 0) {
-            const uint64_t h[4] = {x1.x, x1.y, y1.x, y1.y};
-            set_entry_bits<M32>(bits, d, h);
+        __syncthreads();
+        const uint32_t n = *n_list;
+        // two entries per trip, all four 16-byte halves loaded before the first is used
+        for (uint32_t e = tid; e < n; e += 2 * kBuildSetsThreads) {
+            const uint32_t e2 = e + kBuildSetsThreads;
+            const ulonglong2 *p = reinterpret_cast<const ulonglong2 *>(t.slots + (base + list[e]) * 4);
+            const ulonglong2 x0 = p[0], y0 = p[1];
+            ulonglong2 x1 = make_ulonglong2(0, 0), y1 = x1;
+            if (e2 < n) {
+                const ulonglong2 *q = reinterpret_cast<const ulonglong2 *>(t.slots + (base + list[e2]) * 4);
+                x1 = q[0]; y1 = q[1];
+            }
+            {
+                const uint64_t h[4] = {x0.x, x0.y, y0.x, y0.y};
+                set_entry_bits<M32>(bits, d, h);
+            }
+            if (e2 < n) {
+                const uint64_t h[4] = {x1.x, x1.y, y1.x, y1.y};
+                set_entry_bits<M32>(bits, d, h);
+            }
         }
+        __syncthreads();
     }
 }
 
 __global__ __launch_bounds__(kBuildSetsThreads) void k_build_sets(const SetBuildArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
+    __shared__ uint32_t list[kSetTile];
+    __shared__ uint32_t n_list;
     const SetBuildItem it = a.items[blockIdx.x];
     const DevDesc d = a.desc[it.table];
     const IngestTable t = a.tables[it.table];
@@ -1032,17 +1108,15 @@ __global__ __launch_bounds__(kBuildSetsThreads) void k_build_sets(const SetBuild
     const bool m32 = d.m < (1ull << 31);
     if (it.staged) {
         for (uint32_t i = tid; i < nw; i += kBuildSetsThreads) lds64[i] = 0;
-        __syncthreads();
-        lds_u32 *bits = (lds_u32 *)lds64;
-        if (m32) build_from_slots<true>(t, it, d, bits, tid);
-        else     build_from_slots<false>(t, it, d, bits, tid);
-        __syncthreads();
+        lds_u32 *bits = (lds_u32 *)lds64;                        // (build_from_slots starts with a barrier)
+        if (m32) build_from_slots<true>(t, it, d, bits, tid, list, &n_list);
+        else     build_from_slots<false>(t, it, d, bits, tid, list, &n_list);
         uint64_t *dst = a.out + d.word_off;
         for (uint32_t i = tid; i < nw; i += kBuildSetsThreads) dst[i] = lds64[i];
     } else {
         uint32_t *bits = reinterpret_cast<uint32_t *>(a.out + d.word_off);
-        if (m32) build_from_slots<true>(t, it, d, bits, tid);
-        else     build_from_slots<false>(t, it, d, bits, tid);
+        if (m32) build_from_slots<true>(t, it, d, bits, tid, list, &n_list);
+        else     build_from_slots<false>(t, it, d, bits, tid, list, &n_list);
     }
 }
 

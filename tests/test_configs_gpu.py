@@ -188,32 +188,38 @@ def test_grouped_launches_equal_one_launch_per_arena(ctx):
     for n_blocks in (70, 3, 129, 64, 200, 1, 65):
         plan, _, vocab = H.make_random_arena(rng, n_blocks, absent_frac=0.02)
         plans.append((plan, ctx.build(plan.blob, plan.off, plan.fstart, plan.desc, plan.n_words)))
-    cb = Q.compile_queries([None] + [H.random_expression(rng, vocab, None) for _ in range(520)])
-    ops, poff, _ = cb.arrays()
-    terms = H.gpu_terms(ctx, cb)
-    bid = ctx.batch_create(terms, ops, poff)
-    arenas, nbs, wants = [], [], []
+    # two batches: thousands of distinct terms (k_probe_terms_many, never fused) and a few dozen (k_probe_terms / k_probe_fused)
+    batches = []
+    for n_queries, words in ((520, vocab), (60, vocab[:12])):
+        cb = Q.compile_queries([None] + [H.random_expression(rng, words, None) for _ in range(n_queries)])
+        ops, poff, _ = cb.arrays()
+        terms = H.gpu_terms(ctx, cb)
+        batches.append((cb, ops, poff, terms, ctx.batch_create(terms, ops, poff)))
+    assert np.bincount(batches[0][3]["kind"]).max() > 128 and np.bincount(batches[1][3]["kind"]).max() <= 128
+    arenas, nbs = [], []
     for plan, words in plans:
         arenas.append(ctx.arena_load(words, plan.desc))
         nbs.append(plan.n_blocks)
-        wants.append(O.probe_batch(words, plan.desc.view(O.DESC_DTYPE), terms.view(O.TERM_DTYPE), ops, poff))
-    empty = ctx.arena_load(np.zeros(2, dtype=np.uint64), np.zeros(0, dtype=DESC_DTYPE))
-    arenas.append(empty); nbs.append(0); wants.append(np.zeros((cb.n_queries, 0), dtype=np.uint64))
+    arenas.append(ctx.arena_load(np.zeros(2, dtype=np.uint64), np.zeros(0, dtype=DESC_DTYPE))); nbs.append(0)
     order = [int(i) for i in rng.integers(0, len(arenas), size=75)] + [7, 0, 7]
     try:
-        for limit in (1, 3, 32):
-            ctx.set_probe_group(limit)
-            for flags in (0, _lib.PROBE_NOFUSE, _lib.PROBE_TIMED):
-                got = ctx.probe_many([arenas[i] for i in order], bid, flags, cb.n_queries, [nbs[i] for i in order])
-                for g, i in zip(got, order):
-                    assert np.array_equal(g, wants[i]), (limit, flags, i)
+        for cb, ops, poff, terms, bid in batches:
+            wants = [O.probe_batch(words, plan.desc.view(O.DESC_DTYPE), terms.view(O.TERM_DTYPE), ops, poff) for plan, words in plans]
+            wants.append(np.zeros((cb.n_queries, 0), dtype=np.uint64))
+            for limit in (1, 3, 32):
+                ctx.set_probe_group(limit)
+                for flags in (0, _lib.PROBE_NOFUSE, _lib.PROBE_TIMED):
+                    got = ctx.probe_many([arenas[i] for i in order], bid, flags, cb.n_queries, [nbs[i] for i in order])
+                    for g, i in zip(got, order):
+                        assert np.array_equal(g, wants[i]), (len(terms), limit, flags, i)
     finally:
         ctx.set_probe_group(0)
     t = ctx.timing_read()
     assert t.n_fused > 0 and t.n_probes > 0 and t.n_eval > 0 and t.n_fused_arenas >= t.n_fused
     for a in arenas:
         ctx.arena_free(a)
-    ctx.batch_free(bid)
+    for b in batches:
+        ctx.batch_free(b[4])
 
 
 def test_survivors_to_device_pointer_and_async_host_output(ctx):

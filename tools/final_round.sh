@@ -1,0 +1,16 @@
+#!/bin/bash
+# One GPU-box pass that regenerates everything profiles/ holds for a round: rocprofv3 stats (+ PMC traffic) for the C2,
+# C4-shape and many-term workloads, the SQ counters of the many-term kernel, the driver-shaped and default bench lines.
+# Usage (via gpurun): bash tools/final_round.sh r02
+set -u
+R=${1:-r02}
+mkdir -p gpurun_out
+bash tools/profile.sh ${R}_c2 > /dev/null
+NO_PMC=1 bash tools/profile.sh ${R}_c4 --workload c4 > /dev/null
+NO_PMC=1 bash tools/profile.sh ${R}_needle --workload needle > /dev/null
+bash tools/profile_pmc.sh ${R}_needle --workload needle > /dev/null
+python bench.py --steps 20 --warmup 5 > gpurun_out/${R}_bench_driver_shape.json 2> gpurun_out/${R}_bench_driver_shape.err
+python bench.py > gpurun_out/${R}_bench_default.json 2> gpurun_out/${R}_bench_default.err
+python bench.py --workload needle --cpu-budget 0 --c4-files 0 --ingest-blocks 0 --no-decode --or-union 0 > gpurun_out/${R}_bench_needle.json 2>/dev/null
+python bench.py --workload c4 --cpu-budget 6 --c4-files 0 --ingest-blocks 0 --no-decode --or-union 0 > gpurun_out/${R}_bench_c4.json 2>/dev/null
+ls -la gpurun_out
