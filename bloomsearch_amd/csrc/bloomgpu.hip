@@ -8,6 +8,7 @@
 #include "bloomgpu.h"
 #include "kernels.hip.h"
 #include "ingest.hip.h"
+#include "bin_build.hip.h"
 #include "match.hip.h"
 #include "host/text.hpp"   // the host walker's Unicode tables: the device defers to the same data
 #include <hip/hip_ext.h>
@@ -75,6 +76,7 @@ constexpr uint32_t kLdsBudget = 144 * 1024;   // dynamic LDS a workgroup may req
 constexpr uint32_t kLdsCapWords = kLdsBudget / 8;  // staged-filter cap before the per-launch head is taken off
 constexpr uint64_t kAlignWords = 16;          // filters start on 128-byte boundaries in HBM
 constexpr uint32_t kBuildSliceEntries = 8192; // entries per workgroup for non-staged builds
+constexpr uint64_t kBinScratchBytes = 16ull << 30;   // locations (4 bytes each) one binned build may park in HBM
 constexpr uint64_t kMaxHashCount = 1024;      // k above this is rejected (EstimateParameters: 30 at p = 1e-9, 100 at 1e-30)
 
 uint64_t barrett_magic(uint64_t m)
@@ -261,6 +263,7 @@ struct bsg_ctx {
     uint64_t ingest_chunk_bytes = 64ull << 20;   // rows per upload chunk of bsg_ingest_rows (bsg_set_ingest_chunk)
     uint32_t spin_wait_us = 0;   // synchronous probes poll the stream this long before blocking (bsg_set_spin_wait)
     uint32_t compact_rounds = BSG_COMPACT_ROUNDS;   // many-term probe mode (bsg_set_lab)
+    uint64_t bin_scratch_bytes = kBinScratchBytes;  // 0: bitsets beyond LDS are built with global atomics (bsg_set_lab key 2)
     uint32_t fuse_max_arenas = 4; // groups up to this many arenas ride fused (probe of group i + eval of group i-1)
 };
 
@@ -636,6 +639,36 @@ int32_t bsg_hash_entries(bsg_ctx *ctx, const uint8_t *bytes, const uint32_t *off
     return BSG_OK;
 }
 
+// One bitset beyond LDS from binned locations (bin_build.hip.h): a.t / a.d / a.n_slots / a.n_locs_cap / a.out / a.overflow
+// come filled in; the scratch this takes from the pool is appended to `scratch` (freed by the caller after the stream has
+// drained).  first / last: timestamps of the first and the last dispatch, nullptr for none.
+static int32_t enqueue_binned_build(Device &d, bsg::BinArgs a, bool dense, std::vector<void *> &scratch, hipEvent_t first, hipEvent_t last)
+{
+    a.n_windows = (uint32_t)((a.d.m + bsg::kBinWindowBits - 1) / bsg::kBinWindowBits);
+    HIP_TRY(d.pool.alloc((void **)&a.prefix, ((size_t)a.n_windows + 1) * 4));
+    scratch.push_back(a.prefix);
+    HIP_TRY(d.pool.alloc((void **)&a.cursor, (size_t)a.n_windows * 4));
+    scratch.push_back(a.cursor);
+    HIP_TRY(d.pool.alloc((void **)&a.locs, std::max<size_t>(a.n_locs_cap, 1) * 4));
+    scratch.push_back(a.locs);
+    HIP_TRY(hipMemsetAsync(a.prefix, 0, ((size_t)a.n_windows + 1) * 4, d.stream));
+    const uint32_t tiles = (uint32_t)((a.n_slots + bsg::kBinTile - 1) / bsg::kBinTile);
+    if (dense) hipExtLaunchKernelGGL((bsg::k_bin_pass<false, true>), dim3(tiles), dim3(bsg::kBinThreads), 0, d.stream, first, nullptr, 0, a);
+    else       hipExtLaunchKernelGGL((bsg::k_bin_pass<false, false>), dim3(tiles), dim3(bsg::kBinThreads), 0, d.stream, first, nullptr, 0, a);
+    hipLaunchKernelGGL(bsg::k_bin_scan, dim3(1), dim3(bsg::kBinThreads), 0, d.stream, a);
+    if (dense) hipLaunchKernelGGL((bsg::k_bin_pass<true, true>), dim3(tiles), dim3(bsg::kBinThreads), 0, d.stream, a);
+    else       hipLaunchKernelGGL((bsg::k_bin_pass<true, false>), dim3(tiles), dim3(bsg::kBinThreads), 0, d.stream, a);
+    hipExtLaunchKernelGGL(bsg::k_bin_apply, dim3(a.n_windows), dim3(bsg::kBinThreads), 0, d.stream, nullptr, last, 0, a);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(BSG_E_HIP, "binned build: %s", hipGetErrorString(e));
+    return BSG_OK;
+}
+static bool binned_build_fits(const bsg_ctx *root, uint64_t m, uint64_t n_entries, uint64_t k)
+{
+    const uint64_t n_locs = n_entries * k;
+    return m < (1ull << 31) && n_locs > 0 && n_locs < (1ull << 32) - 4096 && n_locs * 4 <= root->bin_scratch_bytes;
+}
+
 static int32_t build_common(bsg_ctx *ctx, const uint8_t *bytes, const uint32_t *offsets, const uint64_t *h,
                             uint32_t n_entries, const uint32_t *fstart, const bsg_filter_desc *desc,
                             uint32_t n_filters, uint64_t *out_words, uint64_t n_words, const SectionsOut *sections = nullptr)
@@ -658,6 +691,7 @@ static int32_t build_common(bsg_ctx *ctx, const uint8_t *bytes, const uint32_t *
     }
     std::vector<DevDesc> dd(n_filters);
     std::vector<bsg::BuildItem> items;
+    std::vector<uint32_t> binned;                  // bitsets beyond LDS: assembled window by window (bin_build.hip.h)
     uint64_t max_staged = 0;
     for (uint32_t f = 0; f < n_filters; ++f) {
         dd[f] = DevDesc{desc[f].word_off, desc[f].m, barrett_magic(desc[f].m), desc[f].k, 0};
@@ -666,6 +700,8 @@ static int32_t build_common(bsg_ctx *ctx, const uint8_t *bytes, const uint32_t *
         if (nw <= kLdsCapWords) {
             items.push_back({f, fstart[f], fstart[f + 1], 1u});
             max_staged = std::max(max_staged, nw);
+        } else if (binned_build_fits(ctx, desc[f].m, fstart[f + 1] - fstart[f], desc[f].k)) {
+            binned.push_back(f);
         } else {
             for (uint32_t e = fstart[f]; e < fstart[f + 1]; e += kBuildSliceEntries)
                 items.push_back({f, e, std::min(fstart[f + 1], e + kBuildSliceEntries), 0u});
@@ -677,12 +713,15 @@ static int32_t build_common(bsg_ctx *ctx, const uint8_t *bytes, const uint32_t *
     HIP_TRY(d.stage_words.reserve(n_words));
     HIP_TRY(hipMemsetAsync(d.stage_words.p, 0, n_words * 8, d.stream));
     bool launched = false;
-    if (!items.empty()) {
+    std::vector<void *> scratch;
+    struct ScratchGuard { Device &d; std::vector<void *> &v; ~ScratchGuard() { if (!v.empty()) (void)hipStreamSynchronize(d.stream); for (void *p : v) d.pool.free(p); } } sguard{d, scratch};
+    uint32_t *d_over = nullptr;
+    if (!items.empty() || !binned.empty()) {
         HIP_TRY(d.stage_desc.reserve(n_filters));
-        HIP_TRY(d.stage_items.reserve(items.size()));
+        HIP_TRY(d.stage_items.reserve(std::max<size_t>(items.size(), 1)));
         HIP_TRY(hipMemcpyAsync(d.stage_desc.p, dd.data(), dd.size() * sizeof(DevDesc), hipMemcpyHostToDevice, d.stream));
-        HIP_TRY(hipMemcpyAsync(d.stage_items.p, items.data(), items.size() * sizeof(bsg::BuildItem),
-                               hipMemcpyHostToDevice, d.stream));
+        if (!items.empty())
+            HIP_TRY(hipMemcpyAsync(d.stage_items.p, items.data(), items.size() * sizeof(bsg::BuildItem), hipMemcpyHostToDevice, d.stream));
         bsg::BuildArgs a{};
         if (h) {
             HIP_TRY(d.stage_h.reserve((size_t)n_entries * 4));
@@ -696,16 +735,43 @@ static int32_t build_common(bsg_ctx *ctx, const uint8_t *bytes, const uint32_t *
                 HIP_TRY(hipMemcpyAsync(d.stage_off.p, offsets, ((size_t)n_entries + 1) * 4, hipMemcpyHostToDevice, d.stream));
             a.bytes = d.stage_a.p;
             a.off = d.stage_off.p;
+            if (!binned.empty()) HIP_TRY(d.stage_h.reserve((size_t)n_entries * 4));   // the binned filters' entries are hashed once, up front
         }
         a.items = d.stage_items.p;
         a.desc = d.stage_desc.p;
         a.out = d.stage_words.p;
         const size_t lds = std::max<uint64_t>(max_staged, 2) * 8;
         if (!d.kb0) { HIP_TRY(hipEventCreate(&d.kb0)); HIP_TRY(hipEventCreate(&d.kb1)); }
-        hipExtLaunchKernelGGL(bsg::k_build, dim3((uint32_t)items.size()), dim3(bsg::kBuildThreads), (uint32_t)lds, d.stream,
-                              d.kb0, d.kb1, 0, a);
-        HIP_TRY(hipGetLastError());
-        launched = true;
+        // d.kb0 = start of the first dispatch, d.kb1 = end of the last one
+        auto first_ev = [&]() { hipEvent_t s = launched ? nullptr : d.kb0; launched = true; return s; };
+        if (!items.empty()) {
+            hipExtLaunchKernelGGL(bsg::k_build, dim3((uint32_t)items.size()), dim3(bsg::kBuildThreads), (uint32_t)lds, d.stream,
+                                  first_ev(), binned.empty() ? d.kb1 : nullptr, 0, a);
+            HIP_TRY(hipGetLastError());
+        }
+        if (!binned.empty()) {
+            HIP_TRY(d.pool.alloc((void **)&d_over, 64));
+            scratch.push_back(d_over);
+            HIP_TRY(hipMemsetAsync(d_over, 0, 64, d.stream));
+        }
+        for (size_t bi = 0; bi < binned.size(); ++bi) {
+            const uint32_t f = binned[bi];
+            const uint32_t e0 = fstart[f], ne = fstart[f + 1] - fstart[f];
+            if (!h) {
+                // offsets are absolute into the staged bytes: hash entries [e0, e0 + ne) into their places in stage_h
+                hipExtLaunchKernelGGL(bsg::k_hash_entries, dim3((ne + 255) / 256), dim3(256), 0, d.stream, first_ev(), nullptr, 0,
+                                      (const uint8_t *)d.stage_a.p, (const uint32_t *)d.stage_off.p + e0, ne, d.stage_h.p + (size_t)e0 * 4);
+                HIP_TRY(hipGetLastError());
+            }
+            bsg::BinArgs b{};
+            b.t = bsg::IngestTable{d.stage_h.p + (size_t)e0 * 4, nullptr, 0, 0};
+            b.d = dd[f];
+            b.n_slots = ne;
+            b.n_locs_cap = (uint32_t)((uint64_t)ne * desc[f].k);
+            b.overflow = d_over;
+            b.out = d.stage_words.p;
+            if (int32_t rc = enqueue_binned_build(d, b, true, scratch, first_ev(), bi + 1 == binned.size() ? d.kb1 : nullptr)) return rc;
+        }
     }
     if (sections) {      // the words never leave the device: encodeFilterSection runs there too
         if (int32_t rc = encode_sections_device(d, d.stage_words.p, desc, n_filters / 3, sections->region, sections->cap,
@@ -1364,11 +1430,13 @@ extern "C" int32_t bsg_set_probe_group(bsg_ctx *ctx, uint32_t max_arenas_per_lau
     return BSG_OK;
 }
 
-// lab knobs (tools/, bench sweeps): key 1 = compaction rounds of the many-term probe mode
+// lab knobs (tools/, bench sweeps, tests of the paths the defaults no longer take): key 1 = compaction rounds of the
+// many-term probe mode; key 2 = bytes of HBM a binned build of a large bitset may use for its locations (0: global atomics)
 extern "C" int32_t bsg_set_lab(bsg_ctx *ctx, uint32_t key, uint64_t value)
 {
     BSG_ENTER(ctx);
     if (key == 1) { ctx->compact_rounds = (uint32_t)std::min<uint64_t>(value, 16); return BSG_OK; }
+    if (key == 2) { ctx->bin_scratch_bytes = value; return BSG_OK; }
     return fail(BSG_E_INVALID, "unknown lab key %u", key);
 }
 

@@ -280,11 +280,17 @@ def test_tables_grow_from_a_tiny_hint(ctx, flags):
     check_against_sets(res, 1, sets, "parent of one")
 
 
-def test_large_sets_lds_staged_above_64k_and_global_atomics(ctx):
-    # 60 000 distinct tokens -> a 108 KB bitset (LDS-staged, needs the opt-in above 64 KB); 130 000 -> 234 KB (built with
-    # global atomicOr, sliced over several workgroups); the parent holds their union
+@pytest.mark.parametrize("binned", [True, False], ids=["binned", "global-atomics"])
+def test_large_sets_lds_staged_above_64k_and_beyond_lds(ctx, binned):
+    # 60 000 distinct tokens -> a 108 KB bitset (LDS-staged, needs the opt-in above 64 KB); 130 000 -> 234 KB: beyond LDS,
+    # assembled window by window from binned locations (k_bin_*), or — the path m >= 2^31 still takes — with global
+    # atomicOr, sliced over several workgroups; the parent holds their union
     sets = [[b'{"id":"u%d"}' % i for i in range(60000)], [b'{"id":"v%d","n":%d}' % (i, i % 7) for i in range(130000)]]
-    res = I.device_ingest(ctx, sets, FPR, parent_of_set=[0, 0], n_parents=1, flags=TRUSTED)
+    ctx.set_lab(2, (16 << 30) if binned else 0)
+    try:
+        res = I.device_ingest(ctx, sets, FPR, parent_of_set=[0, 0], n_parents=1, flags=TRUSTED)
+    finally:
+        ctx.set_lab(2, 16 << 30)
     assert len(res.fallback_rows) == 0
     want = [({"id"}, {"u%d" % i for i in range(60000)}, {"id::u%d" % i for i in range(60000)}),
             ({"id", "n"}, {"v%d" % i for i in range(130000)} | {str(i) for i in range(7)},
