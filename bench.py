@@ -141,7 +141,7 @@ def ingest_leg(ctx, n_blocks, rows, seed, workers, plan, words, fpr, log, truste
             "rows": n_rows, "row_bytes": int(st.row_bytes), "rows_per_s_device": n_rows / kern_ms * 1e3,
             "row_gb_per_s_walk": st.row_bytes / max(st.ms_walk, 1e-6) / 1e6, "end_to_end_s_incl_h2d": t_e2e,
             "end_to_end_s_incl_h2d_pinned_rows": t_e2e_pinned, "end_to_end_over_kernels_pinned": t_e2e_pinned * 1e3 / kern_ms,
-            "upload": "rows travel in 64 MiB chunks on a copy stream while the chunk before is being walked",
+            "upload": "rows travel in chunks of 64, 128, then 256 MiB on a copy stream while the chunk before is being walked",
             "table_bytes": int(st.table_bytes), "table_grows": int(st.table_grows), "fallback_rows": int(len(fb)),
             "distinct_entries": int(counts[:n_blocks].sum()), "file_level_distinct": [int(x) for x in counts[n_blocks]],
             "check": "bitsets and (m, k) identical to bsg_build of the same blocks' entry sets"}
@@ -197,7 +197,7 @@ def or_reduce_leg(ctx, plan, B, fpr, n_union, world, log):
            "achieved": (B * nw * 8 + nw * 8) / max(local_ms, 1e-6) / 1e6, "unit": "GB/s", "bound": "hbm",
            "check": "equals bsg_build(union of the blocks' entries, m, k) bit for bit"}
     res["frac"] = res["achieved"] / HBM_PEAK_GBPS
-    if world > 1:
+    if world > 1 and COLL_DEVICE() == "cuda":
         # the exchange half, inside the library (bsg_or_allreduce: ncclAllGather over xGMI + k_or_words); the unique id
         # travels over the harness' own channel.  A failure here must not take the probe measurement down with it.
         try:
@@ -306,6 +306,12 @@ def cpu_baseline(words, desc, cb, ops, poff, n_blocks, budget_s, log, terms_per_
     return {"value": value, "unit": "probes/s", "cores": cores, "kind": "port",
             "sample": "%d of %d queries x %d blocks (oracle restatement of parseFilterSection + "
                       "evaluateBloomFilters per (query, block), %d threads, %.1fs)" % (nq2, cb.n_queries, n_blocks, cores, t2)}, out, nq2
+
+
+def COLL_DEVICE():
+    """Where the harness' own small collectives live: the GPU under RCCL, the host under the gloo lab mode."""
+    import torch.distributed as dist
+    return "cuda" if dist.get_backend() == "nccl" else "cpu"
 
 
 class SharedHost:
@@ -437,7 +443,7 @@ class Prober:
         dt = time.perf_counter() - t0
         if self.world > 1:
             import torch.distributed as dist
-            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            t = torch.tensor([dt], dtype=torch.float64, device=COLL_DEVICE())
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         self.log("%d steps: host enqueue %.2f us/step, wall %.2f us/step%s"
@@ -551,7 +557,7 @@ def c4_leg(ctx, args, rank, world, workers, log):
                 ok = False
     if world > 1:
         import torch.distributed as dist
-        flag = torch.tensor([1 if ok else 0], device="cuda")
+        flag = torch.tensor([1 if ok else 0], device=COLL_DEVICE())
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         ok = bool(flag.item())
     if not ok:
@@ -650,6 +656,12 @@ def main():
     ap.add_argument("--no-single", action="store_true", help="skip the one-arena-per-launch sampling pass")
     args = ap.parse_args()
 
+    # stdout carries exactly one JSON line: libraries that print banners through C stdio (librccl writes its version block
+    # to stdout when a communicator is created, flushed at exit — i.e. AFTER the JSON) are pointed at stderr instead
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -662,9 +674,18 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the probe path has no CPU fallback")
+    # lab: BSG_BENCH_SHARE_GPU=1 runs every rank on device 0 with gloo collectives — a functional check of the N > 1 host
+    # paths (sharding, shared-segment gather, rank-0 assembly) on a 1-GPU box; RCCL refuses two ranks on one device, so the
+    # OR all-reduce leg is skipped there and the numbers mean nothing
+    share_gpu = world > 1 and os.environ.get("BSG_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from bloomsearch_amd import _lib, query as Q
     from bloomsearch_amd.arena import plan_blocks
@@ -954,7 +975,7 @@ def main():
             out["cpu_baseline"] = go_reference_baseline(rows, min(B, 100), log) or base
             if out["cpu_baseline"] is not base:
                 out["cpu_baseline_port"] = base
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=json_out, flush=True)
     ctx.batch_free(bid)
     ctx.close()
     if world > 1:
