@@ -9,6 +9,7 @@
 #include "kernels.hip.h"
 #include "ingest.hip.h"
 #include "bin_build.hip.h"
+#include "direct.hip.h"
 #include "match.hip.h"
 #include "host/text.hpp"   // the host walker's Unicode tables: the device defers to the same data
 #include <hip/hip_ext.h>
@@ -186,6 +187,9 @@ struct Device {
     DevBuf<uint64_t> stage_words;
     DevBuf<uint8_t> stage_region;  // encoded filter sections
     std::vector<uint8_t *> idle_staging;   // pinned 4 MiB chunk buffers of finished arena streams
+    std::vector<std::pair<uint64_t *, size_t>> direct_bufs;   // idle page-locked result buffers of k_probe_direct (pointer, bytes)
+    uint32_t *d_direct_count = nullptr;       // finished-workgroup counter of k_probe_direct (0 between launches)
+    uint64_t direct_seq = 0;                  // doorbell value of the last k_probe_direct launch
     std::vector<EventTriple> pending;
     std::vector<EventTriple> free_events;
     uint32_t *d_lower = nullptr;              // unicode.ToLower table for k_ingest_rows (512 KB)
@@ -263,6 +267,7 @@ struct bsg_ctx {
     uint64_t ingest_chunk_bytes = 64ull << 20;   // rows per upload chunk of bsg_ingest_rows (bsg_set_ingest_chunk)
     uint32_t spin_wait_us = 0;   // synchronous probes poll the stream this long before blocking (bsg_set_spin_wait)
     uint32_t compact_rounds = BSG_COMPACT_ROUNDS;   // many-term probe mode (bsg_set_lab)
+    uint32_t direct_max_terms = 16;  // batches of <= 256 queries with at most this many distinct terms take k_probe_direct (bsg_set_lab key 3; 0: never)
     uint64_t bin_scratch_bytes = kBinScratchBytes;  // 0: bitsets beyond LDS are built with global atomics (bsg_set_lab key 2)
     uint32_t fuse_max_arenas = 4; // groups up to this many arenas ride fused (probe of group i + eval of group i-1)
 };
@@ -538,6 +543,8 @@ int32_t bsg_close(bsg_ctx *ctx)
         if (d.kb0) { (void)hipEventDestroy(d.kb0); (void)hipEventDestroy(d.kb1); }
         d.pool.trim(0);
         for (uint8_t *p : d.idle_staging) (void)hipHostFree(p);
+        for (auto &p : d.direct_bufs) (void)hipHostFree(p.first);
+        if (d.d_direct_count) (void)hipFree(d.d_direct_count);
         if (d.d_crc) (void)hipFree(d.d_crc);
         if (d.d_lower) (void)hipFree(d.d_lower);
         for (auto *v : {&d.pending, &d.free_events})
@@ -1209,6 +1216,27 @@ int32_t enqueue_terms(bsg_ctx *ctx, Device &d, const Group &g, const BatchDev &b
     return BSG_OK;
 }
 
+// One dispatch for a small batch: bit tests + programs of every 64-block group (direct.hip.h); survivors to `out`.
+int32_t enqueue_direct(Device &d, const Group &g, const BatchDev &bd, const Batch &B, uint64_t *out, uint64_t *flag, uint64_t seq, EventTriple *ev)
+{
+    bsg::DirectArgs a{};
+    a.done_count = d.d_direct_count; a.flag = flag; a.seq = seq;
+    a.th = bd.d_th; a.prog = bd.d_prog; a.chunk_len = bd.d_chunk_len; a.out = out;
+    a.Tp = B.Tp; a.Wt = std::max(B.Wt, 1u); a.n_queries = B.n_queries; a.Lmax = B.Lmax; a.max_depth = B.max_depth; a.n_kinds = B.n_kinds;
+    for (uint32_t y = 0; y < B.n_kinds; ++y) { a.kind[y] = B.kind[y]; a.term_begin[y] = B.term_begin[y]; a.term_count[y] = B.term_count[y]; }
+    a.n_arenas = (uint32_t)g.shards.size();
+    fill_refs(g, B, a.ar);
+    hipExtLaunchKernelGGL(bsg::k_probe_direct, dim3(g.max_G, 1, a.n_arenas), dim3(bsg::kEvalThreads), bsg::direct_lds_bytes(a.Wt, B.max_depth),
+                          d.stream, ev ? ev->k1s : nullptr, ev ? ev->k1e : nullptr, 0, a);
+    HIP_TRY(hipGetLastError());
+    if (ev) {
+        ev->has_k1 = true; ev->fused = true; ev->n_arenas = a.n_arenas;
+        for (uint32_t y = 0; y < B.n_kinds; ++y)       // algorithmic bytes of the gather regime: k words of 8 bytes per (block, term)
+            for (const ArenaShard *s : g.shards) ev->bytes += (uint64_t)s->n_blocks * B.term_count[y] * 10 * 8;
+    }
+    return BSG_OK;
+}
+
 // K2: programs over V[slot] -> out[slot].
 int32_t enqueue_eval(Device &d, const Group &g, const BatchDev &bd, const Batch &B, uint32_t slot, EventTriple *ev)
 {
@@ -1293,6 +1321,20 @@ int32_t probe_arenas(bsg_ctx *ctx, const std::vector<std::shared_ptr<Arena>> &ar
     // multi-device: every device's shard bitsets land in a host buffer of its own and are interleaved afterwards
     std::vector<std::vector<uint64_t>> parts(nd > 1 && out_survivors ? nd : 0);
     std::vector<std::vector<uint64_t>> part_off(parts.size());
+    struct DirectPending { uint64_t *buf; size_t cap; uint64_t *dst; size_t bytes; Device *dev; uint64_t *flag; uint64_t seq; };
+    std::vector<DirectPending> direct_pending;     // k_probe_direct results waiting in page-locked buffers for the stream to drain
+    struct DirectGuard {                           // the buffers go back to their device whatever way this call ends
+        std::vector<DirectPending> &v;
+        bool drained = false;                      // the kernels that write them are known to be over
+        ~DirectGuard()
+        {
+            for (auto &p : v) {
+                std::lock_guard<std::mutex> lk(p.dev->mu);
+                if (!drained) (void)hipStreamSynchronize(p.dev->stream);
+                p.dev->direct_bufs.emplace_back(p.buf, p.cap);
+            }
+        }
+    } direct_guard{direct_pending};
     for (uint32_t di = 0; di < nd; ++di) {
         Device &d = *ctx->devs[di];
         const BatchDev &bd = B.dev[di];
@@ -1331,6 +1373,43 @@ int32_t probe_arenas(bsg_ctx *ctx, const std::vector<std::shared_ptr<Arena>> &ar
                 HIP_TRY(hipEventCreateWithFlags(&d.ev_eval[s2], hipEventDisableTiming));
                 HIP_TRY(hipEventCreateWithFlags(&d.ev_copy[s2], hipEventDisableTiming));
             }
+        }
+        // one interactive query (a small synchronous batch with a few terms against one group): one dispatch, and the
+        // survivors are written straight into page-locked host memory — one launch and one wait instead of three enqueues
+        uint32_t real_terms = 0;
+        for (uint32_t y = 0; y < B.n_kinds; ++y) real_terms += B.term_count[y];
+        const bool direct = inline_copy && nd == 1 && !(flags & BSG_PROBE_NOFUSE) && B.n_chunks == 1 && B.identity_cw && !B.many_terms &&
+                            real_terms <= ctx->direct_max_terms && bsg::direct_lds_bytes(std::max(B.Wt, 1u), B.max_depth) <= 64 * 1024;
+        if (direct) {
+            EventTriple ev0;
+            const bool t0 = timed;
+            if (t0) if (int32_t rc = take_events(ctx, d, ev0)) return rc;
+            const uint64_t bytes = groups[0].out_words * 8;
+            uint64_t *target = out_dev ? out_dev + goff[0] : nullptr;
+            uint64_t *flag = nullptr;
+            if (!out_dev) {
+                DirectPending p{};
+                const size_t need = bytes + 64;                  // the doorbell word sits behind the survivors
+                for (size_t i = 0; i < d.direct_bufs.size(); ++i)
+                    if (d.direct_bufs[i].second >= need) { p.buf = d.direct_bufs[i].first; p.cap = d.direct_bufs[i].second; d.direct_bufs.erase(d.direct_bufs.begin() + i); break; }
+                if (!p.buf) {
+                    p.cap = std::max<size_t>(64 * 1024, need);
+                    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&p.buf), p.cap, hipHostMallocDefault));
+                }
+                if (!d.d_direct_count) {
+                    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d.d_direct_count), 64));
+                    HIP_TRY(hipMemsetAsync(d.d_direct_count, 0, 64, d.stream));
+                }
+                p.dst = host_base + goff[0]; p.bytes = bytes; p.dev = &d;
+                p.flag = p.buf + (bytes + 7) / 8; p.seq = ++d.direct_seq;
+                *reinterpret_cast<volatile uint64_t *>(p.flag) = 0;
+                flag = p.flag;
+                direct_pending.push_back(p);
+                target = p.buf;
+            }
+            if (int32_t rc = enqueue_direct(d, groups[0], bd, B, target, flag, d.direct_seq, t0 ? &ev0 : nullptr)) return rc;
+            if (t0) d.pending.push_back(ev0);
+            continue;
         }
         std::vector<EventTriple> evs(groups.size());
         std::vector<uint8_t> tflag(groups.size(), 0);
@@ -1383,7 +1462,17 @@ int32_t probe_arenas(bsg_ctx *ctx, const std::vector<std::shared_ptr<Arena>> &ar
         }
     }
     if (flags & BSG_PROBE_ASYNC) return BSG_OK;
-    for (uint32_t di = 0; di < nd; ++di) {
+    // k_probe_direct rings a doorbell in page-locked memory when its last workgroup is done: reading our own memory is
+    // cheaper than asking the runtime; the stream is only waited for if the bell does not ring within a millisecond
+    bool rang = !direct_pending.empty();
+    for (auto &p : direct_pending) {
+        const auto t0 = std::chrono::steady_clock::now();
+        while (__atomic_load_n(p.flag, __ATOMIC_ACQUIRE) != p.seq) {
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(1000)) { rang = false; break; }
+        }
+        if (!rang) break;
+    }
+    for (uint32_t di = 0; di < nd && !rang; ++di) {
         Device &d = *ctx->devs[di];
         std::lock_guard<std::mutex> lk(d.mu);
         if (int32_t rc = use_device(d)) return rc;
@@ -1396,6 +1485,8 @@ int32_t probe_arenas(bsg_ctx *ctx, const std::vector<std::shared_ptr<Arena>> &ar
         if (d.copy_stream) HIP_TRY(hipStreamSynchronize(d.copy_stream));
         d.copy_busy[0] = d.copy_busy[1] = false;
     }
+    for (auto &p : direct_pending) memcpy(p.dst, p.buf, p.bytes);
+    direct_guard.drained = true;                   // the doorbell rang, or the stream was waited for
     if (!parts.empty()) {
         memset(out_survivors, 0, out_off[n_arenas] * 8);
         for (uint32_t di = 0; di < nd; ++di) {
@@ -1431,12 +1522,14 @@ extern "C" int32_t bsg_set_probe_group(bsg_ctx *ctx, uint32_t max_arenas_per_lau
 }
 
 // lab knobs (tools/, bench sweeps, tests of the paths the defaults no longer take): key 1 = compaction rounds of the
-// many-term probe mode; key 2 = bytes of HBM a binned build of a large bitset may use for its locations (0: global atomics)
+// many-term probe mode; key 2 = bytes of HBM a binned build of a large bitset may use for its locations (0: global atomics);
+// key 3 = most distinct terms of a small batch that takes the one-dispatch path k_probe_direct (0: never)
 extern "C" int32_t bsg_set_lab(bsg_ctx *ctx, uint32_t key, uint64_t value)
 {
     BSG_ENTER(ctx);
     if (key == 1) { ctx->compact_rounds = (uint32_t)std::min<uint64_t>(value, 16); return BSG_OK; }
     if (key == 2) { ctx->bin_scratch_bytes = value; return BSG_OK; }
+    if (key == 3) { ctx->direct_max_terms = (uint32_t)std::min<uint64_t>(value, 192); return BSG_OK; }
     return fail(BSG_E_INVALID, "unknown lab key %u", key);
 }
 

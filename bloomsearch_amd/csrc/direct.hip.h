@@ -1,0 +1,136 @@
+// direct.hip.h — one interactive query (or a handful) in ONE dispatch.
+// evaluateBlockFilters for a single Query() call tests a few terms per block (query_exec.go:128-158, 572-615): 30 bit
+// tests per block for a 3-term query.  Through k_probe_terms + k_eval_programs + the copy of the survivors that is three
+// enqueues of ~5 us launch latency each around ~10 us of kernels (measured 30-34 us per synchronous query, bench `q1`).
+// Here a workgroup owns 64 consecutive blocks of one arena end to end: lane = block, the waves share the terms; every
+// (block, term) is tested with <= k word reads straight from L2 / HBM (the gather regime of SURVEY 8d: a 35 KB bitset is
+// never streamed for 30 bits), __ballot turns a term's 64 verdicts into the 64-block mask the program interpreter works
+// on, and the same workgroup runs the batch's programs and writes the survivor words — into device memory or straight
+// into page-locked host memory, so a query costs one launch and one wait.
+// Taken for batches of <= 256 queries with few distinct terms (bsg_set_lab key 3); everything else keeps the streaming kernels.
+#pragma once
+#include "kernels.hip.h"
+
+namespace bsg {
+
+struct DirectArgs {
+    const uint64_t *th;          // SoA term hashes: th[j * Tp + t]
+    const uint32_t *prog;        // the batch's single 256-query chunk, lane-interleaved: prog[j * 256 + lane]
+    const uint32_t *chunk_len;
+    uint64_t *out;               // arena i: [n_queries][G_i] at out + ar[i].out_off (device memory or mapped host memory)
+    uint32_t Tp, Wt, n_queries, Lmax, max_depth, n_kinds;
+    uint32_t kind[3], term_begin[3], term_count[3];
+    uint32_t n_arenas;
+    // completion doorbell (host output only): the last workgroup to finish writes `seq` into page-locked host memory, so the
+    // host learns of the result by reading its own memory instead of asking the runtime (hipStreamSynchronize: ~5 us)
+    uint32_t *done_count;        // device word, 0 between launches
+    uint64_t *flag;              // host-mapped; nullptr: no doorbell
+    uint64_t seq;
+    ArenaRef ar[kMaxGroupArenas];
+};
+
+__host__ __device__ inline uint32_t direct_lds_bytes(uint32_t Wt, uint32_t max_depth)
+{
+    return (Wt * 64u + max_depth * (uint32_t)kEvalThreads) * 8u;
+}
+
+// grid = (most 64-block groups of any arena, 1, arenas); 256 threads
+__global__ __launch_bounds__(kEvalThreads) void k_probe_direct(const DirectArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
+    const ArenaRef &ar = a.ar[blockIdx.z];
+    const uint32_t g = blockIdx.x;
+    const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+    if (g < ar.G) {                                              // (arenas of a group may differ in size)
+    constexpr uint32_t n_waves = kEvalThreads / kWave;
+    uint64_t *VT = lds64;                                        // VT[word * 64 + bit]: 64-block mask of one term
+    uint64_t *stk = lds64 + (uint64_t)a.Wt * 64 + tid;           // per-lane stack, stride kEvalThreads
+    for (uint32_t i = tid; i < a.Wt * 64; i += kEvalThreads) VT[i] = 0;
+    // the program words do not depend on the verdicts: request them before the bit tests
+    constexpr uint32_t kPre = 8;
+    uint32_t pre[kPre];
+    const uint32_t *P = a.prog + tid;
+#pragma unroll
+    for (uint32_t j = 0; j < kPre; ++j) pre[j] = j < a.Lmax ? P[(uint64_t)j * kEvalThreads] : (7u << 28);
+    const uint32_t len = a.chunk_len[0];
+    __syncthreads();
+
+    const uint32_t b = g * 64 + lane;
+    const bool valid = b < ar.n_blocks;
+    for (uint32_t y = 0; y < a.n_kinds; ++y) {
+        DevDesc d{0, 0, 0, 0, 0};
+        if (valid) d = ar.desc[(uint64_t)b * 3 + a.kind[y]];
+        const uint64_t *src = ar.words + d.word_off;
+        const uint32_t t0 = a.term_begin[y];
+        for (uint32_t t = wave; t < a.term_count[y]; t += n_waves) {       // wave-uniform term: its hashes are scalar loads
+            const uint64_t h0 = a.th[t0 + t], h1 = a.th[(uint64_t)a.Tp + t0 + t];
+            const uint64_t h2 = a.th[2ull * a.Tp + t0 + t], h3 = a.th[3ull * a.Tp + t0 + t];
+            // a nil filter cannot disqualify (query_exec.go:137-151); rows past the arena's end are masked at the end
+            bool pass = true;
+            uint32_t i = 0;
+            const uint32_t k = d.m ? d.k : 0u;
+            uint64_t s2 = 0, s3 = 0;                                      // i * h2, i * h3 as running sums
+#ifndef BSG_DIRECT_TRIP
+#define BSG_DIRECT_TRIP 12
+#endif
+            constexpr uint32_t kTrip = BSG_DIRECT_TRIP;                  // locations whose word reads are in flight together (lab: -DBSG_DIRECT_TRIP)
+            while (__ballot(pass && i < k) != 0ull) {
+                uint64_t w[kTrip]; uint32_t bit[kTrip]; bool live[kTrip];
+#pragma unroll
+                for (uint32_t u = 0; u < kTrip; ++u) {
+                    const uint32_t r = (i + u) & 3u;
+                    const uint64_t x = (((i + u) & 1u) ? h1 : h0) + ((r == 1u || r == 2u) ? s3 : s2);
+                    s2 += h2; s3 += h3;
+                    live[u] = pass && i + u < k;
+                    const uint64_t loc = live[u] ? mod_m(x, d.m, d.magic) : 0;
+                    bit[u] = (uint32_t)loc & 63u;
+                    w[u] = live[u] ? src[loc >> 6] : 0;
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < kTrip; ++u)
+                    if (live[u] && !((w[u] >> bit[u]) & 1ull)) pass = false;
+                i += kTrip;
+            }
+            const uint64_t mask = __ballot(pass);
+            if (lane == 0) VT[(uint64_t)(t0 >> 6) * 64 + t] = mask;      // a kind's segment starts on a word boundary
+        }
+    }
+    __syncthreads();
+
+    // evalBloomExpression over 64-block masks (the interpreter of k_eval_programs: 0 TERM | 1 AND2 | 2 OR2 | 3 TRUE | 4 FALSE | 7 NOP)
+    uint64_t top = ~0ULL;                                                // empty program == nil query == true
+    uint32_t sp = 0;
+    auto step = [&](uint32_t op) {
+        const uint32_t opc = op >> 28;
+        if (opc == 7u) return;
+        if (opc == 1u || opc == 2u) {
+            --sp;
+            const uint64_t under = stk[(uint64_t)(sp - 1) * kEvalThreads];
+            top = (opc == 1u) ? (under & top) : (under | top);
+        } else {
+            if (sp > 0) stk[(uint64_t)(sp - 1) * kEvalThreads] = top;
+            ++sp;
+            top = (opc == 0u) ? VT[op & 0x0FFFFFFFu] : (opc == 3u ? ~0ULL : 0ULL);
+        }
+    };
+#pragma unroll
+    for (uint32_t j = 0; j < kPre; ++j) if (j < len) step(pre[j]);
+    for (uint32_t j = kPre; j < len; ++j) step(P[(uint64_t)j * kEvalThreads]);
+    const uint32_t nvalid = ar.n_blocks - g * 64;
+    if (tid < a.n_queries)
+        a.out[ar.out_off + (uint64_t)tid * ar.G + g] = top & (nvalid >= 64 ? ~0ULL : ((1ULL << nvalid) - 1));
+    }
+    if (a.flag) {
+        __threadfence_system();                                  // this workgroup's survivor words reach the host before the count moves
+        __syncthreads();
+        if (tid == 0) {
+            const uint32_t n_wg = gridDim.x * gridDim.z;
+            if (__hip_atomic_fetch_add(a.done_count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u == n_wg) {
+                __hip_atomic_store(a.done_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(a.flag, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
+}
+
+}  // namespace bsg

@@ -273,12 +273,80 @@ def test_gather_regime_equals_streamed_probe(ctx):
         terms = H.gpu_terms(ctx, cb)
         want = O.probe_batch(words, plan.desc.view(O.DESC_DTYPE), terms.view(O.TERM_DTYPE), ops, poff)
         try:
+            ctx.set_lab(3, 0)                                  # the two-kernel path, not the one-dispatch one
             for cost in (0, 256, 1 << 20):
                 ctx.set_gather_cost(cost)
                 assert np.array_equal(ctx.probe(aid, 40, terms, ops, poff), want), cost
+            ctx.set_lab(3, 16)
+            assert np.array_equal(ctx.probe(aid, 40, terms, ops, poff), want)
         finally:
             ctx.set_gather_cost(256)
+            ctx.set_lab(3, 16)
     ctx.arena_free(aid)
+
+
+def test_one_dispatch_path_for_small_batches(ctx):
+    """k_probe_direct: a synchronous batch of <= 256 queries with a few distinct terms is tested AND evaluated by one
+    dispatch, survivors written into page-locked host memory (or a device pointer).  Same bits as the oracle and as the
+    two-kernel path: 1 / 7 / 256 queries, groups of 1 and of 9 arenas of different sizes, nil filters, an arena without
+    blocks, empty / nil / unknown expressions."""
+    rng = np.random.default_rng(77)
+    plans, vocab = [], None
+    for n_blocks in (1, 64, 65, 130, 200, 3, 70, 129, 31):
+        plan, _, vocab = H.make_random_arena(rng, n_blocks, absent_frac=0.1, max_tokens=400, vocab_size=60)
+        words = ctx.build(plan.blob, plan.off, plan.fstart, plan.desc, plan.n_words)
+        plans.append((plan, words, ctx.arena_load(words, plan.desc)))
+    empty = ctx.arena_load(np.zeros(2, dtype=np.uint64), np.zeros(0, dtype=DESC_DTYPE))
+    t_before = ctx.timing_read(reset=True)
+    for n_queries in (1, 7, 256):
+        leaves = [Q.Field("f1"), Q.Field("f44"), Q.Token(vocab[0]), Q.Token(vocab[1]), Q.Token("absent"), Q.FieldToken("f2", vocab[2]),
+                  Q.FieldToken("f3", vocab[0]), Q.FieldToken("f1", "absent"), {"ExpressionType": "CONDITION", "Condition": None},
+                  {"ExpressionType": "XOR", "Children": []}]
+
+        def small_expr(depth=0):
+            if depth >= 3 or rng.random() < 0.4:
+                return leaves[int(rng.integers(0, len(leaves)))]
+            kids = [small_expr(depth + 1) for _ in range(int(rng.integers(0, 5)))]
+            return Q.And(*kids) if rng.random() < 0.5 else Q.Or(*kids)
+        exprs = [small_expr() for _ in range(n_queries)]
+        if n_queries == 7:
+            exprs[0] = None
+        cb = Q.compile_queries(exprs)
+        ops, poff, _ = cb.arrays()
+        terms = H.gpu_terms(ctx, cb)
+        assert len(terms) <= 16
+        try:
+            bid = ctx.batch_create(terms, ops, poff)
+            wants = [O.probe_batch(wd, pl.desc.view(O.DESC_DTYPE), terms.view(O.TERM_DTYPE), ops, poff) for pl, wd, _ in plans]
+            for ids in ([2], [0, 1, 2, 3, 4, 5, 6, 7, 8], [8, 8, 3]):
+                arenas = [plans[i][2] for i in ids]
+                nbs = [plans[i][0].n_blocks for i in ids]
+                if len(ids) == 3:
+                    arenas.insert(1, empty); nbs.insert(1, 0)
+                direct = ctx.probe_many(arenas, bid, _lib.PROBE_TIMED, cb.n_queries, nbs)
+                plain = ctx.probe_many(arenas, bid, _lib.PROBE_NOFUSE, cb.n_queries, nbs)
+                k = 0
+                for a, (g, p2) in enumerate(zip(direct, plain)):
+                    if nbs[a] == 0:
+                        assert g.shape[1] == 0
+                        continue
+                    assert np.array_equal(g, wants[ids[k]]), (n_queries, ids, a)
+                    assert np.array_equal(p2, wants[ids[k]]), (n_queries, ids, a)
+                    k += 1
+            # survivors left at a device pointer
+            G = wants[4].shape[1]
+            dmem = HipMem(cb.n_queries * G * 8)
+            ctx.probe_many_dev([plans[4][2]], bid, dmem.ptr.value)
+            assert np.array_equal(dmem.read().reshape(cb.n_queries, G), wants[4])
+            dmem.free()
+            ctx.batch_free(bid)
+        finally:
+            ctx.set_lab(3, 16)
+    t = ctx.timing_read()
+    assert t.n_fused >= 9 and t.n_probes == 0        # every timed call above was ONE dispatch
+    ctx.arena_free(empty)
+    for _, _, a in plans:
+        ctx.arena_free(a)
 
 
 def test_error_scopes_keep_their_own_message(ctx):
