@@ -325,7 +325,7 @@ typedef struct bsg_ingest_stats {
     uint64_t table_bytes;      /* HBM held by the distinct-entry tables */
     float ms_walk;             /* k_ingest_rows dispatch time (sum over re-runs after a table grew) */
     float ms_union;            /* k_ingest_union into the parents */
-    float ms_build;            /* k_build_sets */
+    float ms_build;            /* k_build_sets (+ k_bin_* for bitsets beyond LDS): first dispatch start to last dispatch end */
     float ms_encode;           /* k_encode_payload + k_crc_sections (bsg_ingest_build_sections) */
 } bsg_ingest_stats;
 
@@ -341,8 +341,8 @@ typedef struct bsg_ingest_stats {
 BSG_API int32_t bsg_ingest_rows(bsg_ctx *ctx, const uint8_t *rows, const uint64_t *row_off, uint32_t n_rows,
                                 const uint32_t *set_first_row, uint32_t n_sets, const uint32_t *parent_of_set,
                                 uint32_t n_parents, const uint32_t *slots_hint, uint32_t flags, uint64_t *out_ingest_id);
-/* bsg_ingest_rows uploads the rows in chunks of about this many bytes (default 64 MiB, 0 restores it): the copy of chunk
- * i+1 overlaps the walk of chunk i. */
+/* bsg_ingest_rows uploads the rows in chunks: the first of about this many bytes (default 64 MiB, 0 restores it), each
+ * later one twice the one before up to four times this; the copy of chunk i+1 overlaps the walk of chunk i. */
 BSG_API int32_t bsg_set_ingest_chunk(bsg_ctx *ctx, uint64_t bytes);
 /* Row indices (ascending) the host walker must finish; rows_out may be NULL to query the count. */
 BSG_API int32_t bsg_ingest_fallback_rows(bsg_ctx *ctx, uint64_t ingest_id, uint32_t *rows_out, uint32_t cap,
