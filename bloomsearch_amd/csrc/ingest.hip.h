@@ -378,6 +378,9 @@ struct Walker {
     bool quiet;              // leaf without a path (scalars at the root): nothing is emitted
     bool in_token;
     bool ft_on;              // keep the path::word stream (the ingest walker); the row matcher only needs the word's own hash
+#ifdef BSG_INGEST_PROF
+    uint32_t iters;          // lab: trips of the walker_step loop
+#endif
     HashStream ps, tok, ft;  // path + "::" prefix state; current word; current path::word
 };
 
@@ -509,13 +512,33 @@ __device__ __forceinline__ uint32_t str_rune(Walker &w, uint32_t r)
     return 0xFFu;
 }
 
-// Runs until the lane has a request pending (w.req), has used up its chunk, is done, or must go to the host.
+struct ChunkCursor {
+    const uint64_t *chunks;
+    uint64_t ci;     // index of the chunk in Walker::cur
+    uint64_t nxt;    // one chunk ahead: its latency hides behind the work on the current one
+};
+
+// Runs until the lane has a request pending (w.req), is done, or must go to the host.  A lane that uses up its 8-byte
+// chunk takes the next one — already in a register, requested one chunk ago — and requests the one after, right here:
+// returning to the wave-converged loop for it put the lanes of a wave out of phase with each other at every chunk
+// boundary (different lanes cross theirs at different steps), and every extra trip runs all the states some lane is in
+// (10 M rows: 31.7 -> 27 ms; the row matcher 15.9 -> 12 ms).  Measured and dropped on top of it: skipping S_COLON /
+// S_KEY_OPEN when their byte sits in the same chunk and a has-dots flag for S_PREFIX (no change), the rare escape /
+// UTF-8 states behind one test (slower: 8.9 -> 11.1 ms per 3 M rows, the structurizer's layout got worse).
 template <bool EMIT>
-__device__ __forceinline__ uint32_t walker_step(Walker &w)
+__device__ __forceinline__ uint32_t walker_step(Walker &w, ChunkCursor &cc)
 {
     lds_u8 *stack = w.path + kPathCap;
-    const uint64_t chunk_end = (w.pos & ~7ULL) + 8;   // bytes of w.cur that may be consumed this step
+    if ((w.pos >> 3) != cc.ci) {                      // the step before ended on the chunk boundary
+        cc.ci += 1;
+        w.cur = cc.nxt;
+        cc.nxt = cc.chunks[cc.ci + 1];
+    }
+    uint64_t chunk_end = (cc.ci + 1) * 8;             // bytes of w.cur end here
     for (;;) {
+#ifdef BSG_INGEST_PROF
+        ++w.iters;
+#endif
         if (w.st == S_PREFIX) {
             // every "."-split prefix of the key is a field entry, empty paths skipped (row_matcher.go:103-135)
             while (EMIT && w.aux < w.key_len) {
@@ -532,7 +555,7 @@ __device__ __forceinline__ uint32_t walker_step(Walker &w)
             }
             return (w.st == S_AFTER && w.depth == 0) ? R_DONE : R_FAIL;
         }
-        if (w.pos >= chunk_end) return R_CONTINUE;                // the next chunk is loaded by the converged part of the loop
+        if (w.pos >= chunk_end) { cc.ci += 1; w.cur = cc.nxt; cc.nxt = cc.chunks[cc.ci + 1]; chunk_end += 8; }
         const uint32_t c = (uint32_t)(w.cur >> ((w.pos & 7u) * 8u)) & 0xFFu;
         switch (w.st) {
         case S_VALUE_OR_CLOSE:
@@ -795,19 +818,13 @@ __device__ __forceinline__ void cache_put(lds_u64i *cache, uint32_t table_id, co
 #define BSG_PROF_DECL uint64_t prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
 #define BSG_PROF_T(var) const uint64_t var = __builtin_readcyclecounter()
 #define BSG_PROF_ADD(slot, t0, t1) prof_acc[slot] += (uint64_t)((t1) - (t0))
-#define BSG_PROF_FLUSH() do { if ((threadIdx.x & 63u) == 0u) for (int pi = 1; pi < 8; ++pi) atomicAdd((unsigned long long *)a.n_fallback + pi, (unsigned long long)prof_acc[pi]); } while (0)
+#define BSG_PROF_FLUSH() do { if ((threadIdx.x & 63u) == 0u) { for (int pi = 1; pi < 8; ++pi) atomicAdd((unsigned long long *)a.n_fallback + pi, (unsigned long long)prof_acc[pi]); atomicAdd((unsigned long long *)a.n_fallback + 8, (unsigned long long)prof_acc[0]); } } while (0)
 #else
 #define BSG_PROF_DECL
 #define BSG_PROF_T(var)
 #define BSG_PROF_ADD(slot, t0, t1)
 #define BSG_PROF_FLUSH()
 #endif
-
-struct ChunkCursor {
-    const uint64_t *chunks;
-    uint64_t ci;     // index of the chunk in Walker::cur
-    uint64_t nxt;    // one chunk ahead: its latency hides behind the work on the current one
-};
 
 __device__ __forceinline__ void walker_reset(Walker &w, ChunkCursor &cc, uint64_t pos, uint64_t end, bool live)
 {
@@ -824,15 +841,7 @@ __device__ __forceinline__ void walker_reset(Walker &w, ChunkCursor &cc, uint64_
 }
 
 template <bool EMIT>
-__device__ __forceinline__ uint32_t advance(Walker &w, ChunkCursor &cc)
-{
-    if ((w.pos >> 3) != cc.ci) {                    // the step before ended on the chunk boundary
-        cc.ci += 1;
-        w.cur = cc.nxt;
-        cc.nxt = cc.chunks[cc.ci + 1];
-    }
-    return walker_step<EMIT>(w);
-}
+__device__ __forceinline__ uint32_t advance(Walker &w, ChunkCursor &cc) { return walker_step<EMIT>(w, cc); }
 
 // One wave walks a contiguous run of rows_per_wave rows, 64 at a time (lane = row); the four waves of a workgroup take
 // neighbouring runs, so a workgroup stays inside one block (or two) and its dedup cache stays warm: a workgroup that
@@ -854,7 +863,11 @@ __global__ __launch_bounds__(kIngestThreads, BSG_INGEST_WPE) void k_ingest_rows(
     w.path = (lds_u8 *)lds_raw + kCacheWords * 8 + threadIdx.x * kLaneLds;
     w.lower = a.lower;
     w.key = a.key;
+#ifdef BSG_LAB_NOFT      // lab only: what the field::token stream costs inside the parse (the sets come out wrong)
+    w.ft_on = false;
+#else
     w.ft_on = true;
+#endif
     BSG_PROF_DECL;
     for (uint64_t tile = run_begin; tile < run_end; tile += 64) {
     const uint32_t r = (uint32_t)tile + lane;
@@ -892,11 +905,22 @@ __global__ __launch_bounds__(kIngestThreads, BSG_INGEST_WPE) void k_ingest_rows(
     res = go ? R_CONTINUE : R_DONE;
     while (__ballot(res == R_CONTINUE || w.req != Q_NONE) != 0ull) {
         BSG_PROF_T(ta0);
+#ifdef BSG_INGEST_PROF
+        w.iters = 0;
+#endif
         while (__ballot(res == R_CONTINUE && w.req == Q_NONE) != 0ull)
             if (res == R_CONTINUE && w.req == Q_NONE) res = advance<true>(w, cc);
         BSG_PROF_T(ta1);
         BSG_PROF_ADD(2, ta0, ta1);
         BSG_PROF_ADD(5, 0, 1);
+#ifdef BSG_INGEST_PROF
+        {   // trips of the wave = those of its slowest lane; and the lanes' own mean
+            uint32_t mx = w.iters, sm = w.iters;
+            for (int o = 32; o > 0; o >>= 1) { mx = max(mx, (uint32_t)__shfl_xor((int)mx, o)); sm += (uint32_t)__shfl_xor((int)sm, o); }
+            prof_acc[7] += mx;
+            prof_acc[0] += sm;
+        }
+#endif
         const uint32_t q = w.req;
         w.req = Q_NONE;
         // (B1) path hashes for Q_FIELD / Q_LEAF

@@ -344,6 +344,18 @@ def test_one_dispatch_path_for_small_batches(ctx):
             ctx.set_lab(3, 16)
     t = ctx.timing_read()
     assert t.n_fused >= 9 and t.n_probes == 0        # every timed call above was ONE dispatch
+    # k = 17 (fpr 1e-5): more locations than one trip of word reads holds; k = 1 (fpr 0.6)
+    for fpr in (1e-5, 0.6):
+        plan, _, vocab = H.make_random_arena(rng, 90, fpr=fpr, absent_frac=0.05, max_tokens=300, vocab_size=40)
+        words = ctx.build(plan.blob, plan.off, plan.fstart, plan.desc, plan.n_words)
+        assert int(plan.desc["k"].max()) == 17 if fpr < 0.1 else int(plan.desc["k"].max()) <= 2
+        cb = Q.compile_queries([Q.And(Q.Token(vocab[0]), Q.Or(Q.Token(vocab[1]), Q.FieldToken("f1", vocab[2]))), Q.Token(vocab[3]), Q.Field("f7")])
+        ops, poff, _ = cb.arrays()
+        terms = H.gpu_terms(ctx, cb)
+        want = O.probe_batch(words, plan.desc.view(O.DESC_DTYPE), terms.view(O.TERM_DTYPE), ops, poff)
+        aid = ctx.arena_load(words, plan.desc)
+        assert np.array_equal(ctx.probe(aid, 90, terms, ops, poff), want)
+        ctx.arena_free(aid)
     ctx.arena_free(empty)
     for _, _, a in plans:
         ctx.arena_free(a)
