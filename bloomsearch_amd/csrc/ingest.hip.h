@@ -524,7 +524,8 @@ struct ChunkCursor {
 // boundary (different lanes cross theirs at different steps), and every extra trip runs all the states some lane is in
 // (10 M rows: 31.7 -> 27 ms; the row matcher 15.9 -> 12 ms).  Measured and dropped on top of it: skipping S_COLON /
 // S_KEY_OPEN when their byte sits in the same chunk and a has-dots flag for S_PREFIX (no change), the rare escape /
-// UTF-8 states behind one test (slower: 8.9 -> 11.1 ms per 3 M rows, the structurizer's layout got worse).
+// UTF-8 states behind one test (slower: 8.9 -> 11.1 ms per 3 M rows, the structurizer's layout got worse), S_STR / S_KEY
+// runs continuing into the next chunk within one trip (8.76 -> 9.05 ms).
 template <bool EMIT>
 __device__ __forceinline__ uint32_t walker_step(Walker &w, ChunkCursor &cc)
 {
