@@ -13,4 +13,13 @@ python bench.py --steps 20 --warmup 5 > gpurun_out/${R}_bench_driver_shape.json 
 python bench.py > gpurun_out/${R}_bench_default.json 2> gpurun_out/${R}_bench_default.err
 python bench.py --workload needle --cpu-budget 0 --c4-files 0 --ingest-blocks 0 --no-decode --or-union 0 > gpurun_out/${R}_bench_needle.json 2>/dev/null
 python bench.py --workload c4 --cpu-budget 6 --c4-files 0 --ingest-blocks 0 --no-decode --or-union 0 > gpurun_out/${R}_bench_c4.json 2>/dev/null
-ls -la gpurun_out
+bash tools/profile_ingest_trace.sh ${R}_ingest 300 > gpurun_out/${R}_ingest_rocprofv3.txt 2>&1
+# what to keep: the summaries and the bench lines (the rocprofv3 databases stay in gpurun_out/)
+mkdir -p gpurun_out/keep
+cp gpurun_out/prof_${R}_c2/summary.txt gpurun_out/keep/${R}_probe_c2_rocprofv3.txt
+cp gpurun_out/prof_${R}_c4/summary.txt gpurun_out/keep/${R}_probe_c4_rocprofv3.txt
+cp gpurun_out/prof_${R}_needle/summary.txt gpurun_out/keep/${R}_probe_needle_rocprofv3.txt
+cp gpurun_out/prof_${R}_c2/traffic.json gpurun_out/keep/${R}_traffic.json
+cp gpurun_out/pmc_${R}_needle/summary.txt gpurun_out/keep/${R}_needle_pmc.txt
+cp gpurun_out/${R}_ingest_rocprofv3.txt gpurun_out/${R}_bench_*.json gpurun_out/keep/
+ls -la gpurun_out/keep
