@@ -26,5 +26,6 @@ print("# for the scattered 8..32-byte accesses of the table kernels the raw valu
 for k, v in sorted(rows.items()):
     f = v.get("FETCH_SIZE", (0, 1)); w = v.get("WRITE_SIZE", (0, 1))
     fk, wk = f[0] / f[1], w[0] / w[1]
-    print("%-18s fetch %12.1f KB  write %12.1f KB  raw %9.2f MB  corrected %9.2f MB  (%d dispatches)" % (k, fk, wk, (fk + wk) * 1024 / 1e6, (2 * fk + wk) * 1024 / 1e6, f[1]))
+    print("%-22s per dispatch: fetch %12.1f KB  write %12.1f KB | all %3d dispatches of the run: raw %9.2f MB  corrected %9.2f MB"
+          % (k, fk, wk, f[1], (f[0] + w[0]) * 1024 / 1e6, (2 * f[0] + w[0]) * 1024 / 1e6))
 PY
