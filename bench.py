@@ -197,42 +197,50 @@ def or_reduce_leg(ctx, plan, B, fpr, n_union, world, log):
            "achieved": (B * nw * 8 + nw * 8) / max(local_ms, 1e-6) / 1e6, "unit": "GB/s", "bound": "hbm",
            "check": "equals bsg_build(union of the blocks' entries, m, k) bit for bit"}
     res["frac"] = res["achieved"] / HBM_PEAK_GBPS
-    if world > 1 and COLL_DEVICE() == "cuda":
-        # the exchange half, inside the library (bsg_or_allreduce: ncclAllGather over xGMI + k_or_words); the unique id
-        # travels over the harness' own channel.  A failure here must not take the probe measurement down with it.
-        try:
-            import torch.distributed as dist
-            from bloomsearch_amd.gpu import Context
-            box = [Context.comm_unique_id() if dist.get_rank() == 0 else None]
-            dist.broadcast_object_list(box, src=0)
-            ctx.comm_init(box[0], dist.get_rank(), world)
-            ts = []
-            for _ in range(6):
-                part = out.clone()
-                dist.barrier()
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                ctx.or_allreduce_dev([part.data_ptr()], nw)
-                ts.append(time.perf_counter() - t1)
-            full = ctx.or_allreduce(aid, 1, nw)            # the whole operation: local OR + exchange + copy out
-            if not np.array_equal(full, part.cpu().numpy().view(np.uint64)):
-                sys.exit("bsg_or_allreduce and bsg_or_allreduce_dev disagree")
-            # every rank must hold every rank's bits: the local partial is a subset of the result
-            if np.any(got & ~full):
-                sys.exit("OR all-reduce lost bits of this rank's partial")
-            ctx.comm_destroy()
-            res["allreduce_ms"] = float(np.median(ts[1:])) * 1e3
-            res["allreduce_wire_bytes_in_per_gpu"] = (world - 1) * nw * 8
-            res["allreduce_gbps_in_per_gpu"] = (world - 1) * nw * 8 / max(res["allreduce_ms"], 1e-9) / 1e6
-            res["allreduce"] = "bsg_or_allreduce_dev: ncclAllGather (RCCL over xGMI) of %d partials + k_or_words, inside libbloomgpu" % world
-        except Exception as exc:  # noqa: BLE001 - reported, not swallowed
-            res["allreduce_error"] = repr(exc)
-            log("OR all-reduce failed: %r" % (exc,))
+    state = {"aid": aid, "out": out, "got": got, "nw": nw} if world > 1 and COLL_DEVICE() == "cuda" else None
+    if state is None:
+        ctx.arena_free(aid)
+    log("OR-reduce: %d filters x %.0f KB in %.1f us = %.0f GB/s (%.0f%% of peak); setup %.1fs"
+        % (B, nw * 8 / 1e3, local_ms * 1e3, res["achieved"], 100 * res["frac"], t_setup))
+    return res, state
+
+
+def or_exchange_leg(ctx, res, state, world, log):
+    """The exchange half of C5, inside the library (bsg_or_allreduce: ncclAllGather over xGMI + k_or_words); the unique id
+    travels over the harness' own channel.  Runs LAST and under a watchdog (main): a collective that never returns must not
+    take the probe measurement down with it."""
+    import torch
+    aid, out, got, nw = state["aid"], state["out"], state["got"], state["nw"]
+    try:
+        import torch.distributed as dist
+        from bloomsearch_amd.gpu import Context
+        box = [Context.comm_unique_id() if dist.get_rank() == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        ctx.comm_init(box[0], dist.get_rank(), world)
+        ts = []
+        for _ in range(6):
+            part = out.clone()
+            dist.barrier()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            ctx.or_allreduce_dev([part.data_ptr()], nw)
+            ts.append(time.perf_counter() - t1)
+        full = ctx.or_allreduce(aid, 1, nw)            # the whole operation: local OR + exchange + copy out
+        if not np.array_equal(full, part.cpu().numpy().view(np.uint64)):
+            sys.exit("bsg_or_allreduce and bsg_or_allreduce_dev disagree")
+        # every rank must hold every rank's bits: the local partial is a subset of the result
+        if np.any(got & ~full):
+            sys.exit("OR all-reduce lost bits of this rank's partial")
+        ctx.comm_destroy()
+        res["allreduce_ms"] = float(np.median(ts[1:])) * 1e3
+        res["allreduce_wire_bytes_in_per_gpu"] = (world - 1) * nw * 8
+        res["allreduce_gbps_in_per_gpu"] = (world - 1) * nw * 8 / max(res["allreduce_ms"], 1e-9) / 1e6
+        res["allreduce"] = "bsg_or_allreduce_dev: ncclAllGather (RCCL over xGMI) of %d partials + k_or_words, inside libbloomgpu" % world
+        log("OR all-reduce over %d ranks: %.2f ms" % (world, res["allreduce_ms"]))
+    except Exception as exc:  # noqa: BLE001 - reported, not swallowed
+        res["allreduce_error"] = repr(exc)
+        log("OR all-reduce failed: %r" % (exc,))
     ctx.arena_free(aid)
-    log("OR-reduce: %d filters x %.0f KB in %.1f us = %.0f GB/s (%.0f%% of peak)%s; setup %.1fs"
-        % (B, nw * 8 / 1e3, local_ms * 1e3, res["achieved"], 100 * res["frac"],
-           ("; all-reduce over %d ranks %.2f ms" % (world, res["allreduce_ms"])) if "allreduce_ms" in res else "", t_setup))
-    return res
 
 
 def go_reference_baseline(rows, n_blocks_sample, log):
@@ -782,9 +790,9 @@ def main():
         log("device section codec: %.1f MB of sections encoded in %.1f us (%.0f GB/s), decoded in %.1f us kernel (%.0f GB/s), "
             "%.3fs incl. H2D" % (sec_bytes / 1e6, enc_ms * 1e3, decode["encode"]["achieved"], dec_ms * 1e3, decode["achieved"], t2 - t1))
 
-    or_reduce = None
+    or_reduce, or_state = None, None
     if args.or_union > 0:
-        or_reduce = or_reduce_leg(ctx, plan, B, args.fpr, args.or_union, world, log)
+        or_reduce, or_state = or_reduce_leg(ctx, plan, B, args.fpr, args.or_union, world, log)
 
     ingest = None
     if rank == 0 and world == 1 and args.ingest_blocks > 0:
@@ -988,7 +996,30 @@ def main():
             out["cpu_baseline"] = go_reference_baseline(rows, min(B, 100), log) or base
             if out["cpu_baseline"] is not base:
                 out["cpu_baseline_port"] = base
-        print(json.dumps(out), file=json_out, flush=True)
+    else:
+        out = None
+    import threading
+    emitted = threading.Lock()
+
+    def emit():
+        if rank == 0 and emitted.acquire(blocking=False):
+            print(json.dumps(out), file=json_out, flush=True)
+
+    if or_state is not None:
+        # the RCCL leg last, under a watchdog: if a collective never returns, rank 0 still prints the line (with the error
+        # noted) and every rank leaves — a hung collective cannot be cancelled from Python
+        done = threading.Event()
+
+        def watchdog():
+            if not done.wait(float(os.environ.get("BSG_BENCH_RCCL_TIMEOUT", "120"))):
+                if rank == 0:
+                    out["or_reduce"]["allreduce_error"] = "no answer within the watchdog's time; the leg was abandoned"
+                    emit()
+                os._exit(0)
+        threading.Thread(target=watchdog, daemon=True).start()
+        or_exchange_leg(ctx, or_reduce, or_state, world, log)
+        done.set()
+    emit()
     ctx.batch_free(bid)
     ctx.close()
     if world > 1:
