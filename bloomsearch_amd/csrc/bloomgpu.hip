@@ -1274,8 +1274,11 @@ int32_t enqueue_fused(bsg_ctx *ctx, Device &d, const Group &g, uint32_t slot, co
     return BSG_OK;
 }
 
-// survivors of device di's shard (local block lb == global block lb * nd + di) -> the caller's global bitset
-void interleave_shard(const uint64_t *part, uint32_t Q, uint32_t n_local, uint32_t di, uint32_t nd, uint64_t *dst, uint64_t Gglobal)
+// survivors of device di's shard (local block lb == global block lb * nd + di) -> the caller's global bitset.
+// An output word holds, from device di, the local bits lo..hi at the positions p0, p0 + nd, ...: one bit-field extract and
+// one parallel deposit (BMI2 pdep) per (word, device) instead of a loop over the set bits — a 10 000-block, 4 096-query
+// result has 17 M of them.  Hosts without BMI2 take the loop.
+static void interleave_shard_loop(const uint64_t *part, uint32_t Q, uint32_t n_local, uint32_t di, uint32_t nd, uint64_t *dst, uint64_t Gglobal)
 {
     const uint32_t G = (n_local + 63) / 64;
     for (uint32_t q = 0; q < Q; ++q) {
@@ -1291,6 +1294,46 @@ void interleave_shard(const uint64_t *part, uint32_t Q, uint32_t n_local, uint32
             }
         }
     }
+}
+
+__attribute__((target("bmi2"))) static void interleave_shard_pdep(const uint64_t *part, uint32_t Q, uint32_t n_local, uint32_t di, uint32_t nd,
+                                                                   uint64_t *dst, uint64_t Gglobal)
+{
+    const uint32_t G = (n_local + 63) / 64;
+    // deposit masks by first position p0 < nd: bits p0, p0 + nd, ... below 64
+    std::vector<uint64_t> masks(nd, 0);
+    for (uint32_t p0 = 0; p0 < nd; ++p0)
+        for (uint32_t p = p0; p < 64; p += nd) masks[p0] |= 1ULL << p;
+    const uint64_t n_global = (uint64_t)(n_local - 1) * nd + di + 1;      // one past this shard's last global block
+    const uint64_t n_words = (n_global + 63) / 64;
+    // per output word: first local bit and first position (the same for every query)
+    std::vector<uint32_t> lo_of(n_words), p0_of(n_words);
+    for (uint64_t ow = 0; ow < n_words; ++ow) {
+        const uint64_t first = ow * 64;                                   // lo = ceil((first - di) / nd), clamped at 0
+        const uint64_t lo = first > di ? (first - di + nd - 1) / nd : 0;
+        lo_of[ow] = (uint32_t)lo;
+        p0_of[ow] = (uint32_t)(lo * nd + di - first);
+    }
+    for (uint32_t q = 0; q < Q; ++q) {
+        const uint64_t *row = part + (size_t)q * G;
+        uint64_t *o = dst + (size_t)q * Gglobal;
+        for (uint64_t ow = 0; ow < n_words; ++ow) {
+            const uint32_t lo = lo_of[ow], p0 = p0_of[ow];
+            if (lo >= n_local || p0 >= 64) continue;
+            const uint32_t wi = lo >> 6, sh = lo & 63u;
+            uint64_t src = row[wi] >> sh;
+            if (sh && wi + 1 < G) src |= row[wi + 1] << (64 - sh);       // (bits past n_local are zero in the survivors)
+            o[ow] |= __builtin_ia32_pdep_di(src, masks[p0]);
+        }
+    }
+}
+
+void interleave_shard(const uint64_t *part, uint32_t Q, uint32_t n_local, uint32_t di, uint32_t nd, uint64_t *dst, uint64_t Gglobal)
+{
+    if (n_local == 0) return;
+    static const bool has_bmi2 = __builtin_cpu_supports("bmi2");
+    if (has_bmi2 && nd <= 64) interleave_shard_pdep(part, Q, n_local, di, nd, dst, Gglobal);
+    else interleave_shard_loop(part, Q, n_local, di, nd, dst, Gglobal);
 }
 
 // Probes batch B against every arena of the list.  Per device the launches are software-pipelined on one in-order stream

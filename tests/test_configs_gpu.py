@@ -103,6 +103,25 @@ def test_c4_10000_blocks_on_an_8_entry_multi_device_context():
         assert np.array_equal(mctx.probe_batch(m_ids[3], mb, nq, per_file), wants[3])
 
 
+@pytest.mark.parametrize("n_entries", [2, 5, 7])
+def test_sharded_context_interleaves_any_block_count(n_entries):
+    """One context over n entries (block b on entry b % n): the host interleave of the shards' survivor bitsets (bit-field
+    extract + parallel deposit per output word) for block counts around the word and shard boundaries, dense and sparse
+    survivors, against the oracle."""
+    rng = np.random.default_rng(1000 + n_entries)
+    with Context((0,) * n_entries) as mctx:
+        for n_blocks in (1, n_entries - 1, n_entries, n_entries + 1, 63, 64, 65, 64 * n_entries - 1, 64 * n_entries + 1, 321):
+            plan, _, vocab = H.make_random_arena(rng, n_blocks, absent_frac=0.05, max_tokens=200, vocab_size=30)
+            words = mctx.build(plan.blob, plan.off, plan.fstart, plan.desc, plan.n_words)
+            cb = Q.compile_queries([None, Q.Token("absent")] + [H.random_expression(rng, vocab, None) for _ in range(70)])
+            ops, poff, _ = cb.arrays()
+            terms = H.gpu_terms(mctx, cb)
+            aid = mctx.arena_load(words, plan.desc)
+            want = O.probe_batch(words, plan.desc.view(O.DESC_DTYPE), terms.view(O.TERM_DTYPE), ops, poff)
+            assert np.array_equal(mctx.probe(aid, n_blocks, terms, ops, poff), want), n_blocks
+            mctx.arena_free(aid)
+
+
 def test_c5_or_reduce_of_1250_fixed_geometry_blocks_equals_oracle_build_of_the_union(ctx):
     """configs[4] as one rank sees it: 1 250 token filters built at the FILE-level geometry (m, k) =
     EstimateParameters(n_union, p); their OR must equal the oracle's build of the union's entries at that geometry
