@@ -1421,7 +1421,7 @@ int32_t probe_arenas(bsg_ctx *ctx, const std::vector<std::shared_ptr<Arena>> &ar
         // survivors are written straight into page-locked host memory — one launch and one wait instead of three enqueues
         uint32_t real_terms = 0;
         for (uint32_t y = 0; y < B.n_kinds; ++y) real_terms += B.term_count[y];
-        const bool direct = inline_copy && nd == 1 && !(flags & BSG_PROBE_NOFUSE) && B.n_chunks == 1 && B.identity_cw && !B.many_terms &&
+        const bool direct = inline_copy && !(flags & BSG_PROBE_NOFUSE) && B.n_chunks == 1 && B.identity_cw && !B.many_terms &&
                             real_terms <= ctx->direct_max_terms && bsg::direct_lds_bytes(std::max(B.Wt, 1u), B.max_depth) <= 64 * 1024;
         if (direct) {
             EventTriple ev0;

@@ -119,6 +119,12 @@ def test_sharded_context_interleaves_any_block_count(n_entries):
             aid = mctx.arena_load(words, plan.desc)
             want = O.probe_batch(words, plan.desc.view(O.DESC_DTYPE), terms.view(O.TERM_DTYPE), ops, poff)
             assert np.array_equal(mctx.probe(aid, n_blocks, terms, ops, poff), want), n_blocks
+            # a single interactive query: every entry answers its shard in one dispatch (k_probe_direct), same interleave
+            c1 = Q.compile_queries([Q.And(Q.Token(vocab[0]), Q.Or(Q.Token(vocab[1]), Q.Field("f3")))])
+            o1, p1, _ = c1.arrays()
+            t1 = H.gpu_terms(mctx, c1)
+            w1 = O.probe_batch(words, plan.desc.view(O.DESC_DTYPE), t1.view(O.TERM_DTYPE), o1, p1)
+            assert np.array_equal(mctx.probe(aid, n_blocks, t1, o1, p1), w1), n_blocks
             mctx.arena_free(aid)
 
 
