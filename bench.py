@@ -752,11 +752,20 @@ def main():
                 fl.append((int(d["m"]), int(d["k"]), words[int(d["word_off"]): int(d["word_off"]) + nw]))
             if Hst.section_encode(fl) != secs[b]:
                 sys.exit("device-encoded section %d differs from the host codec" % b)
+        sec_bytes = sum(len(x) for x in secs)
+        # the kernel by itself: one launch over all sections, after the whole copy (lab key 4 = 1) ...
+        ctx.set_lab(4, 1)
+        sid, st = ctx.arena_load_sections(secs)
+        dec_one_ms = ctx.last_kernel_ms()[2]
+        if st.any():
+            sys.exit("device section decode reported failures on clean sections")
+        ctx.arena_free(sid)
+        # ... and as the call runs by default: four launches, each behind its quarter of the copy
+        ctx.set_lab(4, 4)
         t1 = time.time()
         sid, st = ctx.arena_load_sections(secs)
         t2 = time.time()
         dec_ms = ctx.last_kernel_ms()[2]
-        sec_bytes = sum(len(x) for x in secs)
         if st.any():
             sys.exit("device section decode reported failures on clean sections")
         ctx.arena_free(sid)
@@ -775,9 +784,12 @@ def main():
         if st2.any():
             sys.exit("streamed section decode reported failures on clean sections")
         ctx.arena_free(sid2)
-        decode = {"kernel": "k_decode_sections", "kernel_ms": dec_ms, "section_bytes": sec_bytes,
-                  "algorithmic_bytes": 2 * sec_bytes, "achieved": 2 * sec_bytes / max(dec_ms, 1e-6) / 1e6, "unit": "GB/s",
-                  "note": "CRC32C + BE->LE decode of %d filter sections on the device; bytes = sections read + words written" % B,
+        decode = {"kernel": "k_decode_sections", "kernel_ms": dec_one_ms, "section_bytes": sec_bytes,
+                  "algorithmic_bytes": 2 * sec_bytes, "achieved": 2 * sec_bytes / max(dec_one_ms, 1e-6) / 1e6, "unit": "GB/s",
+                  "note": "CRC32C + BE->LE decode of %d filter sections on the device in one launch; bytes = sections read + words written" % B,
+                  "pieces": {"launches": 4, "kernel_ms_sum": dec_ms, "end_to_end_s_incl_h2d": t2 - t1,
+                             "note": "bsg_arena_load_sections as it runs by default: the decode of each quarter starts behind its part of the copy "
+                                     "(a launch of ~250 one-workgroup sections does not fill 256 CUs, hence the larger sum)"},
                   "end_to_end_s_incl_h2d": t2 - t1,
                   "stream": {"api": "bsg_arena_stream_begin / append (4 MiB chunks) / finish", "chunks": (len(blob_secs) + (4 << 20) - 1) // (4 << 20),
                              "end_to_end_s_incl_h2d": t4 - t3, "decode_kernels_ms_sum": stream_dec_ms,
@@ -787,8 +799,9 @@ def main():
                              "note": "LE->BE + framing + CRC32C of the same sections on the device (bsg_build_sections); bytes = "
                                      "words read + sections written + sections re-read by the checksum pass",
                              "build_and_encode_end_to_end_s_incl_copies": t_enc}}
-        log("device section codec: %.1f MB of sections encoded in %.1f us (%.0f GB/s), decoded in %.1f us kernel (%.0f GB/s), "
-            "%.3fs incl. H2D" % (sec_bytes / 1e6, enc_ms * 1e3, decode["encode"]["achieved"], dec_ms * 1e3, decode["achieved"], t2 - t1))
+        log("device section codec: %.1f MB of sections encoded in %.1f us (%.0f GB/s), decoded in %.1f us by one launch (%.0f GB/s; "
+            "%.1f us as four launches behind the copy), %.3fs incl. H2D"
+            % (sec_bytes / 1e6, enc_ms * 1e3, decode["encode"]["achieved"], dec_one_ms * 1e3, decode["achieved"], dec_ms * 1e3, t2 - t1))
 
     or_reduce, or_state = None, None
     if args.or_union > 0:

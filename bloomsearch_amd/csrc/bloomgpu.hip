@@ -267,6 +267,7 @@ struct bsg_ctx {
     uint64_t ingest_chunk_bytes = 64ull << 20;   // rows per upload chunk of bsg_ingest_rows (bsg_set_ingest_chunk)
     uint32_t spin_wait_us = 0;   // synchronous probes poll the stream this long before blocking (bsg_set_spin_wait)
     uint32_t compact_rounds = BSG_COMPACT_ROUNDS;   // many-term probe mode (bsg_set_lab)
+    uint32_t load_pieces = 4;        // launches bsg_arena_load_sections splits a region's decode into, each behind its part of the copy (bsg_set_lab key 4)
     uint32_t direct_max_terms = 16;  // batches of <= 256 queries with at most this many distinct terms take k_probe_direct (bsg_set_lab key 3; 0: never)
     uint64_t bin_scratch_bytes = kBinScratchBytes;  // 0: bitsets beyond LDS are built with global atomics (bsg_set_lab key 2)
     uint32_t fuse_max_arenas = 4; // groups up to this many arenas ride fused (probe of group i + eval of group i-1)
@@ -1566,13 +1567,15 @@ extern "C" int32_t bsg_set_probe_group(bsg_ctx *ctx, uint32_t max_arenas_per_lau
 
 // lab knobs (tools/, bench sweeps, tests of the paths the defaults no longer take): key 1 = compaction rounds of the
 // many-term probe mode; key 2 = bytes of HBM a binned build of a large bitset may use for its locations (0: global atomics);
-// key 3 = most distinct terms of a small batch that takes the one-dispatch path k_probe_direct (0: never)
+// key 3 = most distinct terms of a small batch that takes the one-dispatch path k_probe_direct (0: never);
+// key 4 = pieces bsg_arena_load_sections decodes a region in (1: one launch after the whole copy)
 extern "C" int32_t bsg_set_lab(bsg_ctx *ctx, uint32_t key, uint64_t value)
 {
     BSG_ENTER(ctx);
     if (key == 1) { ctx->compact_rounds = (uint32_t)std::min<uint64_t>(value, 16); return BSG_OK; }
     if (key == 2) { ctx->bin_scratch_bytes = value; return BSG_OK; }
     if (key == 3) { ctx->direct_max_terms = (uint32_t)std::min<uint64_t>(value, 192); return BSG_OK; }
+    if (key == 4) { ctx->load_pieces = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(value, 1), 64); return BSG_OK; }
     return fail(BSG_E_INVALID, "unknown lab key %u", key);
 }
 

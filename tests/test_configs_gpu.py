@@ -369,6 +369,14 @@ def test_one_dispatch_path_for_small_batches(ctx):
             ctx.set_lab(3, 16)
     t = ctx.timing_read()
     assert t.n_fused >= 9 and t.n_probes == 0        # every timed call above was ONE dispatch
+    # a batch without a single term (nil and unknown expressions only)
+    cb = Q.compile_queries([None, {"ExpressionType": "XOR", "Children": []}, Q.And(), Q.Or()])
+    ops, poff, _ = cb.arrays()
+    terms = H.gpu_terms(ctx, cb)
+    assert len(terms) == 0
+    pl, wd, aid0 = plans[3]
+    want = O.probe_batch(wd, pl.desc.view(O.DESC_DTYPE), terms.view(O.TERM_DTYPE), ops, poff)
+    assert np.array_equal(ctx.probe(aid0, pl.n_blocks, terms, ops, poff), want)
     # k = 17 (fpr 1e-5): more locations than one trip of word reads holds; k = 1 (fpr 0.6)
     for fpr in (1e-5, 0.6):
         plan, _, vocab = H.make_random_arena(rng, 90, fpr=fpr, absent_frac=0.05, max_tokens=300, vocab_size=40)
