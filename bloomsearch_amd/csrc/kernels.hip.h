@@ -714,6 +714,14 @@ __device__ __forceinline__ void eval_role(const EvalArgs &a, const ArenaRef &ar,
     }
     const uint32_t q = c * kEvalThreads + htid;
     uint64_t res[kEvalGroupTile];
+    // this wave's first verdict word of a group (s = wave) is requested one group ahead: the words of group t + 1 are in
+    // flight while the programs of group t run, instead of one dependent round trip per group
+    auto first_word = [&](uint32_t g) -> uint64_t {
+        if (!active || wave >= ncw || (g * 64 + (uint32_t)lane) >= ar.n_blocks) return 0ULL;
+        const uint32_t w = a.identity_cw ? wave : a.cw[cw0 + wave];
+        return V[((uint64_t)g * a.Wt + w) * 64 + lane];
+    };
+    uint64_t xpre = first_word(g0);
 #pragma unroll
     for (uint32_t t = 0; t < kEvalGroupTile; ++t) {
         if (t < gt) {   // workgroup-uniform
@@ -721,12 +729,14 @@ __device__ __forceinline__ void eval_role(const EvalArgs &a, const ArenaRef &ar,
             if (t > 0) __syncthreads();   // everyone is done reading VT of the previous group
             if (active) {
                 const bool row_valid = (g * 64 + (uint32_t)lane) < ar.n_blocks;
-                for (uint32_t s = wave; s < ncw; s += n_waves) {
+                if (wave < ncw) VT[wave * 64 + lane] = wave_transpose64(xpre, lane);
+                for (uint32_t s = wave + n_waves; s < ncw; s += n_waves) {
                     const uint32_t w = a.identity_cw ? s : a.cw[cw0 + s];
                     uint64_t x = row_valid ? V[((uint64_t)g * a.Wt + w) * 64 + lane] : 0ULL;
                     VT[s * 64 + lane] = wave_transpose64(x, lane);
                 }
             }
+            if (t + 1 < gt) xpre = first_word(g + 1);
             __syncthreads();
             uint64_t top = ~0ULL;  // empty program == nil query == true
             if (active) {
