@@ -1,0 +1,76 @@
+"""Seed sweep of build + probe against the oracle (GPU box):  python tools/fuzz_probe.py [first_seed] [n_seeds]
+Per seed: a few random arenas (block counts around the 64-block groups, false-positive rates from 1e-5 to 0.5, nil
+filters, blocks without tokens), the device build compared with the oracle's bitsets, then random query batches — one
+query, a handful, hundreds; few distinct terms (one-dispatch and few-term kernels) or thousands (many-term kernel) —
+probed through every launch shape (group limit 1 / 3 / 32, fused or not, timed or not, sharded contexts) and compared
+with the oracle's surviving-block sets bit for bit.  Exits non-zero on the first difference."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np
+
+import helpers as H
+from bloomsearch_amd import _lib, query as Q
+from bloomsearch_amd._lib import DESC_DTYPE
+from bloomsearch_amd.gpu import Context
+from oracle import oracle as O
+
+
+def main():
+    first = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+    ctxs = {1: Context((0,)), 3: Context((0,) * 3)}
+    n_cases = n_bits = 0
+    for seed in range(first, first + n):
+        rng = np.random.default_rng(seed)
+        fpr = float(10 ** rng.uniform(-5, -0.3))
+        vocab_size = int(rng.choice([8, 40, 400, 5000]))
+        plans = []
+        for _ in range(int(rng.integers(1, 5))):
+            nb = int(rng.choice([1, 2, 63, 64, 65, 127, 128, 129, int(rng.integers(1, 400))]))
+            plan, _, vocab = H.make_random_arena(rng, nb, fpr=fpr, absent_frac=float(rng.choice([0.0, 0.05, 0.5])),
+                                                 max_tokens=int(rng.choice([5, 300, 3000])), vocab_size=vocab_size)
+            plans.append(plan)
+        nd = int(rng.choice([1, 1, 3]))
+        ctx = ctxs[nd]
+        arenas, all_words = [], []
+        for plan in plans:
+            words = ctx.build(plan.blob, plan.off, plan.fstart, plan.desc, plan.n_words)
+            if not np.array_equal(words, H.oracle_words(plan)):
+                sys.exit("seed %d: device build differs from the oracle's bitsets" % seed)
+            all_words.append(words)
+            arenas.append(ctx.arena_load(words, plan.desc))
+        for _ in range(3):
+            nq = int(rng.choice([1, 2, 7, 64, 256, 257, 600]))
+            words_pool = vocab[: int(rng.choice([2, 6, len(vocab)]))]
+            cb = Q.compile_queries([H.random_expression(rng, words_pool, None) if rng.random() > 0.03 else None for _ in range(nq)])
+            ops, poff, _ = cb.arrays()
+            terms = H.gpu_terms(ctx, cb)
+            bid = ctx.batch_create(terms, ops, poff)
+            wants = [O.probe_batch(w, p.desc.view(O.DESC_DTYPE), terms.view(O.TERM_DTYPE), ops, poff) for w, p in zip(all_words, plans)]
+            order = [int(i) for i in rng.integers(0, len(arenas), size=int(rng.integers(1, 40)))]
+            ctx.set_probe_group(int(rng.choice([1, 3, 32])))
+            flags = int(rng.choice([0, _lib.PROBE_NOFUSE, _lib.PROBE_TIMED]))
+            got = ctx.probe_many([arenas[i] for i in order], bid, flags, cb.n_queries, [plans[i].n_blocks for i in order])
+            for g, i in zip(got, order):
+                if not np.array_equal(g, wants[i]):
+                    sys.exit("seed %d: survivors differ (nq %d, %d terms, group order %s, flags %d, %d-entry context, arena %d)"
+                             % (seed, nq, len(terms), order[:8], flags, nd, i))
+                n_bits += g.size * 64
+            n_cases += 1
+            ctx.batch_free(bid)
+        ctx.set_probe_group(0)
+        ctx.timing_read(reset=True)
+        for a in arenas:
+            ctx.arena_free(a)
+        if (seed - first) % 10 == 9:
+            print("seed %d ok (%d batches, %.1f M (query, block) verdicts so far)" % (seed, n_cases, n_bits / 1e6), flush=True)
+    for c in ctxs.values():
+        c.close()
+    print("done: %d batches, %.1f M verdicts, no difference" % (n_cases, n_bits / 1e6))
+
+
+if __name__ == "__main__":
+    main()
