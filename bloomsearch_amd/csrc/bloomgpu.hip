@@ -269,6 +269,7 @@ struct bsg_ctx {
     uint32_t compact_rounds = BSG_COMPACT_ROUNDS;   // many-term probe mode (bsg_set_lab)
     uint32_t load_pieces = 4;        // launches bsg_arena_load_sections splits a region's decode into, each behind its part of the copy (bsg_set_lab key 4)
     uint32_t direct_max_terms = 16;  // batches of <= 256 queries with at most this many distinct terms take k_probe_direct (bsg_set_lab key 3; 0: never)
+    uint64_t bin_min_locs = 4ull << 20;             // fewer locations than this: global atomics (bsg_set_lab key 6)
     uint64_t bin_scratch_bytes = kBinScratchBytes;  // 0: bitsets beyond LDS are built with global atomics (bsg_set_lab key 2)
     uint32_t fuse_max_arenas = 4; // groups up to this many arenas ride fused (probe of group i + eval of group i-1)
 };
@@ -674,10 +675,14 @@ static int32_t enqueue_binned_build(Device &d, bsg::BinArgs a, bool dense, std::
     if (e != hipSuccess) return fail(BSG_E_HIP, "binned build: %s", hipGetErrorString(e));
     return BSG_OK;
 }
+// Binning pays from a few million locations on (three more launches, scratch from the pool); a bitset just beyond LDS with
+// a few ten thousand entries stays L2-resident under its atomics (1 000 such filters in one call: one k_build launch
+// instead of 5 000 small ones).
 static bool binned_build_fits(const bsg_ctx *root, uint64_t m, uint64_t n_entries, uint64_t k)
 {
     const uint64_t n_locs = n_entries * k;
-    return m < (1ull << 31) && n_locs > 0 && n_locs < (1ull << 32) - 4096 && n_locs * 4 <= root->bin_scratch_bytes;
+    return m < (1ull << 31) && n_locs >= std::max<uint64_t>(root->bin_min_locs, 1) && n_locs < (1ull << 32) - 4096 &&
+           n_locs * 4 <= root->bin_scratch_bytes;
 }
 
 static int32_t build_common(bsg_ctx *ctx, const uint8_t *bytes, const uint32_t *offsets, const uint64_t *h,
@@ -1571,12 +1576,14 @@ extern "C" int32_t bsg_set_probe_group(bsg_ctx *ctx, uint32_t max_arenas_per_lau
 // lab knobs (tools/, bench sweeps, tests of the paths the defaults no longer take): key 1 = compaction rounds of the
 // many-term probe mode; key 2 = bytes of HBM a binned build of a large bitset may use for its locations (0: global atomics);
 // key 3 = most distinct terms of a small batch that takes the one-dispatch path k_probe_direct (0: never);
-// key 4 = pieces bsg_arena_load_sections decodes a region in (1: one launch after the whole copy)
+// key 4 = pieces bsg_arena_load_sections decodes a region in (1: one launch after the whole copy);
+// key 6 = fewest locations (entries x k) for which a bitset beyond LDS is built from binned locations (default 4 M)
 extern "C" int32_t bsg_set_lab(bsg_ctx *ctx, uint32_t key, uint64_t value)
 {
     BSG_ENTER(ctx);
     if (key == 1) { ctx->compact_rounds = (uint32_t)std::min<uint64_t>(value, 16); return BSG_OK; }
     if (key == 2) { ctx->bin_scratch_bytes = value; return BSG_OK; }
+    if (key == 6) { ctx->bin_min_locs = value; return BSG_OK; }
     if (key == 3) { ctx->direct_max_terms = (uint32_t)std::min<uint64_t>(value, 192); return BSG_OK; }
     if (key == 4) { ctx->load_pieces = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(value, 1), 64); return BSG_OK; }
     return fail(BSG_E_INVALID, "unknown lab key %u", key);

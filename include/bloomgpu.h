@@ -220,7 +220,8 @@ BSG_API int32_t bsg_set_probe_group(bsg_ctx *ctx, uint32_t max_arenas_per_launch
 /* Lab knobs for tools/, bench sweeps and tests (key 1: compaction rounds of the many-term probe mode; key 2: HBM bytes a
  * binned build of a bitset beyond LDS may park its locations in, 0 = build it with global atomics; key 3: most distinct terms
  * of a synchronous batch of <= 256 queries that is answered by one dispatch, 0 = never; key 4: launches the decode of
- * bsg_arena_load_sections is split into, 1 = one launch after the whole copy); not part of the seam. */
+ * bsg_arena_load_sections is split into, 1 = one launch after the whole copy; key 6: fewest locations (entries x k) from
+ * which a bitset beyond LDS is built from binned locations instead of global atomics); not part of the seam. */
 BSG_API int32_t bsg_set_lab(bsg_ctx *ctx, uint32_t key, uint64_t value);
 /* Synchronous probes poll their stream for up to this long before they block (default 0: block at once).  A single
  * query's kernels finish in ~10 us; being woken from a blocking wait costs more than that. */

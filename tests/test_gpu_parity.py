@@ -55,16 +55,17 @@ def test_build_bit_exact_small_medium_large_empty_absent(ctx):
         want = H.oracle_words(plan)
         # the bitset beyond LDS: binned locations assembled window by window (k_bin_*), then — lab knob 2 = 0 — the
         # global-atomic path filters of 2^31 bits and more still take; also from precomputed hashes
-        got = ctx.build(plan.blob, plan.off, plan.fstart, plan.desc, plan.n_words)
-        assert np.array_equal(got, want)
-        hashed = ctx.build_hashed(ctx.hash_entries(plan.blob, plan.off), plan.fstart, plan.desc, plan.n_words)
-        assert np.array_equal(hashed, want)
-        ctx.set_lab(2, 0)
         try:
+            ctx.set_lab(6, 0)                                  # (by default only bitsets with millions of locations are binned)
             got = ctx.build(plan.blob, plan.off, plan.fstart, plan.desc, plan.n_words)
+            hashed = ctx.build_hashed(ctx.hash_entries(plan.blob, plan.off), plan.fstart, plan.desc, plan.n_words)
+            ctx.set_lab(2, 0)
+            atomics = ctx.build(plan.blob, plan.off, plan.fstart, plan.desc, plan.n_words)
         finally:
             ctx.set_lab(2, 16 << 30)
-        assert np.array_equal(got, want)
+            ctx.set_lab(6, 4 << 20)
+        assert np.array_equal(got, want) and np.array_equal(hashed, want) and np.array_equal(atomics, want)
+        assert np.array_equal(ctx.build(plan.blob, plan.off, plan.fstart, plan.desc, plan.n_words), want)     # the defaults
         # sizing rule: exact distinct counts (TestMeasuredFilterSizing, file_format_test.go:28-94)
         assert plan.desc["m"][1 * 3 + 1] == O.estimate_parameters(20000, fpr)[0]
         assert plan.desc["m"][0 * 3 + 2] == O.estimate_parameters(1, fpr)[0]

@@ -287,10 +287,12 @@ def test_large_sets_lds_staged_above_64k_and_beyond_lds(ctx, binned):
     # atomicOr, sliced over several workgroups; the parent holds their union
     sets = [[b'{"id":"u%d"}' % i for i in range(60000)], [b'{"id":"v%d","n":%d}' % (i, i % 7) for i in range(130000)]]
     ctx.set_lab(2, (16 << 30) if binned else 0)
+    ctx.set_lab(6, 0)                                          # (by default only bitsets with millions of locations are binned)
     try:
         res = I.device_ingest(ctx, sets, FPR, parent_of_set=[0, 0], n_parents=1, flags=TRUSTED)
     finally:
         ctx.set_lab(2, 16 << 30)
+        ctx.set_lab(6, 4 << 20)
     assert len(res.fallback_rows) == 0
     want = [({"id"}, {"u%d" % i for i in range(60000)}, {"id::u%d" % i for i in range(60000)}),
             ({"id", "n"}, {"v%d" % i for i in range(130000)} | {str(i) for i in range(7)},

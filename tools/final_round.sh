@@ -9,6 +9,8 @@ bash tools/profile.sh ${R}_c2 > /dev/null
 NO_PMC=1 bash tools/profile.sh ${R}_c4 --workload c4 > /dev/null
 NO_PMC=1 bash tools/profile.sh ${R}_needle --workload needle > /dev/null
 bash tools/profile_pmc.sh ${R}_needle --workload needle > /dev/null
+# the driver's own command under the kernel trace: the 20-arena launch shape of its timed region next to roofline.kernel_ms
+EXACT_ARGS="--steps 20 --warmup 5 --cpu-budget 0" NO_PMC=1 bash tools/profile.sh ${R}_driver > /dev/null
 python bench.py --steps 20 --warmup 5 > gpurun_out/${R}_bench_driver_shape.json 2> gpurun_out/${R}_bench_driver_shape.err
 python bench.py > gpurun_out/${R}_bench_default.json 2> gpurun_out/${R}_bench_default.err
 python bench.py --workload needle --cpu-budget 0 --c4-files 0 --ingest-blocks 0 --no-decode --or-union 0 > gpurun_out/${R}_bench_needle.json 2>/dev/null
@@ -19,6 +21,7 @@ mkdir -p gpurun_out/keep
 cp gpurun_out/prof_${R}_c2/summary.txt gpurun_out/keep/${R}_probe_c2_rocprofv3.txt
 cp gpurun_out/prof_${R}_c4/summary.txt gpurun_out/keep/${R}_probe_c4_rocprofv3.txt
 cp gpurun_out/prof_${R}_needle/summary.txt gpurun_out/keep/${R}_probe_needle_rocprofv3.txt
+cp gpurun_out/prof_${R}_driver/summary.txt gpurun_out/keep/${R}_bench_driver_shape_rocprofv3.txt
 cp gpurun_out/prof_${R}_c2/traffic.json gpurun_out/keep/${R}_traffic.json
 cp gpurun_out/pmc_${R}_needle/summary.txt gpurun_out/keep/${R}_needle_pmc.txt
 cp gpurun_out/${R}_ingest_rocprofv3.txt gpurun_out/${R}_bench_*.json gpurun_out/keep/

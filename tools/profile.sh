@@ -11,7 +11,9 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
 ARGS="--steps 32 --warmup 32 --group 32 --samples 16 --cpu-budget 0 --no-check --no-decode --ingest-blocks 0 --or-union 0 --scaled 0 --no-q1 --no-single --c4-files 0 $*"
-timeout 500 rocprofv3 --kernel-trace --stats -d $OUT/stats -o bench -- python $REPO/bench.py $ARGS > $OUT/stats.log 2>&1
+# EXACT_ARGS="--steps 20 --warmup 5": profile exactly that bench command instead (the driver's), every leg included
+if [ -n "${EXACT_ARGS:-}" ]; then ARGS="$EXACT_ARGS"; fi
+timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/stats -o bench -- python $REPO/bench.py $ARGS > $OUT/stats.log 2>&1
 if [ -z "${NO_PMC:-}" ]; then
 timeout 500 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o bench -- python $REPO/bench.py $ARGS > $OUT/fetch.log 2>&1
 timeout 500 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o bench -- python $REPO/bench.py $ARGS > $OUT/write.log 2>&1

@@ -28,7 +28,8 @@ if d:
         for n, gx, gy, gz, cnt, mean, mn, mx in d.execute(
                 "select name, grid_x, grid_y, grid_z, count(*), avg(duration), min(duration), max(duration) from kernels "
                 "where name like 'bsg::k_probe%' or name like 'bsg::k_eval%' group by name, grid_x, grid_y, grid_z order by name, count(*) desc"):
-            print("  %-20s grid (%8d,%4d,%3d)  n %4d  mean %10.1f ns  min %9d  max %9d" % (short(n), gx, gy, gz, cnt, mean, mn, mx))
+            v = sorted(r[0] for r in d.execute("select duration from kernels where name = ? and grid_x = ? and grid_y = ? and grid_z = ?", (n, gx, gy, gz)))
+            print("  %-20s grid (%8d,%4d,%3d)  n %4d  mean %10.1f ns  median %9d  min %9d  max %9d" % (short(n), gx, gy, gz, cnt, mean, v[len(v) // 2], mn, mx))
     print("== kernel trace durations (end - start, ns), last 200 dispatches of each bsg kernel")
     names = [r[0] for r in d.execute("select distinct name from kernels where name like 'bsg::%'")]
     for n in names:
