@@ -315,9 +315,12 @@ class Context:
         self._check(self.L.bsg_ingest_finish(self.h, ingest_id, _lib._ptr(counts), _lib._ptr(status)))
         return counts, status
 
-    def ingest_build(self, ingest_id: int, desc, n_words: int) -> np.ndarray:
+    def ingest_build(self, ingest_id: int, desc, n_words: int, out: np.ndarray = None) -> np.ndarray:
+        """out: where the words go (u64, >= n_words; e.g. a view of pinned_array memory: the copy back is then plain DMA)."""
         desc = np.ascontiguousarray(desc, dtype=DESC_DTYPE)
-        out = np.zeros(n_words, dtype=np.uint64)
+        if out is None:
+            out = np.empty(n_words, dtype=np.uint64)
+        assert out.dtype == np.uint64 and len(out) >= n_words
         self._check(self.L.bsg_ingest_build(self.h, ingest_id, _lib._ptr(desc), _lib._ptr(out), n_words))
         return out
 
