@@ -785,8 +785,9 @@ __device__ __forceinline__ uint32_t walker_step(Walker &w, ChunkCursor &cc)
 #endif
 // 2-way sets of (h0 ^ table, h1, fingerprint): the first murmur3 hash of the entry and its keyed fingerprint — what the
 // table itself needs to tell two entries apart once their hashes agree.  Way 0 is the most recently confirmed entry of
-// the set; a new one pushes it to way 1 (two hot entries that share a set no longer evict each other every round:
-// with ~150 hot entries a direct-mapped cache of 512 sent 16 of 32 rounds to the table, see profiles/).
+// the set; a new one pushes it to way 1, so two hot entries that share a set do not evict each other every round.
+// (By itself that moved 15.7 -> 14.7 of a row's 32 rounds to the table: most of them came from COLD caches, which the
+// contiguous runs of rows per wave fix — see k_ingest_rows.)
 constexpr uint32_t kCacheSets = BSG_INGEST_CACHE_SETS;  // lab: -DBSG_INGEST_CACHE_SETS / -DBSG_INGEST_WPE (waves per SIMD the kernel is compiled for)
 constexpr uint32_t kCacheEntryWords = 3;
 constexpr uint32_t kCacheWords = kCacheSets * 2 * kCacheEntryWords;
