@@ -2,6 +2,7 @@
 MaxQueryConcurrency of them — while the flush worker builds): many host threads drive one bsg_ctx at once through
 every family of entry points, and every result must still equal the oracle's, bit for bit.  ctypes releases the GIL
 for the duration of each C call, so the calls really overlap."""
+import os
 import threading
 from concurrent.futures import ThreadPoolExecutor
 
@@ -15,8 +16,8 @@ from tests import helpers as H
 
 pytestmark = pytest.mark.gpu
 
-N_THREADS = 8
-ROUNDS = 6
+N_THREADS = 12
+ROUNDS = int(os.environ.get("BSG_TEST_ROUNDS", "6"))     # raise for a soak run
 
 
 def _probe_job(ctx, seed):
@@ -39,6 +40,27 @@ def _probe_job(ctx, seed):
         ctx.arena_free(aid)
         assert np.array_equal(got, want) and np.array_equal(one, want)
         assert all(np.array_equal(m, want) for m in many)
+    return True
+
+
+def _single_query_job(ctx, seed):
+    """interactive queries: one synchronous 1- or 2-query batch after the other (k_probe_direct: page-locked result
+    buffers from a per-device pool, a completion doorbell) while other threads do the same and more"""
+    rng = np.random.default_rng(seed)
+    plan, _, vocab = H.make_random_arena(rng, int(rng.integers(1, 300)), absent_frac=0.03, max_tokens=200, vocab_size=30)
+    words = ctx.build(plan.blob, plan.off, plan.fstart, plan.desc, plan.n_words)
+    aid = ctx.arena_load(words, plan.desc)
+    for _ in range(ROUNDS * 40):
+        exprs = [Q.And(Q.Token(vocab[int(rng.integers(0, 30))]), Q.Or(Q.FieldToken("f%d" % rng.integers(0, 9), vocab[int(rng.integers(0, 30))]),
+                                                                     Q.Field("f%d" % rng.integers(0, 45))))]
+        if rng.random() < 0.3:
+            exprs.append(Q.Token("absent"))
+        cb = Q.compile_queries(exprs)
+        ops, poff, _ = cb.arrays()
+        terms = H.oracle_terms(cb)
+        want = O.probe_batch(words, plan.desc.view(O.DESC_DTYPE), terms.view(O.TERM_DTYPE), ops, poff)
+        assert np.array_equal(ctx.probe(aid, plan.n_blocks, terms, ops, poff), want)
+    ctx.arena_free(aid)
     return True
 
 
@@ -80,7 +102,7 @@ def test_many_threads_one_context(ctx):
     def run(i):
         try:
             barrier.wait(timeout=60)
-            return (_probe_job, _probe_job, _match_job, _ingest_job)[i % 4](ctx, 100 + i)
+            return (_probe_job, _single_query_job, _match_job, _ingest_job, _single_query_job, _probe_job)[i % 6](ctx, 100 + i)
         except BaseException as exc:  # noqa: BLE001 - reported below with the thread index
             errors.append((i, repr(exc)))
             return False
