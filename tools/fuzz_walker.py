@@ -2,8 +2,10 @@
     python tools/fuzz_walker.py [first_seed] [n_seeds]
 Three generators per seed (the tests' own, re-seeded): the reference's property generator (escapes, UTF-8), printable
 ASCII with random spacing and nesting, multi-script Unicode with every white-space class; each ingested validated and
-trusted, counts and bitsets compared with the oracle's build of the oracle's sets; then random expressions through
-k_match_rows against the host matcher.  Exits non-zero on the first difference."""
+trusted, counts and bitsets compared with the oracle's build of the oracle's sets; the same rows DAMAGED (byte flips,
+deletions, insertions, truncations) through the validating walk, compared with what the host walker alone keeps; then
+random expressions through k_match_rows (intact and damaged rows) against the host matcher.  Exits non-zero on the first
+difference."""
 import json
 import os
 import sys
@@ -67,6 +69,45 @@ def gen_rows(rng, kind, n):
     return rows
 
 
+def mutate(rng, rows):
+    """byte flips, deletions, insertions and truncations of valid rows: what an attacker (or a torn write) hands the walker"""
+    out = []
+    for r in rows:
+        b = bytearray(r)
+        for _ in range(int(rng.integers(1, 4))):
+            if not b:
+                break
+            p = int(rng.integers(0, len(b)))
+            op = int(rng.integers(0, 4))
+            if op == 0:
+                b[p] = int(rng.integers(0, 256))
+            elif op == 1:
+                del b[p]
+            elif op == 2:
+                b.insert(p, int(rng.integers(0, 256)))
+            else:
+                del b[p:]
+        out.append(bytes(b))
+    return out
+
+
+def host_sets(rows):
+    """the C++ host walker's (lenient, Go-like) result: the reference for rows that are not valid JSON"""
+    s = Hst.EntrySets()
+    for r in rows:
+        try:
+            s.index_row(r)
+        except Hst.HostError:
+            pass
+    out = []
+    for kind in range(3):                      # raw bytes: a damaged key may not be UTF-8 any more (keys are copied undecoded)
+        blob, ln = s.export(kind)
+        off = np.concatenate([[0], np.cumsum(ln, dtype=np.int64)]).astype(np.int64)
+        raw = blob.tobytes()
+        out.append({raw[off[i]: off[i + 1]] for i in range(len(ln))})
+    return tuple(out)
+
+
 def oracle_sets(rows):
     sets = (set(), set(), set())
     for r in rows:
@@ -101,6 +142,13 @@ def main():
                     check(res, s_, st, "seed %d generator %d flags %d set %d" % (seed, kind, flags, s_))
                 check(res, 5, union, "seed %d generator %d flags %d file" % (seed, kind, flags))
                 n_fb += len(res.fallback_rows)
+            # the same rows damaged, through the validating walk only: whatever the device keeps of a row it cannot finish, the
+            # result must be what the host walker alone produces (and nothing may hang)
+            bad_sets = [mutate(rng, rs) for rs in row_sets]
+            res = I.device_ingest(ctx, bad_sets, FPR, parent_of_set=[0] * 5, n_parents=1, flags=0)
+            for s_, rs in enumerate(bad_sets):
+                check(res, s_, host_sets(rs), "seed %d generator %d damaged rows set %d" % (seed, kind, s_))
+            n_fb += len(res.fallback_rows)
             rows = [r for rs in row_sets for r in rs]
             n_rows += len(rows)
             vocab, paths = sorted(union[1]) or ["x"], sorted(union[0]) or ["x"]
@@ -123,6 +171,14 @@ def main():
                     bad = [i for i, (a, b) in enumerate(zip(got, want)) if bool(a) != b][:3]
                     sys.exit("seed %d generator %d: k_match_rows differs from the host matcher on rows %s for %s" % (seed, kind, bad, json.dumps(e)))
                 n_match += len(rows)
+                if _ < 2:                                       # the damaged rows through the matcher too
+                    bad_rows = [r for rs in bad_sets for r in rs]
+                    got, fb = ctx.match_rows(bad_rows, Q.CompiledMatcher(e))
+                    for r in fb:
+                        got[r] = Hst.match_row(e, bad_rows[int(r)])
+                    if list(map(bool, got)) != [Hst.match_row(e, r) for r in bad_rows]:
+                        sys.exit("seed %d generator %d: k_match_rows differs from the host matcher on damaged rows for %s" % (seed, kind, json.dumps(e)))
+                    n_match += len(bad_rows)
         print("seed %d ok (%d rows so far, %d handed to the host walker, %d row verdicts)" % (seed, n_rows, n_fb, n_match), flush=True)
     ctx.close()
 
