@@ -124,7 +124,7 @@ inline int32_t parse_filter_section(const uint8_t *section, size_t len, ParsedFi
         const uint64_t m = get_be64(section + pos), k = get_be64(section + pos + 8), blen = get_be64(section + pos + 16);
         // same checks as the device path (bsg_arena_load_sections): the bitset must cover m, and (blen + 63) / 64 must
         // not wrap; k is bounded so that a corrupt section with a valid CRC cannot make a probe loop for minutes
-        if (blen > ~0ull - 63 || m == 0 || k == 0 || k > kMaxHashCount) return kSectionBadFilter;
+        if (blen > ~0ull - 63 || m > ~0ull - 63 || m == 0 || k == 0 || k > kMaxHashCount) return kSectionBadFilter;   // (m + 63 below must not wrap either)
         const uint64_t nw = (blen + 63) / 64;
         if (nw > (flen - 24) / 8 || (m + 63) / 64 > nw) return kSectionBadFilter;
         out[c].present = true; out[c].m = m; out[c].k = k;

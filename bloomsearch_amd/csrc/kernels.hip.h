@@ -1062,7 +1062,7 @@ __device__ inline int32_t parse_section_header(const uint8_t *sec, uint32_t plen
         if (flen > plen - pos) return -4;
         if (flen < 24) return -5;
         const uint64_t mm = rd_be64_dev(sec + pos), kk = rd_be64_dev(sec + pos + 8), bl = rd_be64_dev(sec + pos + 16);
-        if (bl > ~0ull - 63 || mm == 0 || kk == 0 || kk > kMaxHashCountDev) return -5;
+        if (bl > ~0ull - 63 || mm > ~0ull - 63 || mm == 0 || kk == 0 || kk > kMaxHashCountDev) return -5;   // (mm + 63 must not wrap: an m of 2^64 - 1 would pass as 0 words)
         const uint64_t words = (bl + 63) / 64;
         if (words > (flen - 24) / 8 || (mm + 63) / 64 > words) return -5;
         m[c] = mm; k[c] = (uint32_t)kk;

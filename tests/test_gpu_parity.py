@@ -386,12 +386,18 @@ def test_arena_load_sections_device_decode(ctx):
     bad[33] = with_crc(sections[33][:-4] + b"\x00\x00\x00")
     bad[40] = b"\x01\x02\x03"
     bad[41] = b""
+    # crafted headers under a correct checksum: an m whose (m + 63) / 64 wraps, a bitset shorter than m, k = 0, k beyond the cap
+    crafted = lambda m, k, blen: with_crc(bytes([1]) + struct.pack("<I", 32) + struct.pack(">QQQ", m, k, blen) + b"\xAA" * 8)
+    bad[50], bad[51], bad[52], bad[53], bad[54] = (crafted(2 ** 64 - 1, 3, 64), crafted(2 ** 64 - 40, 3, 64), crafted(65, 3, 64),
+                                                   crafted(64, 0, 64), crafted(64, 1025, 64))
     aid, status = ctx.arena_load_sections(bad)
-    expect = {5: -2, 9: -2, 12: -3, 40: -1, 41: 0, 33: -6}
+    expect = {5: -2, 9: -2, 12: -3, 40: -1, 41: 0, 33: -6, 50: -5, 51: -5, 52: -5, 53: -5, 54: -5}
     for b, code in expect.items():
         assert status[b] == code, (b, status[b])
     assert status[20] in (-4, -5)
-    for b in range(n_blocks):          # oracle parse agrees on ok / not ok for every block
+    for b in range(n_blocks):          # oracle parse agrees on ok / not ok for every block ...
+        if 50 <= b <= 54:              # ... but these: bloom/v3 ReadFrom (the oracle) takes m, k and the bitset length as they come;
+            continue                   # the device and the host codec call such a filter bad (deviations)
         try:
             O.parse_filter_section(bad[b]) if bad[b] else None
             ok = True

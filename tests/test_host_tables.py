@@ -295,6 +295,19 @@ def test_section_codec_matches_oracle_bytes():
         Hst.section_parse(bytes(sec))
     assert e.value.code == -2          # ErrInvalidHash
     assert Hst.crc32c(b"123456789") == 0xE3069283
+    # crafted headers under a CORRECT checksum: m so large that (m + 63) / 64 wraps (found by tools/fuzz_sections.py: such a
+    # section used to parse as "m = 2^64 - 1 with zero words"), a bitset length that wraps, k = 0, k beyond the cap
+    import struct
+
+    def crafted(m, k, blen, n_words):
+        body = bytes([1]) + struct.pack("<I", 24 + 8 * n_words) + struct.pack(">QQQ", m, k, blen) + b"\xAA" * (8 * n_words)
+        return body + struct.pack("<I", Hst.crc32c(body))
+    assert Hst.section_parse(crafted(64, 3, 64, 1))[0][:2] == (64, 3)
+    for m, k, blen in ((2 ** 64 - 1, 3, 64), (2 ** 64 - 63, 3, 64), (2 ** 64 - 64, 3, 64), (64, 3, 2 ** 64 - 1), (64, 0, 64), (64, 1025, 64),
+                       (65, 3, 64), (0, 3, 64)):
+        with pytest.raises(Hst.HostError) as e:
+            Hst.section_parse(crafted(m, k, blen, 1))
+        assert e.value.code == -5, (m, k, blen)
 
 
 def test_host_symbols_exported():
