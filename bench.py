@@ -690,6 +690,7 @@ def main():
     ap.add_argument("--c4-files", type=int, default=10, help="files of the c4 leg (0 = skip the leg)")
     ap.add_argument("--c4-blocks-per-file", type=int, default=1000)
     ap.add_argument("--compact-rounds", type=int, default=-1, help="lab: compaction rounds of the many-term probe mode (bsg_set_lab key 1)")
+    ap.add_argument("--fuse-limit", type=int, default=-1, help="lab: largest group whose evaluation rides in the next group's probe launch (bsg_set_fuse_limit)")
     ap.add_argument("--untimed", action="store_true", help="lab: no dispatch timestamps inside the timed region (what they cost)")
     ap.add_argument("--no-q1", action="store_true", help="skip the Q = 1 latency leg")
     ap.add_argument("--no-single", action="store_true", help="skip the one-arena-per-launch sampling pass")
@@ -734,6 +735,8 @@ def main():
     ctx.set_probe_group(args.group)
     if args.compact_rounds >= 0:
         ctx.set_lab(1, args.compact_rounds)
+    if args.fuse_limit >= 0:
+        ctx.set_fuse_limit(args.fuse_limit)
     B, rows, NQ = args.blocks, args.rows_per_block, args.queries
 
     # ---- untimed setup: this rank's shard = global blocks rank, rank + world, ... (round-robin) ----

@@ -370,8 +370,8 @@ BSG_API int32_t bsg_ingest_build(bsg_ctx *ctx, uint64_t ingest_id, const bsg_fil
  * is ignored: the device lays the words out itself); out_sec_off[n_sets + n_parents + 1].
  * out_sets_arena_id / out_parents_arena_id (either may be NULL): the filters just built are also left RESIDENT as
  * probe arenas — "block" i of the first = set i, "block" p of the second = parent p — so the file that is being
- * written can be queried without its sections ever being uploaded or decoded again.  An id of 0 means no arena was
- * kept (contexts opened on several devices shard their arenas: load the sections with bsg_arena_load_sections). */
+ * written can be queried without its sections ever being uploaded or decoded again.  On a context opened on several
+ * devices every device receives its blocks (b % n) device to device. */
 BSG_API int32_t bsg_ingest_build_sections(bsg_ctx *ctx, uint64_t ingest_id, const bsg_filter_desc *desc, uint8_t *out_region,
                                           uint64_t region_cap, uint64_t *out_sec_off, uint64_t *out_sets_arena_id,
                                           uint64_t *out_parents_arena_id);

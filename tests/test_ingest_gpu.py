@@ -350,6 +350,41 @@ def test_resident_arenas_equal_reloaded_sections(ctx):
     ctx.batch_free(bid)
 
 
+@pytest.mark.parametrize("n_entries", [2, 3])
+def test_resident_arenas_on_a_sharded_context(n_entries):
+    """The same on a context over several entries: the filters are built on the first one and every entry receives its
+    blocks (b % n) device to device; probing the resident arenas must equal probing the reloaded sections."""
+    from bloomsearch_amd import query as Q
+    from bloomsearch_amd.gpu import Context
+    from tests import helpers as H
+    with Context((0,) * n_entries) as mctx:
+        row_sets = [synth.rows_json(b * 150, 150) for b in range(11)] + [[]]
+        first = np.zeros(len(row_sets) + 1, dtype=np.uint32)
+        first[1:] = np.cumsum([len(r) for r in row_sets])
+        ing = mctx.ingest_rows([r for rs in row_sets for r in rs], first, [i % 3 for i in range(12)], 3, flags=TRUSTED)
+        counts, _ = mctx.ingest_finish(ing, 15)
+        desc, _ = I.plan_desc(counts, FPR)
+        secs, a_sets, a_parents = mctx.ingest_build_sections(ing, desc, arenas=True)
+        mctx.ingest_free(ing)
+        assert a_sets != 0 and a_parents != 0
+        d = synth.draws(0, 30)
+        exprs = [Q.And(Q.FieldToken("level", synth.LEVELS[d["level"][i]]), Q.FieldToken("user_id", str(int(d["user_id"][i])))) for i in range(30)]
+        exprs += [Q.Token("absent-token"), Q.Field("nested.az"), None, Q.FieldToken("service", "billing")]
+        for batch in (exprs, exprs[:1]):                      # many terms (streaming kernels) and one query (one dispatch per entry)
+            cb = Q.compile_queries(batch)
+            ops, poff, _ = cb.arrays()
+            terms = H.gpu_terms(mctx, cb)
+            bid = mctx.batch_create(terms, ops, poff)
+            for arena, lo, n in ((a_sets, 0, 12), (a_parents, 12, 3)):
+                reloaded, status = mctx.arena_load_sections(secs[lo: lo + n])
+                assert not status.any()
+                assert np.array_equal(mctx.probe_batch(arena, bid, cb.n_queries, n), mctx.probe_batch(reloaded, bid, cb.n_queries, n))
+                mctx.arena_free(reloaded)
+            mctx.batch_free(bid)
+        mctx.arena_free(a_sets)
+        mctx.arena_free(a_parents)
+
+
 def test_rows_from_pinned_host_memory(ctx):
     rows = synth.rows_json(0, 800)
     blob = np.frombuffer(b"".join(rows), dtype=np.uint8)
