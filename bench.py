@@ -14,9 +14,9 @@ To keep every step streaming from HBM instead of the 256 MiB Infinity Cache,
 the arena is loaded at R distinct addresses and step i probes replica i % R
 (R x streamed bytes >= 2 x 256 MiB).
 
-bsg_probe_many covers up to 32 arenas with ONE dispatch (a 35 MB arena streams in about the time a
+bsg_probe_many covers up to 64 arenas with ONE dispatch (a 35 MB arena streams in about the time a
 dispatch takes to ramp up and complete), so consecutive steps are handed to it together and a launch
-probes min(steps, 32) arenas; `roofline` is computed over exactly those launches, `roofline_single_launch`
+probes min(steps, 64) arenas; `roofline` is computed over exactly those launches, `roofline_single_launch`
 over launches of one 1 000-block arena each.
 
 Multi-GPU (torchrun, one process per GPU): blocks shard round-robin across
@@ -604,7 +604,7 @@ def c4_leg(ctx, args, rank, world, workers, log):
     files = None
     pr = Prober(ctx, bid, world, log)
     steps = max(4, min(args.steps, 60))
-    per_call = max(1, 32 // max(n_files, 1))           # steps handed to one bsg_probe_many call (<= 32 arenas per dispatch)
+    per_call = max(1, 64 // max(n_files, 1))           # steps handed to one bsg_probe_many call (<= 64 arenas per dispatch)
     make = lambda i: reps[i % R]
     dt, tm = pr.measure(make, steps, max(2, min(args.warmup, 8)), per_call)
     global PROBE_KERNEL
@@ -685,7 +685,7 @@ def main():
                          "10 M rows (2.5 GB of JSON); 0 = skip")
     ap.add_argument("--scaled", type=int, default=64,
                     help="also time C2': the arena replicated this many times inside one launch (0/1 = skip)")
-    ap.add_argument("--group", type=int, default=32, help="arenas one probe dispatch may cover (bsg_set_probe_group, <= 32)")
+    ap.add_argument("--group", type=int, default=64, help="arenas one probe dispatch may cover (bsg_set_probe_group, <= 64)")
     ap.add_argument("--samples", type=int, default=16, help="timestamped dispatches of each kernel beyond the timed region")
     ap.add_argument("--c4-files", type=int, default=10, help="files of the c4 leg (0 = skip the leg)")
     ap.add_argument("--c4-blocks-per-file", type=int, default=1000)

@@ -1161,7 +1161,6 @@ int32_t make_probe_args(bsg_ctx *ctx, Device &d, const Group &g, const BatchDev 
     a.n_arenas = (uint32_t)g.shards.size();
     a.max_blocks = g.max_blocks;
     a.gather_cost = ctx->gather_cost;
-    fill_refs(g, B, a.ar);
     uint32_t max_tw = 0;
     for (uint32_t y = 0; y < B.n_kinds; ++y) max_tw = std::max(max_tw, (B.term_count[y] + 63) / 64);
     const size_t head = bsg::probe_lds_head_bytes(max_tw);
@@ -1193,7 +1192,6 @@ int32_t make_eval_args(Device &d, const Group &g, const BatchDev &bd, const Batc
     a.cw_cnt = bd.d_cw_cnt; a.cw = bd.d_cw; a.max_cw = B.max_cw; a.Lmax = B.Lmax; a.identity_cw = B.identity_cw ? 1u : 0u;
     a.n_arenas = (uint32_t)g.shards.size();
     a.max_G = g.max_G;
-    fill_refs(g, B, a.ar);
     return BSG_OK;
 }
 
@@ -1214,12 +1212,14 @@ int32_t enqueue_terms(bsg_ctx *ctx, Device &d, const Group &g, const BatchDev &b
     uint32_t lds = 0;
     if (int32_t rc = make_probe_args(ctx, d, g, bd, B, slot, ev, a, lds)) return rc;
     if (B.n_kinds == 0) return BSG_OK;
+    bsg::ArenaTable<bsg::kMaxGroupArenas> t;
+    fill_refs(g, B, t.ar);
     if (B.many_terms)
         hipExtLaunchKernelGGL(bsg::k_probe_terms_many, dim3(g.max_blocks, B.n_kinds, a.n_arenas), dim3(bsg::kProbeThreads), lds, d.stream,
-                              ev ? ev->k1s : nullptr, ev ? ev->k1e : nullptr, 0, a);
+                              ev ? ev->k1s : nullptr, ev ? ev->k1e : nullptr, 0, a, t);
     else
         hipExtLaunchKernelGGL(bsg::k_probe_terms, dim3(g.max_blocks, B.n_kinds, a.n_arenas), dim3(bsg::kProbeThreads), lds, d.stream,
-                              ev ? ev->k1s : nullptr, ev ? ev->k1e : nullptr, 0, a);
+                              ev ? ev->k1s : nullptr, ev ? ev->k1e : nullptr, 0, a, t);
     HIP_TRY(hipGetLastError());
     if (ev) ev->has_k1 = true;
     return BSG_OK;
@@ -1234,9 +1234,10 @@ int32_t enqueue_direct(Device &d, const Group &g, const BatchDev &bd, const Batc
     a.Tp = B.Tp; a.Wt = std::max(B.Wt, 1u); a.n_queries = B.n_queries; a.Lmax = B.Lmax; a.max_depth = B.max_depth; a.n_kinds = B.n_kinds;
     for (uint32_t y = 0; y < B.n_kinds; ++y) { a.kind[y] = B.kind[y]; a.term_begin[y] = B.term_begin[y]; a.term_count[y] = B.term_count[y]; }
     a.n_arenas = (uint32_t)g.shards.size();
-    fill_refs(g, B, a.ar);
+    bsg::ArenaTable<bsg::kMaxGroupArenas> t;
+    fill_refs(g, B, t.ar);
     hipExtLaunchKernelGGL(bsg::k_probe_direct, dim3(g.max_G, 1, a.n_arenas), dim3(bsg::kEvalThreads), bsg::direct_lds_bytes(a.Wt, B.max_depth),
-                          d.stream, ev ? ev->k1s : nullptr, ev ? ev->k1e : nullptr, 0, a);
+                          d.stream, ev ? ev->k1s : nullptr, ev ? ev->k1e : nullptr, 0, a, t);
     HIP_TRY(hipGetLastError());
     if (ev) {
         ev->has_k1 = true; ev->fused = true; ev->n_arenas = a.n_arenas;
@@ -1252,9 +1253,11 @@ int32_t enqueue_eval(Device &d, const Group &g, const BatchDev &bd, const Batch 
     bsg::EvalArgs a;
     if (int32_t rc = make_eval_args(d, g, bd, B, slot, a)) return rc;
     const uint32_t tile = eval_tile_for(g);
+    bsg::ArenaTable<bsg::kMaxGroupArenas> t;
+    fill_refs(g, B, t.ar);
     hipExtLaunchKernelGGL(bsg::k_eval_programs, dim3((g.max_G + tile - 1) / tile, B.n_chunks, a.n_arenas), dim3(bsg::kEvalThreads),
                           bsg::eval_lds_bytes(B.max_cw, B.max_depth), d.stream, ev ? ev->k2s : nullptr,
-                          ev ? ev->k2e : nullptr, 0, a, tile);
+                          ev ? ev->k2e : nullptr, 0, a, t, tile);
     HIP_TRY(hipGetLastError());
     if (ev) ev->has_k2 = true;
     return BSG_OK;
@@ -1276,8 +1279,11 @@ int32_t enqueue_fused(bsg_ctx *ctx, Device &d, const Group &g, uint32_t slot, co
     f.eval_tile = eval_tile_for(pg);
     const uint64_t grid = (uint64_t)f.n_probe + (uint64_t)(pg.max_G + f.eval_tile - 1) / f.eval_tile * f.eval_pairs * f.e.n_arenas;
     if (grid > 0x7FFFFFFFull) return fail(BSG_E_UNSUPPORTED, "fused launch of %llu workgroups", (unsigned long long)grid);
+    bsg::ArenaTable<bsg::kMaxFusedArenas> tp, te;              // (the caller keeps fused groups within kMaxFusedArenas)
+    fill_refs(g, B, tp.ar);
+    fill_refs(pg, B, te.ar);
     hipExtLaunchKernelGGL(bsg::k_probe_fused, dim3((uint32_t)grid), dim3(bsg::kProbeThreads), lds, d.stream, ev ? ev->k1s : nullptr,
-                          ev ? ev->k1e : nullptr, 0, f);
+                          ev ? ev->k1e : nullptr, 0, f, tp, te);
     HIP_TRY(hipGetLastError());
     if (ev) { ev->has_k1 = true; ev->fused = true; }
     return BSG_OK;
@@ -1365,7 +1371,7 @@ int32_t probe_arenas(bsg_ctx *ctx, const std::vector<std::shared_ptr<Arena>> &ar
     // 35 MB per dispatch: fused 5.9 us per arena, k_probe_terms + k_eval_programs 5.2 + 1.0 us with the evaluation
     // costing no HBM time of its own).
     const bool fuse = !(flags & BSG_PROBE_NOFUSE) && !B.many_terms && B.n_kinds > 0 && 2 * bsg::eval_lds_bytes(B.max_cw, B.max_depth) <= 64 * 1024;
-    const uint32_t fuse_max_arenas = ctx->fuse_max_arenas;
+    const uint32_t fuse_max_arenas = std::min(ctx->fuse_max_arenas, bsg::kMaxFusedArenas);
     const uint32_t limit = std::max(1u, std::min(ctx->group_limit, bsg::kMaxGroupArenas));
     std::vector<uint64_t> out_off(n_arenas + 1, 0);   // arena i's survivors start at out_survivors + out_off[i]
     for (uint32_t i = 0; i < n_arenas; ++i)

@@ -26,7 +26,6 @@ struct DirectArgs {
     uint32_t *done_count;        // device word, 0 between launches
     uint64_t *flag;              // host-mapped; nullptr: no doorbell
     uint64_t seq;
-    ArenaRef ar[kMaxGroupArenas];
 };
 
 __host__ __device__ inline uint32_t direct_lds_bytes(uint32_t Wt, uint32_t max_depth)
@@ -35,10 +34,10 @@ __host__ __device__ inline uint32_t direct_lds_bytes(uint32_t Wt, uint32_t max_d
 }
 
 // grid = (most 64-block groups of any arena, 1, arenas); 256 threads
-__global__ __launch_bounds__(kEvalThreads) void k_probe_direct(const DirectArgs a)
+__global__ __launch_bounds__(kEvalThreads) void k_probe_direct(const DirectArgs a, const ArenaTable<kMaxGroupArenas> t)
 {
     extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
-    const ArenaRef &ar = a.ar[blockIdx.z];
+    const ArenaRef &ar = t.ar[blockIdx.z];
     const uint32_t g = blockIdx.x;
     const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
     if (g < ar.G) {                                              // (arenas of a group may differ in size)

@@ -241,7 +241,8 @@ __device__ __forceinline__ uint64_t wave_transpose64(uint64_t x, int lane)
 // One launch probes a GROUP of arenas (the candidate files of one query stage, bsg_probe_many): the per-arena
 // pointers ride in the kernel arguments, so a group costs one dispatch ramp instead of one per arena — at 35 MB
 // per arena the ~3-4 us ramp + completion of a dispatch is as long as the streaming itself.
-constexpr uint32_t kMaxGroupArenas = 32;
+constexpr uint32_t kMaxGroupArenas = 64;      // 64 x 40 B of per-arena records + the scalar arguments stay inside the 4 KB of kernel arguments
+constexpr uint32_t kMaxFusedArenas = 8;       // k_probe_fused carries TWO tables (the group it streams, the group it evaluates)
 
 struct ArenaRef {
     const uint64_t *words;
@@ -251,6 +252,10 @@ struct ArenaRef {
     uint32_t n_blocks;
     uint32_t G;                   // ceil(n_blocks / 64)
 };
+
+// the per-arena records of a dispatch group: a kernel argument of its own, next to the scalars
+template <uint32_t N>
+struct ArenaTable { ArenaRef ar[N]; };
 
 struct ProbeArgs {
     const uint64_t *th;           // SoA term hashes: th[j * Tp + t], j < 4
@@ -266,7 +271,6 @@ struct ProbeArgs {
     uint32_t kind[3];             // referenced kinds, blockIdx.y indexes this
     uint32_t term_begin[3];       // first term (multiple of 64) of that kind
     uint32_t term_count[3];       // real terms of that kind
-    ArenaRef ar[kMaxGroupArenas];
 };
 
 // x mod m for m < 2^31: the remainder candidate x - q*m lies in [0, 2m) so only
@@ -586,14 +590,13 @@ __host__ __device__ inline uint32_t probe_lds_head_bytes(uint32_t n_tw)
 }
 
 template <uint32_t NT = kProbeThreads, bool ONLY_PAR = false>
-__device__ __forceinline__ void probe_role(const ProbeArgs &a, uint32_t ai, uint32_t b, uint32_t y, uint64_t *lds64)
+__device__ __forceinline__ void probe_role(const ProbeArgs &a, const ArenaRef &ar, uint32_t b, uint32_t y, uint64_t *lds64)
 {
     constexpr uint32_t kProbeThreads = NT, kProbeWaves = NT / kWave;   // shadow the 512-thread defaults
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & (kWave - 1);
     const uint32_t wave = tid / kWave;
 
-    const ArenaRef &ar = a.ar[ai];
     if (b >= ar.n_blocks) return;   // arenas of a group may differ in size
     const DevDesc d = ar.desc[(uint64_t)b * 3 + a.kind[y]];
     const uint32_t t0 = a.term_begin[y];
@@ -635,15 +638,15 @@ __device__ __forceinline__ void probe_role(const ProbeArgs &a, uint32_t ai, uint
 
 // grid = (max_blocks, referenced kinds, arenas of the group)
 // k_probe_terms: batches whose kinds all have <= 128 distinct terms (mode A only); k_probe_terms_many: everything else.
-__global__ __launch_bounds__(kProbeThreads) void k_probe_terms(const ProbeArgs a)
+__global__ __launch_bounds__(kProbeThreads) void k_probe_terms(const ProbeArgs a, const ArenaTable<kMaxGroupArenas> t)
 {
     extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
-    probe_role<kProbeThreads, true>(a, blockIdx.z, blockIdx.x, blockIdx.y, lds64);
+    probe_role<kProbeThreads, true>(a, t.ar[blockIdx.z], blockIdx.x, blockIdx.y, lds64);
 }
-__global__ __launch_bounds__(kProbeThreads) void k_probe_terms_many(const ProbeArgs a)
+__global__ __launch_bounds__(kProbeThreads) void k_probe_terms_many(const ProbeArgs a, const ArenaTable<kMaxGroupArenas> t)
 {
     extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
-    probe_role<kProbeThreads, false>(a, blockIdx.z, blockIdx.x, blockIdx.y, lds64);
+    probe_role<kProbeThreads, false>(a, t.ar[blockIdx.z], blockIdx.x, blockIdx.y, lds64);
 }
 
 // (Measured and dropped, twice now: the same kernel with 1 024 threads per block — 16 waves sharing one block's image, 32
@@ -673,7 +676,6 @@ struct EvalArgs {
     uint32_t identity_cw;        // 1: every chunk uses words 0..max_cw-1 in order (small batches): no list to load
     uint32_t n_arenas;
     uint32_t max_G;              // most 64-block groups of any arena of the launch
-    ArenaRef ar[kMaxGroupArenas];
 };
 
 // LDS bytes one 256-query half needs: transposed verdict words + per-lane stack
@@ -770,10 +772,10 @@ __device__ __forceinline__ void eval_role(const EvalArgs &a, const ArenaRef &ar,
 }
 
 // grid = (ceil(max_G / tile), n_chunks, arenas); tile (1 or kEvalGroupTile) is chosen by the host
-__global__ __launch_bounds__(kEvalThreads) void k_eval_programs(const EvalArgs a, const uint32_t tile)
+__global__ __launch_bounds__(kEvalThreads) void k_eval_programs(const EvalArgs a, const ArenaTable<kMaxGroupArenas> t, const uint32_t tile)
 {
     extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
-    const ArenaRef &ar = a.ar[blockIdx.z];
+    const ArenaRef &ar = t.ar[blockIdx.z];
     const uint32_t g0 = blockIdx.x * tile;
     if (g0 >= ar.G) return;
     eval_role(a, ar, g0, min(tile, ar.G - g0), blockIdx.y, threadIdx.x, lds64, true);
@@ -797,7 +799,7 @@ struct FusedArgs {
     uint32_t n_kinds;
 };
 
-__global__ __launch_bounds__(kProbeThreads) void k_probe_fused(const FusedArgs f)
+__global__ __launch_bounds__(kProbeThreads) void k_probe_fused(const FusedArgs f, const ArenaTable<kMaxFusedArenas> tp, const ArenaTable<kMaxFusedArenas> te)
 {
     extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
     const uint32_t id = blockIdx.x;
@@ -808,11 +810,11 @@ __global__ __launch_bounds__(kProbeThreads) void k_probe_fused(const FusedArgs f
         const uint32_t j = id - n_eval;
         const uint32_t per_probe_arena = f.p.max_blocks * f.n_kinds;
         const uint32_t ai = j / per_probe_arena, r = j - ai * per_probe_arena;
-        probe_role<kProbeThreads, true>(f.p, ai, r % f.p.max_blocks, r / f.p.max_blocks, lds64);   // fused launches are few-term launches
+        probe_role<kProbeThreads, true>(f.p, tp.ar[ai], r % f.p.max_blocks, r / f.p.max_blocks, lds64);   // fused launches are few-term launches
     } else {
         const uint32_t ai = id / per_arena, r = id - ai * per_arena;
         const uint32_t gtile = r / f.eval_pairs, pair = r - gtile * f.eval_pairs;
-        const ArenaRef &ar = f.e.ar[ai];
+        const ArenaRef &ar = te.ar[ai];
         const uint32_t g0 = gtile * f.eval_tile;
         if (g0 >= ar.G) return;
         const uint32_t half = threadIdx.x >> 8, htid = threadIdx.x & 255u;

@@ -201,7 +201,7 @@ BSG_API int32_t bsg_probe_batch(bsg_ctx *ctx, uint64_t arena_id, uint64_t batch_
                                 uint64_t *out_survivors);
 
 /* Probe the same batch against each of n_arenas arenas (e.g. the candidate files of one query
- * stage) in one call.  Up to 32 arenas (bsg_set_probe_group) are covered by ONE dispatch — a 35 MB arena streams in
+ * stage) in one call.  Up to 64 arenas (bsg_set_probe_group) are covered by ONE dispatch — a 35 MB arena streams in
  * about the time a dispatch takes to ramp up and complete, so per-arena launches cap the HBM roofline fraction near
  * one half — and dispatches are software-pipelined: the program evaluation of group i rides inside the launch that
  * streams group i+1's bitsets (k_probe_fused).  out_survivors == NULL: enqueue only (results stay on the device; pair
@@ -215,7 +215,7 @@ BSG_API int32_t bsg_probe_many(bsg_ctx *ctx, const uint64_t *arena_ids, uint32_t
 /* Same, survivors left at a DEVICE pointer (single-device contexts; one-process-per-GPU layers that forward them). */
 BSG_API int32_t bsg_probe_many_dev(bsg_ctx *ctx, const uint64_t *arena_ids, uint32_t n_arenas, uint64_t batch_id,
                                    uint32_t flags, void *d_out_survivors);
-/* Arenas one probe dispatch may cover (1..32; 0 = default 32). */
+/* Arenas one probe dispatch may cover (1..64; 0 = default 64). */
 BSG_API int32_t bsg_set_probe_group(bsg_ctx *ctx, uint32_t max_arenas_per_launch);
 /* Lab knobs for tools/, bench sweeps and tests (key 1: compaction rounds of the many-term probe mode; key 2: HBM bytes a
  * binned build of a bitset beyond LDS may park its locations in, 0 = build it with global atomics; key 3: most distinct terms

@@ -206,7 +206,7 @@ def test_rccl_or_allreduce_inside_the_library_world_of_one(ctx):
 
 def test_grouped_launches_equal_one_launch_per_arena(ctx):
     """A dispatch covers a GROUP of arenas (per-arena pointers in the kernel arguments): any grouping — one arena per
-    launch, 3, 32, more arenas than one group holds, arenas of different sizes, an arena without blocks, fused or not —
+    launch, 3, 32, 64, more arenas than one group holds, arenas of different sizes, an arena without blocks, fused or not —
     must return what one probe per arena returns."""
     rng = np.random.default_rng(5)
     plans, vocab = [], None
@@ -231,7 +231,7 @@ def test_grouped_launches_equal_one_launch_per_arena(ctx):
         for cb, ops, poff, terms, bid in batches:
             wants = [O.probe_batch(words, plan.desc.view(O.DESC_DTYPE), terms.view(O.TERM_DTYPE), ops, poff) for plan, words in plans]
             wants.append(np.zeros((cb.n_queries, 0), dtype=np.uint64))
-            for limit in (1, 3, 32):
+            for limit in (1, 3, 32, 64):
                 ctx.set_probe_group(limit)
                 for flags in (0, _lib.PROBE_NOFUSE, _lib.PROBE_TIMED):
                     got = ctx.probe_many([arenas[i] for i in order], bid, flags, cb.n_queries, [nbs[i] for i in order])

@@ -92,7 +92,8 @@ int main(int argc, char **argv)
     a.n_arenas = 1; a.max_blocks = B; a.compact_rounds = 2;
     const uint32_t G = (B + 63) / 64;
     // arena slot i of a dispatch group reads replica r: per-arena pointers ride in the kernel arguments
-    auto set_arena = [&](uint32_t slot, uint32_t r) { a.ar[slot] = ArenaRef{dw[r], dd, (uint64_t)slot * G * (Tp / 64) * 64, 0, B, G}; };
+    ArenaTable<kMaxGroupArenas> tab{};
+    auto set_arena = [&](uint32_t slot, uint32_t r) { tab.ar[slot] = ArenaRef{dw[r], dd, (uint64_t)slot * G * (Tp / 64) * 64, 0, B, G}; };
     set_arena(0, 0);
     const size_t head = probe_lds_head_bytes(Tp / 64);
     a.lds_image_bytes = (uint32_t)((nw + 1) / 2 * 16);
@@ -127,14 +128,14 @@ int main(int argc, char **argv)
         std::vector<double> per(R, 0); std::vector<int> cnt(R, 0);
         for (uint32_t i = 0; i < iters * 2; ++i) {
             const int r = i % R; set_arena(0, r);
-            hipExtLaunchKernelGGL(k_probe_terms, dim3(B, 1), dim3(kProbeThreads), lds, st, e0, e1, 0, a);
+            hipExtLaunchKernelGGL(k_probe_terms, dim3(B, 1), dim3(kProbeThreads), lds, st, e0, e1, 0, a, tab);
             CHECK(hipEventSynchronize(e1)); float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); per[r] += ms; cnt[r]++;
         }
         printf("per-arena avg us:"); for (uint32_t r = 0; r < R; ++r) printf(" %.2f", per[r] / cnt[r] * 1e3); printf("\n");
         // same arena every time (cache resident) for comparison
         double tot = 0; set_arena(0, 0);
         for (uint32_t i = 0; i < iters; ++i) {
-            hipExtLaunchKernelGGL(k_probe_terms, dim3(B, 1), dim3(kProbeThreads), lds, st, e0, e1, 0, a);
+            hipExtLaunchKernelGGL(k_probe_terms, dim3(B, 1), dim3(kProbeThreads), lds, st, e0, e1, 0, a, tab);
             CHECK(hipEventSynchronize(e1)); float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); tot += ms;
         }
         printf("same arena (MALL-resident) avg %.2f us\n", tot / iters * 1e3);
@@ -144,21 +145,21 @@ int main(int argc, char **argv)
             CHECK(hipStreamSynchronize(st));
             CHECK(hipEventRecord(e0, st));
             const int N = 256;
-            for (int i = 0; i < N; ++i) { set_arena(0, i % R); hipExtLaunchKernelGGL(k_probe_terms, dim3(B, 1), dim3(kProbeThreads), lds, st, nullptr, nullptr, flag, a); }
+            for (int i = 0; i < N; ++i) { set_arena(0, i % R); hipExtLaunchKernelGGL(k_probe_terms, dim3(B, 1), dim3(kProbeThreads), lds, st, nullptr, nullptr, flag, a, tab); }
             CHECK(hipEventRecord(e1, st)); CHECK(hipEventSynchronize(e1));
             float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
             if (rep) printf("back-to-back x%d flag=%d: %.2f us per launch\n", N, flag, ms / N * 1e3);
         }
     }
-    timeit("k_probe_terms", [&](int r, hipEvent_t a0, hipEvent_t a1) { set_arena(0, r); hipExtLaunchKernelGGL(k_probe_terms, dim3(B, 1), dim3(kProbeThreads), lds, st, a0, a1, 0, a); });
+    timeit("k_probe_terms", [&](int r, hipEvent_t a0, hipEvent_t a1) { set_arena(0, r); hipExtLaunchKernelGGL(k_probe_terms, dim3(B, 1), dim3(kProbeThreads), lds, st, a0, a1, 0, a, tab); });
     // one dispatch over a GROUP of arenas (grid z): what a launch's ramp + completion cost per arena
-    for (uint32_t n : {2u, 4u, 8u, 16u, 32u}) {
+    for (uint32_t n : {2u, 4u, 8u, 16u, 32u, 64u}) {
         if (n > R) break;
         a.n_arenas = n;
         double tot = 0;
         for (uint32_t i = 0; i < iters + 4; ++i) {
             for (uint32_t s = 0; s < n; ++s) set_arena(s, (i * n + s) % R);
-            hipExtLaunchKernelGGL(k_probe_terms, dim3(B, 1, n), dim3(kProbeThreads), lds, st, e0, e1, 0, a);
+            hipExtLaunchKernelGGL(k_probe_terms, dim3(B, 1, n), dim3(kProbeThreads), lds, st, e0, e1, 0, a, tab);
             CHECK(hipEventSynchronize(e1)); float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); if (i >= 4) tot += ms;
         }
         printf("group of %2u arenas: %.2f us per dispatch, %.2f us per arena, %.1f GB/s\n", n, tot / iters * 1e3, tot / iters * 1e3 / n,
