@@ -1,8 +1,8 @@
 """Crafted filter sections through the device decoder (GPU box):  python tools/fuzz_sections.py [first_seed] [n_seeds]
 A section with a wrong checksum is the easy case; this sweep damages a section's header fields, lengths, m, k, bitset
 length or tail and then RE-SEALS it with a correct CRC32C, so only the structural checks of k_decode_sections stand between
-the bytes and an out-of-bounds read — through bsg_arena_load_sections and through the chunked stream, on a single-device and
-on a sharded context.  Every block must come back either rejected (status != 0, nil filters) exactly when the host codec
+the bytes and an out-of-bounds read — through bsg_arena_load_sections, through the chunked stream in order, and through the
+stream with its chunks scrambled (any order, duplicates, overlaps, chunks never sent), on a single-device and on a sharded context.  Every block must come back either rejected (status != 0, nil filters) exactly when the host codec
 rejects it, or decoded to filters that probe like the host-parsed ones.  Exits non-zero on the first difference."""
 import os
 import struct
@@ -87,7 +87,8 @@ def main():
         ops, poff, _ = cb.arrays()
         terms = H.gpu_terms(ctx, cb)
         want = O.probe_batch(host_words, desc.view(O.DESC_DTYPE), terms.view(O.TERM_DTYPE), ops, poff)
-        for how in ("whole", "stream"):
+        for how in ("whole", "stream", "scrambled"):
+            unread = set()
             if how == "whole":
                 aid, st = ctx.arena_load_sections(secs)
             else:
@@ -95,20 +96,47 @@ def main():
                 offs = np.zeros(len(secs) + 1, dtype=np.uint64)
                 offs[1:] = np.cumsum([len(x) for x in secs])
                 sid = ctx.arena_stream_begin(offs[:-1], offs[1:])
-                step = int(rng.choice([1, 7, 4096, 1 << 20]))
-                for o in range(0, len(blob), step):
-                    ctx.arena_stream_append(sid, o, blob[o: o + step])
+                step = int(rng.choice([1, 7, 4096, 1 << 20])) if how == "stream" else int(rng.choice([13, 200, 4096, 50000]))
+                chunks = [(o, min(o + step, len(blob))) for o in range(0, len(blob), step)]
+                if how == "scrambled":
+                    # chunks in any order, some twice, some widened over their neighbours, some never sent: a section is decoded
+                    # exactly when every byte of it arrived, whatever the order; the others report -7 and stay nil
+                    keep = [c for c in chunks if rng.random() > 0.15] or chunks[:1]
+                    sent = keep + [keep[int(i)] for i in rng.integers(0, len(keep), size=len(keep) // 5)]
+                    sent = [(max(0, a - int(rng.integers(0, 40))), min(len(blob), b + int(rng.integers(0, 40)))) if rng.random() < 0.2 else (a, b) for a, b in sent]
+                    order = rng.permutation(len(sent))
+                    chunks = [sent[int(i)] for i in order]
+                    covered = np.zeros(len(blob) + 1, dtype=np.int32)
+                    for a, b in chunks:
+                        covered[a] += 1; covered[b] -= 1
+                    have = np.cumsum(covered)[:-1] > 0
+                    for b in range(nb):
+                        lo, hi = int(offs[b]), int(offs[b + 1])
+                        if hi > lo and not have[lo:hi].all():
+                            unread.add(b)
+                for a, b in chunks:
+                    ctx.arena_stream_append(sid, a, blob[a:b])
                 aid, st = ctx.arena_stream_finish(sid, len(secs))
             dev_ok = [int(x) == 0 for x in st]
             # (an empty section — no bytes at all — is "the block has no section": status 0 and nil filters on both sides)
             for b in range(nb):
                 if len(secs[b]) == 0:
                     continue
+                if b in unread:
+                    if int(st[b]) != -7:
+                        sys.exit("seed %d block %d (%s): section never completely sent, status %d instead of -7" % (seed, b, how, int(st[b])))
+                    continue
                 if dev_ok[b] != host_ok[b]:
                     sys.exit("seed %d block %d (%s): device status %d, host codec %s the section (%d bytes)"
                              % (seed, b, how, int(st[b]), "accepts" if host_ok[b] else "rejects", len(secs[b])))
+            expect = want
+            if unread:
+                d2 = desc.copy()
+                for b in unread:
+                    d2["m"][b * 3: b * 3 + 3] = 0
+                expect = O.probe_batch(host_words, d2.view(O.DESC_DTYPE), terms.view(O.TERM_DTYPE), ops, poff)
             got = ctx.probe(aid, nb, terms, ops, poff)
-            if not np.array_equal(got, want):
+            if not np.array_equal(got, expect):
                 sys.exit("seed %d (%s): decoded filters probe differently from the host-parsed ones" % (seed, how))
             ctx.arena_free(aid)
         n_sec += nb
