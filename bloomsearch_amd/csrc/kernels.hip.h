@@ -690,7 +690,8 @@ __host__ __device__ inline uint32_t eval_lds_bytes(uint32_t max_cw, uint32_t max
 constexpr uint32_t kEvalGroupTile = BSG_EVAL_GROUP_TILE;   // block groups one eval "half" handles back to back (=> 32-byte stores per lane; lab: -DBSG_EVAL_GROUP_TILE)
 // Measured at 64 arenas per launch (C2 / the 8-term C4 batch): tile 4: 35.7 / 55.9 us, tile 8: 35.0 / 60.4, tile 16 (whole 128-byte
 // rows per lane): 44.5 / 77.5.  Of the 35.7 us the survivor stores are 17 (33 MB as 32-byte pieces of 128-byte rows) and the
-// programs 8; of the 55.9 us of the C4 batch the 15-op programs are 26.
+// programs 8; of the 55.9 us of the C4 batch the 15-op programs are 26.  Non-temporal stores for the survivors: 110 / 117 us
+// (four workgroups complete every 128-byte row at different times; only a write-back L2 can merge them).
 
 // Evaluates chunk c (256 queries) against block groups [g0, g0 + gt) with the 256 threads htid = 0..255
 // of one "half" (a whole k_eval_programs workgroup, or half of a fused workgroup).  The program words
