@@ -508,3 +508,18 @@ BO_API void bo_or_words(uint64_t *dst, const uint64_t *src, uint64_t n_words)
 {
     for (uint64_t i = 0; i < n_words; ++i) dst[i] |= src[i];
 }
+
+/* TestString of one probed string against the `kind` filter of every block of an arena (desc[b*3 + kind];
+ * m == 0 => nil filter => 1, fail-open, query_exec.go:137-151).  out[b] = 0 / 1.  The tree-walking evaluator of
+ * oracle.py (evaluate_tree_blocks) calls this once per distinct leaf and combines the vectors as
+ * evaluateBloomExpression combines the booleans (query_exec.go:89-126) — no postfix program involved. */
+BO_API void bo_test_string_blocks(const uint64_t *arena_words, const bo_filter_desc *desc, uint32_t n_blocks, uint32_t kind,
+                                  const uint8_t *data, uint64_t len, uint8_t *out)
+{
+    uint64_t h[4];
+    bo_base_hashes(data, len, h);
+    for (uint32_t b = 0; b < n_blocks; ++b) {
+        const bo_filter_desc *d = &desc[(uint64_t)b * 3 + kind];
+        out[b] = d->m == 0 ? 1 : (uint8_t)bo_filter_test_hashes(arena_words + d->word_off, d->m, d->k, h);
+    }
+}

@@ -65,6 +65,7 @@ def lib():
                                                C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
         L.bo_probe_reference_style.restype = C.c_int
         L.bo_build_many.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.bo_test_string_blocks.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_char_p, C.c_uint64, C.c_void_p]
         _lib = L
     return _lib
 
@@ -233,3 +234,130 @@ def build_many(blob: np.ndarray, off: np.ndarray, filter_entry_start: np.ndarray
     lib().bo_build_many(blob.ctypes.data, off.ctypes.data, filter_entry_start.ctypes.data,
                         desc.ctypes.data, len(desc), n_threads, words.ctypes.data)
     return words
+
+
+# ---- tree-walking evaluator: evaluateBloomFilters / evaluateBloomExpression / evaluateBloomCondition restated over the
+# expression TREE (dicts in the reference's exported JSON shape), with no postfix program and nothing from the product's
+# lowering (bloomsearch_amd.query.compile_queries) in between.  query_exec.go:75-159. ----
+_COND_KIND = {"FIELD": KIND_FIELD, "TOKEN": KIND_TOKEN, "FIELD_TOKEN": KIND_FIELD_TOKEN}
+
+
+def _probed_string(cond: dict):
+    """(kind, string) TestString is called with for a known condition type, else None (query_exec.go:134-157)."""
+    t = cond.get("Type")
+    if t == "FIELD":
+        return KIND_FIELD, cond.get("Field", "")
+    if t == "TOKEN":
+        return KIND_TOKEN, cond.get("Token", "")
+    if t == "FIELD_TOKEN":
+        return KIND_FIELD_TOKEN, cond.get("Field", "") + "::" + cond.get("Token", "")    # makeFieldTokenKey, tokenizer.go:509-511
+    return None
+
+
+def _enc(s):
+    return s if isinstance(s, bytes) else s.encode("utf-8", "surrogatepass")
+
+
+def evaluate_condition(filters, cond: dict) -> bool:
+    """evaluateBloomCondition (query_exec.go:128-159): filters = [field, token, fieldToken] Filter|None."""
+    ks = _probed_string(cond)
+    if ks is None:
+        return False                      # unknown condition type
+    kind, s = ks
+    f = filters[kind]
+    if f is None:
+        return True                       # nil filter cannot disqualify
+    return f.test(_enc(s))
+
+
+def evaluate_tree(filters, expr) -> bool:
+    """evaluateBloomFilters + evaluateBloomExpression (query_exec.go:75-126), short-circuit order included."""
+    if expr is None:
+        return True
+    et = expr.get("ExpressionType")
+    if et == "CONDITION":
+        cond = expr.get("Condition")
+        return True if cond is None else evaluate_condition(filters, cond)
+    if et == "OR":
+        kids = expr.get("Children") or []
+        if len(kids) == 0:
+            return False
+        for c in kids:
+            if evaluate_tree(filters, c):
+                return True
+        return False
+    if et == "AND":
+        for c in expr.get("Children") or []:
+            if not evaluate_tree(filters, c):
+                return False
+        return True
+    return False
+
+
+def block_filters(words: np.ndarray, desc: np.ndarray, b: int):
+    """[Filter|None] * 3 of block b of an arena (views into words)."""
+    out = []
+    for c in range(3):
+        d = desc[b * 3 + c]
+        m = int(d["m"])
+        out.append(None if m == 0 else Filter(m, int(d["k"]), words[int(d["word_off"]): int(d["word_off"]) + words_for(m)]))
+    return out
+
+
+def evaluate_tree_blocks(words: np.ndarray, desc: np.ndarray, expr, cache: dict | None = None) -> np.ndarray:
+    """evaluate_tree for every block of an arena at once: bool[n_blocks].  The same recursion over the same tree; a leaf is
+    one TestString per block (bo_test_string_blocks), And / Or combine the per-block booleans elementwise — which is what
+    the short-circuit loops compute."""
+    assert desc.dtype == DESC_DTYPE
+    n_blocks = len(desc) // 3
+    words = np.ascontiguousarray(words, dtype=np.uint64)
+    if cache is None:
+        cache = {}
+
+    def leaf(kind, s):
+        key = (kind, s)
+        v = cache.get(key)
+        if v is None:
+            raw = _enc(s)
+            out = np.zeros(max(n_blocks, 1), dtype=np.uint8)
+            lib().bo_test_string_blocks(words.ctypes.data, desc.ctypes.data, n_blocks, kind, raw, len(raw), out.ctypes.data)
+            v = cache[key] = out[:n_blocks].astype(bool)
+        return v
+
+    def walk(e):
+        if e is None:
+            return np.ones(n_blocks, dtype=bool)
+        et = e.get("ExpressionType")
+        if et == "CONDITION":
+            cond = e.get("Condition")
+            if cond is None:
+                return np.ones(n_blocks, dtype=bool)
+            ks = _probed_string(cond)
+            return np.zeros(n_blocks, dtype=bool) if ks is None else leaf(*ks)
+        if et == "OR":
+            acc = np.zeros(n_blocks, dtype=bool)
+            for c in e.get("Children") or []:
+                acc = acc | walk(c)
+            return acc
+        if et == "AND":
+            acc = np.ones(n_blocks, dtype=bool)
+            for c in e.get("Children") or []:
+                acc = acc & walk(c)
+            return acc
+        return np.zeros(n_blocks, dtype=bool)
+
+    return walk(expr)
+
+
+def survivors_tree(words: np.ndarray, desc: np.ndarray, exprs) -> np.ndarray:
+    """Survivor bitsets [len(exprs)][ceil(n_blocks / 64)] (the layout bsg_probe returns) from the tree-walking evaluator."""
+    n_blocks = len(desc) // 3
+    G = (n_blocks + 63) // 64
+    out = np.zeros((len(exprs), G), dtype=np.uint64)
+    cache: dict = {}
+    for q, e in enumerate(exprs):
+        v = evaluate_tree_blocks(words, desc, e, cache)
+        bits = np.zeros(G * 64, dtype=np.uint8)
+        bits[:n_blocks] = v
+        out[q] = np.packbits(bits, bitorder="little").view(np.uint64)
+    return out

@@ -155,8 +155,11 @@ def test_probe_random_arena_random_trees(ctx, n_blocks, seed):
         got = ctx.probe(aid, n_blocks, terms, ops, poff)
     finally:
         ctx.arena_free(aid)
-    want = O.probe_batch(words, plan.desc.view(O.DESC_DTYPE), terms.view(O.TERM_DTYPE), ops, poff)
+    # the checker walks the expression TREES (oracle.evaluate_tree*, query_exec.go:89-159): nothing of the product's
+    # lowering (compile_queries -> postfix) sits between the expressions and the expected survivor sets
+    want = O.survivors_tree(words, plan.desc.view(O.DESC_DTYPE), exprs)
     assert np.array_equal(got, want)
+    assert np.array_equal(want, O.probe_batch(words, plan.desc.view(O.DESC_DTYPE), terms.view(O.TERM_DTYPE), ops, poff))
     assert want.any() and not want.all()
 
 

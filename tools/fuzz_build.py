@@ -1,7 +1,8 @@
 """Seed sweep of bsg_build over filter sizes (GPU box):  python tools/fuzz_build.py [first_seed] [n_seeds]
 Entry counts from 1 to a few million and false-positive rates from 0.5 to 1e-6 put m anywhere from a few bits to tens of
 megabits: LDS-staged filters, filters just beyond LDS (global atomics by default), large ones (binned by 64 KiB window),
-window counts of 1, 2, many, a last window of a few words; several filters per call; from entry bytes and from
+window counts of 1, 2, many, a last window of a few words; every eighth seed one bitset of 2^31 or 2^33 bits
+(64-bit modulo, sliced global atomics); several filters per call; from entry bytes and from
 precomputed hashes; with the binning threshold at its default and at zero.  Bitsets must equal the oracle's.
 Exits non-zero on the first difference."""
 import os
@@ -43,6 +44,11 @@ def main():
         cursor = 0
         for f in range(n_filters):
             m, k = O.estimate_parameters(max(counts[f], 1), fprs[f])
+            # every eighth seed gives one filter a geometry of 2^31 bits or more (the 64-bit-modulo instantiations): the caller
+            # owns (m, k), the entries do not have to fill it
+            if f == 0 and seed % 8 == 0:
+                m = (1 << 31) + 12345 if seed % 16 else (1 << 33) + 7
+                m += int(rng.integers(0, 1 << 20))
             desc[f] = (cursor, m, k, 0)
             cursor += ((m + 63) // 64 + 15) // 16 * 16
         n_words = max(cursor, 2)
