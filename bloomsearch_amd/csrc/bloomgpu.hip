@@ -1521,16 +1521,23 @@ int32_t probe_arenas(bsg_ctx *ctx, const std::vector<std::shared_ptr<Arena>> &ar
     }
     if (flags & BSG_PROBE_ASYNC) return BSG_OK;
     // k_probe_direct rings a doorbell in page-locked memory when its last workgroup is done: reading our own memory is
-    // cheaper than asking the runtime; the stream is only waited for if the bell does not ring within a millisecond
-    bool rang = !direct_pending.empty();
+    // cheaper than asking the runtime.  Completion is tracked PER DEVICE: eligibility for the one-dispatch path is decided
+    // per device (one group, a small result), so on a context over several devices some shards may have gone direct and
+    // others through the streaming kernels + an asynchronous copy — a device is only excused from the stream wait when
+    // every doorbell it owes has rung (a bell that stays silent for a millisecond falls back to the wait as well).
+    std::vector<uint8_t> rang(nd, 0);
     for (auto &p : direct_pending) {
+        uint32_t di = 0;
+        while (di < nd && ctx->devs[di].get() != p.dev) ++di;
         const auto t0 = std::chrono::steady_clock::now();
+        bool ok = true;
         while (__atomic_load_n(p.flag, __ATOMIC_ACQUIRE) != p.seq) {
-            if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(1000)) { rang = false; break; }
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(1000)) { ok = false; break; }
         }
-        if (!rang) break;
+        if (di < nd) rang[di] = ok ? std::max<uint8_t>(rang[di], 1) : 2;     // 2: a bell of this device stayed silent
     }
-    for (uint32_t di = 0; di < nd && !rang; ++di) {
+    for (uint32_t di = 0; di < nd; ++di) {
+        if (rang[di] == 1) continue;                                          // every result of this device is in host memory
         Device &d = *ctx->devs[di];
         std::lock_guard<std::mutex> lk(d.mu);
         if (int32_t rc = use_device(d)) return rc;

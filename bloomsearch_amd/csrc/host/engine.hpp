@@ -357,10 +357,11 @@ public:
             for (size_t i = 0; i < scan.size(); ++i) hit[i] = matcher.match(*scan[i]);
         if (regex) {
             // the regex patterns only run on rows the bloom tree kept AND — when the device matcher is on — on rows whose
-            // guard fields exist: the field guard the probe already used, evaluated per row by k_match_rows
+            // guard fields exist: the field guard the probe already used, evaluated per row by k_match_rows.  Only when every
+            // regex node translated into the guard (regex_guard_is_exact): the reference prunes files and blocks with it, never rows
             std::vector<uint8_t> cand(scan.size(), 1);
             bool guard_on_device = false;
-            if (cfg_.device_match && has_guard && !scan.empty()) {
+            if (cfg_.device_match && has_guard && regex_guard_is_exact(*regex) && !scan.empty()) {
                 RowMatcher guard_host(&guard);
                 if (int32_t rc = match_rows_device(&guard, scan, guard_host, cand, guard_on_device)) return rc;
                 if (!guard_on_device) std::fill(cand.begin(), cand.end(), 1);

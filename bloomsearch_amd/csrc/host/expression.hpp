@@ -175,6 +175,21 @@ inline bool regex_to_bloom_field_expression(const RegexExpression &e, BloomExpre
         return false;
     }
 }
+// True when EVERY node of the regex tree has a counterpart in the guard (no nil condition, no unknown node type).  Only then
+// is the guard a necessary condition of the regex tree for a single ROW: a dropped child changes an Or's meaning
+// (Or(<nil condition>, FieldRegex(f, ..)) is true for every row, its guard Or(Field(f)) is not).  The reference uses the
+// guard for files and blocks only (query_exec.go:220); the engine mirror's per-row pre-selection is gated on this.
+inline bool regex_guard_is_exact(const RegexExpression &e)
+{
+    switch (e.type) {
+    case RegexType::Condition: return e.has_condition;
+    case RegexType::And:
+    case RegexType::Or:
+        for (const RegexExpression &c : e.children) if (!regex_guard_is_exact(c)) return false;
+        return true;
+    default: return false;
+    }
+}
 // RegexFieldGuardBloomQuery (query.go:698-707): nil query / nil expression / untranslatable => no guard
 inline bool regex_field_guard(const RegexExpression *regex, BloomExpression &out)
 {
@@ -193,6 +208,12 @@ inline bool and_bloom_queries(const BloomExpression *left, const BloomExpression
 // The regex half of the final row test (row_matcher.go:548-573): a condition holds when its pattern matches the text of any
 // primitive at or beneath the field path (decoded text for strings, the raw literal for numbers and booleans; null never).
 // Patterns are compiled with std::regex (ECMAScript): the mirror covers the common subset it shares with Go's RE2 syntax.
+// SUPPORTED SUBSET (stated, not discovered): literals, ., character classes incl. \\d \\w \\s and ranges, anchors ^ $, groups
+// ( ) and (?: ), alternation, greedy and lazy quantifiers * + ? {n,m}, and ONE leading (?i).  Matching is per byte on UTF-8
+// (RE2 matches runes: a multi-byte character inside a class or under '.' differs).  NOT supported — query() answers
+// "regex pattern does not compile" where the reference accepts them: \\pL / \\p{..}, (?s) (?m) (?U) and inline flags other than
+// a leading (?i), named groups (?P<n>..), \\Q..\\E, \\z, \\C.  A Go host keeps its own regexp; this mirror exists for the parity
+// tests of the DEVICE path (the field guard and the bloom side of regex queries), which use patterns inside the subset.
 class RegexRowMatcher {
 public:
     explicit RegexRowMatcher(const RegexExpression *e)
@@ -211,7 +232,7 @@ public:
             for (size_t i = 0; i < conds_.size(); ++i) {
                 if (sat_[i]) continue;
                 const std::string &f = conds_[i]->field;
-                const bool under = em.path == f || (em.path.size() > f.size() && em.path.compare(0, f.size(), f) == 0 && em.path[f.size()] == '.');
+                const bool under = em.path == f || (em.path.size() > f.size() && em.path.compare(0, f.size(), f) == 0 && em.path[f.size()] == kDelimiter);   // the walker's delimiter (walker.hpp), not a literal
                 if (under && std::regex_search(em.text.begin(), em.text.end(), res_[i])) sat_[i] = 1;
             }
             return true;

@@ -177,7 +177,9 @@ BSG_API int32_t bsg_arena_load_sections(bsg_ctx *ctx, const uint8_t *region, uin
  * reference), in any order, skipping what it does not need; a section is decoded as soon as its last byte has
  * arrived, while the next chunk is still being copied.
  *   begin : sec_begin[b] / sec_end[b] = FILE offsets of candidate block b's section (equal = no section)
- *   append: bytes[0 .. len) = file bytes [file_offset, file_offset + len); copied out before the call returns
+ *   append: bytes[0 .. len) = file bytes [file_offset, file_offset + len); copied out before the call returns.  Ranges that
+ *           were handed over before are ignored: a byte's FIRST delivery is final (a re-read after a bad read must go
+ *           through a new stream)
  *   finish: out_status[n_blocks] as above, the arena id; the stream id is consumed (abort discards it instead) */
 BSG_API int32_t bsg_arena_stream_begin(bsg_ctx *ctx, const uint64_t *sec_begin, const uint64_t *sec_end, uint32_t n_blocks,
                                        uint64_t *out_stream_id);

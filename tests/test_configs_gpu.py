@@ -539,3 +539,28 @@ def test_many_term_mode_every_compaction_depth(ctx, n_terms):
             ctx.set_lab(1, 2)
             ctx.set_gather_cost(256)
             ctx.arena_free(aid)
+
+
+def test_shards_that_disagree_on_the_one_dispatch_path():
+    """A context over two devices where device 0 holds 65 shards (two launch groups: streaming kernels + an asynchronous
+    copy) and device 1 holds one (k_probe_direct + doorbell): the doorbell of device 1 must not excuse device 0 from its
+    stream wait (round-2 advice: survivors were read before their copy had landed)."""
+    rng = np.random.default_rng(5)
+    with Context((0, 0)) as mctx:
+        plans = []
+        for i in range(65):
+            n_blocks = 2 if i == 40 else 1                     # only arena 40 has a block for device 1
+            plan, _, vocab = H.make_random_arena(rng, n_blocks, absent_frac=0.0, max_tokens=300, vocab_size=50)
+            words = mctx.build(plan.blob, plan.off, plan.fstart, plan.desc, plan.n_words)
+            plans.append((plan, words, mctx.arena_load(words, plan.desc)))
+        exprs = [Q.Token(vocab[i]) for i in range(6)] + [Q.And(Q.Token(vocab[0]), Q.Field("f1")), None]
+        cb = Q.compile_queries(exprs)
+        ops, poff, _ = cb.arrays()
+        terms = H.gpu_terms(mctx, cb)
+        assert len(terms) <= 16
+        bid = mctx.batch_create(terms, ops, poff)
+        for _ in range(20):                                     # the race needed the copy to lose against the bell
+            got = mctx.probe_many([p[2] for p in plans], bid, 0, cb.n_queries, [p[0].n_blocks for p in plans])
+            for (pl, wd, _), g in zip(plans, got):
+                assert np.array_equal(g, O.survivors_tree(wd, pl.desc.view(O.DESC_DTYPE), exprs))
+        mctx.batch_free(bid)
