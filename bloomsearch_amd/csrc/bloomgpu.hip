@@ -911,7 +911,7 @@ const bsg::CrcConsts &crc_consts()
             for (uint32_t i = 0; i < 256; ++i) t.table[k][i] = (t.table[k - 1][i] >> 8) ^ t.table[0][t.table[k - 1][i] & 0xFF];
         uint32_t p = 1u << 30;   // x^1
         t.x2n[0] = p;
-        for (int n = 1; n < 32; ++n) t.x2n[n] = p = bsg::crc_multmodp(p, p);
+        for (int n = 1; n < 64; ++n) t.x2n[n] = p = bsg::crc_multmodp(p, p);
         t.skip = bsg::crc_x2nmodp((uint64_t)bsg::kCrcGranule * (bsg::kDecodeThreads - 1), 3, t.x2n);
         for (uint32_t i = 0; i < 256; ++i) t.gpow[i] = bsg::crc_x2nmodp((uint64_t)bsg::kCrcGranule * i, 3, t.x2n);
         for (uint32_t i = 0; i < bsg::kCrcGranule; ++i) t.bpow[i] = bsg::crc_x2nmodp(i, 3, t.x2n);

@@ -952,7 +952,10 @@ constexpr int kDecodeThreads = 256;
 
 struct CrcConsts {
     uint32_t table[8][256];   // slice-by-8 tables
-    uint32_t x2n[32];         // x^(2^i) mod P, reflected (zlib's x2n_table construction)
+    uint32_t x2n[64];         // x^(2^i) mod P, reflected, i < 64: NO periodicity assumed (zlib indexes its 32-entry table with k & 31 because
+                              // x has order 2^32 - 1 under the CRC-32 polynomial; the Castagnoli polynomial is (x + 1) times a primitive
+                              // polynomial of degree 31, so x has order 2^31 - 1 and a period-32 table is wrong from k = 32 on, i.e. for payloads
+                              // of 2^29 bytes and more — found by tests/test_big_m_gpu.py on a 1 GiB filter section)
     uint32_t skip;            // x^(8 * kCrcGranule * (kDecodeThreads - 1)) mod P: a thread's hop between its granules
     uint32_t pad[3];
     uint32_t gpow[256];       // x^(8 * kCrcGranule * t) mod P: thread t's last granule ends t granules before the tail
@@ -980,7 +983,7 @@ __host__ __device__ inline uint32_t crc_x2nmodp(uint64_t n, uint32_t k, const ui
 {
     uint32_t p = 1u << 31;   // x^0
     while (n) {
-        if (n & 1) p = crc_multmodp(x2n[k & 31], p);
+        if (n & 1) p = crc_multmodp(x2n[k & 63], p);   // k < 64 for every n < 2^61 at the k = 3 this file starts from
         n >>= 1;
         ++k;
     }

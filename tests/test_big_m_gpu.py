@@ -85,7 +85,8 @@ def test_64bit_modulo_build_probe_or_and_wire(ctx, m):
                     assert np.array_equal(ctx.probe(aid, n_blocks, terms, ops, poff), w), name + " (k_probe_terms)"
                 finally:
                     ctx.set_lab(3, 16)
-            assert w.any() and not w.all()
+            bits = [(int(x) >> b) & 1 for x in w[:, 0] for b in range(n_blocks)]
+            assert any(bits) and (name == "one query" or not all(bits))        # hits and misses both occur
         # ---- fixed-geometry OR of the two token filters == build of the union at (m, K) ----
         union = sorted(set(per_filter[1]) | set(per_filter[4]))
         ub, uo = pack_entries(union)
