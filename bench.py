@@ -213,7 +213,7 @@ def or_reduce_leg(ctx, plan, B, fpr, n_union, world, log):
 
 
 def or_exchange_leg(ctx, res, state, world, log):
-    """The exchange half of C5, inside the library (bsg_or_allreduce: ncclAllGather over xGMI + k_or_words); the unique id
+    """The exchange half of C5, inside the library (bsg_or_allreduce: slice-wise ncclSend/ncclRecv + k_or_words + ncclAllGather over xGMI); the unique id
     travels over the harness' own channel.  Runs LAST and under a watchdog (main): a collective that never returns must not
     take the probe measurement down with it."""
     import torch
@@ -240,9 +240,13 @@ def or_exchange_leg(ctx, res, state, world, log):
             sys.exit("OR all-reduce lost bits of this rank's partial")
         ctx.comm_destroy()
         res["allreduce_ms"] = float(np.median(ts[1:])) * 1e3
-        res["allreduce_wire_bytes_in_per_gpu"] = (world - 1) * nw * 8
-        res["allreduce_gbps_in_per_gpu"] = (world - 1) * nw * 8 / max(res["allreduce_ms"], 1e-9) / 1e6
-        res["allreduce"] = "bsg_or_allreduce_dev: ncclAllGather (RCCL over xGMI) of %d partials + k_or_words, inside libbloomgpu" % world
+        from bloomsearch_amd import parallel as P
+        wire = P.or_allreduce_wire_bytes(nw, world)      # 2 (world - 1) / world x S: slice exchange + all-gather of reduced slices
+        res["allreduce_wire_bytes_in_per_gpu"] = wire
+        res["allreduce_wire_bytes_allgather_of_partials"] = (world - 1) * nw * 8      # what round 2's schedule moved
+        res["allreduce_gbps_in_per_gpu"] = wire / max(res["allreduce_ms"], 1e-9) / 1e6
+        res["allreduce"] = ("bsg_or_allreduce_dev: grouped ncclSend/ncclRecv of %d slices (slice j -> rank j) + k_or_words + ncclAllGather of the "
+                            "reduced slices (RCCL over xGMI), inside libbloomgpu" % world)
         log("OR all-reduce over %d ranks: %.2f ms" % (world, res["allreduce_ms"]))
     except Exception as exc:  # noqa: BLE001 - reported, not swallowed
         res["allreduce_error"] = repr(exc)

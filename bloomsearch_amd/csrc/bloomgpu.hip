@@ -1731,13 +1731,19 @@ static int32_t or_reduce_shard(bsg_ctx *ctx, Arena &arena, uint32_t di, uint32_t
     if (s.fixed_m[kind] != 0 && (s.fixed_m[kind] + 63) / 64 != n_words)
         return fail(BSG_E_INVALID, "n_words %llu does not match m %llu", (unsigned long long)n_words,
                     (unsigned long long)s.fixed_m[kind]);
-    const uint32_t gx = (uint32_t)(((n_words + 1) / 2 + 255) / 256);
-    uint32_t group = bsg::kOrBlocksPerGroup;
-    if (const char *e = getenv("BSG_LAB_OR_GROUP")) group = std::max(1, atoi(e));   // lab only
+    const uint64_t gx64 = ((n_words + 1) / 2 + bsg::kOrThreads - 1) / bsg::kOrThreads;
+    if (gx64 > 0x7FFFFFFFull) return fail(BSG_E_UNSUPPORTED, "bitset of %llu words is too large for one OR launch", (unsigned long long)n_words);
+    const uint32_t gx = (uint32_t)std::max<uint64_t>(gx64, 1);
+    // one wave per workgroup: aim at ~8 waves per CU over the whole grid, in groups of 16..kOrMaxGroup blocks
+    const uint64_t want_y = std::max<uint64_t>(1, ((uint64_t)d.n_cus * 8 + gx - 1) / gx);
+    uint32_t group = (uint32_t)std::min<uint64_t>(bsg::kOrMaxGroup, std::max<uint64_t>(16, (s.n_blocks + want_y - 1) / want_y));
+    if (gx >= (uint64_t)d.n_cus * 8) group = std::max(group, std::min(bsg::kOrBlocksPerGroup, bsg::kOrMaxGroup));
+    if (const char *e = getenv("BSG_LAB_OR_GROUP")) group = std::min<uint32_t>(bsg::kOrMaxGroup, std::max(1, atoi(e)));   // lab only
     const uint32_t gy = std::max(1u, (s.n_blocks + group - 1) / group);
+    if (gy > 65535) return fail(BSG_E_UNSUPPORTED, "%u blocks in groups of %u exceed one OR launch", s.n_blocks, group);
     if (gy > 1) HIP_TRY(hipMemsetAsync(d_out, 0, n_words * 8, d.stream));
     if (!d.kb0) { HIP_TRY(hipEventCreate(&d.kb0)); HIP_TRY(hipEventCreate(&d.kb1)); }
-    hipExtLaunchKernelGGL(bsg::k_or_reduce_blocks, dim3(std::max(gx, 1u), gy), dim3(256), 0, d.stream, d.kb0, d.kb1, 0,
+    hipExtLaunchKernelGGL(bsg::k_or_reduce_blocks, dim3(gx, gy), dim3(bsg::kOrThreads), 0, d.stream, d.kb0, d.kb1, 0,
                           s.d_words, s.d_desc, s.n_blocks, kind, n_words, d_out, group);
     HIP_TRY(hipGetLastError());
     d.or_pending = true;

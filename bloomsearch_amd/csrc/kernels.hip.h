@@ -1221,33 +1221,46 @@ __global__ __launch_bounds__(256) void k_or_words(uint64_t *dst, const uint64_t 
 
 // OR of one kind's filter across all blocks of a shard (fixed geometry):
 // out[i] = OR_b words[desc[b*3+kind].word_off + i].
-// grid.x covers the words two at a time (16-byte loads; filters start on 128-byte boundaries), grid.y covers groups of
-// kOrBlocksPerGroup blocks: a thread issues that many independent loads, ORs them and — when there is more than one
-// group — merges into the zeroed output with atomicOr (distinct addresses per lane: nothing hot).
-constexpr uint32_t kOrBlocksPerGroup = 64;   // measured at 1 000 x 360 KB filters: 16 -> 97 us, 32 -> 94, 64 -> 79, 128 -> 117, one group -> 687
+// A pure read-once stream, so it is written like one: a workgroup is ONE wave that owns 64 x 16 bytes of the bitset and a
+// group of blocks; the group's word offsets are read into LDS first (the descriptor load is off the critical path of
+// every data load), then kOrInFlight independent 16-byte non-temporal loads per lane are in flight at a time (16 KiB per
+// wave).  Groups merge into the zeroed output with atomicOr (distinct addresses per lane: nothing hot).
+// Measured on MI355X, 1 000 filters x 360 KB (tools/or_lab.hip): round 2's kernel (256 threads, descriptor chased per
+// block, 4 loads in flight) 79 us = 0.57 of peak; this one 57.7 us = 0.78 at groups of 128-256 blocks; 16 -> 8 loads in
+// flight: 64 us; LDS-DMA (global_load_lds nt, OR out of LDS): 62-66 us — the read-back costs more than the VGPRs it saves.
+constexpr uint32_t kOrThreads = 64;
+constexpr uint32_t kOrInFlight = 16;
+constexpr uint32_t kOrMaxGroup = 256;        // blocks one workgroup folds (LDS offsets); the host picks the group for ~8 waves per CU
+constexpr uint32_t kOrBlocksPerGroup = 128;  // default when the grid is wide enough without splitting further
 
-__global__ __launch_bounds__(256) void k_or_reduce_blocks(const uint64_t *words, const DevDesc *desc,
-                                                          uint32_t n_blocks, uint32_t kind, uint64_t n_words,
-                                                          uint64_t *out, uint32_t group)
+__global__ __launch_bounds__(kOrThreads) void k_or_reduce_blocks(const uint64_t *words, const DevDesc *desc,
+                                                                 uint32_t n_blocks, uint32_t kind, uint64_t n_words,
+                                                                 uint64_t *out, uint32_t group)
 {
-    const uint64_t pair = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;   // words 2*pair, 2*pair + 1
-    if (pair * 2 >= n_words) return;
+    __shared__ uint64_t offs[kOrMaxGroup];
     const uint32_t b0 = blockIdx.y * group;
-    const uint32_t b1 = min(n_blocks, b0 + group);
-    const bool two = pair * 2 + 1 < n_words;
-    uint64_t lo = 0, hi = 0;
-#pragma unroll 4
-    for (uint32_t b = b0; b < b1; ++b) {
-        const DevDesc d = desc[(uint64_t)b * 3 + kind];
-        if (d.m == 0) continue;
-        const uint64_t *p = words + d.word_off + pair * 2;
-        if (two) {
-            const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(p);
-            lo |= v.x; hi |= v.y;
-        } else {
-            lo |= p[0];
-        }
+    const uint32_t nb = min(group, n_blocks - b0);
+    for (uint32_t i = threadIdx.x; i < nb; i += kOrThreads) {
+        const DevDesc d = desc[(uint64_t)(b0 + i) * 3 + kind];
+        offs[i] = d.m ? d.word_off : ~0ull;
     }
+    __syncthreads();
+    const uint64_t pair = (uint64_t)blockIdx.x * kOrThreads + threadIdx.x;   // words 2*pair, 2*pair + 1
+    if (pair * 2 >= n_words) return;
+    const bool two = pair * 2 + 1 < n_words;     // (filters start on 128-byte boundaries and are padded to them: the 16-byte load of a last odd word stays inside)
+    u32x4 acc = {0, 0, 0, 0};
+    for (uint32_t i = 0; i < nb; i += kOrInFlight) {
+        u32x4 v[kOrInFlight];
+#pragma unroll
+        for (uint32_t u = 0; u < kOrInFlight; ++u) {
+            const uint64_t o = i + u < nb ? offs[i + u] : ~0ull;
+            if (o != ~0ull) v[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(words + o) + pair);
+            else v[u] = u32x4{0, 0, 0, 0};
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < kOrInFlight; ++u) acc |= v[u];
+    }
+    const uint64_t lo = (uint64_t)acc.x | ((uint64_t)acc.y << 32), hi = (uint64_t)acc.z | ((uint64_t)acc.w << 32);
     if (gridDim.y == 1) {
         out[pair * 2] = lo;
         if (two) out[pair * 2 + 1] = hi;

@@ -6,8 +6,9 @@ is a host-side gather of the surviving-block bitsets — no data-path collective
 
 The single real exchange on this path is the fixed-geometry OR-reduce of partial file-level bitsets
 (an extension — the reference rebuilds instead of OR-ing, merge.go:447-453).  RCCL
-has no bitwise-OR reduction, so it is an all_gather of the G partial bitsets followed by a local OR
-kernel (bsg_or_words_dev on the GPU; torch.bitwise_or on the gloo/CPU test path).
+has no bitwise-OR reduction, so it is reduce-scatter + all-gather with the OR done locally: slice j of
+every partial travels to rank j, is OR-ed there (bsg_or_words_dev on the GPU; torch.bitwise_or on the
+gloo/CPU test path), and the reduced slices are all-gathered: 2 (G - 1) / G x S on the wire per GPU.
 """
 from __future__ import annotations
 
@@ -55,25 +56,48 @@ def gather_survivors(local: np.ndarray, n_blocks: int, dst: int = 0):
     return interleave_survivors(parts, n_blocks)
 
 
+def or_slice_len(n_words: int, world: int) -> int:
+    """Words per slice of the OR all-reduce's slice schedule: ceil(n_words / world)."""
+    return (n_words + world - 1) // world
+
+
+def or_allreduce_wire_bytes(n_words: int, world: int) -> int:
+    """Bytes one rank receives (and sends) in the slice schedule: (world - 1) slices in the exchange + (world - 1) reduced
+    slices in the all-gather = 2 (world - 1) / world x S, against (world - 1) x S for an all-gather of the full partials."""
+    return 0 if world <= 1 else 2 * (world - 1) * or_slice_len(n_words, world) * 8
+
+
 def or_allreduce_(words, ctx=None):
     """In-place bitwise-OR all-reduce of a 1-D int64 torch tensor of bitset words (all ranks same length).
-    all_gather over RCCL/xGMI (each GPU receives (G-1)/G of the result over its links) + one local OR."""
+    RCCL has no bitwise-OR reduction, so it is reduce-scatter + all-gather with the OR spelled out (the schedule
+    bsg_or_allreduce runs inside the library, csrc/comm_api.inc): all_to_all of the `world` slices of every partial
+    (rank j receives slice j of everyone), a local OR of the received slices (bsg_or_words_dev on the GPU; torch.bitwise_or
+    on the gloo/CPU test path), all_gather of the reduced slices."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size()
     if world == 1:
         return words
-    flat = torch.empty(world * words.numel(), dtype=words.dtype, device=words.device)
-    dist.all_gather_into_tensor(flat, words)
-    gathered = flat.view(world, words.numel())
+    rank = dist.get_rank()
+    n = words.numel()
+    L = or_slice_len(n, world)
+    work = torch.zeros(world * L, dtype=words.dtype, device=words.device)
+    work[:n] = words
+    inbox = torch.empty_like(work)
+    dist.all_to_all_single(inbox, work)                      # inbox[j L : (j + 1) L] = slice `rank` of rank j's partial
+    mine = work[rank * L: (rank + 1) * L]
     if words.is_cuda:
         if ctx is None:
             raise RuntimeError("a bloomgpu Context is required for the device OR (no torch fallback on the GPU path)")
         torch.cuda.current_stream().synchronize()
-        ctx.or_words_dev(words.data_ptr(), gathered.data_ptr(), words.numel(), world)
+        # the inbox holds my own slice too (slot `rank`): OR-ing it in again is harmless
+        ctx.or_words_dev(mine.data_ptr(), inbox.data_ptr(), L, world)
     else:
-        acc = gathered[0]
+        acc = inbox.view(world, L)[0]
         for r in range(1, world):
-            acc = torch.bitwise_or(acc, gathered[r])
-        words.copy_(acc)
+            acc = torch.bitwise_or(acc, inbox.view(world, L)[r])
+        mine.copy_(acc)
+    out = torch.empty_like(work)
+    dist.all_gather_into_tensor(out, mine.contiguous())
+    words.copy_(out[:n])
     return words

@@ -263,8 +263,9 @@ BSG_API int32_t bsg_or_reduce_dev(bsg_ctx *ctx, uint64_t arena_id, uint32_t kind
 BSG_API int32_t bsg_last_or_ms(bsg_ctx *ctx, float *or_ms);
 
 /* ---- the OR-reduce across GPUs: RCCL over xGMI inside the library (a Go host cannot call torch.distributed) ----
- * RCCL has no bitwise-OR reduction: the all-reduce is ncclAllGather of the ranks' partial bitsets (each GPU receives
- * (world - 1) / world of the result over its point-to-point links in parallel) + one local OR kernel.  librccl is bound
+ * RCCL has no bitwise-OR reduction: the all-reduce is reduce-scatter + all-gather with the OR done by a kernel of the library —
+ * slice j of every rank's partial bitset travels to rank j (grouped ncclSend / ncclRecv, one slice per point-to-point link),
+ * is OR-ed there, and the reduced slices are ncclAllGather-ed: 2 (world - 1) / world of the bitset per GPU on the wire.  librccl is bound
  * at run time; without it these calls fail with BSG_E_UNSUPPORTED and everything else keeps working.
  *   one process per GPU : rank 0 calls bsg_comm_unique_id and hands the 128 bytes to the other ranks (any channel);
  *                         every rank calls bsg_comm_init(ctx, id, rank, world) on its single-device context.

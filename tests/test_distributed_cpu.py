@@ -1,5 +1,5 @@
 """world_size-2 gloo tests of the N>1 plumbing (runs on CPU): round-robin block sharding, the host-side
-gather/interleave of survivor bitsets, and the all_gather + OR reduce of partial bitsets.  The per-rank
+gather/interleave of survivor bitsets, and the OR all-reduce of partial bitsets (slice exchange + local OR + all-gather).  The per-rank
 "device" results are stood in by the oracle here (the GPU kernels cannot run on this host); what is under
 test is the distributed layer in bloomsearch_amd/parallel.py."""
 import os
@@ -77,6 +77,17 @@ def _worker(rank, world, port, n_blocks, q):
         for s in universe:
             full.add(s)
         ok = ok and np.array_equal(t.numpy().view(np.uint64), full.words)
+        # the slice schedule with word counts that do not divide by the world size (a padded last slice), incl. 1 word
+        for nw in (1, 2, 3, 1001):
+            rng = np.random.default_rng(1000 + nw)
+            parts = [rng.integers(0, 1 << 62, size=nw, dtype=np.int64) & rng.integers(0, 1 << 62, size=nw, dtype=np.int64) for _ in range(world)]
+            t = torch.from_numpy(parts[rank].copy())
+            P.or_allreduce_(t)
+            want = parts[0]
+            for p2 in parts[1:]:
+                want = want | p2
+            ok = ok and np.array_equal(t.numpy(), want)
+        ok = ok and P.or_allreduce_wire_bytes(1001, 2) == 2 * 1 * 501 * 8 and P.or_allreduce_wire_bytes(8000, 8) == 2 * 7 * 1000 * 8
         q.put((rank, bool(ok)))
     except Exception as exc:   # report instead of letting the parent wait out its timeout
         q.put((rank, repr(exc)))
