@@ -15,6 +15,7 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -25,6 +26,7 @@
 #include <mutex>
 #include <random>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -195,7 +197,8 @@ struct Device {
     uint32_t *d_lower = nullptr;              // unicode.ToLower table for k_ingest_rows (512 KB)
     bsg::CrcConsts *d_crc = nullptr;          // CRC32C slice-by-8 tables + x^(2^i) mod P (k_decode_sections)
     hipEvent_t kb0 = nullptr, kb1 = nullptr;  // start/stop timestamps of the last k_build / k_hash_entries dispatch
-    float last_build_ms = 0.f, last_hash_ms = 0.f, last_decode_ms = 0.f, last_or_ms = 0.f, last_encode_ms = 0.f, last_match_ms = 0.f;
+    std::atomic<uint64_t> calls{0};   // construct / match parts this device has served (bsg_device_calls)
+    float last_or_ms = 0.f;    // this device's last k_or_reduce_blocks (the context keeps the slowest device's: bsg_last_or_ms)
     bool or_pending = false;   // kb0/kb1 hold an un-read k_or_reduce_blocks dispatch
 };
 
@@ -272,6 +275,14 @@ struct bsg_ctx {
     uint64_t bin_min_locs = 4ull << 20;             // fewer locations than this: global atomics (bsg_set_lab key 6)
     uint64_t bin_scratch_bytes = kBinScratchBytes;  // 0: bitsets beyond LDS are built with global atomics (bsg_set_lab key 2)
     uint32_t fuse_max_arenas = 4; // groups up to this many arenas ride fused (probe of group i + eval of group i-1)
+    // write side / matcher over several devices: a call large enough is cut into one part per device (contiguous runs of
+    // filters / sets / rows), each part on a thread of its own; smaller calls take ONE device, chosen round-robin among
+    // the ones whose lock is free, so independent callers (flush worker, merge, block workers) spread over the context
+    std::atomic<uint32_t> next_dev{0};
+    uint64_t shard_min_entries = 1ull << 18;   // bsg_hash_entries / bsg_build*: fewer entries stay on one device (bsg_set_lab key 7)
+    uint64_t shard_min_row_bytes = 8ull << 20; // bsg_ingest_rows / bsg_match_rows: fewer row bytes stay on one device (bsg_set_lab key 8)
+    // device time of the most recent call of each family: the slowest device that took part (bsg_last_*_ms)
+    float last_build_ms = 0.f, last_hash_ms = 0.f, last_decode_ms = 0.f, last_or_ms = 0.f, last_encode_ms = 0.f, last_match_ms = 0.f;
 };
 
 namespace {
@@ -289,6 +300,7 @@ void free_all_streams(bsg_ctx *ctx);   // stream_api.inc
 int32_t ensure_lower_table(Device &d);   // ingest_api.inc: the unicode.ToLower table the walkers fold with
 
 struct SectionsOut { uint8_t *region; uint64_t cap; uint64_t *sec_off; };   // encode_api.inc
+uint64_t section_len(const bsg_filter_desc *d3);
 int32_t encode_sections_device(Device &d, const uint64_t *d_words, const bsg_filter_desc *desc, uint32_t n_blocks,
                                uint8_t *out_region, uint64_t region_cap, uint64_t *out_sec_off, float *ms);
 
@@ -296,6 +308,58 @@ int32_t use_device(Device &d)
 {
     HIP_TRY(hipSetDevice(d.id));
     return BSG_OK;
+}
+
+// The device for a call that stays on ONE device of the context: round-robin, preferring a device nobody holds right now
+// (the flush worker, a merge and the block workers of concurrent queries then land on different GPUs).  The answer is a
+// hint — the caller takes the device's lock the usual way.
+uint32_t pick_device(bsg_ctx *ctx)
+{
+    const uint32_t nd = (uint32_t)ctx->devs.size();
+    if (nd == 1) return 0;
+    const uint32_t start = ctx->next_dev.fetch_add(1, std::memory_order_relaxed) % nd;
+    for (uint32_t i = 0; i < nd; ++i) {
+        const uint32_t di = (start + i) % nd;
+        if (ctx->devs[di]->mu.try_lock()) { ctx->devs[di]->mu.unlock(); return di; }
+    }
+    return start;
+}
+
+// part(i) for i < n, parts 1 .. n-1 on threads of their own and part 0 on the caller's; every thread reports into the
+// error scope the call was made on.  First failing part's status.
+template <class F>
+int32_t run_parts(uint32_t n, F &&part)
+{
+    if (n == 0) return BSG_OK;
+    if (n == 1) return part(0u);
+    std::vector<int32_t> rc(n, BSG_OK);
+    bsg_ctx *scope = tl_scope;
+    std::vector<std::thread> th;
+    th.reserve(n - 1);
+    for (uint32_t i = 1; i < n; ++i)
+        th.emplace_back([&rc, &part, scope, i]() { tl_scope = scope; rc[i] = part(i); tl_scope = nullptr; });
+    rc[0] = part(0u);
+    for (auto &t : th) t.join();
+    for (uint32_t i = 0; i < n; ++i) if (rc[i]) return rc[i];
+    return BSG_OK;
+}
+
+// cuts [0, n) items with the given costs into at most `parts` contiguous runs of about equal cost; returns the run
+// boundaries (size runs + 1).  `unit`: boundaries fall on multiples of it (3 = whole blocks of filters).
+std::vector<uint32_t> balanced_cuts(const std::vector<uint64_t> &cost, uint32_t parts, uint32_t unit = 1)
+{
+    const uint32_t n = (uint32_t)cost.size();
+    std::vector<uint32_t> cuts{0};
+    uint64_t total = 0;
+    for (uint64_t c : cost) total += c;
+    uint64_t acc = 0;
+    uint32_t made = 1;
+    for (uint32_t i = 0; i < n && made < parts; ++i) {
+        acc += cost[i];
+        if ((i + 1) % unit == 0 && i + 1 < n && acc * parts >= total * made) { cuts.push_back(i + 1); ++made; }
+    }
+    cuts.push_back(n);
+    return cuts;
 }
 
 void free_arena(bsg_ctx *ctx, Arena &a)
@@ -622,6 +686,29 @@ int32_t bsg_estimate_parameters(uint64_t n, double p, uint64_t *m, uint64_t *k)
     return BSG_OK;
 }
 
+// entries [e0, e1) on one device
+static int32_t hash_entries_on(Device &d, const uint8_t *bytes, const uint32_t *offsets, uint32_t e0, uint32_t e1, uint64_t *out_h, float *ms)
+{
+    const uint32_t n = e1 - e0, b0 = offsets[e0], n_bytes = offsets[e1] - b0;
+    d.calls.fetch_add(1, std::memory_order_relaxed);
+    std::lock_guard<std::mutex> lk(d.mu);
+    if (int32_t rc = use_device(d)) return rc;
+    HIP_TRY(d.stage_a.reserve((size_t)n_bytes + 64));
+    HIP_TRY(d.stage_off.reserve((size_t)n + 1));
+    HIP_TRY(d.stage_h.reserve((size_t)n * 4));
+    if (n_bytes) HIP_TRY(hipMemcpyAsync(d.stage_a.p, bytes + b0, n_bytes, hipMemcpyHostToDevice, d.stream));
+    HIP_TRY(hipMemcpyAsync(d.stage_off.p, offsets + e0, ((size_t)n + 1) * 4, hipMemcpyHostToDevice, d.stream));
+    if (!d.kb0) { HIP_TRY(hipEventCreate(&d.kb0)); HIP_TRY(hipEventCreate(&d.kb1)); }
+    // the offsets stay absolute: the byte pointer is moved back by the run's first offset instead (never dereferenced below the buffer)
+    hipExtLaunchKernelGGL(bsg::k_hash_entries, dim3((n + 255) / 256), dim3(256), 0, d.stream, d.kb0, d.kb1, 0,
+                          (const uint8_t *)d.stage_a.p - b0, (const uint32_t *)d.stage_off.p, n, d.stage_h.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out_h + (size_t)e0 * 4, d.stage_h.p, (size_t)n * 32, hipMemcpyDeviceToHost, d.stream));
+    HIP_TRY(hipStreamSynchronize(d.stream));
+    HIP_TRY(hipEventElapsedTime(ms, d.kb0, d.kb1));
+    return BSG_OK;
+}
+
 int32_t bsg_hash_entries(bsg_ctx *ctx, const uint8_t *bytes, const uint32_t *offsets, uint32_t n_entries,
                          uint64_t *out_h)
 {
@@ -633,21 +720,18 @@ int32_t bsg_hash_entries(bsg_ctx *ctx, const uint8_t *bytes, const uint32_t *off
         if (offsets[e + 1] < offsets[e]) return fail(BSG_E_INVALID, "offsets not monotone at %u", e);
     const uint32_t n_bytes = offsets[n_entries];
     if (n_bytes && !bytes) return fail(BSG_E_INVALID, "bytes is null");
-    Device &d = *ctx->devs[0];
-    std::lock_guard<std::mutex> lk(d.mu);
-    if (int32_t rc = use_device(d)) return rc;
-    HIP_TRY(d.stage_a.reserve((size_t)n_bytes + 64));
-    HIP_TRY(d.stage_off.reserve((size_t)n_entries + 1));
-    HIP_TRY(d.stage_h.reserve((size_t)n_entries * 4));
-    if (n_bytes) HIP_TRY(hipMemcpyAsync(d.stage_a.p, bytes, n_bytes, hipMemcpyHostToDevice, d.stream));
-    HIP_TRY(hipMemcpyAsync(d.stage_off.p, offsets, ((size_t)n_entries + 1) * 4, hipMemcpyHostToDevice, d.stream));
-    if (!d.kb0) { HIP_TRY(hipEventCreate(&d.kb0)); HIP_TRY(hipEventCreate(&d.kb1)); }
-    hipExtLaunchKernelGGL(bsg::k_hash_entries, dim3((n_entries + 255) / 256), dim3(256), 0, d.stream, d.kb0, d.kb1, 0,
-                          (const uint8_t *)d.stage_a.p, (const uint32_t *)d.stage_off.p, n_entries, d.stage_h.p);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(out_h, d.stage_h.p, (size_t)n_entries * 32, hipMemcpyDeviceToHost, d.stream));
-    HIP_TRY(hipStreamSynchronize(d.stream));
-    HIP_TRY(hipEventElapsedTime(&d.last_hash_ms, d.kb0, d.kb1));
+    // a large batch is cut into one contiguous run of entries per device; a small one takes one device
+    const uint32_t nd = (uint32_t)ctx->devs.size();
+    const uint32_t parts = (nd > 1 && n_entries >= ctx->shard_min_entries) ? std::min<uint32_t>(nd, n_entries) : 1;
+    std::vector<float> ms(parts, 0.f);
+    const uint32_t first = parts == 1 ? pick_device(ctx) : 0;
+    const int32_t rc = run_parts(parts, [&](uint32_t i) -> int32_t {
+        const uint32_t e0 = (uint32_t)((uint64_t)n_entries * i / parts), e1 = (uint32_t)((uint64_t)n_entries * (i + 1) / parts);
+        return hash_entries_on(*ctx->devs[(first + i) % nd], bytes, offsets, e0, e1, out_h, &ms[i]);
+    });
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->last_hash_ms = *std::max_element(ms.begin(), ms.end());
     return BSG_OK;
 }
 
@@ -685,32 +769,33 @@ static bool binned_build_fits(const bsg_ctx *root, uint64_t m, uint64_t n_entrie
            n_locs * 4 <= root->bin_scratch_bytes;
 }
 
-static int32_t build_common(bsg_ctx *ctx, const uint8_t *bytes, const uint32_t *offsets, const uint64_t *h,
-                            uint32_t n_entries, const uint32_t *fstart, const bsg_filter_desc *desc,
-                            uint32_t n_filters, uint64_t *out_words, uint64_t n_words, const SectionsOut *sections = nullptr)
+// One part of a build: filters [f0, f1) — whose entries [fstart[f0], fstart[f1]) are contiguous — on one device.  The
+// part's filters occupy words [w_lo, w_hi) of the caller's arena (disjoint from every other part's); sections: the part's
+// blocks f0 / 3 .. f1 / 3 are serialised at region + region_off (their offsets, relative to the part, into sec_off_local).
+struct BuildPart {
+    uint32_t f0 = 0, f1 = 0;
+    uint64_t w_lo = 0, w_hi = 0;
+    uint64_t region_off = 0, region_len = 0;
+    std::vector<uint64_t> sec_off_local;
+    float ms = 0.f, encode_ms = 0.f;
+};
+
+static int32_t build_on_device(bsg_ctx *ctx, Device &d, BuildPart &P, const uint8_t *bytes, const uint32_t *offsets, const uint64_t *h,
+                               const uint32_t *fstart, const bsg_filter_desc *desc, uint64_t *out_words, const SectionsOut *sections)
 {
-    BSG_ENTER(ctx);
-    if (!ctx) return fail(BSG_E_INVALID, "ctx is null");
-    if (n_filters == 0) { if (sections) sections->sec_off[0] = 0; return BSG_OK; }
-    if (!fstart || !desc || (!out_words && !sections)) return fail(BSG_E_INVALID, "null argument");
-    if (int32_t rc = validate_descs(desc, n_filters, n_words)) return rc;
-    if (fstart[n_filters] != n_entries) return fail(BSG_E_INVALID, "filter_entry_start[n_filters] != n_entries");
-    for (uint32_t f = 0; f < n_filters; ++f)
-        if (fstart[f + 1] < fstart[f]) return fail(BSG_E_INVALID, "filter_entry_start not monotone at %u", f);
-    uint32_t n_bytes = 0;
-    if (!h) {
-        if (n_entries && !offsets) return fail(BSG_E_INVALID, "offsets is null");
-        for (uint32_t e = 0; e < n_entries; ++e)
-            if (offsets[e + 1] < offsets[e]) return fail(BSG_E_INVALID, "offsets not monotone at %u", e);
-        n_bytes = n_entries ? offsets[n_entries] : 0;
-        if (n_bytes && !bytes) return fail(BSG_E_INVALID, "bytes is null");
-    }
-    std::vector<DevDesc> dd(n_filters);
+    const uint32_t f0 = P.f0, f1 = P.f1, nf = f1 - f0;
+    const uint32_t e0 = fstart[f0], e1 = fstart[f1], ne_all = e1 - e0;
+    const uint32_t b0 = (!h && ne_all) ? offsets[e0] : 0, n_bytes = (!h && ne_all) ? offsets[e1] - b0 : 0;
+    const uint64_t n_words = std::max<uint64_t>(P.w_hi - P.w_lo, 2);
+    std::vector<DevDesc> dd(nf);
+    std::vector<bsg_filter_desc> local(nf);          // the part's descriptors with word offsets relative to the part
     std::vector<bsg::BuildItem> items;
     std::vector<uint32_t> binned;                  // bitsets beyond LDS: assembled window by window (bin_build.hip.h)
     uint64_t max_staged = 0;
-    for (uint32_t f = 0; f < n_filters; ++f) {
-        dd[f] = DevDesc{desc[f].word_off, desc[f].m, barrett_magic(desc[f].m), desc[f].k, 0};
+    for (uint32_t f = f0; f < f1; ++f) {
+        local[f - f0] = desc[f];
+        if (desc[f].m) local[f - f0].word_off = desc[f].word_off - P.w_lo;
+        dd[f - f0] = DevDesc{local[f - f0].word_off, desc[f].m, barrett_magic(desc[f].m), desc[f].k, 0};
         if (desc[f].m == 0) continue;
         const uint64_t nw = (desc[f].m + 63) / 64;
         if (nw <= kLdsCapWords) {
@@ -723,7 +808,7 @@ static int32_t build_common(bsg_ctx *ctx, const uint8_t *bytes, const uint32_t *
                 items.push_back({f, e, std::min(fstart[f + 1], e + kBuildSliceEntries), 0u});
         }
     }
-    Device &d = *ctx->devs[0];
+    d.calls.fetch_add(1, std::memory_order_relaxed);
     std::lock_guard<std::mutex> lk(d.mu);
     if (int32_t rc = use_device(d)) return rc;
     HIP_TRY(d.stage_words.reserve(n_words));
@@ -733,28 +818,30 @@ static int32_t build_common(bsg_ctx *ctx, const uint8_t *bytes, const uint32_t *
     struct ScratchGuard { Device &d; std::vector<void *> &v; ~ScratchGuard() { if (!v.empty()) (void)hipStreamSynchronize(d.stream); for (void *p : v) d.pool.free(p); } } sguard{d, scratch};
     uint32_t *d_over = nullptr;
     if (!items.empty() || !binned.empty()) {
-        HIP_TRY(d.stage_desc.reserve(n_filters));
+        HIP_TRY(d.stage_desc.reserve(nf));
         HIP_TRY(d.stage_items.reserve(std::max<size_t>(items.size(), 1)));
         HIP_TRY(hipMemcpyAsync(d.stage_desc.p, dd.data(), dd.size() * sizeof(DevDesc), hipMemcpyHostToDevice, d.stream));
         if (!items.empty())
             HIP_TRY(hipMemcpyAsync(d.stage_items.p, items.data(), items.size() * sizeof(bsg::BuildItem), hipMemcpyHostToDevice, d.stream));
+        // Items keep the caller's ABSOLUTE entry and filter indices; the device arrays hold the part's run only, so their
+        // base pointers are moved back by the run's first index (never dereferenced below the buffers).
         bsg::BuildArgs a{};
         if (h) {
-            HIP_TRY(d.stage_h.reserve((size_t)n_entries * 4));
-            if (n_entries) HIP_TRY(hipMemcpyAsync(d.stage_h.p, h, (size_t)n_entries * 32, hipMemcpyHostToDevice, d.stream));
-            a.h = d.stage_h.p;
+            HIP_TRY(d.stage_h.reserve((size_t)std::max(ne_all, 1u) * 4));
+            if (ne_all) HIP_TRY(hipMemcpyAsync(d.stage_h.p, h + (size_t)e0 * 4, (size_t)ne_all * 32, hipMemcpyHostToDevice, d.stream));
+            a.h = d.stage_h.p - (size_t)e0 * 4;
         } else {
             HIP_TRY(d.stage_a.reserve((size_t)n_bytes + 64));
-            HIP_TRY(d.stage_off.reserve((size_t)n_entries + 1));
-            if (n_bytes) HIP_TRY(hipMemcpyAsync(d.stage_a.p, bytes, n_bytes, hipMemcpyHostToDevice, d.stream));
-            if (n_entries)
-                HIP_TRY(hipMemcpyAsync(d.stage_off.p, offsets, ((size_t)n_entries + 1) * 4, hipMemcpyHostToDevice, d.stream));
-            a.bytes = d.stage_a.p;
-            a.off = d.stage_off.p;
-            if (!binned.empty()) HIP_TRY(d.stage_h.reserve((size_t)n_entries * 4));   // the binned filters' entries are hashed once, up front
+            HIP_TRY(d.stage_off.reserve((size_t)ne_all + 1));
+            if (n_bytes) HIP_TRY(hipMemcpyAsync(d.stage_a.p, bytes + b0, n_bytes, hipMemcpyHostToDevice, d.stream));
+            if (ne_all)
+                HIP_TRY(hipMemcpyAsync(d.stage_off.p, offsets + e0, ((size_t)ne_all + 1) * 4, hipMemcpyHostToDevice, d.stream));
+            a.bytes = d.stage_a.p - b0;
+            a.off = d.stage_off.p - e0;
+            if (!binned.empty()) HIP_TRY(d.stage_h.reserve((size_t)std::max(ne_all, 1u) * 4));   // the binned filters' entries are hashed once, up front
         }
         a.items = d.stage_items.p;
-        a.desc = d.stage_desc.p;
+        a.desc = d.stage_desc.p - f0;
         a.out = d.stage_words.p;
         const size_t lds = std::max<uint64_t>(max_staged, 2) * 8;
         if (!d.kb0) { HIP_TRY(hipEventCreate(&d.kb0)); HIP_TRY(hipEventCreate(&d.kb1)); }
@@ -772,16 +859,16 @@ static int32_t build_common(bsg_ctx *ctx, const uint8_t *bytes, const uint32_t *
         }
         for (size_t bi = 0; bi < binned.size(); ++bi) {
             const uint32_t f = binned[bi];
-            const uint32_t e0 = fstart[f], ne = fstart[f + 1] - fstart[f];
+            const uint32_t fe0 = fstart[f], ne = fstart[f + 1] - fstart[f];
+            uint64_t *hslot = d.stage_h.p + (size_t)(fe0 - e0) * 4;     // this filter's hashes inside the part's staging
             if (!h) {
-                // offsets are absolute into the staged bytes: hash entries [e0, e0 + ne) into their places in stage_h
                 hipExtLaunchKernelGGL(bsg::k_hash_entries, dim3((ne + 255) / 256), dim3(256), 0, d.stream, first_ev(), nullptr, 0,
-                                      (const uint8_t *)d.stage_a.p, (const uint32_t *)d.stage_off.p + e0, ne, d.stage_h.p + (size_t)e0 * 4);
+                                      (const uint8_t *)d.stage_a.p - b0, (const uint32_t *)d.stage_off.p + (fe0 - e0), ne, hslot);
                 HIP_TRY(hipGetLastError());
             }
             bsg::BinArgs b{};
-            b.t = bsg::IngestTable{d.stage_h.p + (size_t)e0 * 4, nullptr, 0, 0};
-            b.d = dd[f];
+            b.t = bsg::IngestTable{hslot, nullptr, 0, 0};
+            b.d = dd[f - f0];
             b.n_slots = ne;
             b.n_locs_cap = (uint32_t)((uint64_t)ne * desc[f].k);
             b.overflow = d_over;
@@ -790,14 +877,97 @@ static int32_t build_common(bsg_ctx *ctx, const uint8_t *bytes, const uint32_t *
         }
     }
     if (sections) {      // the words never leave the device: encodeFilterSection runs there too
-        if (int32_t rc = encode_sections_device(d, d.stage_words.p, desc, n_filters / 3, sections->region, sections->cap,
-                                                sections->sec_off, nullptr)) return rc;
+        P.sec_off_local.assign((size_t)nf / 3 + 1, 0);
+        if (int32_t rc = encode_sections_device(d, d.stage_words.p, local.data(), nf / 3, sections->region + P.region_off, P.region_len,
+                                                P.sec_off_local.data(), &P.encode_ms)) return rc;
     } else {
-        HIP_TRY(hipMemcpyAsync(out_words, d.stage_words.p, n_words * 8, hipMemcpyDeviceToHost, d.stream));
+        HIP_TRY(hipMemcpyAsync(out_words + P.w_lo, d.stage_words.p, (P.w_hi - P.w_lo) * 8, hipMemcpyDeviceToHost, d.stream));
         HIP_TRY(hipStreamSynchronize(d.stream));
     }
-    d.last_build_ms = 0.f;
-    if (launched) HIP_TRY(hipEventElapsedTime(&d.last_build_ms, d.kb0, d.kb1));
+    P.ms = 0.f;
+    if (launched) HIP_TRY(hipEventElapsedTime(&P.ms, d.kb0, d.kb1));
+    return BSG_OK;
+}
+
+static int32_t build_common(bsg_ctx *ctx, const uint8_t *bytes, const uint32_t *offsets, const uint64_t *h,
+                            uint32_t n_entries, const uint32_t *fstart, const bsg_filter_desc *desc,
+                            uint32_t n_filters, uint64_t *out_words, uint64_t n_words, const SectionsOut *sections = nullptr)
+{
+    BSG_ENTER(ctx);
+    if (!ctx) return fail(BSG_E_INVALID, "ctx is null");
+    if (n_filters == 0) { if (sections) sections->sec_off[0] = 0; return BSG_OK; }
+    if (!fstart || !desc || (!out_words && !sections)) return fail(BSG_E_INVALID, "null argument");
+    if (int32_t rc = validate_descs(desc, n_filters, n_words)) return rc;
+    if (fstart[n_filters] != n_entries) return fail(BSG_E_INVALID, "filter_entry_start[n_filters] != n_entries");
+    for (uint32_t f = 0; f < n_filters; ++f)
+        if (fstart[f + 1] < fstart[f]) return fail(BSG_E_INVALID, "filter_entry_start not monotone at %u", f);
+    if (!h) {
+        if (n_entries && !offsets) return fail(BSG_E_INVALID, "offsets is null");
+        for (uint32_t e = 0; e < n_entries; ++e)
+            if (offsets[e + 1] < offsets[e]) return fail(BSG_E_INVALID, "offsets not monotone at %u", e);
+        if (n_entries && offsets[n_entries] && !bytes) return fail(BSG_E_INVALID, "bytes is null");
+    }
+    // ---- parts: contiguous runs of filters, one per device (the build shards by block; partitions are independent,
+    // flush.go:191-254).  A run owns the words [first filter's offset, end of its last filter): the layout must ascend with
+    // the filter index for the runs' word ranges to be disjoint — any other layout stays on one device. ----
+    const uint32_t nd = (uint32_t)ctx->devs.size();
+    const uint32_t unit = sections ? 3u : 1u;
+    uint32_t want_parts = (nd > 1 && n_entries >= ctx->shard_min_entries) ? std::min<uint32_t>(nd, n_filters / unit) : 1;
+    if (want_parts > 1) {
+        uint64_t prev_end = 0;
+        for (uint32_t f = 0; f < n_filters && want_parts > 1; ++f) {
+            if (desc[f].m == 0) continue;
+            if (desc[f].word_off < prev_end) want_parts = 1;
+            prev_end = desc[f].word_off + (desc[f].m + 63) / 64;
+        }
+    }
+    std::vector<uint32_t> cuts{0, n_filters};
+    if (want_parts > 1) {
+        std::vector<uint64_t> cost(n_filters);
+        for (uint32_t f = 0; f < n_filters; ++f) cost[f] = (uint64_t)(fstart[f + 1] - fstart[f]) * 8 + (desc[f].m + 63) / 64 + 16;
+        cuts = balanced_cuts(cost, want_parts, unit);
+    }
+    const uint32_t n_parts = (uint32_t)cuts.size() - 1;
+    std::vector<BuildPart> parts(n_parts);
+    uint64_t region_cursor = 0;
+    for (uint32_t i = 0; i < n_parts; ++i) {
+        BuildPart &P = parts[i];
+        P.f0 = cuts[i]; P.f1 = cuts[i + 1];
+        uint64_t lo = ~0ull, hi = 0;
+        for (uint32_t f = P.f0; f < P.f1; ++f) {
+            if (desc[f].m == 0) continue;
+            lo = std::min(lo, desc[f].word_off);
+            hi = std::max(hi, desc[f].word_off + (desc[f].m + 63) / 64);
+        }
+        if (lo == ~0ull) lo = hi = 0;
+        if (n_parts == 1) { lo = 0; hi = n_words; }          // the single-device call keeps its round-1 contract: the whole arena comes back, zero-filled
+        P.w_lo = lo; P.w_hi = hi;
+        if (sections) {
+            P.region_off = region_cursor;
+            for (uint32_t b = P.f0 / 3; b < P.f1 / 3; ++b) P.region_len += section_len(desc + (size_t)b * 3);
+            region_cursor += P.region_len;
+        }
+    }
+    if (sections && region_cursor > sections->cap)
+        return fail(BSG_E_INVALID, "section region needs %llu bytes, caller gave %llu", (unsigned long long)region_cursor, (unsigned long long)sections->cap);
+    if (!sections && n_parts > 1) {                            // words no part owns (gaps, absent filters) are zero, as the single-device call leaves them
+        uint64_t at = 0;
+        for (const BuildPart &P : parts) { if (P.w_lo > at) memset(out_words + at, 0, (P.w_lo - at) * 8); at = std::max(at, P.w_hi); }
+        if (n_words > at) memset(out_words + at, 0, (n_words - at) * 8);
+    }
+    const uint32_t first = n_parts == 1 ? pick_device(ctx) : 0;
+    if (int32_t rc = run_parts(n_parts, [&](uint32_t i) -> int32_t {
+            return build_on_device(ctx, *ctx->devs[(first + i) % nd], parts[i], bytes, offsets, h, fstart, desc, out_words, sections);
+        })) return rc;
+    float ms = 0.f, ems = 0.f;
+    for (const BuildPart &P : parts) { ms = std::max(ms, P.ms); ems = std::max(ems, P.encode_ms); }
+    if (sections) {
+        for (const BuildPart &P : parts)
+            for (uint32_t b = P.f0 / 3; b <= P.f1 / 3; ++b) sections->sec_off[b] = P.region_off + P.sec_off_local[b - P.f0 / 3];
+    }
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->last_build_ms = ms;
+    if (sections) ctx->last_encode_ms = ems;
     return BSG_OK;
 }
 
@@ -1590,7 +1760,9 @@ extern "C" int32_t bsg_set_probe_group(bsg_ctx *ctx, uint32_t max_arenas_per_lau
 // many-term probe mode; key 2 = bytes of HBM a binned build of a large bitset may use for its locations (0: global atomics);
 // key 3 = most distinct terms of a small batch that takes the one-dispatch path k_probe_direct (0: never);
 // key 4 = pieces bsg_arena_load_sections decodes a region in (1: one launch after the whole copy);
-// key 6 = fewest locations (entries x k) for which a bitset beyond LDS is built from binned locations (default 4 M)
+// key 6 = fewest locations (entries x k) for which a bitset beyond LDS is built from binned locations (default 4 M);
+// key 7 = fewest entries of a bsg_hash_entries / bsg_build* call that is cut into one part per device (default 256 K);
+// key 8 = fewest row bytes of a bsg_ingest_rows / bsg_match_rows call that is cut into one part per device (default 8 MiB)
 extern "C" int32_t bsg_set_lab(bsg_ctx *ctx, uint32_t key, uint64_t value)
 {
     BSG_ENTER(ctx);
@@ -1599,6 +1771,8 @@ extern "C" int32_t bsg_set_lab(bsg_ctx *ctx, uint32_t key, uint64_t value)
     if (key == 6) { ctx->bin_min_locs = value; return BSG_OK; }
     if (key == 3) { ctx->direct_max_terms = (uint32_t)std::min<uint64_t>(value, 192); return BSG_OK; }
     if (key == 4) { ctx->load_pieces = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(value, 1), 64); return BSG_OK; }
+    if (key == 7) { ctx->shard_min_entries = value; return BSG_OK; }
+    if (key == 8) { ctx->shard_min_row_bytes = value; return BSG_OK; }
     return fail(BSG_E_INVALID, "unknown lab key %u", key);
 }
 
@@ -1690,11 +1864,18 @@ int32_t bsg_last_kernel_ms(bsg_ctx *ctx, float *build_ms, float *hash_ms, float 
 {
     BSG_ENTER(ctx);
     if (!ctx) return fail(BSG_E_INVALID, "ctx is null");
-    Device &d = *ctx->devs[0];
-    std::lock_guard<std::mutex> lk(d.mu);
-    if (build_ms) *build_ms = d.last_build_ms;
-    if (hash_ms) *hash_ms = d.last_hash_ms;
-    if (decode_ms) *decode_ms = d.last_decode_ms;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (build_ms) *build_ms = ctx->last_build_ms;
+    if (hash_ms) *hash_ms = ctx->last_hash_ms;
+    if (decode_ms) *decode_ms = ctx->last_decode_ms;
+    return BSG_OK;
+}
+
+int32_t bsg_device_calls(bsg_ctx *ctx, uint64_t *out_calls, uint32_t cap)
+{
+    BSG_ENTER(ctx);
+    if (!out_calls) return fail(BSG_E_INVALID, "null argument");
+    for (uint32_t i = 0; i < cap && i < ctx->devs.size(); ++i) out_calls[i] = ctx->devs[i]->calls.load(std::memory_order_relaxed);
     return BSG_OK;
 }
 
@@ -1702,9 +1883,8 @@ int32_t bsg_last_or_ms(bsg_ctx *ctx, float *or_ms)
 {
     BSG_ENTER(ctx);
     if (!ctx || !or_ms) return fail(BSG_E_INVALID, "null argument");
-    Device &d = *ctx->devs[0];
-    std::lock_guard<std::mutex> lk(d.mu);
-    *or_ms = d.last_or_ms;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    *or_ms = ctx->last_or_ms;
     return BSG_OK;
 }
 
@@ -1764,6 +1944,7 @@ int32_t bsg_or_reduce_dev(bsg_ctx *ctx, uint64_t arena_id, uint32_t kind, void *
     if (int32_t rc = or_reduce_shard(ctx, *arena, 0, kind, n_words, static_cast<uint64_t *>(d_out))) return rc;
     HIP_TRY(hipStreamSynchronize(d.stream));
     if (d.or_pending) { HIP_TRY(hipEventElapsedTime(&d.last_or_ms, d.kb0, d.kb1)); d.or_pending = false; }
+    { std::lock_guard<std::mutex> lk2(ctx->mu); ctx->last_or_ms = d.last_or_ms; }
     return BSG_OK;
 }
 
@@ -1853,7 +2034,8 @@ int32_t bsg_or_reduce(bsg_ctx *ctx, uint64_t arena_id, uint32_t kind, uint64_t *
         if (e == hipSuccess) e = hipStreamSynchronize(d0.stream);
         if (e != hipSuccess) rc = fail(BSG_E_HIP, "or_reduce copy out: %s", hipGetErrorString(e));
     }
-    if (rc == BSG_OK)
+    if (rc == BSG_OK) {
+        float slowest = 0.f;
         for (uint32_t di = 0; di < nd; ++di) {
             Device &d = *ctx->devs[di];
             if (!d.or_pending) continue;
@@ -1861,8 +2043,11 @@ int32_t bsg_or_reduce(bsg_ctx *ctx, uint64_t arena_id, uint32_t kind, uint64_t *
             (void)hipStreamSynchronize(d.stream);
             (void)hipEventElapsedTime(&d.last_or_ms, d.kb0, d.kb1);
             d.or_pending = false;
+            slowest = std::max(slowest, d.last_or_ms);
         }
-    else
+        std::lock_guard<std::mutex> lk2(ctx->mu);
+        ctx->last_or_ms = slowest;
+    } else
         for (uint32_t di = 0; di < nd; ++di) { (void)hipSetDevice(ctx->devs[di]->id); (void)hipStreamSynchronize(ctx->devs[di]->stream); }
     cleanup();
     return rc;

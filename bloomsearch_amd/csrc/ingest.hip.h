@@ -1050,6 +1050,34 @@ __global__ __launch_bounds__(256) void k_ingest_union(const IngestTable *src_tab
         __hip_atomic_fetch_add(dst_counts + it.dst, wg_fresh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// ---------------- occupied slots of a table, densely packed (the form a partial file-level set travels between devices in) ----------------
+// out_slots[pos][4] / out_fps[pos] for pos < *counter: order is whatever the waves' reservations make it (a set has none).
+// A partial parent table is ~0.25 full and 40 bytes per slot: what crosses xGMI is count x 40 bytes instead of capacity x 40.
+__global__ __launch_bounds__(256) void k_table_compact(const IngestTable t, uint64_t *out_slots, uint64_t *out_fps, uint32_t *counter, uint32_t cap_out)
+{
+    const uint64_t cap = (uint64_t)t.mask + 1;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t wave = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (uint64_t)gridDim.x * 4;
+    for (uint64_t base = wave * 64; base < cap; base += n_waves * 64) {
+        const uint64_t i = base + lane;
+        const uint64_t f = i < cap ? t.fps[i] : 0;
+        const uint64_t mask = __ballot(f != 0);
+        if (mask == 0) continue;
+        uint32_t at = 0;
+        if (lane == (uint32_t)__builtin_ctzll(mask)) at = __hip_atomic_fetch_add(counter, (uint32_t)__builtin_popcountll(mask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        at = __shfl(at, (int)__builtin_ctzll(mask), 64);
+        if (f != 0) {
+            const uint32_t pos = at + lane_rank(mask);
+            if (pos < cap_out) {
+                const ulonglong2 *p = reinterpret_cast<const ulonglong2 *>(t.slots + i * 4);
+                ulonglong2 *o = reinterpret_cast<ulonglong2 *>(out_slots + (uint64_t)pos * 4);
+                o[0] = p[0]; o[1] = p[1];
+                out_fps[pos] = f;
+            }
+        }
+    }
+}
+
 // ---------------- bitsets from distinct sets ----------------
 struct SetBuildItem {
     uint32_t table;       // source table == filter index (desc[table])

@@ -64,6 +64,12 @@ class Context:
     def sync(self):
         self._check(self.L.bsg_sync(self.h))
 
+    def device_calls(self) -> np.ndarray:
+        """Construct / match parts each device of the context has served so far."""
+        out = np.zeros(self.n_devices, dtype=np.uint64)
+        self._check(self.L.bsg_device_calls(self.h, _lib._ptr(out), len(out)))
+        return out
+
     # ---- construct ----
     def hash_entries(self, blob: np.ndarray, off: np.ndarray) -> np.ndarray:
         n = len(off) - 1

@@ -127,6 +127,13 @@ BSG_API int32_t bsg_scope_open(bsg_ctx *ctx, bsg_ctx **out_scope);
 BSG_API int32_t bsg_open_err(const int32_t *device_ids, int32_t n_devices, bsg_ctx **out_ctx, char *errbuf, uint64_t cap);
 BSG_API int32_t bsg_sync(bsg_ctx *ctx);
 
+/* Construct / match work on a context over several devices (bsg_hash_entries, bsg_build*, bsg_ingest_*, bsg_match_rows): a call
+ * large enough is cut into one part per device — contiguous runs of entries / filters / sets / rows, each on a thread of its
+ * own (partitions are independent in flush.go:191-254, surviving blocks in query_exec.go:729-764) — and a smaller call takes ONE
+ * device, chosen round-robin among those nobody holds, so the flush worker, a merge and concurrent queries' block workers
+ * land on different GPUs.  Results do not depend on the number of devices.  out_calls[i]: parts device i has served so far. */
+BSG_API int32_t bsg_device_calls(bsg_ctx *ctx, uint64_t *out_calls, uint32_t cap);
+
 /* ---- sizing: bloom/v3 EstimateParameters + New's clamps, as called by
  * buildSizedBloomFilter with n = max(len(set), 1) (ingest.go:139-140).  Pure host
  * arithmetic for non-Go hosts; a Go host keeps calling bloom.EstimateParameters so
@@ -223,7 +230,8 @@ BSG_API int32_t bsg_set_probe_group(bsg_ctx *ctx, uint32_t max_arenas_per_launch
  * binned build of a bitset beyond LDS may park its locations in, 0 = build it with global atomics; key 3: most distinct terms
  * of a synchronous batch of <= 256 queries that is answered by one dispatch, 0 = never; key 4: launches the decode of
  * bsg_arena_load_sections is split into, 1 = one launch after the whole copy; key 6: fewest locations (entries x k) from
- * which a bitset beyond LDS is built from binned locations instead of global atomics); not part of the seam. */
+ * which a bitset beyond LDS is built from binned locations instead of global atomics; keys 7 / 8: fewest entries / row bytes from
+ * which a construct or match call on a context over several devices is cut into one part per device); not part of the seam. */
 BSG_API int32_t bsg_set_lab(bsg_ctx *ctx, uint32_t key, uint64_t value);
 /* Synchronous probes poll their stream for up to this long before they block (default 0: block at once).  A single
  * query's kernels finish in ~10 us; being woken from a blocking wait costs more than that. */
@@ -244,8 +252,8 @@ BSG_API int32_t bsg_timing_read(bsg_ctx *ctx, bsg_timing *out, int32_t reset);
 /* With BSG_PROBE_TIMED, only every stride-th dispatch group is timestamped (default 1 = all). */
 BSG_API int32_t bsg_set_timed_stride(bsg_ctx *ctx, uint32_t stride);
 /* Device time (the dispatch's own start/stop timestamps) of the most recent k_build / k_hash_entries /
- * k_decode_sections launch made through bsg_build* / bsg_hash_entries / bsg_arena_load_sections on the
- * context's first device (any pointer may be NULL). */
+ * k_decode_sections launch made through bsg_build* / bsg_hash_entries / bsg_arena_load_sections (the slowest device
+ * of the call, when it was cut over several; any pointer may be NULL). */
 BSG_API int32_t bsg_last_kernel_ms(bsg_ctx *ctx, float *build_ms, float *hash_ms, float *decode_ms);
 
 /* ---- fixed-geometry OR-reduce (extension) ----
@@ -259,7 +267,7 @@ BSG_API int32_t bsg_or_reduce(bsg_ctx *ctx, uint64_t arena_id, uint32_t kind, ui
 BSG_API int32_t bsg_or_words_dev(bsg_ctx *ctx, void *d_dst, const void *d_src, uint64_t n_words, uint32_t n_src);
 /* Per-device partial OR left on the device: writes n_words u64 at d_out. */
 BSG_API int32_t bsg_or_reduce_dev(bsg_ctx *ctx, uint64_t arena_id, uint32_t kind, void *d_out, uint64_t n_words);
-/* Device time of the most recent k_or_reduce_blocks dispatch on the context's first device. */
+/* Device time of the most recent k_or_reduce_blocks dispatch (the slowest device's). */
 BSG_API int32_t bsg_last_or_ms(bsg_ctx *ctx, float *or_ms);
 
 /* ---- the OR-reduce across GPUs: RCCL over xGMI inside the library (a Go host cannot call torch.distributed) ----
@@ -290,7 +298,7 @@ BSG_API int32_t bsg_sections_size(const bsg_filter_desc *desc, uint32_t n_blocks
 BSG_API int32_t bsg_build_sections(bsg_ctx *ctx, const uint8_t *bytes, const uint32_t *offsets, uint32_t n_entries,
                                    const uint32_t *filter_entry_start, const bsg_filter_desc *desc, uint32_t n_filters,
                                    uint64_t n_words, uint8_t *out_region, uint64_t region_cap, uint64_t *out_sec_off);
-/* Device time of the most recent k_encode_payload + k_crc_sections pair on the context's first device. */
+/* Device time of the most recent k_encode_payload + k_crc_sections pair (the slowest device's). */
 BSG_API int32_t bsg_last_encode_ms(bsg_ctx *ctx, float *encode_ms);
 
 /* ---- pinned host memory ----
@@ -400,7 +408,7 @@ BSG_API int32_t bsg_match_rows(bsg_ctx *ctx, const uint8_t *rows, const uint64_t
                                const uint32_t *prog_ops, uint32_t n_ops,
                                uint64_t *out_bits, uint32_t *out_fallback_rows, uint32_t fallback_cap,
                                uint32_t *out_n_fallback);
-/* Device time of the most recent k_match_rows dispatch on the context's first device. */
+/* Device time of the most recent k_match_rows dispatch (the slowest device's). */
 BSG_API int32_t bsg_last_match_ms(bsg_ctx *ctx, float *match_ms);
 
 #ifdef __cplusplus
