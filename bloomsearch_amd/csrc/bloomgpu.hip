@@ -1860,6 +1860,158 @@ int32_t bsg_probe(bsg_ctx *ctx, uint64_t arena_id, const bsg_term *terms, uint32
     return rc;
 }
 
+// ---- one interactive Query() in ONE call: strings in, survivors out (direct.hip.h: k_query_direct) ----
+int32_t bsg_query(bsg_ctx *ctx, const uint64_t *arena_ids, uint32_t n_arenas, const uint8_t *term_bytes, const uint32_t *term_off,
+                  const uint32_t *term_kinds, uint32_t n_terms, const uint32_t *prog_ops, const uint32_t *prog_off, uint32_t n_queries,
+                  uint64_t *out_survivors)
+{
+    BSG_ENTER(ctx);
+    if (n_arenas && !arena_ids) return fail(BSG_E_INVALID, "arena_ids is null");
+    if (n_queries && (!prog_off || !out_survivors)) return fail(BSG_E_INVALID, "null argument");
+    if (n_terms && (!term_off || !term_kinds)) return fail(BSG_E_INVALID, "terms are null");
+    for (uint32_t t = 0; t < n_terms; ++t) {
+        if (term_off[t + 1] < term_off[t]) return fail(BSG_E_INVALID, "term_off not monotone at %u", t);
+        if (term_kinds[t] > 2) return fail(BSG_E_INVALID, "term %u has unknown kind %u", t, term_kinds[t]);
+    }
+    if (n_terms && term_off[n_terms] && !term_bytes) return fail(BSG_E_INVALID, "term_bytes is null");
+    if (n_queries == 0 || n_arenas == 0) return BSG_OK;
+    // the probed strings are hashed HERE, on the host, by the function the kernels hash entries with (TestString hashes
+    // inside the call too, query_exec.go:141-154): no device launch for a handful of strings
+    std::vector<bsg_term> terms(n_terms);
+    for (uint32_t t = 0; t < n_terms; ++t) {
+        bsg::base_hashes(term_bytes + term_off[t], term_off[t + 1] - term_off[t], terms[t].h);
+        terms[t].kind = term_kinds[t];
+        terms[t].reserved = 0;
+    }
+    std::vector<std::shared_ptr<Arena>> arenas(n_arenas);
+    for (uint32_t i = 0; i < n_arenas; ++i) if (int32_t rc = get_arena(ctx, arena_ids[i], arenas[i])) return rc;
+    const uint32_t nd = (uint32_t)ctx->devs.size();
+    // ---- does the call fit one dispatch per device with everything in the kernel arguments? ----
+    bool fast = n_terms <= bsg::kQueryMaxTerms && n_queries <= bsg::kEvalThreads;
+    for (uint32_t di = 0; di < nd && fast; ++di) {
+        uint32_t n = 0;
+        for (auto &a : arenas) n += a->shards[di].n_blocks ? 1u : 0u;
+        if (n > bsg::kQueryMaxArenas) fast = false;
+    }
+    bsg::QueryKernArgs q{};
+    Batch B;                                            // host-only stand-in: geometry for fill_refs, nothing on a device
+    uint32_t max_depth = 1, Lmax = 1;
+    if (fast) {
+        // compact term layout: grouped by kind, no padding (<= 16 terms: one verdict word)
+        uint32_t count[3] = {0, 0, 0}, begin[3] = {0, 0, 0}, fill[3] = {0, 0, 0};
+        for (uint32_t t = 0; t < n_terms; ++t) count[terms[t].kind]++;
+        uint32_t cursor = 0;
+        for (uint32_t c = 0; c < 3; ++c) {
+            if (!count[c]) continue;
+            q.a.kind[q.a.n_kinds] = c; q.a.term_begin[q.a.n_kinds] = cursor; q.a.term_count[q.a.n_kinds] = count[c];
+            begin[c] = cursor; cursor += count[c]; q.a.n_kinds++;
+        }
+        std::vector<uint32_t> term_pos(n_terms);
+        for (uint32_t t = 0; t < n_terms; ++t) {
+            const uint32_t pos = begin[terms[t].kind] + fill[terms[t].kind]++;
+            term_pos[t] = pos;
+            for (int j = 0; j < 4; ++j) q.th[(size_t)j * bsg::kQueryMaxTerms + pos] = terms[t].h[j];
+        }
+        std::vector<std::vector<uint32_t>> lowered(n_queries);
+        for (uint32_t i = 0; i < n_queries; ++i) {
+            if (prog_off[i + 1] < prog_off[i]) return fail(BSG_E_INVALID, "prog_off not monotone at %u", i);
+            const uint32_t n_ops = prog_off[i + 1] - prog_off[i];
+            if (n_ops && !prog_ops) return fail(BSG_E_INVALID, "prog_ops is null");
+            uint32_t depth = 1;
+            if (int32_t rc = lower_program(prog_ops + prog_off[i], n_ops, n_terms, term_pos, lowered[i], depth)) return rc;
+            max_depth = std::max(max_depth, depth);
+            Lmax = std::max<uint32_t>(Lmax, (uint32_t)lowered[i].size());
+        }
+        if ((uint64_t)Lmax * n_queries > bsg::kQueryMaxProgWords || bsg::direct_lds_bytes(1, max_depth) > 64 * 1024) fast = false;
+        else {
+            for (uint32_t w = 0; w < bsg::kQueryMaxProgWords; ++w) q.prog[w] = 7u << 28;
+            for (uint32_t i = 0; i < n_queries; ++i)
+                for (size_t j = 0; j < lowered[i].size(); ++j) q.prog[j * n_queries + i] = lowered[i][j];      // TERM arg = position = verdict slot
+            q.len = Lmax; q.stride = n_queries;
+            q.a.Tp = bsg::kQueryMaxTerms; q.a.Wt = 1; q.a.n_queries = n_queries; q.a.Lmax = Lmax; q.a.max_depth = max_depth;
+            B.n_queries = n_queries; B.Wt = 1;
+        }
+    }
+    if (!fast) {                                        // a larger batch: the batch object after all (hashes still from the host)
+        uint64_t bid = 0;
+        if (int32_t rc = bsg_batch_create(ctx, terms.data(), n_terms, prog_ops, prog_off, n_queries, &bid)) return rc;
+        std::shared_ptr<Batch> batch;
+        int32_t rc = get_batch(ctx, bid, batch);
+        if (!rc) rc = probe_arenas(ctx, arenas, *batch, 0, out_survivors, nullptr);
+        const std::string saved = rc ? g_err : std::string();
+        (void)bsg_batch_free(ctx, bid);
+        if (rc) fail(rc, "%s", saved.c_str());
+        return rc;
+    }
+    // ---- one k_query_direct per device that holds blocks; survivors land in page-locked memory, a doorbell says when ----
+    std::vector<uint64_t> out_off(n_arenas + 1, 0);
+    for (uint32_t i = 0; i < n_arenas; ++i) out_off[i + 1] = out_off[i] + (uint64_t)n_queries * (((uint64_t)arenas[i]->n_blocks + 63) / 64);
+    struct Pending { uint64_t *buf; size_t cap; size_t words; Device *dev; uint64_t *flag; uint64_t seq; uint32_t di; };
+    std::vector<Pending> pend;
+    struct Guard {
+        std::vector<Pending> &v; bool drained = false;
+        ~Guard() { for (auto &p : v) { std::lock_guard<std::mutex> lk(p.dev->mu); if (!drained) (void)hipStreamSynchronize(p.dev->stream); p.dev->direct_bufs.emplace_back(p.buf, p.cap); } }
+    } guard{pend};
+    for (uint32_t di = 0; di < nd; ++di) {
+        Device &d = *ctx->devs[di];
+        Group g;
+        for (uint32_t i = 0; i < n_arenas; ++i) if (arenas[i]->shards[di].n_blocks) group_add(g, B, arenas[i]->shards[di], i);
+        if (g.shards.empty()) continue;
+        std::lock_guard<std::mutex> lk(d.mu);
+        if (int32_t rc = use_device(d)) return rc;
+        Pending p{};
+        const size_t bytes = g.out_words * 8, need = bytes + 64;
+        for (size_t i = 0; i < d.direct_bufs.size(); ++i)
+            if (d.direct_bufs[i].second >= need) { p.buf = d.direct_bufs[i].first; p.cap = d.direct_bufs[i].second; d.direct_bufs.erase(d.direct_bufs.begin() + i); break; }
+        if (!p.buf) {
+            p.cap = std::max<size_t>(64 * 1024, need);
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&p.buf), p.cap, hipHostMallocDefault));
+        }
+        p.words = g.out_words; p.dev = &d; p.di = di;
+        p.flag = p.buf + g.out_words; p.seq = ++d.direct_seq;
+        *reinterpret_cast<volatile uint64_t *>(p.flag) = 0;
+        pend.push_back(p);
+        if (!d.d_direct_count) {
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d.d_direct_count), 64));
+            HIP_TRY(hipMemsetAsync(d.d_direct_count, 0, 64, d.stream));
+        }
+        bsg::QueryKernArgs k = q;
+        k.a.done_count = d.d_direct_count; k.a.flag = p.flag; k.a.seq = p.seq; k.a.out = p.buf;
+        k.a.n_arenas = (uint32_t)g.shards.size();
+        fill_refs(g, B, k.t.ar);
+        hipLaunchKernelGGL(bsg::k_query_direct, dim3(g.max_G, 1, k.a.n_arenas), dim3(bsg::kEvalThreads), bsg::direct_lds_bytes(1, max_depth), d.stream, k);
+        HIP_TRY(hipGetLastError());
+    }
+    for (auto &p : pend) {
+        const auto t0 = std::chrono::steady_clock::now();
+        bool ok = true;
+        while (__atomic_load_n(p.flag, __ATOMIC_ACQUIRE) != p.seq)
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(1000)) { ok = false; break; }
+        if (!ok) {                                      // the bell did not ring within a millisecond: ask the runtime
+            std::lock_guard<std::mutex> lk(p.dev->mu);
+            if (int32_t rc = use_device(*p.dev)) return rc;
+            HIP_TRY(hipStreamSynchronize(p.dev->stream));
+        }
+    }
+    guard.drained = true;
+    if (nd == 1) {
+        // one device: a group's arenas are the caller's non-empty arenas in order, their words back to back — as out_survivors wants them
+        if (!pend.empty()) memcpy(out_survivors, pend[0].buf, pend[0].words * 8);
+        return BSG_OK;
+    }
+    memset(out_survivors, 0, out_off[n_arenas] * 8);
+    for (auto &p : pend) {
+        uint64_t o = 0;
+        for (uint32_t i = 0; i < n_arenas; ++i) {
+            const ArenaShard &s = arenas[i]->shards[p.di];
+            if (s.n_blocks == 0) continue;
+            interleave_shard(p.buf + o, n_queries, s.n_blocks, p.di, nd, out_survivors + out_off[i], ((uint64_t)arenas[i]->n_blocks + 63) / 64);
+            o += (uint64_t)n_queries * ((s.n_blocks + 63) / 64);
+        }
+    }
+    return BSG_OK;
+}
+
 int32_t bsg_last_kernel_ms(bsg_ctx *ctx, float *build_ms, float *hash_ms, float *decode_ms)
 {
     BSG_ENTER(ctx);

@@ -33,25 +33,25 @@ __host__ __device__ inline uint32_t direct_lds_bytes(uint32_t Wt, uint32_t max_d
     return (Wt * 64u + max_depth * (uint32_t)kEvalThreads) * 8u;
 }
 
-// grid = (most 64-block groups of any arena, 1, arenas); 256 threads
-__global__ __launch_bounds__(kEvalThreads) void k_probe_direct(const DirectArgs a, const ArenaTable<kMaxGroupArenas> t)
+// The shared body: th = SoA term hashes th[j * a.Tp + pos]; prog = the chunk's programs, op j of lane l at prog[j * prog_stride + l];
+// len = ops of the longest program.  A kind's terms sit at positions term_begin .. term_begin + term_count of th AND of VT.
+__device__ __forceinline__ void direct_body(const DirectArgs &a, const uint64_t *th, const uint32_t *prog, uint32_t prog_stride, uint32_t len,
+                                            const ArenaRef &ar, uint64_t *lds64)
 {
-    extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
-    const ArenaRef &ar = t.ar[blockIdx.z];
     const uint32_t g = blockIdx.x;
     const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
     if (g < ar.G) {                                              // (arenas of a group may differ in size)
     constexpr uint32_t n_waves = kEvalThreads / kWave;
-    uint64_t *VT = lds64;                                        // VT[word * 64 + bit]: 64-block mask of one term
+    uint64_t *VT = lds64;                                        // VT[position]: 64-block mask of one term
     uint64_t *stk = lds64 + (uint64_t)a.Wt * 64 + tid;           // per-lane stack, stride kEvalThreads
     for (uint32_t i = tid; i < a.Wt * 64; i += kEvalThreads) VT[i] = 0;
     // the program words do not depend on the verdicts: request them before the bit tests
     constexpr uint32_t kPre = 8;
     uint32_t pre[kPre];
-    const uint32_t *P = a.prog + tid;
+    const bool has_prog = tid < prog_stride;                     // (the compact layout of k_query_direct holds n_queries lanes only)
+    const uint32_t *P = prog + tid;
 #pragma unroll
-    for (uint32_t j = 0; j < kPre; ++j) pre[j] = j < a.Lmax ? P[(uint64_t)j * kEvalThreads] : (7u << 28);
-    const uint32_t len = a.chunk_len[0];
+    for (uint32_t j = 0; j < kPre; ++j) pre[j] = (has_prog && j < a.Lmax) ? P[(uint64_t)j * prog_stride] : (7u << 28);
     __syncthreads();
 
     const uint32_t b = g * 64 + lane;
@@ -62,8 +62,8 @@ __global__ __launch_bounds__(kEvalThreads) void k_probe_direct(const DirectArgs 
         const uint64_t *src = ar.words + d.word_off;
         const uint32_t t0 = a.term_begin[y];
         for (uint32_t t = wave; t < a.term_count[y]; t += n_waves) {       // wave-uniform term: its hashes are scalar loads
-            const uint64_t h0 = a.th[t0 + t], h1 = a.th[(uint64_t)a.Tp + t0 + t];
-            const uint64_t h2 = a.th[2ull * a.Tp + t0 + t], h3 = a.th[3ull * a.Tp + t0 + t];
+            const uint64_t h0 = th[t0 + t], h1 = th[(uint64_t)a.Tp + t0 + t];
+            const uint64_t h2 = th[2ull * a.Tp + t0 + t], h3 = th[3ull * a.Tp + t0 + t];
             // a nil filter cannot disqualify (query_exec.go:137-151); rows past the arena's end are masked at the end
             bool pass = true;
             uint32_t i = 0;
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(kEvalThreads) void k_probe_direct(const DirectArgs 
                 i += kTrip;
             }
             const uint64_t mask = __ballot(pass);
-            if (lane == 0) VT[(uint64_t)(t0 >> 6) * 64 + t] = mask;      // a kind's segment starts on a word boundary
+            if (lane == 0) VT[t0 + t] = mask;                            // (a batch's kind segments start on word boundaries: t0 is their slot * 64)
         }
     }
     __syncthreads();
@@ -112,9 +112,11 @@ __global__ __launch_bounds__(kEvalThreads) void k_probe_direct(const DirectArgs 
             top = (opc == 0u) ? VT[op & 0x0FFFFFFFu] : (opc == 3u ? ~0ULL : 0ULL);
         }
     };
+    if (has_prog) {
 #pragma unroll
-    for (uint32_t j = 0; j < kPre; ++j) if (j < len) step(pre[j]);
-    for (uint32_t j = kPre; j < len; ++j) step(P[(uint64_t)j * kEvalThreads]);
+        for (uint32_t j = 0; j < kPre; ++j) if (j < len) step(pre[j]);
+        for (uint32_t j = kPre; j < len; ++j) step(P[(uint64_t)j * prog_stride]);
+    }
     const uint32_t nvalid = ar.n_blocks - g * 64;
     if (tid < a.n_queries)
         a.out[ar.out_off + (uint64_t)tid * ar.G + g] = top & (nvalid >= 64 ? ~0ULL : ((1ULL << nvalid) - 1));
@@ -130,6 +132,43 @@ __global__ __launch_bounds__(kEvalThreads) void k_probe_direct(const DirectArgs 
             }
         }
     }
+}
+
+// grid = (most 64-block groups of any arena, 1, arenas); 256 threads
+__global__ __launch_bounds__(kEvalThreads) void k_probe_direct(const DirectArgs a, const ArenaTable<kMaxGroupArenas> t)
+{
+    extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
+    direct_body(a, a.th, a.prog, kEvalThreads, a.chunk_len[0], t.ar[blockIdx.z], lds64);
+}
+
+// ---- the same dispatch with NOTHING uploaded beforehand: bsg_query ----
+// One Query() of the reference hashes its few terms inside TestString and walks its expression per block
+// (query_exec.go:128-158).  Through the batch API that is a device launch to hash three strings, five small uploads for
+// the batch object, and the probe.  Here the term hashes (computed on the host by the same base_hashes) and the lowered
+// programs ride IN THE KERNEL ARGUMENTS: strings in, survivors out, one dispatch, nothing allocated, nothing uploaded.
+constexpr uint32_t kQueryMaxTerms = 16;        // distinct terms of one call (th: 4 x 16 x 8 B of arguments)
+constexpr uint32_t kQueryMaxProgWords = 128;   // longest program x queries of one call
+constexpr uint32_t kQueryMaxArenas = 32;       // arenas (per device) one call covers; more take the batch path
+
+struct QueryKernArgs {
+    DirectArgs a;                              // th / prog / chunk_len unused: the kernel reads the arrays below
+    uint32_t len, stride, pad0, pad1;          // ops of the longest program; lanes per op row (= n_queries)
+    uint64_t th[4 * kQueryMaxTerms];           // th[j * kQueryMaxTerms + pos]
+    uint32_t prog[kQueryMaxProgWords];         // prog[j * stride + q]
+    ArenaTable<kQueryMaxArenas> t;
+};
+static_assert(sizeof(QueryKernArgs) <= 4096, "kernel arguments must stay within 4 KB");
+
+__global__ __launch_bounds__(kEvalThreads) void k_query_direct(const QueryKernArgs q)
+{
+    extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
+    // the arrays are indexed dynamically: read them where they already are — the kernel-argument segment — instead of
+    // letting the compiler copy a by-value struct into scratch
+    const char *ka = (const char *)__builtin_amdgcn_kernarg_segment_ptr();      // (constant address space -> generic)
+    const uint64_t *th = reinterpret_cast<const uint64_t *>(ka + offsetof(QueryKernArgs, th));
+    const uint32_t *prog = reinterpret_cast<const uint32_t *>(ka + offsetof(QueryKernArgs, prog));
+    const ArenaRef *ar = reinterpret_cast<const ArenaRef *>(ka + offsetof(QueryKernArgs, t)) + blockIdx.z;
+    direct_body(q.a, th, prog, q.stride, q.len, *ar, lds64);
 }
 
 }  // namespace bsg

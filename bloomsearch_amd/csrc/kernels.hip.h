@@ -38,9 +38,9 @@ struct DevDesc {
     uint32_t pad;
 };
 
-__device__ __forceinline__ uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+__host__ __device__ __forceinline__ uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
 
-__device__ __forceinline__ uint64_t fmix64(uint64_t k)
+__host__ __device__ __forceinline__ uint64_t fmix64(uint64_t k)
 {
     k ^= k >> 33;
     k *= 0xff51afd7ed558ccdULL;
@@ -53,22 +53,22 @@ __device__ __forceinline__ uint64_t fmix64(uint64_t k)
 constexpr uint64_t kC1 = 0x87c37b91114253d5ULL;
 constexpr uint64_t kC2 = 0x4cf5ad432745937fULL;
 
-__device__ __forceinline__ void mix_k1(uint64_t &h1, uint64_t k1)
+__host__ __device__ __forceinline__ void mix_k1(uint64_t &h1, uint64_t k1)
 {
     k1 *= kC1; k1 = rotl64(k1, 31); k1 *= kC2; h1 ^= k1;
 }
-__device__ __forceinline__ void mix_k2(uint64_t &h2, uint64_t k2)
+__host__ __device__ __forceinline__ void mix_k2(uint64_t &h2, uint64_t k2)
 {
     k2 *= kC2; k2 = rotl64(k2, 33); k2 *= kC1; h2 ^= k2;
 }
-__device__ __forceinline__ void bmix(uint64_t &h1, uint64_t &h2, uint64_t k1, uint64_t k2)
+__host__ __device__ __forceinline__ void bmix(uint64_t &h1, uint64_t &h2, uint64_t k1, uint64_t k2)
 {
     mix_k1(h1, k1);
     h1 = rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729ULL;
     mix_k2(h2, k2);
     h2 = rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5ULL;
 }
-__device__ __forceinline__ void murmur_finalize(uint64_t h1, uint64_t h2, uint64_t len, uint64_t &o1, uint64_t &o2)
+__host__ __device__ __forceinline__ void murmur_finalize(uint64_t h1, uint64_t h2, uint64_t len, uint64_t &o1, uint64_t &o2)
 {
     h1 ^= len; h2 ^= len;
     h1 += h2; h2 += h1;
@@ -78,9 +78,10 @@ __device__ __forceinline__ void murmur_finalize(uint64_t h1, uint64_t h2, uint64
 }
 
 // bloom/v3 sum256: (h0,h1) = murmur3_x64_128(d), (h2,h3) = murmur3_x64_128(d || 0x01), seed 0,
-// computed in one pass without materialising the appended byte.
+// computed in one pass without materialising the appended byte.  __host__ too: bsg_query hashes an interactive query's
+// few terms on the host with this very function (one source for both sides; tests compare them).
 template <typename BytePtr>
-__device__ __forceinline__ void base_hashes(BytePtr p, uint32_t len, uint64_t h[4])
+__host__ __device__ __forceinline__ void base_hashes(BytePtr p, uint32_t len, uint64_t h[4])
 {
     uint64_t h1 = 0, h2 = 0;
     const uint32_t nb = len >> 4;

@@ -219,6 +219,27 @@ class Context:
                                      nq, _lib._ptr(out)))
         return out
 
+    def query(self, arena_ids, n_blocks, cb, out: np.ndarray = None):
+        """bsg_query: one call, strings in -> survivors out.  cb: query.CompiledBatch (term strings + kinds + programs);
+        n_blocks: blocks per arena.  -> list of [n_queries, ceil(n_blocks_i / 64)] u64 arrays."""
+        ids = np.ascontiguousarray(arena_ids, dtype=np.uint64)
+        if not hasattr(cb, "_packed"):
+            tb, to = pack_entries(cb.term_strings)
+            ops, poff, kinds = cb.arrays()
+            cb._packed = (tb, to, np.ascontiguousarray(kinds, dtype=np.uint32), ops, poff)
+        tb, to, kinds, ops, poff = cb._packed
+        nq = len(poff) - 1
+        sizes = [nq * ((nb + 63) // 64) for nb in n_blocks]
+        if out is None:
+            out = np.zeros(max(sum(sizes), 1), dtype=np.uint64)
+        self._check(self.L.bsg_query(self.h, _lib._ptr(ids), len(ids), _lib._ptr(tb), _lib._ptr(to), _lib._ptr(kinds), len(kinds),
+                                     _lib._ptr(ops), _lib._ptr(poff), nq, _lib._ptr(out)))
+        res, o = [], 0
+        for sz, nb in zip(sizes, n_blocks):
+            res.append(out[o: o + sz].reshape(nq, (nb + 63) // 64))
+            o += sz
+        return res
+
     def timing_read(self, reset: bool = True) -> Timing:
         t = Timing()
         self._check(self.L.bsg_timing_read(self.h, C.byref(t), 1 if reset else 0))

@@ -248,6 +248,18 @@ BSG_API int32_t bsg_probe(bsg_ctx *ctx, uint64_t arena_id, const bsg_term *terms
                           const uint32_t *prog_ops, const uint32_t *prog_off, uint32_t n_queries,
                           uint64_t *out_survivors);
 
+/* One interactive Query() in ONE call — strings in, survivors out (Query -> evaluateBlockFilters, query_exec.go:201-225, 572-615).
+ * Term t = the probed STRING term_bytes[term_off[t] .. term_off[t + 1]) (Field, Token, or Field + "::" + Token) and its filter
+ * kind; programs as for bsg_batch_create; out_survivors as for bsg_probe_many (arena i's [n_queries][ceil(n_blocks_i / 64)] words
+ * back to back).  The strings are hashed on the host inside the call (TestString hashes inside the call too — a device launch for
+ * three strings costs more than the probe), and for <= 16 distinct terms, <= 256 queries whose lowered programs hold <= 128
+ * words in all, and <= 32 arenas per device, the hashes and programs ride in the kernel arguments of ONE dispatch per device
+ * (k_query_direct): no batch object, nothing uploaded, survivors written straight into page-locked memory with a doorbell.
+ * Anything larger takes the batch path inside the same call.  Re-entrant like every other entry point. */
+BSG_API int32_t bsg_query(bsg_ctx *ctx, const uint64_t *arena_ids, uint32_t n_arenas,
+                          const uint8_t *term_bytes, const uint32_t *term_off, const uint32_t *term_kinds, uint32_t n_terms,
+                          const uint32_t *prog_ops, const uint32_t *prog_off, uint32_t n_queries, uint64_t *out_survivors);
+
 BSG_API int32_t bsg_timing_read(bsg_ctx *ctx, bsg_timing *out, int32_t reset);
 /* With BSG_PROBE_TIMED, only every stride-th dispatch group is timestamped (default 1 = all). */
 BSG_API int32_t bsg_set_timed_stride(bsg_ctx *ctx, uint32_t stride);

@@ -564,3 +564,51 @@ def test_shards_that_disagree_on_the_one_dispatch_path():
             for (pl, wd, _), g in zip(plans, got):
                 assert np.array_equal(g, O.survivors_tree(wd, pl.desc.view(O.DESC_DTYPE), exprs))
         mctx.batch_free(bid)
+
+
+def test_bsg_query_one_call_strings_in_survivors_out(ctx):
+    """bsg_query: the term STRINGS go in, hashed on the host by the kernels' own base_hashes; for a handful of terms the hashes
+    and programs ride in the kernel arguments of one dispatch (k_query_direct) — no batch object, nothing uploaded.  Same bits as
+    the tree-walking oracle and as hash + batch_create + probe_many, for the one-dispatch shape and for everything that falls
+    back to the batch path inside the call (17+ terms, long programs, 33+ arenas), on single- and multi-device contexts."""
+    rng = np.random.default_rng(2026)
+    plans, vocab = [], None
+    for n_blocks in (1, 64, 65, 130, 200, 3):
+        plan, _, vocab = H.make_random_arena(rng, n_blocks, absent_frac=0.1, max_tokens=400, vocab_size=60)
+        words = ctx.build(plan.blob, plan.off, plan.fstart, plan.desc, plan.n_words)
+        plans.append((plan, words))
+    unicode_tok = [t for t in vocab if not t.isascii()][0]
+    shapes = {
+        "one 3-term query": [Q.And(Q.FieldToken("f1", vocab[0]), Q.Token(vocab[1]), Q.Field("f2"))],
+        "nil query": [None],
+        "no terms at all": [Q.And(), Q.Or(), {"ExpressionType": "XOR"}],
+        "seven queries": [Q.Token(vocab[i]) for i in range(5)] + [Q.Or(Q.Token("absent"), Q.Field("f3"), Q.Token(unicode_tok)), None],
+        "16 distinct terms": [Q.Or(*[Q.Token(vocab[i]) for i in range(16)])],
+        "17 distinct terms (batch path)": [Q.Or(*[Q.Token(vocab[i]) for i in range(17)])],
+        "long programs (batch path)": [Q.And(*[Q.Or(Q.Token(vocab[i % 8]), Q.Field("f%d" % (i % 5))) for i in range(40)]) for _ in range(4)],
+        "many queries (batch path)": [Q.Token(vocab[i % 12]) for i in range(300)],
+    }
+    for n_dev in (1, 3):
+        with Context((0,) * n_dev) as c:
+            ids = [c.arena_load(w, p.desc) for p, w in plans]
+            empty = c.arena_load(np.zeros(2, dtype=np.uint64), np.zeros(0, dtype=DESC_DTYPE))
+            nbs = [p.n_blocks for p, _ in plans]
+            for name, exprs in shapes.items():
+                cb = Q.compile_queries(exprs)
+                got = c.query(ids[:2] + [empty] + ids[2:], nbs[:2] + [0] + nbs[2:], cb)
+                del got[2]
+                for (p, w), g in zip(plans, got):
+                    assert np.array_equal(g, O.survivors_tree(w, p.desc.view(O.DESC_DTYPE), exprs)), (n_dev, name)
+            # 33 arenas on one device: beyond what one k_query_direct covers -> the batch path, same bits
+            many_ids = (ids * 6)[:33] if n_dev == 1 else (ids * 20)[:100]
+            many_nbs = (nbs * 20)[: len(many_ids)]
+            cb = Q.compile_queries(shapes["one 3-term query"])
+            got = c.query(many_ids, many_nbs, cb)
+            for i, g in enumerate(got):
+                p, w = plans[i % len(plans)]
+                assert np.array_equal(g, O.survivors_tree(w, p.desc.view(O.DESC_DTYPE), shapes["one 3-term query"]))
+            # malformed input is rejected before any launch
+            with pytest.raises(BloomGpuError):
+                bad = Q.compile_queries([Q.Token("x")])
+                bad._packed = (np.zeros(1, np.uint8), np.asarray([0, 1], np.uint32), np.asarray([7], np.uint32), *bad.arrays()[:2])
+                c.query(ids[:1], nbs[:1], bad)
