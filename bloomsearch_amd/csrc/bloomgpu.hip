@@ -241,6 +241,11 @@ struct Batch {
     bool identity_cw = false;       // few verdict words: every chunk transposes all of them, no per-chunk list
     bool many_terms = false;        // some kind has more than 128 distinct terms: k_probe_terms_many, never fused
     std::vector<BatchDev> dev;
+    // A batch beyond what one launch holds (distinct terms of a kind, verdict words per 256-query chunk) is a COMPOSITE: runs of
+    // its queries, each a batch of its own with only the terms its queries reference (the reference's evaluator has no such
+    // limit, query_exec.go:89-126).  sub_q0[i] = first query of subs[i]; the fields above are unused then.
+    std::vector<std::shared_ptr<Batch>> subs;
+    std::vector<uint32_t> sub_q0;
 };
 
 struct Ingest;   // ingest_api.inc
@@ -373,6 +378,8 @@ void free_arena(bsg_ctx *ctx, Arena &a)
 
 void free_batch(bsg_ctx *ctx, Batch &b)
 {
+    for (auto &sub : b.subs) free_batch(ctx, *sub);
+    b.subs.clear();
     for (size_t i = 0; i < b.dev.size(); ++i) {
         (void)hipSetDevice(ctx->devs[i]->id);
         if (b.dev[i].d_th) (void)hipFree(b.dev[i].d_th);
@@ -1116,13 +1123,15 @@ int32_t bsg_arena_free(bsg_ctx *ctx, uint64_t arena_id)
     return BSG_OK;
 }
 
-int32_t bsg_batch_create(bsg_ctx *ctx, const bsg_term *terms, uint32_t n_terms, const uint32_t *prog_ops,
-                         const uint32_t *prog_off, uint32_t n_queries, uint64_t *out_batch_id)
+}  // extern "C"
+
+namespace {
+
+// One batch that fits one launch's limits.  *too_big: the failure (BSG_E_UNSUPPORTED) is one a smaller run of queries may not have.
+int32_t create_simple_batch(bsg_ctx *ctx, const bsg_term *terms, uint32_t n_terms, const uint32_t *prog_ops, const uint32_t *prog_off,
+                            uint32_t n_queries, std::shared_ptr<Batch> &out, bool *too_big)
 {
-    BSG_ENTER(ctx);
-    if (!ctx || !out_batch_id) return fail(BSG_E_INVALID, "null argument");
-    if (n_terms && !terms) return fail(BSG_E_INVALID, "terms is null");
-    if (n_queries && !prog_off) return fail(BSG_E_INVALID, "prog_off is null");
+    *too_big = false;
     auto batch = std::make_shared<Batch>();
     Batch &B = *batch;
     B.n_queries = n_queries;
@@ -1204,19 +1213,24 @@ int32_t bsg_batch_create(bsg_ctx *ctx, const bsg_term *terms, uint32_t n_terms, 
                 packed[((size_t)c * B.Lmax + j) * bsg::kEvalThreads + i] = op;
             }
     }
-    if (packed.size() > (1ull << 30))
-        return fail(BSG_E_UNSUPPORTED, "padded program table of %zu ops is too large; split the batch by program length", packed.size());
+    if (packed.size() > (1ull << 30)) {
+        *too_big = true;
+        return fail(BSG_E_UNSUPPORTED, "padded program table of %zu ops is too large for one launch", packed.size());
+    }
     const size_t lds_need = ((size_t)B.max_cw * 64 + (size_t)B.max_depth * bsg::kEvalThreads) * 8;
-    if (lds_need > 64 * 1024)
+    if (lds_need > 64 * 1024) {
+        *too_big = true;
         return fail(BSG_E_UNSUPPORTED, "a 256-query chunk needs %zu B of LDS (%u verdict words, stack depth %u)", lds_need,
                     B.max_cw, B.max_depth);
+    }
     {
         // k_probe_terms keeps per-kind verdict words + wave queues in LDS beside the bitset image
         uint32_t max_tw = 0;
         for (uint32_t y = 0; y < B.n_kinds; ++y) max_tw = std::max(max_tw, (B.term_count[y] + 63) / 64);
-        if (bsg::probe_lds_head_bytes(max_tw) > 48 * 1024)
-            return fail(BSG_E_UNSUPPORTED, "%u distinct terms of one kind exceed what one probe launch holds; split the batch",
-                        max_tw * 64);
+        if (bsg::probe_lds_head_bytes(max_tw) > 48 * 1024) {
+            *too_big = true;
+            return fail(BSG_E_UNSUPPORTED, "%u distinct terms of one kind exceed what one probe launch holds", max_tw * 64);
+        }
     }
     B.dev.resize(ctx->devs.size());
     for (size_t di = 0; di < ctx->devs.size(); ++di) {
@@ -1241,6 +1255,70 @@ int32_t bsg_batch_create(bsg_ctx *ctx, const bsg_term *terms, uint32_t n_terms, 
             return fail(e == hipErrorOutOfMemory ? BSG_E_NOMEM : BSG_E_HIP, "batch upload failed: %s", hipGetErrorString(e));
         }
     }
+    out = batch;
+    return BSG_OK;
+}
+
+// A batch of any size: one simple batch when it fits a launch, otherwise runs of queries (halved until they fit), each with the
+// terms its own queries reference.  A single query beyond the limits stays unsupported.
+int32_t create_batch_tree(bsg_ctx *ctx, const bsg_term *terms, uint32_t n_terms, const uint32_t *prog_ops, const uint32_t *prog_off,
+                          uint32_t q0, uint32_t q1, std::vector<std::shared_ptr<Batch>> &subs, std::vector<uint32_t> &sub_q0)
+{
+    // the run's own terms and programs (term indices renumbered densely in order of first use)
+    std::vector<uint32_t> remap(n_terms, 0xFFFFFFFFu), ops, off{0};
+    std::vector<bsg_term> used;
+    for (uint32_t q = q0; q < q1; ++q) {
+        for (uint32_t j = prog_off[q]; j < prog_off[q + 1]; ++j) {
+            uint32_t op = prog_ops[j];
+            if ((op >> 28) == BSG_OP_TERM) {
+                const uint32_t t = op & 0x0FFFFFFFu;
+                if (t >= n_terms) return fail(BSG_E_INVALID, "program references term %u of %u", t, n_terms);
+                if (remap[t] == 0xFFFFFFFFu) { remap[t] = (uint32_t)used.size(); used.push_back(terms[t]); }
+                op = BSG_OP(BSG_OP_TERM, remap[t]);
+            }
+            ops.push_back(op);
+        }
+        off.push_back((uint32_t)ops.size());
+    }
+    std::shared_ptr<Batch> b;
+    bool too_big = false;
+    const int32_t rc = create_simple_batch(ctx, used.data(), (uint32_t)used.size(), ops.data(), off.data(), q1 - q0, b, &too_big);
+    if (rc == BSG_OK) { subs.push_back(b); sub_q0.push_back(q0); return BSG_OK; }
+    if (!too_big || q1 - q0 <= 1) return rc;
+    // halves on 256-query (chunk) boundaries where the run is long enough
+    uint32_t mid = q0 + (q1 - q0) / 2;
+    if (q1 - q0 > 2 * bsg::kEvalThreads) mid = q0 + (mid - q0 + bsg::kEvalThreads - 1) / bsg::kEvalThreads * bsg::kEvalThreads;
+    if (int32_t rc2 = create_batch_tree(ctx, terms, n_terms, prog_ops, prog_off, q0, mid, subs, sub_q0)) return rc2;
+    return create_batch_tree(ctx, terms, n_terms, prog_ops, prog_off, mid, q1, subs, sub_q0);
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t bsg_batch_create(bsg_ctx *ctx, const bsg_term *terms, uint32_t n_terms, const uint32_t *prog_ops,
+                         const uint32_t *prog_off, uint32_t n_queries, uint64_t *out_batch_id)
+{
+    BSG_ENTER(ctx);
+    if (!ctx || !out_batch_id) return fail(BSG_E_INVALID, "null argument");
+    if (n_terms && !terms) return fail(BSG_E_INVALID, "terms is null");
+    if (n_queries && !prog_off) return fail(BSG_E_INVALID, "prog_off is null");
+    for (uint32_t q = 0; q < n_queries; ++q) {
+        if (prog_off[q + 1] < prog_off[q]) return fail(BSG_E_INVALID, "prog_off not monotone at %u", q);
+        if (prog_off[q + 1] > prog_off[q] && !prog_ops) return fail(BSG_E_INVALID, "prog_ops is null");
+    }
+    std::shared_ptr<Batch> batch;
+    bool too_big = false;
+    int32_t rc = create_simple_batch(ctx, terms, n_terms, prog_ops, prog_off, n_queries, batch, &too_big);
+    if (rc && too_big && n_queries > 1) {
+        // beyond one launch: a composite of runs of queries (the caller sees one batch; the evaluator it replaces has no limit)
+        auto comp = std::make_shared<Batch>();
+        comp->n_queries = n_queries;
+        rc = create_batch_tree(ctx, terms, n_terms, prog_ops, prog_off, 0, n_queries, comp->subs, comp->sub_q0);
+        if (rc) { const std::string saved = g_err; free_batch(ctx, *comp); return fail(rc, "%s", saved.c_str()); }
+        batch = comp;
+    }
+    if (rc) return rc;
     std::lock_guard<std::mutex> lk(ctx->mu);
     const uint64_t id = ctx->next_id++;
     ctx->batches[id] = batch;
@@ -1535,6 +1613,30 @@ int32_t probe_arenas(bsg_ctx *ctx, const std::vector<std::shared_ptr<Arena>> &ar
     const uint32_t nd = (uint32_t)ctx->devs.size();
     const uint32_t n_arenas = (uint32_t)arenas.size();
     if (B.n_queries == 0 || n_arenas == 0) return BSG_OK;
+    if (!B.subs.empty()) {
+        // a composite batch: every run of queries probes on its own; its rows are scattered into the caller's layout
+        // (arena i: [n_queries][G_i], the runs' rows [q0, q0 + nq) of it) on the host
+        if (out_dev) return fail(BSG_E_UNSUPPORTED, "a batch beyond one launch's limits cannot leave its survivors at a device pointer");
+        if (!out_survivors) {
+            for (auto &sub : B.subs) if (int32_t rc = probe_arenas(ctx, arenas, *sub, flags, nullptr, nullptr)) return rc;
+            return BSG_OK;
+        }
+        if (flags & BSG_PROBE_ASYNC) return fail(BSG_E_UNSUPPORTED, "a batch beyond one launch's limits needs a synchronous probe");
+        std::vector<uint64_t> G(n_arenas), aoff(n_arenas + 1, 0);
+        for (uint32_t i = 0; i < n_arenas; ++i) { G[i] = ((uint64_t)arenas[i]->n_blocks + 63) / 64; aoff[i + 1] = aoff[i] + (uint64_t)B.n_queries * G[i]; }
+        std::vector<uint64_t> tmp;
+        for (size_t si = 0; si < B.subs.size(); ++si) {
+            const Batch &S = *B.subs[si];
+            tmp.assign(std::max<uint64_t>(1, (uint64_t)S.n_queries * (aoff[n_arenas] / std::max(B.n_queries, 1u))), 0);
+            if (int32_t rc = probe_arenas(ctx, arenas, S, flags, tmp.data(), nullptr)) return rc;
+            uint64_t o = 0;
+            for (uint32_t i = 0; i < n_arenas; ++i) {
+                memcpy(out_survivors + aoff[i] + (uint64_t)B.sub_q0[si] * G[i], tmp.data() + o, (uint64_t)S.n_queries * G[i] * 8);
+                o += (uint64_t)S.n_queries * G[i];
+            }
+        }
+        return BSG_OK;
+    }
     const bool timed = flags & BSG_PROBE_TIMED;
     // Fusing pays while a dispatch is short enough for its ramp + completion to matter (a few arenas); behind a large
     // group the evaluation workgroups only take LDS and issue slots from the streaming (measured at 20-32 arenas of
@@ -2020,6 +2122,29 @@ int32_t bsg_last_kernel_ms(bsg_ctx *ctx, float *build_ms, float *hash_ms, float 
     if (build_ms) *build_ms = ctx->last_build_ms;
     if (hash_ms) *hash_ms = ctx->last_hash_ms;
     if (decode_ms) *decode_ms = ctx->last_decode_ms;
+    return BSG_OK;
+}
+
+// The last step of the probe as the reference takes it: evaluateBlockFilters appends blockScanCandidate{index} per surviving
+// block, in the order the blocks were consulted — ascending RowDataOffset (query_exec.go:321, 603).  An arena's blocks are in
+// the caller's order, so the ascending bit positions of a query's survivor row ARE that list.  Pure host arithmetic.
+int32_t bsg_survivor_list(const uint64_t *survivor_row, uint32_t n_blocks, uint32_t *out_blocks, uint32_t cap, uint32_t *out_n)
+{
+    if (!out_n || (n_blocks && !survivor_row)) return fail(BSG_E_INVALID, "null argument");
+    uint32_t n = 0;
+    const uint32_t G = (n_blocks + 63) / 64;
+    for (uint32_t g = 0; g < G; ++g) {
+        uint64_t w = survivor_row[g];
+        if (g == G - 1 && (n_blocks & 63u)) w &= (1ull << (n_blocks & 63u)) - 1;      // bits past the arena's end never count
+        while (w) {
+            const uint32_t bit = (uint32_t)__builtin_ctzll(w);
+            w &= w - 1;
+            if (out_blocks && n < cap) out_blocks[n] = g * 64 + bit;
+            ++n;
+        }
+    }
+    *out_n = n;
+    if (out_blocks && n > cap) return fail(BSG_E_INVALID, "%u blocks survive, the caller's list holds %u", n, cap);
     return BSG_OK;
 }
 

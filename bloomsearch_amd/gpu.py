@@ -23,6 +23,18 @@ def pack_entries(entries):
     return blob, off
 
 
+def survivor_list(row: np.ndarray, n_blocks: int) -> np.ndarray:
+    """bsg_survivor_list: the surviving block indices of one query's survivor row, ascending (host arithmetic)."""
+    L = _lib.load()
+    row = np.ascontiguousarray(row, dtype=np.uint64)
+    n = C.c_uint32()
+    out = np.zeros(max(n_blocks, 1), dtype=np.uint32)
+    rc = L.bsg_survivor_list(_lib._ptr(row), n_blocks, _lib._ptr(out), len(out), C.byref(n))
+    if rc:
+        raise BloomGpuError(rc, L.bsg_last_error(None).decode())
+    return out[: n.value].copy()
+
+
 def estimate_parameters(n: int, p: float):
     """bloom/v3 EstimateParameters with New()'s clamps (host arithmetic, no GPU needed)."""
     L = _lib.load()

@@ -196,7 +196,11 @@ BSG_API int32_t bsg_arena_stream_abort(bsg_ctx *ctx, uint64_t stream_id);
 BSG_API int32_t bsg_arena_free(bsg_ctx *ctx, uint64_t arena_id);
 
 /* Compile + upload a batch of queries: n_terms distinct terms and, per query q,
- * the postfix program prog_ops[prog_off[q] .. prog_off[q+1]). */
+ * the postfix program prog_ops[prog_off[q] .. prog_off[q+1]).  No limit on the batch: one launch holds ~22 000 distinct terms
+ * of a kind and ~100 verdict words per 256-query chunk, and a batch beyond that is cut — inside the library — into runs of
+ * queries that probe one after the other (the caller sees one batch and one result; evaluateBloomExpression has no such limit,
+ * query_exec.go:89-126).  Only a SINGLE query beyond those limits is BSG_E_UNSUPPORTED, and such a batch cannot leave its
+ * survivors at a device pointer (bsg_probe_many_dev). */
 BSG_API int32_t bsg_batch_create(bsg_ctx *ctx, const bsg_term *terms, uint32_t n_terms,
                                  const uint32_t *prog_ops, const uint32_t *prog_off, uint32_t n_queries,
                                  uint64_t *out_batch_id);
@@ -259,6 +263,12 @@ BSG_API int32_t bsg_probe(bsg_ctx *ctx, uint64_t arena_id, const bsg_term *terms
 BSG_API int32_t bsg_query(bsg_ctx *ctx, const uint64_t *arena_ids, uint32_t n_arenas,
                           const uint8_t *term_bytes, const uint32_t *term_off, const uint32_t *term_kinds, uint32_t n_terms,
                           const uint32_t *prog_ops, const uint32_t *prog_off, uint32_t n_queries, uint64_t *out_survivors);
+
+/* The surviving blocks of ONE query as the reference's probe hands them on: blockScanCandidate{index} per survivor in the order
+ * the blocks were consulted (ascending RowDataOffset, query_exec.go:321, 603) = the ascending bit positions of the query's row
+ * survivor_row[ceil(n_blocks / 64)] of a bsg_probe* / bsg_query result, for an arena loaded in that block order.  out_blocks may be
+ * NULL to ask for the count.  Host arithmetic, no context. */
+BSG_API int32_t bsg_survivor_list(const uint64_t *survivor_row, uint32_t n_blocks, uint32_t *out_blocks, uint32_t cap, uint32_t *out_n);
 
 BSG_API int32_t bsg_timing_read(bsg_ctx *ctx, bsg_timing *out, int32_t reset);
 /* With BSG_PROBE_TIMED, only every stride-th dispatch group is timestamped (default 1 = all). */

@@ -121,3 +121,17 @@ def test_plain_c99_program_links_against_the_boundary(lib, tmp_path):
     out = run_c_caller(tmp_path)
     if lib.bsg_device_count() == 0:
         assert "open=-6" in out
+
+
+def test_survivor_list_is_the_ascending_bit_positions():
+    """bsg_survivor_list (host arithmetic, runs without a GPU): blockScanCandidate order = ascending block index, bits past
+    the arena's end never count, a short list is reported (query_exec.go:321, 603)."""
+    import numpy as np
+    from bloomsearch_amd.gpu import survivor_list
+    rng = np.random.default_rng(3)
+    for n_blocks in (0, 1, 63, 64, 65, 130, 1000):
+        bits = rng.integers(0, 2, size=n_blocks, dtype=np.uint8)
+        padded = np.ones((n_blocks + 63) // 64 * 64, dtype=np.uint8)          # garbage past the end must be ignored
+        padded[:n_blocks] = bits
+        row = np.packbits(padded, bitorder="little").view(np.uint64) if n_blocks else np.zeros(0, dtype=np.uint64)
+        assert survivor_list(row, n_blocks).tolist() == np.flatnonzero(bits).tolist()

@@ -612,3 +612,46 @@ def test_bsg_query_one_call_strings_in_survivors_out(ctx):
                 bad = Q.compile_queries([Q.Token("x")])
                 bad._packed = (np.zeros(1, np.uint8), np.asarray([0, 1], np.uint32), np.asarray([7], np.uint32), *bad.arrays()[:2])
                 c.query(ids[:1], nbs[:1], bad)
+
+
+def test_batches_beyond_one_launch_are_split_inside_the_library(ctx):
+    """The reference's evaluator has no batch limit (query_exec.go:89-126).  One probe launch holds ~22 000 distinct terms of a
+    kind and ~100 verdict words per 256-query chunk: a batch beyond either is cut into runs of queries inside bsg_batch_create
+    and probed run by run — the caller sees one batch and one result, bit-identical to the tree-walking oracle."""
+    rng = np.random.default_rng(31)
+    plan, blocks_str, vocab = H.make_random_arena(rng, 70, absent_frac=0.05, max_tokens=500, vocab_size=40000)
+    words = ctx.build(plan.blob, plan.off, plan.fstart, plan.desc, plan.n_words)
+    aid = ctx.arena_load(words, plan.desc)
+    aid2 = ctx.arena_load(words, plan.desc)
+    members = [t for b in range(0, 70, 7) for t in blocks_str[b][1][:20]]
+    cases = {
+        # 30 000 distinct Token terms (> 22 000 of one kind), one or two per query
+        "30000 terms": [Q.Token(vocab[i]) for i in range(30000)] + [Q.And(Q.Token(m), Q.Token(vocab[7])) for m in members],
+        # 256 queries x 40 terms spread over 10 240 distinct terms: 160 verdict words in one chunk
+        "160 verdict words per chunk": [Q.Or(*[Q.Token(vocab[(q * 40 + j) % 40000]) for j in range(40)]) for q in range(256)] + [Q.Token(members[0]), None],
+    }
+    for name, exprs in cases.items():
+        cb = Q.compile_queries(exprs)
+        ops, poff, _ = cb.arrays()
+        terms = H.gpu_terms(ctx, cb)
+        bid = ctx.batch_create(terms, ops, poff)
+        want = O.survivors_tree(words, plan.desc.view(O.DESC_DTYPE), exprs)
+        got = ctx.probe_many([aid, aid2], bid, 0, cb.n_queries, [70, 70])
+        assert np.array_equal(got[0], want) and np.array_equal(got[1], want), name
+        assert np.array_equal(ctx.probe_batch(aid, bid, cb.n_queries, 70), want), name
+        ctx.batch_free(bid)
+        assert want.any()
+        # and through the one-call entry point (falls back to the same composite inside)
+        assert np.array_equal(ctx.query([aid], [70], cb)[0], want), name
+    # a SINGLE query beyond the limits stays unsupported, with a message
+    cb = Q.compile_queries([Q.Or(*[Q.Token(vocab[i]) for i in range(23000)])])
+    ops, poff, _ = cb.arrays()
+    with pytest.raises(BloomGpuError) as e:
+        ctx.batch_create(H.gpu_terms(ctx, cb), ops, poff)
+    assert e.value.code == _lib.BSG_E_UNSUPPORTED
+    # survivor lists: ascending block indices == the set bits
+    from bloomsearch_amd.gpu import survivor_list
+    row = want[0]
+    assert survivor_list(row, 70).tolist() == [b for b in range(70) if (int(row[b >> 6]) >> (b & 63)) & 1]
+    ctx.arena_free(aid)
+    ctx.arena_free(aid2)
