@@ -388,6 +388,61 @@ func (g *Context) Probe(a Arena, terms []Term, progOps, progOff []uint32) ([]uin
 	return out[0], nil
 }
 
+// Query is one interactive Query() in ONE call (bsg_query): the probed STRINGS go in — keys[t] with kinds[t], i.e. Field, Token or
+// Field + "::" + Token — and, per arena, survivors[q*ceil(blocks/64) + b>>6] bit b&63 comes out.  The strings are hashed on the
+// host inside the call; for a handful of terms the hashes and programs ride in the kernel arguments of one dispatch per device: no
+// batch object, no upload.  Larger batches take the batch path inside the same call.
+func (g *Context) Query(arenas []Arena, keys []string, kinds, progOps, progOff []uint32) ([][]uint64, error) {
+	nq := len(progOff) - 1
+	if len(arenas) == 0 || nq <= 0 {
+		return nil, nil
+	}
+	if len(kinds) != len(keys) {
+		return nil, errors.New("bloomgpu: one kind per key")
+	}
+	bytes, offsets := PackEntries(keys)
+	ids := make([]uint64, len(arenas))
+	total := 0
+	for i, a := range arenas {
+		ids[i] = a.ID
+		total += nq * int((a.Blocks+63)/64)
+	}
+	flat := make([]uint64, total+1)
+	rc := C.bsg_query(g.c, u64p(ids), C.uint32_t(len(ids)), u8p(bytes), u32p(offsets), u32p(kinds), C.uint32_t(len(keys)),
+		u32p(progOps), u32p(progOff), C.uint32_t(nq), u64p(flat))
+	if err := g.err(rc); err != nil {
+		return nil, err
+	}
+	out := make([][]uint64, len(arenas))
+	o := 0
+	for i, a := range arenas {
+		n := nq * int((a.Blocks+63)/64)
+		out[i] = flat[o : o+n : o+n]
+		o += n
+	}
+	return out, nil
+}
+
+// SurvivorList is bsg_survivor_list: the surviving block indices of one query's survivor row, ascending — the order
+// evaluateBlockFilters appends blockScanCandidate{index} in (query_exec.go:603) for an arena loaded in that block order.
+func SurvivorList(row []uint64, blocks uint32) ([]uint32, error) {
+	if blocks == 0 {
+		return nil, nil
+	}
+	out := make([]uint32, blocks)
+	var n C.uint32_t
+	if rc := C.bsg_survivor_list(u64p(row), C.uint32_t(blocks), u32p(out), C.uint32_t(blocks), &n); rc != C.BSG_OK {
+		return nil, &Error{Code: int(rc), Message: C.GoString(C.bsg_last_error(nil))}
+	}
+	return out[:n], nil
+}
+
+// DeviceCalls is bsg_device_calls: construct / match parts each device of the context has served so far.
+func (g *Context) DeviceCalls(nDevices int) ([]uint64, error) {
+	out := make([]uint64, nDevices)
+	return out, g.err(C.bsg_device_calls(g.c, u64p(out), C.uint32_t(nDevices)))
+}
+
 // OrReduce is bsg_or_reduce (north-star extension: OR of fixed-geometry filters; the reference rebuilds instead).
 func (g *Context) OrReduce(a Arena, kind uint32, nWords uint64) ([]uint64, error) {
 	out := make([]uint64, nWords)

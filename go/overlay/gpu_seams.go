@@ -9,7 +9,8 @@
 //   buildFiltersGPU ........... entries.buildFilters per partition + file level, flush.go:204,253; merge.go:771,516
 //   buildFiltersFromRowsGPU ... indexRow per row + buildFilters (ingest.go:450, merge.go:746) for the default tokenizer
 //   loadArena / loadArenaSections ... cursor.filtersFor + parseFilterSection per block, file_format.go:392-448,575
-//   probeBlocks ............... evaluateBlockFilters' per-block loop, query_exec.go:572-615
+//   probeBlocks ............... evaluateBlockFilters' per-block loop, query_exec.go:572-615 (one bsg_query call)
+//   gpu_engine.go ............. the engine methods engine_gpu.patch hooks into handleFlush / merge / evaluateBlockFilters / processDataBlock
 //   matchRowsGPU .............. matchRowBytes per row of the surviving blocks, query_exec.go:729-764
 package bloomsearch
 
@@ -261,17 +262,24 @@ func compileBloomQueries(g *bloomgpu.Context, queries []*BloomQuery) (bloomgpu.B
 // query_handles_test.go:1062).
 func probeBlocks(g *bloomgpu.Context, arenas []bloomgpu.Arena, q *BloomQuery) (survivors [][]uint64, perBlock time.Duration, err error) {
 	start := time.Now()
-	batch, err := compileBloomQueries(g, []*BloomQuery{q})
-	if err != nil {
-		return nil, 0, err
+	// one call: the probed strings go in (hashed on the host inside bsg_query, as TestString hashes inside the call), the
+	// survivor bitsets come out — no hash launch, no batch object (round 2 needed three calls here)
+	var l loweredQuery
+	if q != nil && q.Expression != nil {
+		l.emit(q.Expression)
 	}
-	defer g.BatchFree(batch)
-	survivors, err = g.ProbeMany(arenas, batch)
+	survivors, err = g.Query(arenas, l.keys, l.kinds, l.ops, []uint32{0, uint32(len(l.ops))})
 	blocks := 0
 	for _, a := range arenas {
 		blocks += int(a.Blocks)
 	}
 	return survivors, blockDuration(time.Since(start), blocks), err
+}
+
+// survivingBlocks turns one arena's survivor row into the index list evaluateBlockFilters builds: ascending block order
+// (query_exec.go:321, 603).
+func survivingBlocks(row []uint64, a bloomgpu.Arena) ([]uint32, error) {
+	return bloomgpu.SurvivorList(row, a.Blocks)
 }
 
 // blockDuration spreads a batch's wall time over its blocks, never returning zero for a block that was evaluated.
