@@ -168,3 +168,70 @@ def test_full_size_device_ingest_equals_entry_set_route(ctx, c2):
     for t in union[0]:
         ff.add(t)
     assert np.array_equal(ff.words, got[int(df["word_off"]): int(df["word_off"]) + O.words_for(int(df["m"]))])
+
+
+def test_full_size_c4_eight_term_or_batch_single_and_eight_entry_context(ctx, c2):
+    """BASELINE configs[3]'s query shape at FULL block size: one file of 1 000 blocks x 10 000 rows, Q = 4 096 eight-term
+    Or(FieldToken...) queries (the bench's generator + needles built from real rows), on the single-device context and on a
+    context of 8 entries (block b on entry b % 8, survivors interleaved on the host):
+      * no false negatives: an Or holding one (field, value) of a real row survives in that row's block;
+      * Or == bitwise OR of its eight single-term probes;
+      * idempotence across launch groupings (1 / 3 arenas per dispatch, fused or not) and across the two contexts;
+      * a RANDOM sample of 48 queries equals the tree-walking oracle over all 1 000 blocks, bit for bit."""
+    from bloomsearch_amd.gpu import Context
+    from tests import helpers as H
+    plan, words = c2
+    rng = np.random.default_rng(8)
+    d = synth.draws(0, B * ROWS)
+    exprs = synth.make_queries(NQ - 512, "c4", seed=99)
+    must = []
+    for r in rng.integers(0, B * ROWS, size=512):
+        uid = str(int(d["user_id"][r]))
+        absent = [Q.FieldToken("level", "absent-level-%d" % rng.integers(0, 4)), Q.FieldToken("service", "absent-svc-%d" % rng.integers(0, 4)),
+                  Q.FieldToken("nested.region", "region-%d" % rng.integers(8, 12)), Q.FieldToken("nested.az", "az-%d" % rng.integers(3, 6)),
+                  Q.FieldToken("tags", "absent-word-%d" % rng.integers(0, 8)), Q.FieldToken("message", "absent-word-%d" % rng.integers(0, 8)),
+                  Q.FieldToken("user_id", "nobody-%d" % rng.integers(0, 99))]
+        pos = int(rng.integers(0, 8))
+        exprs.append(Q.Or(*(absent[:pos] + [Q.FieldToken("user_id", uid)] + absent[pos:])))
+        must.append((len(exprs) - 1, int(r) // ROWS))
+    cb = Q.compile_queries(exprs)
+    ops, poff, _ = cb.arrays()
+    terms = H.gpu_terms(ctx, cb)
+    aid = ctx.arena_load(words, plan.desc)
+    bid = ctx.batch_create(terms, ops, poff)
+    got = ctx.probe_batch(aid, bid, NQ, B)
+    for q, b in must:
+        assert (int(got[q, b >> 6]) >> (b & 63)) & 1, (q, b)
+    needle_rows = got[[q for q, _ in must]]
+    survive = np.unpackbits(needle_rows.view(np.uint8), axis=1, bitorder="little")[:, :B].sum(axis=1)
+    assert 60 < survive.mean() < 150                             # a user's events: ~100 rows in ~95 of the 1 000 blocks (+ ~7 false positives), not all of them
+    # Or == bitwise OR of the single-term probes (first 40 queries)
+    for q in range(0, 40):
+        kids = exprs[q]["Children"]
+        sub = Q.compile_queries(kids)
+        so, sp, _ = sub.arrays()
+        s = ctx.probe(aid, B, H.gpu_terms(ctx, sub), so, sp)
+        assert np.array_equal(np.bitwise_or.reduce(s, axis=0), got[q]), q
+    # idempotence across groupings
+    try:
+        for group in (1, 3):
+            ctx.set_probe_group(group)
+            many = ctx.probe_many([aid, aid, aid, aid], bid, 0, NQ, [B] * 4)
+            assert all(np.array_equal(m, got) for m in many), group
+    finally:
+        ctx.set_probe_group(0)
+    # random oracle sample
+    sel = np.sort(rng.choice(NQ, size=48, replace=False))
+    want = O.survivors_tree(words, plan.desc.view(O.DESC_DTYPE), [exprs[int(i)] for i in sel])
+    assert np.array_equal(got[sel], want)
+    assert not (got[:, -1] >> np.uint64(40)).any()
+    ctx.batch_free(bid)
+    ctx.arena_free(aid)
+    # the same file and batch on a context of 8 entries
+    with Context((0,) * 8) as m8:
+        a8 = m8.arena_load(words, plan.desc)
+        b8 = m8.batch_create(terms, ops, poff)
+        g8 = m8.probe_batch(a8, b8, NQ, B)
+        assert np.array_equal(g8, got)
+        many = m8.probe_many([a8, a8], b8, 0, NQ, [B, B])
+        assert np.array_equal(many[0], got) and np.array_equal(many[1], got)
