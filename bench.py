@@ -1015,15 +1015,20 @@ def main():
         # coalesced reads on gfx950, + WRITE_SIZE), committed under profiles/.
         traffic = traffic_src = None
         try:
-            rec = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
+            tname = "r03_traffic.json" if os.path.exists(os.path.join(ROOT, "profiles", "r03_traffic.json")) else "r02_traffic.json"
+            rec = json.load(open(os.path.join(ROOT, "profiles", tname)))
             per_arena = rec[dom]["hbm_bytes_corrected_per_arena"]
             if args.workload == "c2" and B == 1000 and k:
                 traffic = per_arena * k["arenas_per_launch"]
-                traffic_src = "profiles/r02_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py; per 1 000-block arena x arenas per launch)"
+                traffic_src = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py; per 1 000-block arena x arenas per launch)" % tname
         except Exception:
             pass
         out = {
             "metric": "block-bloom probes/sec", "value": value, "unit": "probes/s", "n_gpus": world,
+            # `value` leaves the survivor bitsets on the device (inputs and outputs resident, nothing crosses PCIe in the timed
+            # region); the north star's "host-side gather of surviving block IDs" costs what the next field says — the same steps
+            # with every rank's survivors DMA-ed into host memory (details under host_gather)
+            "value_survivors_delivered_to_host": probes_per_step * args.steps / h_elapsed,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": "%s probe: %d rows/block x %d blocks per GPU, Q=%d %s [%s], "

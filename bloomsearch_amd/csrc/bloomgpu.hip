@@ -286,6 +286,8 @@ struct bsg_ctx {
     std::atomic<uint32_t> next_dev{0};
     uint64_t shard_min_entries = 1ull << 18;   // bsg_hash_entries / bsg_build*: fewer entries stay on one device (bsg_set_lab key 7)
     uint64_t shard_min_row_bytes = 8ull << 20; // bsg_ingest_rows / bsg_match_rows: fewer row bytes stay on one device (bsg_set_lab key 8)
+    uint32_t union_coarsen = 0;                // lab: the partitioned union starts with 2^this x too few partitions (bsg_set_lab key 10)
+    uint32_t union_mode = 0;                   // file-level union: 0 = partitions in LDS (k_union_partitions), 1 = global hash tables (bsg_set_lab key 9)
     // device time of the most recent call of each family: the slowest device that took part (bsg_last_*_ms)
     float last_build_ms = 0.f, last_hash_ms = 0.f, last_decode_ms = 0.f, last_or_ms = 0.f, last_encode_ms = 0.f, last_match_ms = 0.f;
 };
@@ -565,6 +567,7 @@ int32_t bsg_open(const int32_t *device_ids, int32_t n_devices, bsg_ctx **out_ctx
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(bsg::k_probe_fused), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(bsg::k_build), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(bsg::k_build_sets), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget - bsg::kSetListBytes));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(bsg::k_union_partitions), hipFuncAttributeMaxDynamicSharedMemorySize, bsg::kPartLdsBytes));
 
         ctx->devs.push_back(std::move(d));
     }
@@ -874,7 +877,7 @@ static int32_t build_on_device(bsg_ctx *ctx, Device &d, BuildPart &P, const uint
                 HIP_TRY(hipGetLastError());
             }
             bsg::BinArgs b{};
-            b.t = bsg::IngestTable{hslot, nullptr, 0, 0};
+            b.t = bsg::IngestTable{hslot, nullptr, 0, 0};      // (a dense list of hashes: never inserted into)
             b.d = dd[f - f0];
             b.n_slots = ne;
             b.n_locs_cap = (uint32_t)((uint64_t)ne * desc[f].k);
@@ -1864,7 +1867,9 @@ extern "C" int32_t bsg_set_probe_group(bsg_ctx *ctx, uint32_t max_arenas_per_lau
 // key 4 = pieces bsg_arena_load_sections decodes a region in (1: one launch after the whole copy);
 // key 6 = fewest locations (entries x k) for which a bitset beyond LDS is built from binned locations (default 4 M);
 // key 7 = fewest entries of a bsg_hash_entries / bsg_build* call that is cut into one part per device (default 256 K);
-// key 8 = fewest row bytes of a bsg_ingest_rows / bsg_match_rows call that is cut into one part per device (default 8 MiB)
+// key 8 = fewest row bytes of a bsg_ingest_rows / bsg_match_rows call that is cut into one part per device (default 8 MiB);
+// key 9 = 1: the file-level union goes through global hash tables (round 2's path) instead of LDS partitions; key 10 = start the
+// partitioned union with 2^value x too few partitions (exercises its retry and its fallback; 32 + v: 2^v x too many — runs of a few, one, less than one home slot)
 extern "C" int32_t bsg_set_lab(bsg_ctx *ctx, uint32_t key, uint64_t value)
 {
     BSG_ENTER(ctx);
@@ -1875,6 +1880,8 @@ extern "C" int32_t bsg_set_lab(bsg_ctx *ctx, uint32_t key, uint64_t value)
     if (key == 4) { ctx->load_pieces = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(value, 1), 64); return BSG_OK; }
     if (key == 7) { ctx->shard_min_entries = value; return BSG_OK; }
     if (key == 8) { ctx->shard_min_row_bytes = value; return BSG_OK; }
+    if (key == 9) { ctx->union_mode = (uint32_t)std::min<uint64_t>(value, 1); return BSG_OK; }
+    if (key == 10) { ctx->union_coarsen = (uint32_t)std::min<uint64_t>(value, 56); return BSG_OK; }
     return fail(BSG_E_INVALID, "unknown lab key %u", key);
 }
 

@@ -42,9 +42,14 @@ constexpr uint32_t kTableOk = 0, kTableOverflow = 1, kTableExotic = 2;
 struct IngestTable {
     uint64_t *slots;   // [mask + 1][4]
     uint64_t *fps;     // [mask + 1]: keyed fingerprint of the entry stored in the slot (0 while its claimer is still writing)
-    uint32_t mask;     // capacity - 1 (capacity is a power of two)
-    uint32_t pad;
+    uint32_t mask;     // capacity - 1 (a power of two for tables that are inserted into; a DENSE list of n entries has mask = n - 1)
+    uint32_t shift;    // 32 - log2(capacity): an entry's home slot is the TOP log2(capacity) bits of table_key(h)
 };
+
+// An entry's position key: 32 bits of h1 (h0 is the claim word).  The home slot is its TOP bits, so that for any two tables —
+// whatever their capacities — "the entries whose key starts with these b bits" is ONE contiguous run of slots (plus the linear-
+// probe spill behind it): k_union_partitions unions a file's children partition by partition without moving an entry first.
+__device__ __forceinline__ uint32_t table_key(const uint64_t h[4]) { return (uint32_t)(h[1] >> 20); }
 
 // Exactness where the reference is exact.  Go's map compares BYTES; the tables compare the 256 bits of bloom/v3's sum256,
 // and MurmurHash3_x64_128 has seed-independent internal-state collisions: for any entry of >= 24 bytes an attacker can
@@ -221,7 +226,7 @@ __device__ __forceinline__ void count_add(uint32_t *count, bool flag)
 
 __device__ __forceinline__ void insert_begin(InsertState &x, const IngestTable t, const uint64_t h[4], bool active, uint32_t *status)
 {
-    x.idx = (uint32_t)(h[1] >> 20) & t.mask;   // h0 is the claim word; index with bits of h1
+    x.idx = table_key(h) >> t.shift;            // h0 is the claim word; the home slot is the top bits of the key (see table_key)
     x.probes = x.spins = 0;
     x.present = false;
     x.fresh = false;
@@ -1048,6 +1053,165 @@ __global__ __launch_bounds__(256) void k_ingest_union(const IngestTable *src_tab
     __syncthreads();
     if (threadIdx.x == 0 && wg_fresh)
         __hip_atomic_fetch_add(dst_counts + it.dst, wg_fresh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---------------- the file-level union, partition by partition, deduplicated in LDS ----------------
+// flush.go:221,253: the file's entry sets are the unions of its blocks' sets, and their exact sizes size the file-level
+// filters.  Round 2 inserted every child entry into a global hash table per parent: 39 M CAS round trips at C3 (4.5 ms, all
+// of it the CAS), tables of 2 x the children's entries rounded up to a power of two (5.4 GB), and a memset of all of it.
+// Here a workgroup owns ONE PARTITION of one parent — the entries whose table_key starts with log2P given bits.  In every
+// child table those entries sit in one run of slots (home slot = top bits of the key) plus whatever linear probing pushed
+// behind it, so the workgroup walks that run in each child — lane = child — until the first empty slot at or past its end,
+// keeps the entries whose key really is the partition's, and deduplicates them in an LDS table (exact: four hash words + the
+// keyed fingerprint; equal hashes under different fingerprints flag the parent like the global tables do).  What is left is
+// the partition's distinct entries: the workgroup adds their number to the parent's counter — ONE global atomic per workgroup,
+// and the counter ends up as the exact distinct count — and writes them densely at the offset the add returned.  The parent
+// is then a dense list (mask = count - 1, every fingerprint non-zero): k_build_sets, the binned build, k_table_compact and
+// k_ingest_union read it like any table.  Memory: 40 bytes per CHILD entry (an upper bound of the union), no memset.
+constexpr uint32_t kPartSlots = 2048;                 // LDS table of a partition: 80 KB of dynamic LDS, two workgroups per CU
+constexpr uint32_t kPartFill = kPartSlots * 3 / 4;    // more distinct entries than this: the partitioning was too coarse (status overflow)
+constexpr uint32_t kPartTarget = 1280;                // child entries per partition the host aims at (duplicates included): at C3 a partition is then
+                                                      // 4 home slots per child = one 32-byte sector of fingerprints; finer partitions re-read sectors
+constexpr uint32_t kPartThreads = 512;
+constexpr uint32_t kPartProbes = 48;                  // linear-probe bound inside the LDS table
+constexpr uint32_t kPartAhead = 4;                    // slots of a child a lane fetches per trip
+constexpr uint32_t kPartLdsBytes = kPartSlots * 5 * 8;
+
+struct PartParent {
+    uint64_t *out_slots, *out_fps;   // dense output, room for cap_out entries
+    uint32_t cap_out;
+    uint32_t log2P;                  // partitions = 1 << log2P
+    uint32_t child_begin, child_end; // this parent's children in child_list
+    uint32_t table;                  // the parent's own table index: counts[table] / status[table]
+    uint32_t pad;
+};
+
+__global__ __launch_bounds__(kPartThreads) void k_union_partitions(const IngestTable *tables, const uint32_t *child_list, const PartParent *parents,
+                                                                   uint32_t *counts, uint32_t *status)
+{
+    extern __shared__ __attribute__((aligned(16))) uint64_t part_lds[];
+    uint64_t *L0 = part_lds, *L1 = L0 + kPartSlots, *L2 = L1 + kPartSlots, *L3 = L2 + kPartSlots, *LF = L3 + kPartSlots;
+    __shared__ uint32_t n_fresh, out_base, cursor, overflow;
+    const PartParent pp = parents[blockIdx.y];
+    const uint32_t p = blockIdx.x, tid = threadIdx.x, lane = tid & 63u;
+    if (p >= (1u << pp.log2P)) return;
+    for (uint32_t i = tid; i < kPartSlots; i += kPartThreads) { L0[i] = 0; LF[i] = 0; }
+    if (tid == 0) { n_fresh = 0; cursor = 0; overflow = 0; }
+    __syncthreads();
+    uint32_t fresh = 0;
+    const uint32_t n_children = pp.child_end - pp.child_begin;
+    for (uint32_t c0 = 0; c0 < n_children; c0 += kPartThreads) {
+        const bool have = c0 + tid < n_children;
+        IngestTable t{nullptr, nullptr, 0, 0};
+        if (have) t = tables[child_list[pp.child_begin + c0 + tid]];
+        const uint64_t cap = (uint64_t)t.mask + 1;
+        // the partition's run of home slots in this child: [floor(p cap / P), ceil((p + 1) cap / P))
+        uint64_t s = ((uint64_t)p * cap) >> pp.log2P;
+        const uint64_t e = (((uint64_t)(p + 1) * cap) + ((1ull << pp.log2P) - 1)) >> pp.log2P;
+        bool scanning = have;
+        uint32_t scanned = 0;
+        while (__ballot(scanning) != 0ull) {
+            // ---- every lane looks at kPartAhead consecutive slots of its child: their fingerprints in one go, then the hashes of
+            // the occupied ones together — two dependent round trips per trip instead of two per slot (a run is 1-2 home slots
+            // plus the probe spill, so one trip nearly always finishes a child) ----
+            if (scanning && *(volatile uint32_t *)&overflow) scanning = false;      // the partition is already known to be too coarse: stop reading
+            uint64_t f[kPartAhead];
+            ulonglong2 hx[kPartAhead], hy[kPartAhead];
+            bool cand[kPartAhead];
+#pragma unroll
+            for (uint32_t u = 0; u < kPartAhead; ++u) f[u] = scanning ? t.fps[(uint32_t)(s + u) & t.mask] : 0;     // (the last partition's spill wraps to slot 0)
+            // a slot past the run's end can only hold one of ours if every slot from the run's last one up to it is occupied
+            // (linear probing leaves no gap between an entry's home and its place): the others' hashes are not even fetched,
+            // and the first gap at or after the run's last slot ends the child
+            bool chain = true;
+            bool look[kPartAhead];
+#pragma unroll
+            for (uint32_t u = 0; u < kPartAhead; ++u) {
+                hx[u] = hy[u] = make_ulonglong2(0, 0);
+                look[u] = scanning && f[u] != 0 && (s + u < e || chain);
+                if (look[u]) {
+                    const ulonglong2 *q = reinterpret_cast<const ulonglong2 *>(t.slots + (uint64_t)((uint32_t)(s + u) & t.mask) * 4);
+                    hx[u] = q[0]; hy[u] = q[1];
+                }
+                if (s + u + 1 >= e && f[u] == 0) chain = false;   // (from the run's last slot on)
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < kPartAhead; ++u) {
+                cand[u] = false;
+                if (look[u]) {
+                    const uint32_t key = (uint32_t)(hx[u].y >> 20);                   // table_key
+                    cand[u] = pp.log2P == 0 || (key >> (32u - pp.log2P)) == p;
+                }
+            }
+            scanned += kPartAhead;
+            if (scanned > cap) scanning = false;                                      // a table without an empty slot: one lap
+            s += kPartAhead;
+            if (s >= e && !chain) scanning = false;                   // the run is done and there is a gap at or behind its last slot: nothing of ours lies beyond
+            // ---- the candidates of the wave go into the LDS table together (wave-uniform exit: see set_insert2's SIMT note) ----
+#pragma unroll
+            for (uint32_t u = 0; u < kPartAhead; ++u) {
+                if (__ballot(cand[u]) == 0ull) continue;
+                const uint64_t h0 = hx[u].x, h1 = hx[u].y, h2 = hy[u].x, h3 = hy[u].y, fp = f[u];
+                bool done = !cand[u];
+                uint32_t idx = (uint32_t)(h2 >> 17) & (kPartSlots - 1), probes = 0, spins = 0;
+                do {
+                    if (!done) {
+                        unsigned long long old = 0;
+                        const bool won = __hip_atomic_compare_exchange_strong((unsigned long long *)&L0[idx], &old, (unsigned long long)h0, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                                              __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (won) {
+                            L1[idx] = h1; L2[idx] = h2; L3[idx] = h3;
+                            __hip_atomic_store(&LF[idx], fp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            done = true;
+                            ++fresh;
+                        } else if (old == h0) {
+                            const uint64_t f2 = __hip_atomic_load(&LF[idx], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            if (f2 == 0) {                            // the claimer's words are still in flight
+                                if (++spins > kSpinLimit) { __hip_atomic_fetch_max(status + pp.table, kTableExotic, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); done = true; }
+                            } else if (L1[idx] == h1 && L2[idx] == h2 && L3[idx] == h3) {
+                                if (f2 != fp) __hip_atomic_fetch_max(status + pp.table, kTableExotic, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // equal hashes, another entry
+                                done = true;                          // a duplicate
+                            } else {
+                                idx = (idx + 1) & (kPartSlots - 1); ++probes;
+                            }
+                        } else {
+                            idx = (idx + 1) & (kPartSlots - 1); ++probes;
+                        }
+                        if (!done && probes >= kPartProbes) { overflow = 1; done = true; }     // a chain this long: the table is as good as full
+                    }
+                } while (__ballot(!done) != 0ull);
+            }
+        }
+    }
+    if (fresh) atomicAdd(&n_fresh, fresh);
+    __syncthreads();
+    if (n_fresh > kPartFill) overflow = 1;
+    __syncthreads();
+    if (overflow) {                                               // too coarse a partitioning: the host repeats the launch with more partitions
+        if (tid == 0) __hip_atomic_fetch_max(status + pp.table, kTableOverflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    if (tid == 0 && n_fresh) out_base = __hip_atomic_fetch_add(counts + pp.table, n_fresh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (n_fresh == 0) return;
+    for (uint32_t i0 = 0; i0 < kPartSlots; i0 += kPartThreads) {
+        const uint32_t i = i0 + tid;
+        const uint64_t f = LF[i];
+        const uint64_t mask = __ballot(f != 0);
+        if (mask == 0) continue;
+        uint32_t at = 0;
+        if (lane == (uint32_t)__builtin_ctzll(mask)) at = atomicAdd(&cursor, (uint32_t)__builtin_popcountll(mask));
+        at = __shfl(at, (int)__builtin_ctzll(mask), 64);
+        if (f != 0) {
+            const uint32_t pos = out_base + at + lane_rank(mask);
+            if (pos < pp.cap_out) {
+                ulonglong2 *o = reinterpret_cast<ulonglong2 *>(pp.out_slots + (uint64_t)pos * 4);
+                o[0] = make_ulonglong2(L0[i], L1[i]);
+                o[1] = make_ulonglong2(L2[i], L3[i]);
+                pp.out_fps[pos] = f;
+            }
+        }
+    }
 }
 
 // ---------------- occupied slots of a table, densely packed (the form a partial file-level set travels between devices in) ----------------

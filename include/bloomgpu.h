@@ -235,7 +235,8 @@ BSG_API int32_t bsg_set_probe_group(bsg_ctx *ctx, uint32_t max_arenas_per_launch
  * of a synchronous batch of <= 256 queries that is answered by one dispatch, 0 = never; key 4: launches the decode of
  * bsg_arena_load_sections is split into, 1 = one launch after the whole copy; key 6: fewest locations (entries x k) from
  * which a bitset beyond LDS is built from binned locations instead of global atomics; keys 7 / 8: fewest entries / row bytes from
- * which a construct or match call on a context over several devices is cut into one part per device); not part of the seam. */
+ * which a construct or match call on a context over several devices is cut into one part per device; key 9: 1 = file-level unions
+ * through global hash tables instead of LDS partitions, key 10: start that partitioning 2^value x too coarse); not part of the seam. */
 BSG_API int32_t bsg_set_lab(bsg_ctx *ctx, uint32_t key, uint64_t value);
 /* Synchronous probes poll their stream for up to this long before they block (default 0: block at once).  A single
  * query's kernels finish in ~10 us; being woken from a blocking wait costs more than that. */

@@ -9,7 +9,7 @@ Follows (reference file:line):
   bloomEntrySets.indexRow / addFieldToken .................... ingest.go:55-102
   buildRowMatchSets / matchesBloomExpression ................. tokenizer.go:236-330
 Pinned by the language-neutral tables of tokenizer_test.go:10-190,
-query_test.go:91-111 and no_false_negatives_test.go:103-321 (tests/test_walker_tables.py).
+query_test.go:91-111 and no_false_negatives_test.go:103-321 (tests/test_host_tables.py, tests/test_ingest_gpu.py, tests/test_match_gpu.py).
 
 gjson (v1.18.0, un-vendored) semantics relied on: Parse + ForEach visit object
 members in document order including duplicate keys; key.String()/value.Str are

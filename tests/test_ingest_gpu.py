@@ -451,3 +451,39 @@ def test_every_chunk_alignment(ctx):
     # bitsets of one alignment family in full
     for i in range(1, 16, 2):
         check_against_sets(res, i, cache[rows[i]], rows[i])
+
+
+def test_file_level_union_in_lds_partitions_equals_global_tables_retry_and_fallback(ctx):
+    """flush.go:221,253: the file's entry sets are the unions of its blocks'.  k_union_partitions deduplicates them partition by
+    partition in LDS (dense parents, one atomic per workgroup); lab key 9 = 1 takes round 2's global hash tables, key 10 starts
+    the partitioning 2^v x too coarse so that the 4-x-finer retry (v = 4) and the fall-back to the global tables (v = 14) run.
+    Counts, statuses and bitsets must be identical on every route — and equal the oracle's build of the union."""
+    row_sets = [synth.rows_json(b * 900, 900) for b in range(64)] + [[]]
+    parents = [0] * 52 + [1] * 12 + [1]          # file 0: ~95 k distinct tokens — more than 64 LDS partitions hold, so v = 14 cannot be rescued by three 4-x-finer retries
+    routes = {}
+    try:
+        # 32 + v: 2^v x FINER than needed: a partition's run in a child shrinks to 2 slots, 1 slot, a fraction of a slot — the probe
+        # spill behind a run then crosses several partitions (a 2-slot run at load 0.6 miscounted partition 0 before its fix)
+        for name, mode, coarsen in (("partitions", 0, 0), ("global tables", 1, 0), ("retry", 0, 4), ("fallback", 0, 14), ("finer x16", 0, 36),
+                                    ("finer x32", 0, 37), ("finer x128", 0, 39), ("finer x1024", 0, 42)):
+            ctx.set_lab(9, mode)
+            ctx.set_lab(10, coarsen)
+            routes[name] = I.device_ingest(ctx, row_sets, FPR, parent_of_set=parents, n_parents=3)      # parent 2 has no children at all
+    finally:
+        ctx.set_lab(9, 0)
+        ctx.set_lab(10, 0)
+    base = routes["partitions"]
+    assert not base.status.any() and base.stats.ms_union > 0
+    assert routes["retry"].stats.table_grows >= 1 and routes["fallback"].stats.table_grows >= 4, (routes["retry"].stats.table_grows, routes["fallback"].stats.table_grows)
+    for name, res in routes.items():
+        assert np.array_equal(res.counts, base.counts), name
+        assert np.array_equal(res.status, base.status), name
+        assert np.array_equal(res.words, base.words), name
+    assert base.stats.table_bytes < routes["global tables"].stats.table_bytes       # 40 B per child entry vs 2 x rounded up to a power of two
+    unions = [(set(), set(), set()) for _ in range(3)]
+    for s, rows in enumerate(row_sets):
+        for u, x in zip(unions[parents[s]], oracle_sets(rows)):
+            u |= x
+    for p in range(3):
+        check_against_sets(base, len(row_sets) + p, unions[p], "file %d" % p)
+    assert [int(x) for x in base.counts[len(row_sets) + 2]] == [0, 0, 0]
