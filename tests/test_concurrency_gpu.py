@@ -60,6 +60,7 @@ def _single_query_job(ctx, seed):
         terms = H.oracle_terms(cb)
         want = O.probe_batch(words, plan.desc.view(O.DESC_DTYPE), terms.view(O.TERM_DTYPE), ops, poff)
         assert np.array_equal(ctx.probe(aid, plan.n_blocks, terms, ops, poff), want)
+        assert np.array_equal(ctx.query([aid], [plan.n_blocks], cb)[0], want)        # the one-call path: hashes + programs in the kernel arguments
     ctx.arena_free(aid)
     return True
 
@@ -111,3 +112,29 @@ def test_many_threads_one_context(ctx):
         results = list(pool.map(run, range(N_THREADS)))
     assert not errors, errors
     assert all(results)
+
+
+def test_many_threads_one_sharded_context():
+    """The same mix on a context of three entries whose construct / match calls are all cut into parts (threads inside the
+    library on top of the callers' threads): per-device locks are only ever taken one at a time, so nothing can deadlock, and
+    every result still equals the oracle's."""
+    from bloomsearch_amd.gpu import Context
+    errors = []
+    with Context((0, 0, 0)) as m:
+        m.set_lab(7, 1)
+        m.set_lab(8, 1)
+        barrier = threading.Barrier(9)
+
+        def run(i):
+            try:
+                barrier.wait(timeout=60)
+                return (_probe_job, _ingest_job, _match_job, _single_query_job, _ingest_job, _probe_job, _match_job, _ingest_job, _single_query_job)[i % 9](m, 300 + i)
+            except BaseException as exc:  # noqa: BLE001
+                errors.append((i, repr(exc)))
+                return False
+
+        with ThreadPoolExecutor(9) as pool:
+            results = list(pool.map(run, range(9)))
+        assert not errors, errors
+        assert all(results)
+        assert (m.device_calls() > 0).all()
