@@ -142,7 +142,7 @@ def ingest_leg(ctx, n_blocks, rows, seed, workers, plan, words, fpr, log, truste
              "matches": int(hits.sum()), "end_to_end_s_incl_h2d": t_match, "check": "equals the generator's draws row for row"}
     return {"workload": "C3 from rows: %d blocks x %d JSON rows -> %d block filters + 3 file-level filters" % (n_blocks, rows, 3 * n_blocks),
             "match": match,
-            "kernels": {"k_ingest_rows_ms": st.ms_walk, "k_ingest_union_ms": st.ms_union, "k_build_sets_ms": st.ms_build},
+            "kernels": {"k_ingest_rows_ms": st.ms_walk, "k_union_partitions_ms": st.ms_union, "k_build_sets_ms": st.ms_build},
             "rows": n_rows, "row_bytes": int(st.row_bytes), "rows_per_s_device": n_rows / kern_ms * 1e3,
             "row_gb_per_s_walk": st.row_bytes / max(st.ms_walk, 1e-6) / 1e6, "end_to_end_s_incl_h2d": t_e2e,
             "end_to_end_s_incl_h2d_pinned_rows": t_e2e_pinned, "end_to_end_over_kernels_pinned": t_e2e_pinned * 1e3 / kern_ms,

@@ -1,9 +1,9 @@
 #!/bin/bash
 # One GPU-box pass that regenerates everything profiles/ holds for a round: rocprofv3 stats (+ PMC traffic) for the C2,
 # C4-shape and many-term workloads, the SQ counters of the many-term kernel, the driver-shaped and default bench lines.
-# Usage (via gpurun): bash tools/final_round.sh r02
+# Usage (via gpurun): bash tools/final_round.sh r03
 set -u
-R=${1:-r02}
+R=${1:-r03}
 mkdir -p gpurun_out
 bash tools/profile.sh ${R}_c2 > /dev/null
 NO_PMC=1 bash tools/profile.sh ${R}_c4 --workload c4 > /dev/null
@@ -16,6 +16,9 @@ python bench.py > gpurun_out/${R}_bench_default.json 2> gpurun_out/${R}_bench_de
 python bench.py --workload needle --cpu-budget 0 --c4-files 0 --ingest-blocks 0 --no-decode --or-union 0 > gpurun_out/${R}_bench_needle.json 2>/dev/null
 python bench.py --workload c4 --cpu-budget 6 --c4-files 0 --ingest-blocks 0 --no-decode --or-union 0 > gpurun_out/${R}_bench_c4.json 2>/dev/null
 bash tools/profile_ingest_trace.sh ${R}_ingest 300 > gpurun_out/${R}_ingest_rocprofv3.txt 2>&1
+bash tools/profile_build_pmc.sh ${R}_build > /dev/null 2>&1
+tools/or_lab 1000 44976 20 > gpurun_out/${R}_or_lab.txt 2>&1
+NB=1000 bash tools/union_ab.sh > gpurun_out/${R}_union_ab.txt 2>&1
 # what to keep: the summaries and the bench lines (the rocprofv3 databases stay in gpurun_out/)
 mkdir -p gpurun_out/keep
 cp gpurun_out/prof_${R}_c2/summary.txt gpurun_out/keep/${R}_probe_c2_rocprofv3.txt
@@ -24,5 +27,6 @@ cp gpurun_out/prof_${R}_needle/summary.txt gpurun_out/keep/${R}_probe_needle_roc
 cp gpurun_out/prof_${R}_driver/summary.txt gpurun_out/keep/${R}_bench_driver_shape_rocprofv3.txt
 cp gpurun_out/prof_${R}_c2/traffic.json gpurun_out/keep/${R}_traffic.json
 cp gpurun_out/pmc_${R}_needle/summary.txt gpurun_out/keep/${R}_needle_pmc.txt
-cp gpurun_out/${R}_ingest_rocprofv3.txt gpurun_out/${R}_bench_*.json gpurun_out/keep/
+cp gpurun_out/${R}_ingest_rocprofv3.txt gpurun_out/${R}_bench_*.json gpurun_out/${R}_or_lab.txt gpurun_out/${R}_union_ab.txt gpurun_out/keep/
+cp gpurun_out/pmc_${R}_build/summary.txt gpurun_out/keep/${R}_build_pmc.txt
 ls -la gpurun_out/keep
