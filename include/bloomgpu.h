@@ -297,7 +297,9 @@ BSG_API int32_t bsg_last_or_ms(bsg_ctx *ctx, float *or_ms);
  * RCCL has no bitwise-OR reduction: the all-reduce is reduce-scatter + all-gather with the OR done by a kernel of the library —
  * slice j of every rank's partial bitset travels to rank j (grouped ncclSend / ncclRecv, one slice per point-to-point link),
  * is OR-ed there, and the reduced slices are ncclAllGather-ed: 2 (world - 1) / world of the bitset per GPU on the wire.  librccl is bound
- * at run time; without it these calls fail with BSG_E_UNSUPPORTED and everything else keeps working.
+ * at run time; without it these calls fail with BSG_E_UNSUPPORTED and everything else keeps working.  (BSG_RCCL_LIBRARY in the
+ * environment names the library the communicator symbols are bound from instead: an RCCL build under test, or the suite's
+ * in-process loopback, tests/loopback_ccl.cpp, through which one GPU runs the world > 1 schedule.)
  *   one process per GPU : rank 0 calls bsg_comm_unique_id and hands the 128 bytes to the other ranks (any channel);
  *                         every rank calls bsg_comm_init(ctx, id, rank, world) on its single-device context.
  *   one process, N GPUs : bsg_comm_init(ctx, NULL, 0, 0) makes every device of the context a rank (ncclCommInitAll).
