@@ -233,11 +233,22 @@ def or_exchange_leg(ctx, res, state, world, log):
             ctx.or_allreduce_dev([part.data_ptr()], nw)
             ts.append(time.perf_counter() - t1)
         full = ctx.or_allreduce(aid, 1, nw)            # the whole operation: local OR + exchange + copy out
+        # a wrong result is reported in the line (allreduce_error) like a failed call: this leg is the extension of the path, and
+        # it must not take the probe measurement down with it
         if not np.array_equal(full, part.cpu().numpy().view(np.uint64)):
-            sys.exit("bsg_or_allreduce and bsg_or_allreduce_dev disagree")
-        # every rank must hold every rank's bits: the local partial is a subset of the result
+            raise RuntimeError("bsg_or_allreduce and bsg_or_allreduce_dev disagree")
+        # every rank must hold every rank's bits: the local partial is a subset of the result, and all ranks hold the same words
         if np.any(got & ~full):
-            sys.exit("OR all-reduce lost bits of this rank's partial")
+            raise RuntimeError("OR all-reduce lost bits of this rank's partial")
+        if world > 1:
+            digest = torch.tensor([int(np.bitwise_xor.reduce(full) >> np.uint64(1)), int(full.sum(dtype=np.uint64) >> np.uint64(1))],
+                                  dtype=torch.int64, device=COLL_DEVICE())
+            lo, hi = digest.clone(), digest.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            if not torch.equal(lo, hi):
+                raise RuntimeError("the ranks hold different results after the OR all-reduce")
+            res["allreduce_check"] = "every rank's partial is a subset of the result; xor / sum digests of the result equal on all %d ranks" % world
         ctx.comm_destroy()
         res["allreduce_ms"] = float(np.median(ts[1:])) * 1e3
         from bloomsearch_amd import parallel as P
