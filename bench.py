@@ -338,6 +338,31 @@ def cpu_baseline(words, desc, cb, ops, poff, n_blocks, budget_s, log, terms_per_
                       "evaluateBloomFilters per (query, block), %d threads, %.1fs)" % (nq2, cb.n_queries, n_blocks, cores, t2)}, out, nq2
 
 
+def measured_copy_gbps(log):
+    """the roofline fraction is quoted against the vendor's 8 TB/s AND against what a plain device-to-device copy
+    reaches on this very box (1 GiB hipMemcpyAsync D2D through torch, bytes read + bytes written over the copy's own events)."""
+    import torch
+    try:
+        n = 1 << 30
+        a = torch.zeros(n, dtype=torch.uint8, device="cuda")
+        b = torch.empty_like(a)
+        for _ in range(3):
+            b.copy_(a)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            b.copy_(a)
+        e1.record()
+        e1.synchronize()
+        gbps = 2.0 * n * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del a, b
+        log("device-to-device copy of 1 GiB: %.0f GB/s (read + write)" % gbps)
+        return gbps
+    except Exception as exc:  # noqa: BLE001 - a calibration figure, never fatal
+        log("copy bandwidth not measured: %r" % (exc,))
+        return None
+
+
 def COLL_DEVICE():
     """Where the harness' own small collectives live: the GPU under RCCL, the host under the gloo lab mode."""
     import torch.distributed as dist
@@ -1034,6 +1059,7 @@ def main():
                 traffic_src = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py; per 1 000-block arena x arenas per launch)" % tname
         except Exception:
             pass
+        copy_gbps = measured_copy_gbps(log)
         out = {
             "metric": "block-bloom probes/sec", "value": value, "unit": "probes/s", "n_gpus": world,
             # `value` leaves the survivor bitsets on the device (inputs and outputs resident, nothing crosses PCIe in the timed
@@ -1054,6 +1080,10 @@ def main():
                          "unit": "GB/s", "frac": k.get("frac"), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": k.get("algorithmic_bytes_per_launch"), "kernel_ms": k.get("kernel_ms"),
                          "samples": k.get("samples"), "arenas_per_launch": k.get("arenas_per_launch"),
+                         "copy_gbps": copy_gbps,
+                         "frac_of_copy": (k.get("achieved") / copy_gbps) if (copy_gbps and k.get("achieved")) else None,
+                         "copy_note": "copy_gbps = bytes read + written by a 1 GiB device-to-device copy on this box, measured in this run (SURVEY 8d: "
+                                      "quote the fraction of the vendor peak and of the measured copy bandwidth)",
                          "timed_region": timed_region, "sampling_passes": samples, "all": allk},
             "host_gather": {"ms_per_step": h_elapsed / args.steps * 1e3, "value": probes_per_step * args.steps / h_elapsed,
                             "survivor_bytes_per_step_per_gpu": wps * 8, "page_locked": page_locked,
