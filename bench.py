@@ -154,6 +154,90 @@ def ingest_leg(ctx, n_blocks, rows, seed, workers, plan, words, fpr, log, truste
             "check": "bitsets and (m, k) identical to bsg_build of the same blocks' entry sets"}
 
 
+def multi_device_context_leg(ctx, device_ids, plan, words, block_ids, rows, seed, fpr, terms, ops, poff, got, log):
+    """The OTHER way the library spans GPUs: ONE process, one context over several devices (what the Go engine opens:
+    GPUDevices = [0 .. N-1]).  bench.py's contract is one process per GPU, so this in-process path is otherwise only ever run
+    on one physical GPU (contexts that name device 0 several times).  Rank 0 runs it once, after every timed leg, when the
+    job has several GPUs in sight: arena sharded block b -> device b % N, the C2 batch probed there (survivors interleaved on
+    the host), one interactive query, the C3 build cut into one part per device (parts on threads, each over its own PCIe
+    link), a device ingest whose parents are merged across devices (peer copies) and whose sections become resident arenas,
+    and the fixed-geometry OR with the partials moved device to device.  Everything is compared with the single-device
+    context's results, which the legs above compared with the oracle.  Never fatal: the outcome goes into the line."""
+    from bloomsearch_amd import ingest as I, query as Q
+    from bloomsearch_amd.gpu import Context
+    B = len(block_ids)
+    res = {"devices": [int(d) for d in device_ids]}
+    with Context(tuple(device_ids)) as m:
+        aid = m.arena_load(words, plan.desc)
+        t0 = time.perf_counter()
+        if not np.array_equal(m.probe(aid, B, terms, ops, poff), got):
+            raise RuntimeError("survivors of the multi-device context differ from the single-device context's")
+        res["probe_wall_ms"] = (time.perf_counter() - t0) * 1e3
+        one = Q.compile_queries([Q.And(Q.FieldToken("level", "error"), Q.FieldToken("service", "payment"), Q.FieldToken("nested.region", "region-3"))])
+        a1 = ctx.arena_load(words, plan.desc)
+        same = np.array_equal(m.query([aid], [B], one)[0], ctx.query([a1], [B], one)[0])
+        ctx.arena_free(a1)
+        m.arena_free(aid)
+        if not same:
+            raise RuntimeError("bsg_query on the multi-device context differs")
+        # the C3 build, one part per device
+        t0 = time.perf_counter()
+        w_m = m.build(plan.blob, plan.off, plan.fstart, plan.desc, plan.n_words)
+        t_m = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        w_s = ctx.build(plan.blob, plan.off, plan.fstart, plan.desc, plan.n_words)
+        t_s = time.perf_counter() - t0
+        if not (np.array_equal(w_m, words) and np.array_equal(w_s, words)):
+            raise RuntimeError("bitsets of the sharded build differ")
+        res["build_wall_ms"] = {"one_device": t_s * 1e3, "sharded": t_m * 1e3,
+                                "note": "bsg_build of %d entries incl. the upload of the entry bytes and the bitsets' way back" % (len(plan.off) - 1)}
+        # device ingest of the first blocks' rows: parts per device, parents merged across devices, sections + resident arenas
+        nb = min(B, 64)
+        parts = [_gen_rows((int(block_ids[b]), rows, seed)) for b in range(nb)]
+        blob = np.frombuffer(b"".join(p[0] for p in parts), dtype=np.uint8)
+        off = np.zeros(sum(len(p[1]) for p in parts) + 1, dtype=np.uint64)
+        np.cumsum(np.concatenate([p[1] for p in parts]), out=off[1:])
+        first = np.arange(nb + 1, dtype=np.uint32) * rows
+        outs = []
+        for c in (m, ctx):
+            ing = c.ingest_rows((blob, off), first, np.zeros(nb, dtype=np.uint32), 1, flags=1)
+            counts, status = c.ingest_finish(ing, nb + 1)
+            desc, n_words = I.plan_desc(counts, fpr)
+            secs, sets_arena, parents_arena = c.ingest_build_sections(ing, desc, arenas=True)
+            c.ingest_free(ing)
+            surv = c.probe(sets_arena, nb, terms, ops, poff)
+            c.arena_free(sets_arena)
+            c.arena_free(parents_arena)
+            outs.append((counts, status, [bytes(x) for x in secs], surv))
+        if not (np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]) and outs[0][2] == outs[1][2]
+                and np.array_equal(outs[0][3], outs[1][3])):
+            raise RuntimeError("device ingest on the multi-device context differs (counts, section bytes or the resident arena's survivors)")
+        if nb == 64 and not np.array_equal(outs[0][3][:, 0], got[:, 0]):      # blocks 0..63 are the first survivor word of the loaded arena
+            raise RuntimeError("the resident arena of the first blocks answers differently from the loaded arena")
+        # fixed-geometry OR, partials device to device
+        rng = np.random.default_rng(5)
+        mm, nblk = 1000003, 96
+        nw = (mm + 63) // 64
+        stride = (nw + 15) // 16 * 16
+        from bloomsearch_amd import _lib
+        d2 = np.zeros(nblk * 3, dtype=_lib.DESC_DTYPE)
+        w2 = np.zeros(nblk * stride, dtype=np.uint64)
+        for b in range(nblk):
+            d2[b * 3 + 1] = (b * stride, mm, 7, 0)
+            w2[b * stride: b * stride + nw] = rng.integers(0, 1 << 63, nw, dtype=np.uint64) & rng.integers(0, 1 << 63, nw, dtype=np.uint64)
+            w2[b * stride + nw - 1] &= np.uint64((1 << (mm & 63)) - 1)
+        a2 = m.arena_load(w2, d2)
+        got_or = m.or_reduce(a2, 1, nw)
+        m.arena_free(a2)
+        if not np.array_equal(got_or, np.bitwise_or.reduce(w2.reshape(nblk, stride)[:, :nw], axis=0)):
+            raise RuntimeError("bsg_or_reduce across the context's devices differs from numpy's OR")
+        res["device_calls"] = [int(x) for x in m.device_calls()]
+    res["check"] = ("probe (batch + one bsg_query), bsg_build, device ingest -> sections + resident arenas, bsg_or_reduce: identical to the "
+                    "single-device context on %d devices in one process" % len(device_ids))
+    log("multi-device context over devices %s: ok (build %.0f ms sharded vs %.0f ms on one device)" % (list(device_ids), t_m * 1e3, t_s * 1e3))
+    return res
+
+
 def or_reduce_leg(ctx, plan, B, fpr, n_union, world, log):
     """BASELINE configs[4] / SURVEY C5: OR-reduce of this rank's B fixed-geometry token filters into one partial
     file-level bitset (k_or_reduce_blocks), then — for world > 1 — the one real exchange of the path: all_gather of the
@@ -1129,6 +1213,33 @@ def main():
         if rank == 0 and emitted.acquire(blocking=False):
             print(json.dumps(out), file=json_out, flush=True)
 
+    # ---- one process, one context over every GPU of the job (rank 0, after every timed leg; the other ranks wait at the
+    # barrier below).  BSG_BENCH_MULTI_CTX=n (lab): a context of n entries that all name this rank's GPU. ----
+    if rank == 0:
+        import torch
+        n_lab = int(os.environ.get("BSG_BENCH_MULTI_CTX", "0"))
+        ids = [local_rank] * n_lab if n_lab > 1 else (
+            list(range(world)) if world > 1 and COLL_DEVICE() == "cuda" and torch.cuda.device_count() >= world else None)
+        if ids:
+            finished = threading.Event()
+
+            def giving_up():
+                if not finished.wait(float(os.environ.get("BSG_BENCH_MULTI_CTX_TIMEOUT", "300"))):
+                    out["multi_device_context"] = {"devices": ids, "error": "no answer within the watchdog's time; the leg was abandoned"}
+                    emit()
+                    os._exit(0)
+            threading.Thread(target=giving_up, daemon=True).start()
+            try:
+                out["multi_device_context"] = multi_device_context_leg(ctx, ids, plan, words, block_ids, rows, 0xB100F5EA4C4, args.fpr,
+                                                                       terms, ops, poff, got, log)
+            except Exception as exc:  # noqa: BLE001 - reported in the line
+                out["multi_device_context"] = {"devices": ids, "error": repr(exc)}
+                log("multi-device context leg failed: %r" % (exc,))
+            finished.set()
+        elif world > 1:
+            out["multi_device_context"] = {"skipped": "%d device(s) visible to rank 0" % torch.cuda.device_count()}
+    if world > 1:
+        dist.barrier()
     if or_state is not None:
         # the RCCL leg last, under a watchdog: if a collective never returns, rank 0 still prints the line (with the error
         # noted) and every rank leaves — a hung collective cannot be cancelled from Python
