@@ -66,6 +66,48 @@ C_PROGRAM = r"""
 #include "bloomgpu.h"
 #include "bloomsearch_host.h"
 
+/* TestEvaluateBloomFilters (bloom_tree_engine_test.go:357-442) from C, the way a cgo caller would run it: three (959, 7) filters
+ * built and serialised on the device (bsg_build_sections), loaded back from the section bytes (bsg_arena_load_sections), the eight
+ * expressions answered by ONE bsg_query call with the probed strings as they are, survivors listed by bsg_survivor_list. */
+static int evaluate_fixture(bsg_ctx *ctx)
+{
+    static const char entries[] = "user.name" "user.age" "alice" "30" "user.name::alice" "user.age::30";
+    const uint32_t off[7] = {0, 9, 17, 22, 24, 40, 52};
+    const uint32_t fstart[4] = {0, 2, 4, 6};
+    static const char probed[] = "user.name" "nonexistent.field" "alice" "user.name::alice";
+    const uint32_t term_off[5] = {0, 9, 26, 31, 47};
+    const uint32_t term_kinds[4] = {BSG_KIND_FIELD, BSG_KIND_FIELD, BSG_KIND_TOKEN, BSG_KIND_FIELD_TOKEN};
+    /* nil query; field exists; field does not exist; token exists; field-token exists; OR one match; AND one mismatch; OR field / field-token */
+    const uint32_t ops[14] = {BSG_OP(BSG_OP_TRUE, 0), BSG_OP(BSG_OP_TERM, 0), BSG_OP(BSG_OP_TERM, 1), BSG_OP(BSG_OP_TERM, 2), BSG_OP(BSG_OP_TERM, 3),
+                              BSG_OP(BSG_OP_TERM, 1), BSG_OP(BSG_OP_TERM, 0), BSG_OP(BSG_OP_OR, 2),
+                              BSG_OP(BSG_OP_TERM, 1), BSG_OP(BSG_OP_TERM, 0), BSG_OP(BSG_OP_AND, 2),
+                              BSG_OP(BSG_OP_TERM, 1), BSG_OP(BSG_OP_TERM, 3), BSG_OP(BSG_OP_OR, 2)};
+    const uint32_t prog_off[9] = {0, 1, 2, 3, 4, 5, 8, 11, 14};
+    bsg_filter_desc d[3];
+    uint8_t region[1024];
+    uint64_t sec_off[2] = {0, 0}, arena = 0, total = 0, survivors[8];
+    uint32_t blocks[4], n = 0;
+    int32_t status[1] = {0};
+    int i;
+    memset(d, 0, sizeof d);
+    for (i = 0; i < 3; ++i) { d[i].word_off = (uint64_t)i * 16; d[i].m = 959; d[i].k = 7; }
+    if (bsg_sections_size(d, 1, &total) != BSG_OK || total > sizeof region) return 10;
+    if (bsg_build_sections(ctx, (const uint8_t *)entries, off, 6, fstart, d, 3, 48, region, sizeof region, sec_off) != BSG_OK) return 11;
+    if (sec_off[0] != 0 || sec_off[1] != total) return 12;
+    printf("section=");
+    for (i = 0; i < (int)total; ++i) printf("%02x", region[i]);
+    printf("\n");
+    if (bsg_arena_load_sections(ctx, region, total, sec_off, 1, status, &arena) != BSG_OK || status[0] != 0) return 13;
+    if (bsg_query(ctx, &arena, 1, (const uint8_t *)probed, term_off, term_kinds, 4, ops, prog_off, 8, survivors) != BSG_OK) return 14;
+    printf("verdicts=");
+    for (i = 0; i < 8; ++i) printf("%d", (int)(survivors[i] & 1));
+    printf("\n");
+    if (bsg_survivor_list(&survivors[1], 1, blocks, 4, &n) != BSG_OK || n != 1 || blocks[0] != 0) return 15;
+    if (bsg_survivor_list(&survivors[2], 1, blocks, 4, &n) != BSG_OK || n != 0) return 16;
+    if (bsg_arena_free(ctx, arena) != BSG_OK) return 17;
+    return 0;
+}
+
 int main(void)
 {
     uint64_t m = 0, k = 0, total = 0;
@@ -87,6 +129,7 @@ int main(void)
         const uint32_t off[2] = {0, 5};
         if (bsg_hash_entries(ctx, (const uint8_t *)"hello", off, 1, h) != BSG_OK) return 5;
         printf("hello=%016llx %016llx\n", (unsigned long long)h[0], (unsigned long long)h[1]);
+        if ((rc = evaluate_fixture(ctx)) != 0) return rc;
         bsg_close(ctx);
     } else if (rc != BSG_E_NODEVICE) {
         return 6;
@@ -117,7 +160,8 @@ def run_c_caller(tmp_path):
 def test_plain_c99_program_links_against_the_boundary(lib, tmp_path):
     """include/*.h are C99 headers and libbloomgpu.so is an ordinary shared library: a C program compiled with gcc
     (-std=c99 -Wall -Werror -pedantic) links, runs, sizes sections on the host and — without a GPU — is refused by
-    bsg_open with BSG_E_NODEVICE.  (tests/test_gpu_parity.py runs the same program where a GPU is present.)"""
+    bsg_open with BSG_E_NODEVICE.  (tests/test_gpu_parity.py runs the same program where a GPU is present: there it also
+    runs the reference's TestEvaluateBloomFilters fixture through bsg_build_sections / bsg_arena_load_sections / bsg_query.)"""
     out = run_c_caller(tmp_path)
     if lib.bsg_device_count() == 0:
         assert "open=-6" in out

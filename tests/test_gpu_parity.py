@@ -1,6 +1,8 @@
 """GPU parity tests proper: every result of the HIP path (through the C-ABI) is
 compared bit-for-bit with the CPU oracle on the same seeded inputs.  Integer /
 byte work => the bar is exact equality."""
+import os
+
 import numpy as np
 import pytest
 
@@ -29,6 +31,13 @@ def test_plain_c99_caller_hashes_on_the_gpu(tmp_path):
     from tests.test_cabi import run_c_caller
     out = run_c_caller(tmp_path)
     assert "open=0" in out and "hello=cbd8a7b341bd9b02 5b1e906a48ae1d19" in out
+    # ... and the reference's own TestEvaluateBloomFilters fixture, run from C: the section bytes bsg_build_sections wrote are the
+    # golden wire bytes, and the eight verdicts of ONE bsg_query call are the reference's (bloom_tree_engine_test.go:382-427)
+    import json
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "bloom_vectors.json")))["evaluate_bloom_filters_fixture"]
+    lines = dict(l.split("=", 1) for l in out.splitlines() if "=" in l and " " not in l.split("=", 1)[0])
+    assert lines["section"] == fx["section_hex"]
+    assert lines["verdicts"] == "".join("1" if c["expected"] else "0" for c in fx["cases"]) == "11011101"
 
 
 def test_hash_entries_large_batch(ctx):
