@@ -29,6 +29,8 @@ struct MatchArgs {
     uint32_t *fallback_rows;
     uint32_t *n_fallback;
     uint32_t n_rows, n_conds, n_ops;
+    uint32_t row_base;           // added to the row indices reported in fallback_rows (a launch covers rows [row_base, row_base + n_rows) of the call;
+                                 // row_off / out_bits already point at its first row / word)
     FpKey key;
 };
 
@@ -114,7 +116,7 @@ __global__ __launch_bounds__(kIngestThreads) void k_match_rows(const MatchArgs a
     if ((threadIdx.x & 63u) == 0u && (r & ~63u) < a.n_rows) a.out_bits[r >> 6] = word;
     if (res == R_FAIL) {
         const uint32_t slot = __hip_atomic_fetch_add(a.n_fallback, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        a.fallback_rows[slot] = r;
+        a.fallback_rows[slot] = a.row_base + r;
     }
 }
 

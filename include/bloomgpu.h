@@ -427,6 +427,7 @@ BSG_API int32_t bsg_ingest_free(bsg_ctx *ctx, uint64_t ingest_id);
  * walker's envelope (see bsg_ingest_rows), and rows in which an emission has the base hashes of a condition string but
  * not its keyed fingerprint — a MurmurHash3 state collision, where only matchRowBytes' byte compare is exact.
  * Target tokens are never normalised (Token("ALICE") misses, row_matcher_test.go:99-100).
+ * The rows of a large call are uploaded in chunks (bsg_set_ingest_chunk) on a copy stream while the chunk before is matched.
  * Limits: 64 conditions, expression depth 64 (BSG_E_UNSUPPORTED beyond). */
 BSG_API int32_t bsg_match_rows(bsg_ctx *ctx, const uint8_t *rows, const uint64_t *row_off, uint32_t n_rows,
                                const uint8_t *cond_bytes, const uint32_t *cond_off, const uint32_t *cond_kinds, uint32_t n_conds,

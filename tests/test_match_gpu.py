@@ -161,3 +161,35 @@ def test_compiled_matcher_equivalence_with_derived_queries(ctx):
                 assert [W.matches_bloom_expression(r, q) for r in rows] == want
             n_pos += sum(want)
     assert n_pos > 400
+
+
+def test_chunked_upload_overlapping_the_match(ctx):
+    """The rows travel in chunks on the copy stream while the chunk before is matched (bsg_match_rows, as bsg_ingest_rows
+    does): verdicts, the rows handed back (indices of the CALL, whatever chunk they sat in) and the device time must not
+    depend on where the chunks were cut — chunk sizes from a few rows to everything in one piece, on single- and
+    multi-entry contexts (whose parts are chunked in turn)."""
+    from bloomsearch_amd.gpu import Context
+    rows = synth.rows_json(20000, 6000)
+    bad = [b'{"s":"\\xff\\xfe bad utf8 token"}', b'{"a": [1, 2', ('{' + '"a":{' * 17 + '"x":1' + '}' * 17 + '}').encode()]
+    where = [0, 255, 256, 257, 1023, 1024, 3000, 5998]
+    for i, r in enumerate(where):
+        rows[r] = bad[i % len(bad)]
+    d = synth.draws(20000, 6000)
+    e = Q.Or(Q.And(Q.FieldToken("level", "error"), Q.FieldToken("nested.region", "region-3")), Q.Token("ok"))
+    want = (d["level"] == synth.LEVELS.index("error")) & (d["region"] == 3)
+    want[where] = False
+    got0, fb0 = ctx.match_rows(rows, Q.CompiledMatcher(e))
+    assert sorted(int(x) for x in fb0) == where and np.array_equal(got0, want) and want.sum() > 50
+    try:
+        for chunk in (1 << 16, 70001, 1 << 18, 1 << 30):                # (the library takes no chunk below 64 KiB)
+            ctx.set_ingest_chunk(chunk)
+            got, fb = ctx.match_rows(rows, Q.CompiledMatcher(e))
+            assert np.array_equal(got, got0) and sorted(int(x) for x in fb) == where, chunk
+            assert ctx.last_match_ms() > 0
+    finally:
+        ctx.set_ingest_chunk(0)
+    with Context((0, 0, 0)) as m:
+        m.set_lab(8, 1)                                     # shard whatever the size
+        m.set_ingest_chunk(1 << 16)
+        got, fb = m.match_rows(rows, Q.CompiledMatcher(e))
+        assert np.array_equal(got, got0) and sorted(int(x) for x in fb) == where
