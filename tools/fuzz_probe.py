@@ -2,7 +2,8 @@
 Per seed: a few random arenas (block counts around the 64-block groups, false-positive rates from 1e-5 to 0.5, nil
 filters, blocks without tokens), the device build compared with the oracle's bitsets, then random query batches — one
 query, a handful, hundreds; few distinct terms (one-dispatch and few-term kernels) or thousands (many-term kernel) —
-probed through every launch shape (group limit 1 / 3 / 32, fused or not, timed or not, sharded contexts) and compared
+probed through every launch shape (group limit 1 / 3 / 32, fused or not, timed or not, sharded contexts) and through the one-call
+bsg_query (strings in; kernel-argument fast path or the batch path inside the call) and compared
 with the oracle's surviving-block sets bit for bit.  Exits non-zero on the first difference."""
 import os
 import sys
@@ -43,7 +44,7 @@ def main():
             all_words.append(words)
             arenas.append(ctx.arena_load(words, plan.desc))
         for _ in range(3):
-            nq = int(rng.choice([1, 2, 7, 64, 256, 257, 600]))
+            nq = int(rng.choice([1, 1, 2, 3, 7, 12, 64, 256, 257, 600]))
             words_pool = vocab[: int(rng.choice([2, 6, len(vocab)]))]
             cb = Q.compile_queries([H.random_expression(rng, words_pool, None) if rng.random() > 0.03 else None for _ in range(nq)])
             ops, poff, _ = cb.arrays()
@@ -58,6 +59,14 @@ def main():
                 if not np.array_equal(g, wants[i]):
                     sys.exit("seed %d: survivors differ (nq %d, %d terms, group order %s, flags %d, %d-entry context, arena %d)"
                              % (seed, nq, len(terms), order[:8], flags, nd, i))
+                n_bits += g.size * 64
+            # the same batch through the one-call path (bsg_query: strings in, hashed on the host; one k_query_direct dispatch per
+            # device when <= 16 terms / 128 program words / 32 arenas fit the kernel arguments, the batch path inside the call otherwise)
+            sub = [int(i) for i in rng.integers(0, len(arenas), size=int(rng.choice([1, 2, 5, 33])))]
+            gq = ctx.query([arenas[i] for i in sub], [plans[i].n_blocks for i in sub], cb)
+            for g, i in zip(gq, sub):
+                if not np.array_equal(g, wants[i]):
+                    sys.exit("seed %d: bsg_query differs (nq %d, %d terms, %d arenas, %d-entry context, arena %d)" % (seed, nq, len(terms), len(sub), nd, i))
                 n_bits += g.size * 64
             n_cases += 1
             ctx.batch_free(bid)
