@@ -1,5 +1,7 @@
-import time, numpy as np, sys
-sys.path.insert(0, "/root/repo")
+"""Where the time of a large bsg_match_rows call goes (GPU box): BSG_LAB_TRACE=1 python tools/match_trace.py"""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bloomsearch_amd import synth, query as Q
 from bloomsearch_amd.gpu import Context
 import bench
