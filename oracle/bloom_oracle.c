@@ -14,7 +14,14 @@
  * and its own tests hold no golden hash / bitset / serialized bytes.  This
  * file therefore restates the *published* algorithm of those modules
  * (assumptions B1..B5 of SURVEY.md §8c) and is pinned on what exists:
- *   - MurmurHash3_x64_128 public vectors (external truth),
+ *   - MurmurHash3_x64_128 public vectors (external truth), and — where the image
+ *     holds it — Austin Appleby's own reference implementation (the MurmurHash3.cpp
+ *     scikit-learn bundles, compiled from where it lies by oracle.py::appleby into
+ *     oracle/_third_party/): bo_murmur3_x64_128 and both halves of bo_base_hashes
+ *     equal it on every length 0..300 and thousands of random inputs, and so does
+ *     the HIP kernel directly (tests/test_gpu_parity.py).  That pins the HASH of
+ *     assumption B2 independently; bloom/v3's USE of it (d || 0x01, the location
+ *     formula, the wire layout) remains unpinned,
  *   - the (n,p)->(m,k) values the reference's tests name
  *     (bloom_tree_engine_test.go:368-376 -> (959,7); lifecycle test (2,0.02)),
  *   - the hash-dependent outcomes W1..W4 harvested from the reference's tests

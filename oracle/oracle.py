@@ -80,6 +80,59 @@ def murmur3_x64_128(data: bytes, seed: int = 0):
     return int(out[0]), int(out[1])
 
 
+# ---- an INDEPENDENT MurmurHash3_x64_128: Austin Appleby's public-domain reference implementation ----
+# scikit-learn ships the original MurmurHash3.cpp (sklearn/utils/src/); where that file exists it is compiled FROM WHERE IT
+# LIES (nothing of it enters this repository) into oracle/_third_party/ and the restatement in bloom_oracle.c — and the HIP
+# kernels — are compared with it on arbitrary inputs, not only on the three public vectors.  It pins the hash function of
+# SURVEY 8c's assumption B2 for every length and tail; what it cannot pin is bloom/v3's use of it (the "data || 0x01" second
+# hash, the location formula, the wire layout): those stay with the Go parity harness.
+_APPLEBY = None
+
+
+def appleby_source():
+    try:
+        import sklearn
+    except Exception:  # noqa: BLE001 - absent package: the pin is skipped, nothing else depends on it
+        return None
+    src = os.path.join(os.path.dirname(sklearn.__file__), "utils", "src", "MurmurHash3.cpp")
+    return src if os.path.exists(src) else None
+
+
+def appleby():
+    """ctypes handle on MurmurHash3_x64_128 (key, len, seed, out[2 x u64]) of the third-party reference, or None."""
+    global _APPLEBY
+    if _APPLEBY is not None:
+        return _APPLEBY or None
+    src = appleby_source()
+    out_dir = os.path.join(_HERE, "_third_party")
+    so = os.path.join(out_dir, "libmurmur3_appleby.so")
+    if src is None and not os.path.exists(so):
+        _APPLEBY = False
+        return None
+    if src is not None and (not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src)):
+        os.makedirs(out_dir, exist_ok=True)
+        subprocess.check_call(["g++", "-O2", "-shared", "-fPIC", "-I", os.path.dirname(src), "-o", so, src])
+    L = C.CDLL(so)
+    fn = None
+    for name in ("MurmurHash3_x64_128", "_Z19MurmurHash3_x64_128PKvijPv"):      # (C or C++ linkage, whatever the header asks for)
+        if hasattr(L, name):
+            fn = getattr(L, name)
+            break
+    if fn is None:
+        _APPLEBY = False
+        return None
+    fn.argtypes = [C.c_char_p, C.c_int, C.c_uint32, C.c_void_p]
+    fn.restype = None
+    _APPLEBY = fn
+    return fn
+
+
+def appleby_x64_128(data: bytes, seed: int = 0):
+    out = (C.c_uint64 * 2)()
+    appleby()(data, len(data), seed, out)
+    return int(out[0]), int(out[1])
+
+
 def base_hashes(data: bytes):
     out = (C.c_uint64 * 4)()
     lib().bo_base_hashes(data, len(data), out)

@@ -25,6 +25,20 @@ def test_hash_entries_bit_exact(ctx):
     assert np.array_equal(got, want)
 
 
+def test_device_hashes_equal_the_independent_murmur3(ctx):
+    """k_hash_entries against Austin Appleby's own MurmurHash3_x64_128 (oracle.appleby: scikit-learn's bundled MurmurHash3.cpp,
+    compiled from where it lies) — not via the restatement: (h0, h1) = murmur(d), (h2, h3) = murmur(d + 0x01) for every length
+    0..300 and a few thousand more bytes, so the HIP hash is pinned by an implementation written by neither side."""
+    if O.appleby() is None:
+        pytest.skip("scikit-learn's MurmurHash3.cpp is not in this image")
+    rng = np.random.default_rng(77)
+    ents = [rng.integers(0, 256, size=n, dtype=np.uint8).tobytes() for n in range(0, 301) for _ in range(2)]
+    ents += [rng.integers(0, 256, size=int(n), dtype=np.uint8).tobytes() for n in rng.integers(301, 4000, size=100)]
+    got = ctx.hash_strings(ents)
+    for row, d in zip(got, ents):
+        assert tuple(int(x) for x in row) == O.appleby_x64_128(d) + O.appleby_x64_128(d + b"\x01"), len(d)
+
+
 def test_plain_c99_caller_hashes_on_the_gpu(tmp_path):
     """The C program of tests/test_cabi.py, where a GPU is present: bsg_open succeeds and bsg_hash_entries returns the
     public MurmurHash3_x64_128 vector for "hello" — the boundary works without Python or torch in the process."""

@@ -31,6 +31,26 @@ def test_base_hashes_are_murmur_of_d_and_d_plus_one():
         assert h[2:] == O.murmur3_x64_128(d + b"\x01")
 
 
+def test_hashes_equal_an_independent_murmur3_x64_128_on_arbitrary_input():
+    """The restated hash against Austin Appleby's own MurmurHash3.cpp (the public-domain reference implementation, as shipped
+    inside scikit-learn and compiled from where it lies — oracle.appleby): every length 0..300 incl. all 16 tail lengths on
+    both sides of each block boundary, random bytes, plus text entries of the hot path's shape.  With it, B2's HASH is pinned by
+    an implementation that is neither the reference's dependency nor written here; bo_base_hashes' streaming 'd || 0x01' half
+    is compared with the same function over the materialised d + b'\\x01'."""
+    if O.appleby() is None:
+        pytest.skip("scikit-learn's MurmurHash3.cpp is not in this image")
+    assert O.appleby_x64_128(b"hello") == (0xCBD8A7B341BD9B02, 0x5B1E906A48AE1D19)       # the loader really calls x64_128, seed 0
+    rng = np.random.default_rng(20260927)
+    inputs = [rng.integers(0, 256, size=n, dtype=np.uint8).tobytes() for n in range(0, 301) for _ in range(3)]
+    inputs += [rng.integers(0, 256, size=int(n), dtype=np.uint8).tobytes() for n in rng.integers(301, 5000, size=200)]
+    inputs += [b"\x00" * n for n in range(0, 40)] + [b"\xff" * n for n in range(0, 40)] + [b"\x01" * n for n in range(0, 40)]
+    inputs += [("user.name::%s" % w).encode() for w in ("alice", "héllo", "日本語", "")] + [b"nested.region::region-%d" % i for i in range(64)]
+    for d in inputs:
+        ref = O.appleby_x64_128(d) + O.appleby_x64_128(d + b"\x01")
+        assert O.murmur3_x64_128(d) == ref[:2], len(d)
+        assert O.base_hashes(d) == ref, len(d)
+
+
 def test_location_formula():
     # B3: i=0:h0; 1:h1+h3; 2:h0+2h3; 3:h1+3h2; 4:h0+4h2; 5:h1+5h3; 6:h0+6h3; 7:h1+7h2 (wrapping)
     h = (0xFFFFFFFFFFFFFFF0, 0x1111111111111111, 0x8000000000000001, 0x7FFFFFFFFFFFFFFF)
