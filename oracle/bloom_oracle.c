@@ -22,6 +22,8 @@
  *     the HIP kernel directly (tests/test_gpu_parity.py).  That pins the HASH of
  *     assumption B2 independently; bloom/v3's USE of it (d || 0x01, the location
  *     formula, the wire layout) remains unpinned,
+ *   - CRC-32C: the public check value and the CPU's own SSE4.2 crc32 instruction
+ *     (oracle/hw_crc32c.c) on arbitrary input,
  *   - the (n,p)->(m,k) values the reference's tests name
  *     (bloom_tree_engine_test.go:368-376 -> (959,7); lifecycle test (2,0.02)),
  *   - the hash-dependent outcomes W1..W4 harvested from the reference's tests

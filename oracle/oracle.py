@@ -214,6 +214,38 @@ def crc32c(data: bytes) -> int:
     return int(lib().bo_crc32c(buf.ctypes.data if len(data) else None, len(data)))
 
 
+_HWCRC = None
+
+
+def hw_crc32c_fn():
+    """CRC-32C by the CPU's SSE4.2 crc32 instruction (oracle/hw_crc32c.c), or None on a CPU without it: an implementation of
+    the checksum independent of the oracle's table walk, of the host codec and of the library's kernels."""
+    global _HWCRC
+    if _HWCRC is not None:
+        return _HWCRC or None
+    try:
+        if "sse4_2" not in open("/proc/cpuinfo").read():
+            raise OSError("no sse4.2")
+        out_dir = os.path.join(_HERE, "_third_party")
+        so, src = os.path.join(out_dir, "libhwcrc32c.so"), os.path.join(_HERE, "hw_crc32c.c")
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            os.makedirs(out_dir, exist_ok=True)
+            subprocess.check_call(["gcc", "-O2", "-msse4.2", "-shared", "-fPIC", "-o", so, src])
+        fn = C.CDLL(so).hw_crc32c
+        fn.argtypes = [C.c_void_p, C.c_size_t]
+        fn.restype = C.c_uint32
+        _HWCRC = fn
+        return fn
+    except Exception:  # noqa: BLE001 - the pin is skipped where the instruction or gcc is missing
+        _HWCRC = False
+        return None
+
+
+def hw_crc32c(data) -> int:
+    buf = np.frombuffer(data, dtype=np.uint8)
+    return int(hw_crc32c_fn()(buf.ctypes.data if len(buf) else None, len(buf)))
+
+
 def encode_filter_section(filters) -> bytes:
     """filters: [Filter|None] * 3 in field/token/fieldtoken order."""
     present = (C.c_int * 3)(*[1 if f is not None else 0 for f in filters])

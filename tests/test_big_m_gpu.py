@@ -108,6 +108,9 @@ def test_64bit_modulo_build_probe_or_and_wire(ctx, m):
             fl.append(O.Filter(int(d["m"]), int(d["k"]), want[int(d["word_off"]): int(d["word_off"]) + O.words_for(int(d["m"]))]))
         assert secs[b] == O.encode_filter_section(fl), "section %d" % b
         del fl
+        if O.hw_crc32c_fn() is not None:      # the device's checksum of a section of up to 1 GiB vs the CPU's crc32 instruction
+            sec = np.frombuffer(secs[b], dtype=np.uint8)
+            assert int(sec[-4:].view("<u4")[0]) == O.hw_crc32c(sec[:-4]), "CRC32C of section %d" % b
     aid2, status = ctx.arena_load_sections(secs)
     del secs
     try:

@@ -115,6 +115,9 @@ def test_build_sections_bytes_equal_oracle_and_host_codec(ctx):
         assert ctx.last_encode_ms() > 0
         words = H.oracle_words(plan)
         assert ctx.sections_size(plan.desc) == sum(len(x) for x in secs)
+        if O.hw_crc32c_fn() is not None:      # k_crc_sections against the CPU's own crc32 instruction (oracle/hw_crc32c.c)
+            for x in secs:
+                assert int(np.frombuffer(x[-4:], dtype="<u4")[0]) == O.hw_crc32c(x[:-4])
         for b in range(len(blocks)):
             fl_o, fl_h = [], []
             for c in range(3):

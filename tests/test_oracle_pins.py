@@ -129,6 +129,29 @@ def test_crc32c_known_answer():
     assert O.crc32c(b"") == 0
 
 
+def test_crc32c_equals_the_cpus_own_crc32_instruction():
+    """CRC-32C three ways against the SSE4.2 crc32 instruction (oracle/hw_crc32c.c: the Castagnoli polynomial in silicon): the
+    oracle's table walk, the C++ host codec's checksum and the trailing CRC of sections the host codec writes, on every length
+    0..600 and larger random buffers."""
+    if O.hw_crc32c_fn() is None:
+        pytest.skip("no SSE4.2 crc32 instruction / gcc here")
+    from bloomsearch_amd import host as Hst
+    assert O.hw_crc32c(b"123456789") == 0xE3069283
+    rng = np.random.default_rng(9)
+    for n in list(range(0, 601)) + [int(x) for x in rng.integers(601, 300000, size=40)]:
+        d = rng.integers(0, 256, size=n, dtype=np.uint8).tobytes()
+        want = O.hw_crc32c(d)
+        assert O.crc32c(d) == want, n
+        assert Hst.crc32c(d) == want, n
+    for m in (15, 959, 4096, 100003):
+        f = O.Filter(m, 7)
+        for i in range(50):
+            f.add(b"tok%d" % i)
+        sec = Hst.section_encode([(m, 7, f.words.copy()), None, (m, 7, f.words.copy())])
+        assert struct.unpack("<I", sec[-4:])[0] == O.hw_crc32c(sec[:-4])
+        assert O.encode_filter_section([f, None, f]) == sec
+
+
 def test_filter_section_codec_roundtrip_and_errors():
     f = O.build_sized(["user.name", "user.age"], 0.01)
     t = O.build_sized(["alice", "30"], 0.01)
