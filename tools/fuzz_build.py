@@ -19,7 +19,11 @@ from oracle import oracle as O
 def main():
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 1
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 30
-    ctx = Context((0,))
+    # one-entry context, and contexts of 2 / 3 entries that cut EVERY call into one part per entry (lab key 7: no minimum size),
+    # so the sharded build (parts on threads, absolute indices over rebased staging, disjoint word ranges) is swept as well
+    ctxs = [Context((0,)), Context((0, 0)), Context((0, 0, 0))]
+    for c in ctxs[1:]:
+        c.set_lab(7, 1)
     total = 0
     for seed in range(first, first + n):
         rng = np.random.default_rng(seed)
@@ -53,6 +57,7 @@ def main():
             cursor += ((m + 63) // 64 + 15) // 16 * 16
         n_words = max(cursor, 2)
         want = O.build_many(blob, off, fstart, desc.view(O.DESC_DTYPE), n_words)
+        ctx = ctxs[seed % 3] if n_filters > 1 else ctxs[0]
         ctx.set_lab(6, 0 if seed % 2 else 4 << 20)
         got = ctx.build(blob, off, fstart, desc, n_words)
         if not np.array_equal(got, want):
@@ -63,8 +68,8 @@ def main():
         total += int(sum(counts))
         if (seed - first) % 10 == 9:
             print("seed %d ok (%.1f M entries so far)" % (seed, total / 1e6), flush=True)
-    ctx.set_lab(6, 4 << 20)
-    ctx.close()
+    for c in ctxs:
+        c.close()
     print("done: %d calls, %.1f M entries, no difference" % (n, total / 1e6))
 
 
