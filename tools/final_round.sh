@@ -17,6 +17,7 @@ python bench.py --workload needle --cpu-budget 0 --c4-files 0 --ingest-blocks 0 
 python bench.py --workload c4 --cpu-budget 6 --c4-files 0 --ingest-blocks 0 --no-decode --or-union 0 > gpurun_out/${R}_bench_c4.json 2>/dev/null
 bash tools/profile_ingest_trace.sh ${R}_ingest 300 > gpurun_out/${R}_ingest_rocprofv3.txt 2>&1
 bash tools/profile_build_pmc.sh ${R}_build > /dev/null 2>&1
+bash tools/profile_ingest_traffic.sh ${R}_ingest_traffic 300 > gpurun_out/${R}_ingest_traffic.txt 2>&1
 tools/or_lab 1000 44976 20 > gpurun_out/${R}_or_lab.txt 2>&1
 NB=1000 bash tools/union_ab.sh > gpurun_out/${R}_union_ab.txt 2>&1
 # what to keep: the summaries and the bench lines (the rocprofv3 databases stay in gpurun_out/)
@@ -27,6 +28,6 @@ cp gpurun_out/prof_${R}_needle/summary.txt gpurun_out/keep/${R}_probe_needle_roc
 cp gpurun_out/prof_${R}_driver/summary.txt gpurun_out/keep/${R}_bench_driver_shape_rocprofv3.txt
 cp gpurun_out/prof_${R}_c2/traffic.json gpurun_out/keep/${R}_traffic.json
 cp gpurun_out/pmc_${R}_needle/summary.txt gpurun_out/keep/${R}_needle_pmc.txt
-cp gpurun_out/${R}_ingest_rocprofv3.txt gpurun_out/${R}_bench_*.json gpurun_out/${R}_or_lab.txt gpurun_out/${R}_union_ab.txt gpurun_out/keep/
+cp gpurun_out/${R}_ingest_rocprofv3.txt gpurun_out/${R}_ingest_traffic.txt gpurun_out/${R}_bench_*.json gpurun_out/${R}_or_lab.txt gpurun_out/${R}_union_ab.txt gpurun_out/keep/
 cp gpurun_out/pmc_${R}_build/summary.txt gpurun_out/keep/${R}_build_pmc.txt
 ls -la gpurun_out/keep
