@@ -316,6 +316,11 @@ def or_exchange_leg(ctx, res, state, world, log):
         box = [Context.comm_unique_id() if dist.get_rank() == 0 else None]
         dist.broadcast_object_list(box, src=0)
         ctx.comm_init(box[0], dist.get_rank(), world)
+        n_seen, rank_seen, from_lib = ctx.comm_info()          # ncclCommCount / ncclCommUserRank of the library's own communicator
+        res["n_ranks_seen_by_rccl"] = n_seen
+        res["n_ranks_source"] = "ncclCommCount" if from_lib else "bsg_comm_init arguments (the bound library lacks ncclCommCount)"
+        if n_seen != world or rank_seen != dist.get_rank():
+            raise RuntimeError("RCCL sees rank %d of %d, the job is rank %d of %d" % (rank_seen, n_seen, dist.get_rank(), world))
         ts = []
         for _ in range(6):
             part = out.clone()
@@ -713,7 +718,7 @@ def q1_latency(ctx, arena, B, n_terms_hash, log):
             "survivors": int(sum(bin(int(x)).count("1") for x in first.ravel())), **res}
 
 
-def c4_leg(ctx, args, rank, world, workers, log):
+def c4_leg(ctx, args, rank, world, workers, log, headline=False):
     """BASELINE configs[3] / SURVEY C4: 100 M rows / 10 000 blocks as 10 files of 1 000 blocks, block b on rank b % N
     (strong scaling: the total is fixed), Q = 4096 8-term Or(FieldToken) queries.  One step probes the whole set once;
     every rank probes the blocks it holds of every file with bsg_probe_many (one arena per file)."""
@@ -771,10 +776,12 @@ def c4_leg(ctx, args, rank, world, workers, log):
         sys.exit("c4: survivor sets differ from the oracle — refusing to report")
     files = None
     pr = Prober(ctx, bid, world, log)
-    steps = max(4, min(args.steps, 60))
+    # as the line's headline (N > 1) the leg times EXACTLY --steps steps after --warmup untimed ones, like the contract says;
+    # as a side leg (N = 1) it is bounded
+    steps = max(1, args.steps) if headline else max(4, min(args.steps, 60))
     per_call = max(1, 64 // max(n_files, 1))           # steps handed to one bsg_probe_many call (<= 64 arenas per dispatch)
     make = lambda i: reps[i % R]
-    dt, tm = pr.measure(make, steps, max(2, min(args.warmup, 8)), per_call)
+    dt, tm = pr.measure(make, steps, max(0, args.warmup) if headline else max(2, min(args.warmup, 8)), per_call)
     global PROBE_KERNEL
     saved_kernel, PROBE_KERNEL = PROBE_KERNEL, "k_probe_terms"      # 77 distinct terms: the few-term kernel
     c4_kernels = kernel_stats(tm, len(terms))
@@ -784,8 +791,18 @@ def c4_leg(ctx, args, rank, world, workers, log):
                        "%d address-distinct replicas rotated per step" % (rows, total_blocks, n_files, world, NQ, len(terms), R),
            "scaling": "strong", "n_gpus": world, "steps": steps, "ms_per_step": dt / steps * 1e3, "value": probes * steps / dt,
            "unit": "probes/s", "probes_per_step": probes, "stream_bytes_per_step_per_gpu": ft_bytes,
-           "kernels": c4_kernels,
+           "kernels": c4_kernels, "warmup": max(0, args.warmup) if headline else max(2, min(args.warmup, 8)),
+           "blocks_held_by_rank0": int(sum(local_blocks)),
            "check": "every rank's shard of every file bit-exact vs the tree-walking oracle on %d randomly chosen queries" % nchk}
+    if world > 1:
+        # every rank's own kernel time and launch count (rank order): a straggler GPU shows here, not in the max-over-ranks wall time
+        import torch.distributed as dist
+        mine = torch.tensor([tm.ms_terms_kernel / max(tm.n_probes, 1), float(tm.n_probes), tm.ms_eval_kernel / max(tm.n_eval, 1),
+                             float(sum(local_blocks))], dtype=torch.float64, device=COLL_DEVICE())
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        res["per_rank"] = [{"rank": r, "k_probe_terms_ms": float(t[0]), "launches": int(t[1]), "k_eval_programs_ms": float(t[2]),
+                            "blocks": int(t[3])} for r, t in enumerate(allr)]
     # the same steps with the host-side gather inside the timed region
     slot_words = words_per_step * per_call
     n_slots = 2
@@ -831,6 +848,30 @@ def c4_leg(ctx, args, rank, world, workers, log):
     return res
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (no RANK / WORLD_SIZE in the environment): this process
+    replaces itself with `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P
+    bench.py <the same arguments>` — one rank per GPU, the same command the driver's scaling tier uses; stdout (the one JSON
+    line rank 0 prints) stays this process' stdout."""
+    if args.gpus <= 1 or "RANK" in os.environ or "WORLD_SIZE" in os.environ:
+        return
+    import socket
+    import torch
+    n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if n_dev < args.gpus and os.environ.get("BSG_BENCH_SHARE_GPU") != "1":
+        sys.exit("bench.py --gpus %d: %d GPU(s) visible (BSG_BENCH_SHARE_GPU=1 runs every rank on device 0 as a functional check "
+                 "of the N > 1 host paths; its numbers mean nothing)" % (args.gpus, n_dev))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("[bench] --gpus %d without a launcher: re-executing as %s" % (args.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    sys.stdout.flush()
+    os.execve(sys.executable, cmd, env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -863,6 +904,7 @@ def main():
     ap.add_argument("--no-q1", action="store_true", help="skip the Q = 1 latency leg")
     ap.add_argument("--no-single", action="store_true", help="skip the one-arena-per-launch sampling pass")
     args = ap.parse_args()
+    self_launch(args)
 
     # stdout carries exactly one JSON line: libraries that print banners through C stdio (librccl writes its version block
     # to stdout when a communicator is created, flushed at exit — i.e. AFTER the JSON) are pointed at stderr instead
@@ -875,7 +917,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
-            sys.exit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+            sys.exit("bench.py --gpus %d found itself alone after the self-launch (WORLD_SIZE=1)" % args.gpus)
+        sys.exit("bench.py --gpus %d launched with WORLD_SIZE=%d" % (args.gpus, world))
     log = (lambda *a: print("[bench]", *a, file=sys.stderr, flush=True)) if rank == 0 else (lambda *a: None)
 
     import torch
@@ -1127,7 +1170,7 @@ def main():
 
     c4 = None
     if args.c4_files > 0:
-        c4 = c4_leg(ctx, args, rank, world, workers, log)
+        c4 = c4_leg(ctx, args, rank, world, workers, log, headline=world > 1)
 
     probes_per_step = NQ * B * terms_per_query * world
     value = probes_per_step * args.steps / elapsed
@@ -1182,6 +1225,28 @@ def main():
                             "note": "same steps, every rank's survivors DMA-ed (copy stream, overlapped with the next dispatch) into one shared "
                                     "page-locked host segment that rank 0 reads: PCIe-inclusive, never `value`"},
         }
+        if world > 1 and c4:
+            # N > 1: the line's headline is BASELINE configs[3] — C4, STRONG scaling (10 000 blocks in total, block b on rank
+            # b % N, the 8-term Or batch, exactly --steps timed steps) — and the weak-scaling C2 run above moves to `c2_weak`.
+            # The C4 curve over N reads: this line's `value` at N > 1, and the `c4.value` of the N = 1 line.
+            ck = (c4.get("kernels") or {}).get("k_probe_terms") or {}
+            c2 = {key: out[key] for key in ("value", "value_survivors_delivered_to_host", "steps", "warmup", "ms_per_step", "scaling", "config",
+                                            "roofline", "host_gather")}
+            out["c2_weak"] = c2
+            out.update({
+                "value": c4["value"], "value_survivors_delivered_to_host": c4["host_gather"]["value"], "steps": c4["steps"],
+                "warmup": c4["warmup"], "ms_per_step": c4["ms_per_step"], "scaling": "strong",
+                "config": {"workload": c4["workload"], "blocks_total": args.c4_files * args.c4_blocks_per_file, "queries": NQ,
+                           "probes_per_step": c4["probes_per_step"], "sharding": "block b -> rank b % N, no collective; survivors left on the "
+                           "device (host_gather: delivered to one shared page-locked host segment)",
+                           "curve": "strong scaling of BASELINE configs[3]: compare with `c4.value` of the N = 1 line (same 10 000 blocks on one GPU)"},
+                "roofline": {"bound": "hbm", "kernel": "k_probe_terms", "achieved": ck.get("achieved"), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                             "frac": ck.get("frac"), "traffic": None, "algorithmic_bytes_per_launch": ck.get("algorithmic_bytes_per_launch"),
+                             "kernel_ms": ck.get("kernel_ms"), "samples": ck.get("samples"), "arenas_per_launch": ck.get("arenas_per_launch"),
+                             "copy_gbps": copy_gbps,
+                             "note": "rank 0's dispatches of the timed region; every rank's own kernel time is under c4.per_rank"},
+                "host_gather": c4["host_gather"],
+            })
         if single:
             s1 = single.get(PROBE_KERNEL, {})
             out["roofline_single_launch"] = dict(s1, bound="hbm", kernel=PROBE_KERNEL, peak=HBM_PEAK_GBPS, unit="GB/s",

@@ -56,7 +56,7 @@ EXPORTS = [
     "bsg_arena_stream_begin", "bsg_arena_stream_append", "bsg_arena_stream_finish", "bsg_arena_stream_abort",
     "bsg_batch_create", "bsg_batch_free", "bsg_probe_batch", "bsg_probe_many", "bsg_probe", "bsg_query", "bsg_survivor_list", "bsg_timing_read", "bsg_set_timed_stride", "bsg_last_kernel_ms",
     "bsg_or_reduce", "bsg_or_words_dev", "bsg_or_reduce_dev", "bsg_last_or_ms",
-    "bsg_comm_unique_id", "bsg_comm_init", "bsg_comm_destroy", "bsg_or_allreduce", "bsg_or_allreduce_dev",
+    "bsg_comm_unique_id", "bsg_comm_init", "bsg_comm_destroy", "bsg_comm_info", "bsg_or_allreduce", "bsg_or_allreduce_dev",
     "bsg_ingest_rows", "bsg_ingest_fallback_rows", "bsg_ingest_add_entries", "bsg_ingest_finish", "bsg_ingest_build",
     "bsg_ingest_stats_read", "bsg_ingest_free", "bsg_ingest_build_sections",
     "bsg_sections_size", "bsg_build_sections", "bsg_last_encode_ms",
@@ -121,6 +121,7 @@ def load():
     L.bsg_comm_unique_id.argtypes = [vp]
     L.bsg_comm_init.argtypes = [vp, vp, i32, i32]
     L.bsg_comm_destroy.argtypes = [vp]
+    L.bsg_comm_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     L.bsg_or_allreduce.argtypes = [vp, u64, u32, vp, u64]
     L.bsg_or_allreduce_dev.argtypes = [vp, vp, u64]
     L.bsg_ingest_rows.argtypes = [vp, vp, vp, u32, vp, u32, vp, u32, vp, u32, C.POINTER(u64)]

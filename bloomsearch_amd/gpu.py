@@ -292,6 +292,12 @@ class Context:
             buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
             self._check(self.L.bsg_comm_init(self.h, buf, rank, world))
 
+    def comm_info(self):
+        """(ranks, this rank, asked_the_library) as the communicator library itself reports them (ncclCommCount / ncclCommUserRank)."""
+        w, r, lib = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        self._check(self.L.bsg_comm_info(self.h, C.byref(w), C.byref(r), C.byref(lib)))
+        return int(w.value), int(r.value), bool(lib.value)
+
     def comm_destroy(self):
         self._check(self.L.bsg_comm_destroy(self.h))
 

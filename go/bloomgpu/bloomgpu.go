@@ -464,6 +464,16 @@ func (g *Context) CommInit(id []byte, rank, world int) error {
 	return g.err(C.bsg_comm_init(g.c, u8p(id), C.int32_t(rank), C.int32_t(world)))
 }
 
+// CommInfo is bsg_comm_info: the number of ranks and this context's rank as the communicator library itself reports
+// them (ncclCommCount / ncclCommUserRank); fromLibrary is false when the bound library lacks the two symbols.
+func (g *Context) CommInfo() (world, rank int, fromLibrary bool, err error) {
+	var w, r, lib C.int32_t
+	if err = g.err(C.bsg_comm_info(g.c, &w, &r, &lib)); err != nil {
+		return 0, 0, false, err
+	}
+	return int(w), int(r), lib != 0, nil
+}
+
 // CommDestroy is bsg_comm_destroy.
 func (g *Context) CommDestroy() error { return g.err(C.bsg_comm_destroy(g.c)) }
 

@@ -308,6 +308,10 @@ BSG_API int32_t bsg_last_or_ms(bsg_ctx *ctx, float *or_ms);
 BSG_API int32_t bsg_comm_unique_id(uint8_t *out_id);
 BSG_API int32_t bsg_comm_init(bsg_ctx *ctx, const uint8_t *id, int32_t rank, int32_t world);
 BSG_API int32_t bsg_comm_destroy(bsg_ctx *ctx);
+/* What the communicator library itself reports for the context's (first) communicator — ncclCommCount / ncclCommUserRank:
+ * the ranks RCCL sees, not the numbers the caller passed to bsg_comm_init.  *from_library = 0 when the bound library lacks
+ * the two symbols (the values of bsg_comm_init are returned then).  Any out pointer may be NULL. */
+BSG_API int32_t bsg_comm_info(bsg_ctx *ctx, int32_t *out_world, int32_t *out_rank, int32_t *from_library);
 BSG_API int32_t bsg_or_allreduce(bsg_ctx *ctx, uint64_t arena_id, uint32_t kind, uint64_t *out_words, uint64_t n_words);
 /* In place on device memory: d_words[i] = n_words u64 on the context's device i (one pointer for a single-device context). */
 BSG_API int32_t bsg_or_allreduce_dev(bsg_ctx *ctx, void *const *d_words, uint64_t n_words);

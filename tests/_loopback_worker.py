@@ -96,7 +96,81 @@ def entries_of_one_context(entries, n_blocks, nw_target):
     return out
 
 
+def c5_at_full_block_count(world=8, n_blocks=10000, rows=5):
+    """BASELINE configs[4] at its stated size: 10 000 FIXED-GEOMETRY token filters (m, k) = EstimateParameters(|union|, p),
+    block b on rank b % 8 (1 250 per rank), every rank ORs its shard (k_or_reduce_blocks) and the partials go through the
+    library's slice exchange + k_or_words + all-gather.  Every rank's result must equal the ORACLE's build of the union of
+    all 10 000 blocks' token sets at that geometry (OR == rebuild exactly under a fixed geometry)."""
+    from bloomsearch_amd.gpu import pack_entries
+    from oracle import oracle as O
+    from tests.test_configs_gpu import gen_blocks
+    blocks = gen_blocks(np.arange(n_blocks), rows)
+    per_block, union = [], set()
+    for sets in blocks:
+        blob, lens = sets[1]
+        off = np.zeros(len(lens) + 1, dtype=np.int64)
+        np.cumsum(lens, out=off[1:])
+        raw = blob.tobytes()
+        toks = [raw[off[i]: off[i + 1]] for i in range(len(lens))]
+        per_block.append(toks)
+        union.update(toks)
+    m, k = O.estimate_parameters(len(union), 0.001)
+    nw = O.words_for(m)
+    stride = (nw + 15) // 16 * 16
+    want = O.Filter(m, k)
+    for t in union:
+        want.add(t)
+    uid = Context.comm_unique_id()
+    errors = []
+    barrier = threading.Barrier(world)
+
+    def rank(r):
+        try:
+            mine = list(range(r, n_blocks, world))
+            desc = np.zeros(len(mine) * 3, dtype=DESC_DTYPE)
+            fstart, ents = [0], []
+            for i, b in enumerate(mine):
+                fstart.append(len(ents))                 # field: absent
+                desc[i * 3 + 1] = (i * stride, m, k, 0)
+                ents += per_block[b]
+                fstart += [len(ents), len(ents)]         # field::token: absent
+            blob, off = pack_entries(ents)
+            with Context((0,)) as ctx:
+                words = ctx.build(blob, off, np.asarray(fstart, dtype=np.uint32), desc, len(mine) * stride)
+                ctx.comm_init(uid, r, world)
+                seen, me, from_lib = ctx.comm_info()
+                if (seen, me) != (world, r) or not from_lib:
+                    errors.append("rank %d: the communicator reports rank %d of %d" % (r, me, seen))
+                aid = ctx.arena_load(words, desc)
+                del words
+                got = ctx.or_allreduce(aid, 1, nw)
+                if not np.array_equal(got, want.words):
+                    errors.append("c5 world %d rank %d: %d words differ from the oracle's build of the union" % (world, r, int((got != want.words).sum())))
+                ctx.arena_free(aid)
+                barrier.wait(timeout=120)
+                ctx.comm_destroy()
+        except Exception as e:                                  # noqa: BLE001 — reported by the parent
+            errors.append("c5 world %d rank %d: %r" % (world, r, e))
+            barrier.abort()
+
+    th = [threading.Thread(target=rank, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(600)
+    if any(t.is_alive() for t in th):
+        errors.append("c5 world %d: a rank is still waiting" % world)
+    print("c5: %d fixed-geometry filters (m = %d, k = %d, union of %d tokens), %d per rank on %d ranks: %s"
+          % (n_blocks, m, k, len(union), n_blocks // world, world, "ok" if not errors else "FAILED"))
+    return errors
+
+
 def main():
+    if "c5" in sys.argv[1:]:
+        errors = c5_at_full_block_count()
+        for e in errors:
+            print("FAIL", e)
+        sys.exit(1 if errors else 0)
     errors = []
     for world, nw in ((2, 1001), (3, 1001), (4, 1001), (4, 5), (4, 3), (8, 4099), (2, 1)):
         e = ranks_as_threads(world, nw)

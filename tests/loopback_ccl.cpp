@@ -175,6 +175,9 @@ ncclResult_t ncclCommInitAll(ncclComm_t *comms, int n, const int *)
 
 ncclResult_t ncclCommDestroy(ncclComm_t comm) { delete reinterpret_cast<Comm *>(comm); return ncclSuccess; }
 
+ncclResult_t ncclCommCount(const ncclComm_t comm, int *count) { *count = reinterpret_cast<const Comm *>(comm)->w->world; return ncclSuccess; }
+ncclResult_t ncclCommUserRank(const ncclComm_t comm, int *rank) { *rank = reinterpret_cast<const Comm *>(comm)->rank; return ncclSuccess; }
+
 ncclResult_t ncclGroupStart() { ++tl_depth; return ncclSuccess; }
 
 ncclResult_t ncclGroupEnd()

@@ -37,6 +37,32 @@ def new_engine(ctx, **cfg):
     return Hst.Engine(ctx, **cfg)
 
 
+def oracle_section(rows, fpr):
+    """What the reference stores for these rows: indexRow over every row (ingest.go:55-89), one right-sized filter per
+    kind (buildSizedBloomFilter, ingest.go:127-145), encodeFilterSection (file_format.go:343-384) — all by the oracle."""
+    sets = (set(), set(), set())
+    for r in rows:
+        W.index_row(r, sets)
+    return O.encode_filter_section([O.build_sized(sorted(s), fpr) for s in sets]), sets
+
+
+def assert_file_equals_oracle(e, file_index, rows_of_partition, fpr):
+    """Every block section and the file-level section of file `file_index` == the oracle's encode of the oracle's build of
+    the oracle's entry sets of the rows that block / file holds (merge.go:516,771 and flush.go:204,253: rebuilt, right-sized)."""
+    d = e.describe()["files"][file_index]
+    all_rows = []
+    for b, blk in enumerate(d["blocks"]):
+        rows = rows_of_partition[blk["PartitionID"]]
+        assert blk["Rows"] == len(rows)
+        want, sets = oracle_section(rows, fpr)
+        assert e.section_bytes(file_index, b) == want, "block %d (partition %r) differs from the oracle" % (b, blk["PartitionID"])
+        assert blk["BloomEntryCounts"] == {"Fields": len(sets[0]), "Tokens": len(sets[1]), "FieldTokens": len(sets[2])}
+        all_rows += rows
+    want, sets = oracle_section(all_rows, fpr)
+    assert e.section_bytes(file_index, -1) == want, "file-level section differs from the oracle"
+    assert d["BloomEntryCounts"] == {"Fields": len(sets[0]), "Tokens": len(sets[1]), "FieldTokens": len(sets[2])}
+
+
 def ingest_and_flush(engine, rows):
     engine.ingest_rows([go_marshal(r) for r in rows])
     engine.flush()
@@ -227,12 +253,19 @@ def test_surviving_block_sets_match_oracle(ctx):
 def test_merge_rebuilds_right_sized_filters(ctx):
     # file_format_test.go:940-1055: merged file's filters are rebuilt for the UNION's distinct counts (never OR-ed)
     e = new_engine(ctx)
-    ingest_and_flush(e, [{"id": "a%d" % i, "kind": "x"} for i in range(20)])
-    ingest_and_flush(e, [{"id": "b%d" % i, "kind": "x"} for i in range(200)])
+    small, large = [{"id": "a%d" % i, "kind": "x"} for i in range(20)], [{"id": "b%d" % i, "kind": "x"} for i in range(200)]
+    ingest_and_flush(e, small)
+    ingest_and_flush(e, large)
     assert len(e.describe()["files"]) == 2
+    pid = e.describe()["files"][0]["blocks"][0]["PartitionID"]
+    assert_file_equals_oracle(e, 0, {pid: [go_marshal(r) for r in small]}, 0.001)      # the flushed files first (flush.go:204,253)
+    assert_file_equals_oracle(e, 1, {pid: [go_marshal(r) for r in large]}, 0.001)
     e.merge()
     d = e.describe()
     assert len(d["files"]) == 1 and len(d["files"][0]["blocks"]) == 1
+    # the merged file against the ORACLE, not against another mode of the product: block and file sections are the oracle's
+    # encode of the oracle's right-sized build of the union's entry sets (merge.go:516,771)
+    assert_file_equals_oracle(e, 0, {pid: [go_marshal(r) for r in small + large]}, 0.001)
     want = {"Fields": 2, "Tokens": 221, "FieldTokens": 221}
     assert d["files"][0]["BloomEntryCounts"] == want and d["files"][0]["blocks"][0]["BloomEntryCounts"] == want
     assert d["files"][0]["filters"][1]["m"] == O.estimate_parameters(221, 0.001)[0]
@@ -350,3 +383,11 @@ def test_device_ingest_writes_the_same_bytes_as_host_ingest(ctx):
         e.merge()
     (d0, s0), (d1, s1) = snapshot(engines[0]), snapshot(engines[1])
     assert d0 == d1 and s0 == s1 and len(d0["files"]) == 1
+    # ... and both equal the oracle: four merged blocks (one per partition, the rows of both flushes) and the file-level
+    # filters rebuilt at the union's size (merge.go:706-804, :516)
+    by_partition = {}
+    for rows in batches:
+        for i, r in enumerate(rows):
+            by_partition.setdefault("p%d" % (i % 4), []).append(r)
+    for e in engines:
+        assert_file_equals_oracle(e, 0, by_partition, 0.001)

@@ -29,7 +29,7 @@ def test_the_loopback_library_builds_and_exports_what_comm_api_binds():
     import ctypes
     lib = ctypes.CDLL(so)
     for sym in ("ncclGetUniqueId", "ncclCommInitRank", "ncclCommInitAll", "ncclCommDestroy", "ncclAllGather", "ncclSend", "ncclRecv",
-                "ncclGroupStart", "ncclGroupEnd", "ncclGetErrorString"):
+                "ncclGroupStart", "ncclGroupEnd", "ncclGetErrorString", "ncclCommCount", "ncclCommUserRank"):
         assert hasattr(lib, sym), sym
     # and comm_api.inc binds exactly these
     text = open(os.path.join(HERE, "..", "bloomsearch_amd", "csrc", "comm_api.inc")).read()
@@ -52,6 +52,16 @@ def test_or_allreduce_at_worlds_of_2_3_4_8_ranks_and_on_contexts_of_several_entr
     bad = subprocess.run([sys.executable, os.path.join(HERE, "_loopback_worker.py")], env=dict(env, LOOPBACK_CCL_BREAK="1"), cwd=root,
                          capture_output=True, text=True, timeout=600)
     assert bad.returncode == 1 and "words differ" in bad.stdout, bad.stdout[-3000:] + bad.stderr[-3000:]
+
+
+@pytest.mark.gpu
+def test_c5_ten_thousand_fixed_geometry_filters_over_a_world_of_8_equal_the_oracle_build_of_the_union():
+    """BASELINE configs[4] at its stated 10 000 block filters, 1 250 per rank on 8 ranks (threads over the loopback double on this
+    box's one GPU): local OR + the library's exchange == the oracle's build of the union at the fixed geometry."""
+    root = os.path.join(HERE, "..")
+    env = dict(os.environ, BSG_RCCL_LIBRARY=build_loopback(), PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    r = subprocess.run([sys.executable, os.path.join(HERE, "_loopback_worker.py"), "c5"], env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "10000 fixed-geometry filters" in r.stdout and ": ok" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 
 
 @pytest.mark.gpu
