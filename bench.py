@@ -538,9 +538,24 @@ def kernel_stats(tm, n_terms):
                                 "kernel_ms": ms, "algorithmic_bytes_per_launch": by, "achieved": by / ms / 1e6,
                                 "frac": by / ms / 1e6 / HBM_PEAK_GBPS,
                                 "note": "probe role of group i + program evaluation of group i-1 in one dispatch; bytes count the probe role's bitsets only"}
+    if tm.n_folded:
+        ms = tm.ms_folded_kernel / tm.n_folded
+        by = tm.folded_stream_bytes / tm.n_folded + 33 * n_terms
+        out["k_probe_eval"] = {"samples": int(tm.n_folded), "arenas_per_launch": tm.n_folded_arenas / tm.n_folded,
+                               "kernel_ms": ms, "algorithmic_bytes_per_launch": by, "achieved": by / ms / 1e6,
+                               "frac": by / ms / 1e6 / HBM_PEAK_GBPS,
+                               "note": "k_probe_terms with the program evaluation folded in per tile of blocks: ONE dispatch per group of arenas streams "
+                                       "the bitsets AND writes the survivors; bytes count the bitsets + term table only (the survivor words it also "
+                                       "writes are not credited)"}
     if tm.n_eval:
         out["k_eval_programs"] = {"samples": int(tm.n_eval), "kernel_ms": tm.ms_eval_kernel / tm.n_eval}
     return out
+
+
+def dominant_kernel(tm):
+    """The kernel that streamed the bitsets of a timed region: the folded dispatch when the batch takes it."""
+    best = max((tm.ms_folded_kernel, "k_probe_eval"), (tm.ms_fused_kernel, "k_probe_fused"), (tm.ms_terms_kernel, PROBE_KERNEL))
+    return best[1]
 
 
 def merge_timing(a, b):
@@ -658,6 +673,8 @@ def q1_latency(ctx, arena, B, n_terms_hash, log):
         res[name] = {"latency_us_median": float(np.median(lat)) * 1e6, "latency_us_p90": float(np.percentile(lat, 90)) * 1e6}
         if direct:
             res[name]["k_probe_direct_us"] = tm.ms_fused_kernel / max(tm.n_fused, 1) * 1e3
+        elif tm.n_folded:
+            res[name]["k_probe_eval_us"] = tm.ms_folded_kernel / tm.n_folded * 1e3       # one dispatch: bit tests + programs per tile
         else:
             res[name]["k_probe_terms_us"] = tm.ms_terms_kernel / max(tm.n_probes, 1) * 1e3
             res[name]["k_eval_programs_us"] = tm.ms_eval_kernel / max(tm.n_eval, 1) * 1e3
@@ -703,7 +720,8 @@ def q1_latency(ctx, arena, B, n_terms_hash, log):
     alg = k * 8 * len(terms) * B                      # SURVEY 8d gather regime: k x 8 B per (block, term) probe
     g = res["gather"]
     g["algorithmic_bytes"] = alg
-    g["achieved"] = alg / (g["k_probe_terms_us"] * 1e-6) / 1e9
+    g_us = g.get("k_probe_eval_us") or g.get("k_probe_terms_us")
+    g["achieved"] = alg / (g_us * 1e-6) / 1e9
     g["frac_of_hbm_peak"] = g["achieved"] / HBM_PEAK_GBPS
     g["note"] = "8-byte words out of 64-byte sectors: 12.5% of peak is the ceiling of this regime; at Q = 1 the kernel is launch-latency-bound"
     o = res["one_dispatch"]
@@ -713,7 +731,7 @@ def q1_latency(ctx, arena, B, n_terms_hash, log):
         "synchronous query in one dispatch (kernel %.1f us; %.1f us with a spin wait); two kernels + copy: %.1f us gathered (kernels %.1f + %.1f us), %.1f us streamed"
         % (res["end_to_end_bsg_query"]["latency_us_median"], res["end_to_end_three_calls"]["latency_us_median"],
            o["latency_us_median"], o["k_probe_direct_us"], res["one_dispatch_spin_wait"]["latency_us_median"], g["latency_us_median"],
-           g["k_probe_terms_us"], g["k_eval_programs_us"], res["stream"]["latency_us_median"]))
+           g_us, g.get("k_eval_programs_us", 0.0), res["stream"]["latency_us_median"]))
     return {"workload": "Q = 1: And(FT(level,error), FT(service,payment), FT(nested.region,region-3)) x %d blocks, survivors to host" % B,
             "survivors": int(sum(bin(int(x)).count("1") for x in first.ravel())), **res}
 
@@ -781,27 +799,36 @@ def c4_leg(ctx, args, rank, world, workers, log, headline=False):
     steps = max(1, args.steps) if headline else max(4, min(args.steps, 60))
     per_call = max(1, 64 // max(n_files, 1))           # steps handed to one bsg_probe_many call (<= 64 arenas per dispatch)
     make = lambda i: reps[i % R]
-    dt, tm = pr.measure(make, steps, max(0, args.warmup) if headline else max(2, min(args.warmup, 8)), per_call)
+    c4_warm = max(0, args.warmup) if headline else max(2, min(args.warmup, 8))
+    if args.events_in_headline:
+        dt, tm = pr.measure(make, steps, c4_warm, per_call)
+        dt_ev = dt
+    else:                                                # bare first (the number), then the same steps with dispatch timestamps (the kernel durations)
+        dt, _ = pr.measure(make, steps, c4_warm, per_call, timed=False)
+        dt_ev, tm = pr.measure(make, steps, 2, per_call)
     global PROBE_KERNEL
     saved_kernel, PROBE_KERNEL = PROBE_KERNEL, "k_probe_terms"      # 77 distinct terms: the few-term kernel
     c4_kernels = kernel_stats(tm, len(terms))
+    c4_dom = dominant_kernel(tm)
     PROBE_KERNEL = saved_kernel
     probes = NQ * total_blocks * 8
     res = {"workload": "C4: %d rows/block x %d blocks in %d files, block b on rank b %% %d, Q=%d 8-term Or(FieldToken), %d distinct terms; "
                        "%d address-distinct replicas rotated per step" % (rows, total_blocks, n_files, world, NQ, len(terms), R),
            "scaling": "strong", "n_gpus": world, "steps": steps, "ms_per_step": dt / steps * 1e3, "value": probes * steps / dt,
+           "ms_per_step_with_dispatch_timestamps": dt_ev / steps * 1e3,
            "unit": "probes/s", "probes_per_step": probes, "stream_bytes_per_step_per_gpu": ft_bytes,
-           "kernels": c4_kernels, "warmup": max(0, args.warmup) if headline else max(2, min(args.warmup, 8)),
+           "kernels": c4_kernels, "dominant_kernel": c4_dom, "warmup": c4_warm,
            "blocks_held_by_rank0": int(sum(local_blocks)),
            "check": "every rank's shard of every file bit-exact vs the tree-walking oracle on %d randomly chosen queries" % nchk}
     if world > 1:
         # every rank's own kernel time and launch count (rank order): a straggler GPU shows here, not in the max-over-ranks wall time
         import torch.distributed as dist
-        mine = torch.tensor([tm.ms_terms_kernel / max(tm.n_probes, 1), float(tm.n_probes), tm.ms_eval_kernel / max(tm.n_eval, 1),
+        kd = c4_kernels.get(c4_dom) or {}
+        mine = torch.tensor([kd.get("kernel_ms", 0.0), float(kd.get("samples", 0)), tm.ms_eval_kernel / max(tm.n_eval, 1),
                              float(sum(local_blocks))], dtype=torch.float64, device=COLL_DEVICE())
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
-        res["per_rank"] = [{"rank": r, "k_probe_terms_ms": float(t[0]), "launches": int(t[1]), "k_eval_programs_ms": float(t[2]),
+        res["per_rank"] = [{"rank": r, "kernel": c4_dom, "kernel_ms": float(t[0]), "launches": int(t[1]), "k_eval_programs_ms": float(t[2]),
                             "blocks": int(t[3])} for r, t in enumerate(allr)]
     # the same steps with the host-side gather inside the timed region
     slot_words = words_per_step * per_call
@@ -900,7 +927,9 @@ def main():
     ap.add_argument("--c4-blocks-per-file", type=int, default=1000)
     ap.add_argument("--compact-rounds", type=int, default=-1, help="lab: compaction rounds of the many-term probe mode (bsg_set_lab key 1)")
     ap.add_argument("--fuse-limit", type=int, default=-1, help="lab: largest group whose evaluation rides in the next group's probe launch (bsg_set_fuse_limit)")
-    ap.add_argument("--untimed", action="store_true", help="lab: no dispatch timestamps inside the timed region (what they cost)")
+    ap.add_argument("--events-in-headline", action="store_true",
+                    help="carry the per-dispatch HIP timestamps inside the headline region too (they cost ~17 us per 2-dispatch call: the default "
+                         "times the K steps bare, then repeats them with the timestamps on and reports both)")
     ap.add_argument("--no-q1", action="store_true", help="skip the Q = 1 latency leg")
     ap.add_argument("--no-single", action="store_true", help="skip the one-arena-per-launch sampling pass")
     args = ap.parse_args()
@@ -1091,7 +1120,16 @@ def main():
     # may be fewer than one dispatch covers)
     pr.run(pr.plan([make(i) for i in range(min(per_call, args.steps))], per_call), 0)
     ctx.sync()
-    elapsed, tm = pr.measure(make, args.steps, args.warmup, per_call, timed=not args.untimed)
+    # The K steps twice: bare (the headline: what a caller who does not ask for timestamps pays), then the same K steps with the
+    # dispatch's own start/stop timestamps on every launch (BSG_PROBE_TIMED) — the kernel durations of the roofline come from
+    # these and from the sampling passes below.  A profiled dispatch costs the host ~8 us more than a bare one (ROCclr takes a
+    # completion signal per profiled command), which at 20 steps = one call of two dispatches is 10% of the region.
+    if args.events_in_headline:
+        elapsed, tm = pr.measure(make, args.steps, args.warmup, per_call, timed=True)
+        elapsed_ev = elapsed
+    else:
+        elapsed, _ = pr.measure(make, args.steps, args.warmup, per_call, timed=False)
+        elapsed_ev, tm = pr.measure(make, args.steps, min(args.warmup, 4), per_call, timed=True)
     timed_region = kernel_stats(tm, len(terms))
 
     # the same steps with the host-side gather inside the timed region: survivors of every step DMA-ed into a shared,
@@ -1179,7 +1217,7 @@ def main():
         # roofline of the dominant kernel of the timed region: algorithmic bytes per launch (streaming regime) =
         # every referenced bitset of the launch's arenas once + the term table; over the mean of the dispatch's own
         # start/stop timestamps, timed region and sampling passes together (same launch shape).
-        dom = "k_probe_fused" if tm.ms_fused_kernel > tm.ms_terms_kernel else PROBE_KERNEL
+        dom = dominant_kernel(tm)
         k = allk.get(dom) or {}
         # HBM bytes per launch from the PMC counters: collected in separate rocprofv3 --pmc passes of this same
         # command (tools/profile.sh), corrected as MI355X_MICROARCH.md prescribes (FETCH_SIZE x2 for wide
@@ -1202,6 +1240,11 @@ def main():
             # with every rank's survivors DMA-ed into host memory (details under host_gather)
             "value_survivors_delivered_to_host": probes_per_step * args.steps / h_elapsed,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step_with_dispatch_timestamps": elapsed_ev / args.steps * 1e3,
+            "timing_note": "value / ms_per_step: exactly K steps between barrier + synchronize, launches bare; the same K steps were then repeated "
+                           "with HIP timestamps on every dispatch (hipExtLaunchKernelGGL start/stop events on the library's stream): "
+                           "ms_per_step_with_dispatch_timestamps, and roofline.timed_region holds those dispatches' durations"
+                           if not args.events_in_headline else "HIP timestamps on every dispatch of the headline region",
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": "%s probe: %d rows/block x %d blocks per GPU, Q=%d %s [%s], "
                                    "fpr %g, %d address-distinct arena replicas rotated per step, %d arenas (steps) per dispatch"
@@ -1229,7 +1272,7 @@ def main():
             # N > 1: the line's headline is BASELINE configs[3] — C4, STRONG scaling (10 000 blocks in total, block b on rank
             # b % N, the 8-term Or batch, exactly --steps timed steps) — and the weak-scaling C2 run above moves to `c2_weak`.
             # The C4 curve over N reads: this line's `value` at N > 1, and the `c4.value` of the N = 1 line.
-            ck = (c4.get("kernels") or {}).get("k_probe_terms") or {}
+            ck = (c4.get("kernels") or {}).get(c4.get("dominant_kernel")) or {}
             c2 = {key: out[key] for key in ("value", "value_survivors_delivered_to_host", "steps", "warmup", "ms_per_step", "scaling", "config",
                                             "roofline", "host_gather")}
             out["c2_weak"] = c2
@@ -1240,7 +1283,7 @@ def main():
                            "probes_per_step": c4["probes_per_step"], "sharding": "block b -> rank b % N, no collective; survivors left on the "
                            "device (host_gather: delivered to one shared page-locked host segment)",
                            "curve": "strong scaling of BASELINE configs[3]: compare with `c4.value` of the N = 1 line (same 10 000 blocks on one GPU)"},
-                "roofline": {"bound": "hbm", "kernel": "k_probe_terms", "achieved": ck.get("achieved"), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "roofline": {"bound": "hbm", "kernel": c4.get("dominant_kernel"), "achieved": ck.get("achieved"), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                              "frac": ck.get("frac"), "traffic": None, "algorithmic_bytes_per_launch": ck.get("algorithmic_bytes_per_launch"),
                              "kernel_ms": ck.get("kernel_ms"), "samples": ck.get("samples"), "arenas_per_launch": ck.get("arenas_per_launch"),
                              "copy_gbps": copy_gbps,

@@ -29,7 +29,9 @@ class Timing(C.Structure):
     _fields_ = [("n_probes", C.c_uint64), ("ms_terms_kernel", C.c_double), ("ms_eval_kernel", C.c_double),
                 ("stream_bytes", C.c_uint64), ("n_probe_arenas", C.c_uint64), ("n_eval", C.c_uint64),
                 ("n_fused", C.c_uint64), ("ms_fused_kernel", C.c_double), ("fused_stream_bytes", C.c_uint64),
-                ("n_fused_arenas", C.c_uint64)]
+                ("n_fused_arenas", C.c_uint64),
+                ("n_folded", C.c_uint64), ("ms_folded_kernel", C.c_double), ("folded_stream_bytes", C.c_uint64),
+                ("n_folded_arenas", C.c_uint64)]
 
 
 class IngestStats(C.Structure):

@@ -111,7 +111,7 @@ struct DevBuf {
 
 // start/stop timestamps of the two dispatches themselves (hipExtLaunchKernel), i.e. the same
 // begin/end a rocprofv3 kernel trace reports — not events bracketing the launches.
-struct EventTriple { hipEvent_t k1s, k1e, k2s, k2e; uint64_t bytes; uint32_t n_arenas; bool has_k1, has_k2, fused; };
+struct EventTriple { hipEvent_t k1s, k1e, k2s, k2e; uint64_t bytes; uint32_t n_arenas; bool has_k1, has_k2, fused, folded; };
 
 // Short-lived device buffers of the ingest / match / encode calls come from a per-device cache instead of
 // hipMalloc / hipFree (a flush of 1 000 rows made ~16 of each: 0.8 ms of fixed cost, 2/3 of the call).  Blocks are kept
@@ -180,6 +180,7 @@ struct Device {
     std::mutex mu;                 // serialises enqueue + scratch reuse on this device
     DevBuf<uint64_t> V[2];         // verdict scratch (two slots: bsg_probe_many software-pipelines launches)
     DevBuf<uint64_t> out[2];       // survivors scratch
+    uint64_t fold_seq = 0;         // k_probe_eval: number of the last launch = the tag of its verdict entries
     DevBuf<uint8_t> stage_a;       // build/hash staging
     DevBuf<uint32_t> stage_off;
     DevBuf<uint64_t> stage_h;
@@ -280,6 +281,11 @@ struct bsg_ctx {
     uint64_t bin_min_locs = 4ull << 20;             // fewer locations than this: global atomics (bsg_set_lab key 6)
     uint64_t bin_scratch_bytes = kBinScratchBytes;  // 0: bitsets beyond LDS are built with global atomics (bsg_set_lab key 2)
     uint32_t fuse_max_arenas = 4; // groups up to this many arenas ride fused (probe of group i + eval of group i-1)
+    // k_probe_eval (probe + per-tile program evaluation in ONE dispatch): workgroups of a tile that share its evaluation; 0 = off,
+    // the default — measured on MI355X (tools/fold_lab.py, C2, per 20 / 64 arenas): kernels 119-122 / 385 us folded vs 104 + 15.5 /
+    // 322 + 39 us as two dispatches; wall 134.8 vs 133.2 us.  The survivor words written under the stream leave L2 as partial lines
+    // before the other tiles complete them, which costs what the second dispatch's ramp would (bsg_set_lab key 11 turns it on)
+    uint32_t fold_helpers = 0;
     // write side / matcher over several devices: a call large enough is cut into one part per device (contiguous runs of
     // filters / sets / rows), each part on a thread of its own; smaller calls take ONE device, chosen round-robin among
     // the ones whose lock is free, so independent callers (flush worker, merge, block workers) spread over the context
@@ -401,7 +407,12 @@ int32_t drain_timing(bsg_ctx *ctx, Device &d)
         if (t.has_k1) HIP_TRY(hipEventElapsedTime(&a, t.k1s, t.k1e));
         if (t.has_k2) HIP_TRY(hipEventElapsedTime(&b, t.k2s, t.k2e));
         std::lock_guard<std::mutex> lk(ctx->mu);
-        if (t.has_k1 && t.fused) {
+        if (t.has_k1 && t.folded) {
+            ctx->timing.n_folded += 1;
+            ctx->timing.ms_folded_kernel += a;
+            ctx->timing.folded_stream_bytes += t.bytes;
+            ctx->timing.n_folded_arenas += t.n_arenas;
+        } else if (t.has_k1 && t.fused) {
             ctx->timing.n_fused += 1;
             ctx->timing.ms_fused_kernel += a;
             ctx->timing.fused_stream_bytes += t.bytes;
@@ -1363,7 +1374,7 @@ int32_t take_events(bsg_ctx *ctx, Device &d, EventTriple &ev)
         HIP_TRY(hipEventCreate(&ev.k2s)); HIP_TRY(hipEventCreate(&ev.k2e));
     }
     ev.bytes = 0;
-    ev.has_k1 = ev.has_k2 = ev.fused = false;
+    ev.has_k1 = ev.has_k2 = ev.fused = ev.folded = false;
     ev.n_arenas = 0;
     return BSG_OK;
 }
@@ -1506,11 +1517,63 @@ int32_t enqueue_eval(Device &d, const Group &g, const BatchDev &bd, const Batch 
     const uint32_t tile = eval_tile_for(g);
     bsg::ArenaTable<bsg::kMaxGroupArenas> t;
     fill_refs(g, B, t.ar);
-    hipExtLaunchKernelGGL(bsg::k_eval_programs, dim3((g.max_G + tile - 1) / tile, B.n_chunks, a.n_arenas), dim3(bsg::kEvalThreads),
-                          bsg::eval_lds_bytes(B.max_cw, B.max_depth), d.stream, ev ? ev->k2s : nullptr,
-                          ev ? ev->k2e : nullptr, 0, a, t, tile);
+    // batches with the identity word list transpose a whole tile's words at once (eval_role_all) when that fits 64 KB of LDS
+    static const bool lab_serial = getenv("BSG_LAB_EVAL_SERIAL") != nullptr;   // lab only: the per-group walk for every batch
+    uint32_t lds = bsg::eval_lds_bytes(B.max_cw, B.max_depth);
+    if (B.identity_cw && !lab_serial && bsg::eval_lds_bytes(B.max_cw * bsg::kEvalGroupTile, B.max_depth) <= 64 * 1024) {
+        a.identity_cw |= 2u;
+        lds = bsg::eval_lds_bytes(B.max_cw * bsg::kEvalGroupTile, B.max_depth);
+    }
+    const uint32_t nx = (g.max_G + tile - 1) / tile;
+    const uint64_t n_wg = (uint64_t)(B.n_chunks * (uint64_t)a.n_arenas + 7) / 8 * 8 * nx;
+    if (n_wg > 0x7FFFFFFFull) return fail(BSG_E_UNSUPPORTED, "evaluation launch of %llu workgroups", (unsigned long long)n_wg);
+    hipExtLaunchKernelGGL(bsg::k_eval_programs, dim3((uint32_t)n_wg), dim3(bsg::kEvalThreads),
+                          lds, d.stream, ev ? ev->k2s : nullptr,
+                          ev ? ev->k2e : nullptr, 0, a, t, tile, nx, B.n_chunks);
     HIP_TRY(hipGetLastError());
     if (ev) ev->has_k2 = true;
+    return BSG_OK;
+}
+
+// One launch per group, evaluation folded in per tile of 64 x tile_groups blocks (k_probe_eval): verdicts into V[slot],
+// survivors into out[slot] by the last arrivals of every tile.
+bool fold_applies(const bsg_ctx *ctx, const Batch &B, uint32_t flags)
+{
+    return ctx->fold_helpers > 0 && !(flags & BSG_PROBE_NOFUSE) && !B.many_terms && B.n_kinds > 0 && B.identity_cw && B.max_cw == std::max(B.Wt, 1u) &&
+           bsg::fold_eval_lds_bytes(bsg::kFoldGroupTile, B.max_cw, B.max_depth) <= 64 * 1024;
+}
+
+int32_t enqueue_fold(bsg_ctx *ctx, Device &d, const Group &g, const BatchDev &bd, const Batch &B, uint32_t slot, EventTriple *ev)
+{
+    bsg::FoldArgs f{};
+    uint32_t lds = 0;
+    if (int32_t rc = make_probe_args(ctx, d, g, bd, B, slot, ev, f.p, lds)) return rc;
+    if (int32_t rc = make_eval_args(d, g, bd, B, slot, f.e)) return rc;
+    // verdict entries are 16 bytes here (word + tag): twice the words of the plain layout, zeroed when (re)allocated so that no
+    // entry can carry a tag by accident
+    const uint64_t v_need = 2 * std::max<uint64_t>(g.v_words, 1);
+    if (v_need > d.V[slot].cap) {
+        HIP_TRY(hipStreamSynchronize(d.stream));
+        HIP_TRY(d.V[slot].reserve(v_need));
+        HIP_TRY(hipMemsetAsync(d.V[slot].p, 0, d.V[slot].cap * sizeof(uint64_t), d.stream));
+    }
+    f.p.V = d.V[slot].p;
+    f.e.V = d.V[slot].p;
+    f.p.seq = ++d.fold_seq;
+    f.tile_groups = eval_tile_for(g) > 1 ? bsg::kFoldGroupTile : 1u;
+    f.helpers = ctx->fold_helpers;
+    static const bool lab_skip = getenv("BSG_LAB_FOLD_SKIP") != nullptr;   // lab only: nobody evaluates (what the probe side of the fold costs by itself)
+    if (lab_skip) f.helpers = 0;
+    static const uint32_t lab_fold = getenv("BSG_LAB_FOLD") ? (uint32_t)atoi(getenv("BSG_LAB_FOLD")) : 0u;
+    f.lab = lab_fold;
+    f.n_kinds = B.n_kinds;
+    lds = std::max(lds, bsg::fold_eval_lds_bytes(f.tile_groups, B.max_cw, B.max_depth));
+    bsg::ArenaTable<bsg::kMaxGroupArenas> t;
+    fill_refs(g, B, t.ar);
+    hipExtLaunchKernelGGL(bsg::k_probe_eval, dim3(g.max_blocks, B.n_kinds, f.p.n_arenas), dim3(bsg::kProbeThreads), lds, d.stream,
+                          ev ? ev->k1s : nullptr, ev ? ev->k1e : nullptr, 0, f, t);
+    HIP_TRY(hipGetLastError());
+    if (ev) { ev->has_k1 = true; ev->folded = true; }
     return BSG_OK;
 }
 
@@ -1767,11 +1830,19 @@ int32_t probe_arenas(bsg_ctx *ctx, const std::vector<std::shared_ptr<Arena>> &ar
             if (d.copy_busy[slot]) { HIP_TRY(hipStreamWaitEvent(d.stream, d.ev_copy[slot], 0)); d.copy_busy[slot] = false; }
             return BSG_OK;
         };
+        const bool fold = fold_applies(ctx, B, flags);
         for (size_t gi = 0; gi < groups.size(); ++gi) {
             const uint32_t slot = (uint32_t)(gi & 1);
             tflag[gi] = timed && (ctx->timed_stride <= 1 || (ctx->timed_counter++ % ctx->timed_stride) == ctx->timed_stride / 2);
             if (tflag[gi]) if (int32_t rc = take_events(ctx, d, evs[gi])) return rc;
             EventTriple *ev = tflag[gi] ? &evs[gi] : nullptr;
+            if (fold) {
+                // one dispatch per group: the survivors of group gi are complete when its kernel is
+                if (int32_t rc = before_eval(slot)) return rc;
+                if (int32_t rc = enqueue_fold(ctx, d, groups[gi], bd, B, slot, ev)) return rc;
+                if (int32_t rc = after_eval(gi, slot)) return rc;
+                continue;
+            }
             if (gi > 0 && fuse && groups[gi].shards.size() <= fuse_max_arenas && groups[gi - 1].shards.size() <= fuse_max_arenas) {
                 // a fused launch's own timestamps cover the streaming of group gi AND the evaluation of group gi-1
                 if (int32_t rc = before_eval(slot ^ 1)) return rc;
@@ -1786,7 +1857,7 @@ int32_t probe_arenas(bsg_ctx *ctx, const std::vector<std::shared_ptr<Arena>> &ar
                 if (int32_t rc = enqueue_terms(ctx, d, groups[gi], bd, B, slot, ev)) return rc;
             }
         }
-        {
+        if (!fold) {
             const size_t gl = groups.size() - 1;
             const uint32_t slot = (uint32_t)(gl & 1);
             if (int32_t rc = before_eval(slot)) return rc;
@@ -1881,6 +1952,7 @@ extern "C" int32_t bsg_set_lab(bsg_ctx *ctx, uint32_t key, uint64_t value)
     if (key == 7) { ctx->shard_min_entries = value; return BSG_OK; }
     if (key == 8) { ctx->shard_min_row_bytes = value; return BSG_OK; }
     if (key == 9) { ctx->union_mode = (uint32_t)std::min<uint64_t>(value, 1); return BSG_OK; }
+    if (key == 11) { ctx->fold_helpers = (uint32_t)std::min<uint64_t>(value, 64); return BSG_OK; }
     if (key == 10) { ctx->union_coarsen = (uint32_t)std::min<uint64_t>(value, 56); return BSG_OK; }
     return fail(BSG_E_INVALID, "unknown lab key %u", key);
 }

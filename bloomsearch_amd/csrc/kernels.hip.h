@@ -21,6 +21,14 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #define BSG_DMA_AUX 2
 #endif
 
+// Register budget of the streaming kernels (measured on MI355X, tools/fold_lab.py with -DBSG_LAB_VGPR_PAD): k_probe_terms with
+// its SGPR allocation padded past 80 (incl. VCC / XNACK / FLAT_SCRATCH: > 74 numbered) runs 12-17% slower — 104.9 -> 118 us per
+// 20 arenas at s79, 122.9 at s95 — although nothing else changes: 800 SGPRs per SIMD / 96 = 8 waves, exactly the four
+// 8-wave workgroups the LDS admits per CU, so a new workgroup can only start once a whole old one has retired on every
+// SIMD; at <= 80 there is room for 10 waves and the turnover overlaps.  VGPR padding up to 64 costs nothing measurable.
+#ifndef BSG_STREAM_SGPRS
+#define BSG_STREAM_SGPRS 72
+#endif
 constexpr int kWave = 64;
 constexpr int kProbeThreads = 512;
 constexpr int kEvalThreads = 256;
@@ -272,6 +280,7 @@ struct ProbeArgs {
     uint32_t kind[3];             // referenced kinds, blockIdx.y indexes this
     uint32_t term_begin[3];       // first term (multiple of 64) of that kind
     uint32_t term_count[3];       // real terms of that kind
+    uint64_t seq;                 // k_probe_eval: this launch's number, the tag of its verdict entries
 };
 
 // x mod m for m < 2^31: the remainder candidate x - q*m lies in [0, 2m) so only
@@ -529,7 +538,40 @@ __device__ __forceinline__ void probe_rounds(const ProbeArgs &a, const DevDesc &
 // ONLY_PAR: the kernel for batches of <= 128 terms per kind carries no many-term code at all (k_probe_terms); sharing one
 // kernel cost the 29-term C2 probe 9% in a grouped launch and 25% in a single one (5.03 -> 5.47 us, 7.9 -> 9.9 us per
 // 1 000 blocks) through nothing but register allocation and scheduling around code it never runs.
-template <bool M32, bool STAGED, uint32_t NT, bool ONLY_PAR>
+// TAGGED (k_probe_eval): a verdict word leaves as one 16-byte agent-scope (write-through, sc1) store {word, seq ^ mix(word)},
+// seq = the launch's number.  The evaluators of the same dispatch — on other XCDs — poll the entry until its tag matches:
+// no counter, no atomic, no fence on the probe side.  (Measured alternatives: a release fence per workgroup = buffer_wbl2,
+// a walk of the whole L2: 1.17 ms for a 0.12 ms launch; one returning atomic per workgroup on a per-tile counter: 0.27-0.39 ms —
+// 256 same-address device-scope atomics per tile serialise at ~50 ns each.)  The tag is keyed with the word, so a reader that
+// saw the two halves of an entry from different stores (were a 16-byte store ever torn) rejects it unless the words are equal.
+constexpr uint64_t kTagMix = 0x9E3779B97F4A7C15ULL;   // odd: w -> w * kTagMix is a bijection
+__device__ __forceinline__ void store_tagged(uint64_t *p, uint64_t v, uint64_t seq)
+{
+    const uint64_t tag = seq ^ (v * kTagMix);
+    const u32x4 d = {(uint32_t)v, (uint32_t)(v >> 32), (uint32_t)tag, (uint32_t)(tag >> 32)};
+#ifdef BSG_LAB_PLAIN_V    // lab only (with BSG_LAB_FOLD_SKIP): a write-back store, invisible to the other XCDs — what the write-through costs
+    asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(d) : "memory");
+#else
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(d) : "memory");
+#endif
+}
+// -> true when the entry at p belongs to launch `seq`; v = its word
+__device__ __forceinline__ bool load_tagged(const uint64_t *p, uint64_t seq, uint64_t &v)
+{
+    u32x4 d;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(d) : "v"(p) : "memory");
+    v = ((uint64_t)d.y << 32) | d.x;
+    const uint64_t tag = ((uint64_t)d.w << 32) | d.z;
+    return (tag ^ (v * kTagMix)) == seq;
+}
+template <bool TAGGED>
+__device__ __forceinline__ void store_verdict(uint64_t *vout, uint32_t w, uint64_t v, uint64_t seq)
+{
+    if (TAGGED) store_tagged(vout + (uint64_t)w * 128, v, seq);      // 16-byte entries: twice the stride
+    else vout[(uint64_t)w * 64] = v;
+}
+
+template <bool M32, bool STAGED, uint32_t NT, bool ONLY_PAR, bool VSC1 = false>
 __device__ __forceinline__ void probe_block(const ProbeArgs &a, const DevDesc &d, const uint64_t *src, char *image,
                                             uint32_t t0, uint32_t n_real, uint32_t n_tw, lds_u64 *vw, lds_u16 *queues,
                                             uint64_t *vout, uint32_t tid)
@@ -580,7 +622,7 @@ __device__ __forceinline__ void probe_block(const ProbeArgs &a, const DevDesc &d
         }
     }
     __syncthreads();
-    for (uint32_t w = tid; w < n_tw; w += kProbeThreads) vout[(uint64_t)w * 64] = vw[w];
+    for (uint32_t w = tid; w < n_tw; w += kProbeThreads) store_verdict<VSC1>(vout, w, vw[w], a.seq);
 }
 
 // LDS carve of k_probe_terms: [bitset image: a.lds_image_bytes, at offset 0 so a bit address needs no base add]
@@ -590,7 +632,7 @@ __host__ __device__ inline uint32_t probe_lds_head_bytes(uint32_t n_tw)
     return (n_tw * 8u + n_tw * 128u + 15u) & ~15u;
 }
 
-template <uint32_t NT = kProbeThreads, bool ONLY_PAR = false>
+template <uint32_t NT = kProbeThreads, bool ONLY_PAR = false, bool VSC1 = false>
 __device__ __forceinline__ void probe_role(const ProbeArgs &a, const ArenaRef &ar, uint32_t b, uint32_t y, uint64_t *lds64)
 {
     constexpr uint32_t kProbeThreads = NT, kProbeWaves = NT / kWave;   // shadow the 512-thread defaults
@@ -603,10 +645,11 @@ __device__ __forceinline__ void probe_role(const ProbeArgs &a, const ArenaRef &a
     const uint32_t t0 = a.term_begin[y];
     const uint32_t n_real = a.term_count[y];
     const uint32_t n_tw = (n_real + 63) >> 6;
-    uint64_t *vout = a.V + ar.v_off + ((uint64_t)(b >> 6) * a.Wt + (t0 >> 6)) * 64 + (b & 63);
+    // (k_probe_eval's verdict entries are 16 bytes: word + tag)
+    uint64_t *vout = a.V + (ar.v_off + ((uint64_t)(b >> 6) * a.Wt + (t0 >> 6)) * 64 + (b & 63)) * (VSC1 ? 2 : 1);
 
     if (d.m == 0) {  // nil filter: cannot disqualify (query_exec.go:137-151)
-        for (uint32_t w = tid; w < n_tw; w += kProbeThreads) vout[(uint64_t)w * 64] = ~0ULL;
+        for (uint32_t w = tid; w < n_tw; w += kProbeThreads) store_verdict<VSC1>(vout, w, ~0ULL, a.seq);
         return;
     }
     char *image = reinterpret_cast<char *>(lds64);
@@ -629,11 +672,11 @@ __device__ __forceinline__ void probe_role(const ProbeArgs &a, const ArenaRef &a
             if (boff < nbytes)
                 __builtin_amdgcn_global_load_lds((glb_void *)(g + boff), (lds_void *)(image + c), 16, 0, BSG_DMA_AUX);
         }
-        if (m32) probe_block<true, true, NT, ONLY_PAR>(a, d, src, image, t0, n_real, n_tw, vw, queues, vout, tid);
-        else     probe_block<false, true, NT, ONLY_PAR>(a, d, src, image, t0, n_real, n_tw, vw, queues, vout, tid);
+        if (m32) probe_block<true, true, NT, ONLY_PAR, VSC1>(a, d, src, image, t0, n_real, n_tw, vw, queues, vout, tid);
+        else     probe_block<false, true, NT, ONLY_PAR, VSC1>(a, d, src, image, t0, n_real, n_tw, vw, queues, vout, tid);
     } else {
-        if (m32) probe_block<true, false, NT, ONLY_PAR>(a, d, src, image, t0, n_real, n_tw, vw, queues, vout, tid);
-        else     probe_block<false, false, NT, ONLY_PAR>(a, d, src, image, t0, n_real, n_tw, vw, queues, vout, tid);
+        if (m32) probe_block<true, false, NT, ONLY_PAR, VSC1>(a, d, src, image, t0, n_real, n_tw, vw, queues, vout, tid);
+        else     probe_block<false, false, NT, ONLY_PAR, VSC1>(a, d, src, image, t0, n_real, n_tw, vw, queues, vout, tid);
     }
 }
 
@@ -642,8 +685,14 @@ __device__ __forceinline__ void probe_role(const ProbeArgs &a, const ArenaRef &a
 __global__ __launch_bounds__(kProbeThreads) void k_probe_terms(const ProbeArgs a, const ArenaTable<kMaxGroupArenas> t)
 {
     extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
+#ifdef BSG_LAB_VGPR_PAD      // lab only: the same code with a larger register allocation (does the allocation size itself cost time?)
+#define BSG_STR2(x) #x
+#define BSG_STR(x) BSG_STR2(x)
+    asm volatile("" ::: BSG_STR(BSG_LAB_VGPR_PAD));     // -DBSG_LAB_VGPR_PAD=s63 / v31 ...
+#endif
     probe_role<kProbeThreads, true>(a, t.ar[blockIdx.z], blockIdx.x, blockIdx.y, lds64);
 }
+// (no SGPR cap here: the many-term mode is bound by VALU issue, not by workgroup turnover — capped at 72 it spills and runs 1.4% slower)
 __global__ __launch_bounds__(kProbeThreads) void k_probe_terms_many(const ProbeArgs a, const ArenaTable<kMaxGroupArenas> t)
 {
     extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
@@ -674,7 +723,8 @@ struct EvalArgs {
     uint32_t n_queries;
     uint32_t max_cw;             // max words of any chunk (LDS carve + cw stride)
     uint32_t Lmax;               // max program length of any chunk (prog stride)
-    uint32_t identity_cw;        // 1: every chunk uses words 0..max_cw-1 in order (small batches): no list to load
+    uint32_t identity_cw;        // bit 0: every chunk uses words 0..max_cw-1 in order (small batches): no list to load; bit 1 (k_eval_programs
+                                 // only): take eval_role_all — the launch's LDS holds the transposed words of a whole tile
     uint32_t n_arenas;
     uint32_t max_G;              // most 64-block groups of any arena of the launch
 };
@@ -779,14 +829,105 @@ __device__ __forceinline__ void eval_role(const EvalArgs &a, const ArenaRef &ar,
     }
 }
 
-// grid = (ceil(max_G / tile), n_chunks, arenas); tile (1 or kEvalGroupTile) is chosen by the host
-__global__ __launch_bounds__(kEvalThreads) void k_eval_programs(const EvalArgs a, const ArenaTable<kMaxGroupArenas> t, const uint32_t tile)
+// The same evaluation for batches whose chunks all reference the batch's few verdict words in order (identity word list: C2, C4,
+// interactive batches): the words of ALL gt groups are requested at once, transposed by the waves in parallel and parked in
+// LDS behind ONE barrier, then the programs of the gt groups run back to back.  eval_role pays a dependent global round trip,
+// two barriers and a serial transpose per group (round 4: 15.5 -> see profiles/r04 per 20 arenas of C2).
+// LDS: gt x max_cw transposed words + the per-lane stacks (eval_lds_bytes(max_cw * tile, depth)).
+__device__ __forceinline__ void eval_role_all(const EvalArgs &a, const ArenaRef &ar, uint32_t g0, uint32_t gt, uint32_t c, uint32_t tid, uint64_t *lds)
+{
+    const uint64_t *V = a.V + ar.v_off;
+    const uint32_t lane = tid & (kWave - 1);
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid / kWave);
+    constexpr uint32_t n_waves = kEvalThreads / kWave;
+    const uint32_t ncw = a.max_cw;
+    uint64_t *VT = lds;                                                          // VT[(t * ncw + s) * 64 + bit]
+    uint64_t *stk = lds + (uint64_t)kEvalGroupTile * ncw * 64 + tid;             // per-lane stack, stride kEvalThreads
+    constexpr uint32_t kPre = 8;
+    uint32_t pre[kPre];
+    const uint32_t *P = a.prog + (uint64_t)c * a.Lmax * kEvalThreads + tid;
+#pragma unroll
+    for (uint32_t j = 0; j < kPre; ++j) pre[j] = j < a.Lmax ? P[(uint64_t)j * kEvalThreads] : (7u << 28);
+    const uint32_t len = a.chunk_len[c];
+    // every row this wave transposes, requested before the first transpose starts
+    constexpr uint32_t kRows = 4;                                                // rows per wave per trip
+    const uint32_t n_rows = gt * ncw;
+    for (uint32_t r0 = wave; r0 < n_rows; r0 += n_waves * kRows) {
+        uint64_t x[kRows];
+#pragma unroll
+        for (uint32_t u = 0; u < kRows; ++u) {
+            const uint32_t idx = r0 + u * n_waves;
+            x[u] = 0ULL;
+            if (idx < n_rows) {
+                const uint32_t tt = idx / ncw, s = idx - tt * ncw, g = g0 + tt;
+                if (g * 64u + lane < ar.n_blocks) x[u] = V[((uint64_t)g * a.Wt + s) * 64 + lane];
+            }
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < kRows; ++u) {
+            const uint32_t idx = r0 + u * n_waves;
+            if (idx < n_rows) VT[(uint64_t)idx * 64 + lane] = wave_transpose64(x[u], (int)lane);
+        }
+    }
+    __syncthreads();
+    const uint32_t q = c * kEvalThreads + tid;
+    uint64_t res[kEvalGroupTile];
+#pragma unroll
+    for (uint32_t tt = 0; tt < kEvalGroupTile; ++tt) {
+        if (tt < gt) {
+            const uint64_t *vt = VT + (uint64_t)tt * ncw * 64;
+            uint64_t top = ~0ULL;                                                // empty program == nil query == true
+            uint32_t sp = 0;
+            auto step = [&](uint32_t op) {
+                const uint32_t opc = op >> 28;
+                if (opc == 7u) return;
+                if (opc == 1u || opc == 2u) {
+                    --sp;
+                    const uint64_t under = stk[(uint64_t)(sp - 1) * kEvalThreads];
+                    top = (opc == 1u) ? (under & top) : (under | top);
+                } else {
+                    if (sp > 0) stk[(uint64_t)(sp - 1) * kEvalThreads] = top;
+                    ++sp;
+                    top = (opc == 0u) ? vt[op & 0x0FFFFFFFu] : (opc == 3u ? ~0ULL : 0ULL);
+                }
+            };
+#pragma unroll
+            for (uint32_t j = 0; j < kPre; ++j) if (j < len) step(pre[j]);
+            for (uint32_t j = kPre; j < len; ++j) step(P[(uint64_t)j * kEvalThreads]);
+            const uint32_t nvalid = ar.n_blocks - (g0 + tt) * 64u;
+            res[tt] = top & (nvalid >= 64 ? ~0ULL : ((1ULL << nvalid) - 1));
+        }
+    }
+    if (q < a.n_queries) {
+        uint64_t *dst = a.out + ar.out_off + (uint64_t)q * ar.G + g0;
+#pragma unroll
+        for (uint32_t tt = 0; tt < kEvalGroupTile; ++tt) if (tt < gt) dst[tt] = res[tt];
+    }
+}
+
+// 1-D grid of eval_grid_blocks(...) workgroups; tile (1 or kEvalGroupTile) is chosen by the host.
+// XCD-aware numbering: a query's survivor row is written by nx = ceil(max_G / tile) workgroups, tile x 8 bytes each.  Block b
+// runs on XCD b % 8 and the XCDs' L2s do not merge each other's lines, so with the tile index varying fastest the four
+// 32-byte pieces of every 128-byte row left four different L2s as four partial-line writes.  Here the nx workgroups of one
+// (chunk, arena) are 8 apart in the block numbering: same XCD, dispatched within 8 nx blocks of each other, so the row is
+// whole in one L2 before it is written back.  (A speed affinity only: any placement gives the same bits.)
+__host__ __device__ inline uint32_t eval_grid_blocks(uint32_t nx, uint32_t n_chunks, uint32_t n_arenas)
+{
+    return (n_chunks * n_arenas + 7u) / 8u * 8u * nx;
+}
+__global__ __launch_bounds__(kEvalThreads) void k_eval_programs(const EvalArgs a, const ArenaTable<kMaxGroupArenas> t, const uint32_t tile, const uint32_t nx,
+                                                                const uint32_t n_chunks)
 {
     extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
-    const ArenaRef &ar = t.ar[blockIdx.z];
-    const uint32_t g0 = blockIdx.x * tile;
+    const uint32_t L = blockIdx.x, span = 8u * nx;
+    const uint32_t r = L % span, combo = L / span * 8u + (r & 7u), tx = r >> 3;
+    if (combo >= n_chunks * a.n_arenas) return;
+    const uint32_t c = combo % n_chunks;
+    const ArenaRef &ar = t.ar[combo / n_chunks];
+    const uint32_t g0 = tx * tile;
     if (g0 >= ar.G) return;
-    eval_role(a, ar, g0, min(tile, ar.G - g0), blockIdx.y, threadIdx.x, lds64, true);
+    if (a.identity_cw & 2u) eval_role_all(a, ar, g0, min(tile, ar.G - g0), c, threadIdx.x, lds64);
+    else eval_role(a, ar, g0, min(tile, ar.G - g0), c, threadIdx.x, lds64, true);
 }
 
 // ---------------------------------------------------------------------------
@@ -830,6 +971,162 @@ __global__ __launch_bounds__(kProbeThreads) void k_probe_fused(const FusedArgs f
         const uint32_t n_chunks = (f.e.n_queries + kEvalThreads - 1) / kEvalThreads;
         eval_role(f.e, ar, g0, min(f.eval_tile, ar.G - g0), c, htid, lds64 + (uint64_t)half * (f.eval_lds_half / 8), c < n_chunks);
     }
+}
+
+// ---------------------------------------------------------------------------
+// K1 + K2 in ONE dispatch, per TILE (round 4): k_probe_eval.  Probe workgroups are exactly k_probe_terms, except that a
+// verdict word leaves as a tagged 16-byte entry (store_tagged).  A tile = tile_groups x 64 consecutive blocks of one arena x
+// the referenced kinds; the workgroups of the tile's last `helpers` blocks (last kind's pass) stay after their own probe:
+// they poll the tile's entries until all carry this launch's tag (a bounded wait: whoever they wait for precedes them in
+// the in-order dispatch), then share the tile's 256-query chunks among them: transpose the tile's verdict words once
+// (identity word list: every chunk references the batch's few words), run the lowered programs on 64-block masks, store
+// the survivor words.  The evaluation of tile i therefore runs under the streaming of the tiles behind it, the verdicts
+// are read back while they are still in L2 / MALL, and the dispatch boundary + the serial k_eval_programs (15 us per 20
+// arenas at C2) are gone.  No atomics, no fences, no counters to reset.
+// Taken for few-term batches whose chunks all use the identity word list (C2, C4, interactive batches); everything
+// else keeps k_probe_terms(_many) + k_eval_programs.
+// ---------------------------------------------------------------------------
+#ifndef BSG_FOLD_TILE
+#define BSG_FOLD_TILE 4
+#endif
+constexpr uint32_t kFoldGroupTile = BSG_FOLD_TILE;   // 64-block groups per evaluation tile of a large launch (lab: -DBSG_FOLD_TILE=8 / 16)
+struct FoldArgs {
+    ProbeArgs p;             // p.V: 16-byte tagged entries (2 x the u64 of the plain layout), p.seq: the launch's tag
+    EvalArgs e;
+    uint32_t tile_groups;    // 64-block groups per tile (1 or kFoldGroupTile)
+    uint32_t helpers;        // workgroups of a tile that share its evaluation (>= 1)
+    uint32_t n_kinds;
+    uint32_t lab;            // lab only (BSG_LAB_FOLD): 1 = evaluators store nothing, 2 = evaluators do not wait for the tags
+};
+
+// LDS the evaluation of one tile needs with kProbeThreads threads: transposed words of every group + per-lane stacks
+__host__ __device__ inline uint32_t fold_eval_lds_bytes(uint32_t tile_groups, uint32_t max_cw, uint32_t max_depth)
+{
+    return (tile_groups * max_cw * 64u + max_depth * (uint32_t)kProbeThreads) * 8u;
+}
+
+// The program words of an evaluator's first chunk pair: they depend on nothing but the workgroup's position, so they are
+// requested BEFORE its own probe — under a saturated memory system every dependent round trip in the evaluator's chain
+// costs microseconds at the end of the launch.
+constexpr uint32_t kFoldPre = 8;
+struct FoldPrefetch { uint32_t pre[kFoldPre]; uint32_t len; };
+
+__device__ __forceinline__ void fold_prefetch(const EvalArgs &a, uint32_t pair, FoldPrefetch &pf)
+{
+    const uint32_t half = threadIdx.x >> 8, htid = threadIdx.x & 255u;
+    const uint32_t n_chunks = (a.n_queries + kEvalThreads - 1) / kEvalThreads;
+    const uint32_t c = min(pair * 2 + half, n_chunks - 1);                       // (a half without a chunk loads a valid one and drops it)
+    const uint32_t *P = a.prog + (uint64_t)c * a.Lmax * kEvalThreads + htid;
+#pragma unroll
+    for (uint32_t j = 0; j < kFoldPre; ++j) pf.pre[j] = j < a.Lmax ? P[(uint64_t)j * kEvalThreads] : (7u << 28);
+    pf.len = a.chunk_len[c];
+}
+
+__device__ __forceinline__ void fold_tail(const FoldArgs &f, const ArenaRef &ar, uint32_t b, uint32_t y, uint64_t *lds64, FoldPrefetch pf)
+{
+    const EvalArgs &a = f.e;
+    const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1);
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid / kWave);
+    const uint32_t T = f.tile_groups, T64 = T * 64u;
+    const uint32_t tile = b / T64, first = tile * T64;
+    const uint32_t nb = min(ar.n_blocks - first, T64);                          // blocks of this tile
+    const uint32_t n_chunks = (a.n_queries + kEvalThreads - 1) / kEvalThreads, n_pairs = (n_chunks + 1) / 2;
+    const uint32_t K = min(min(f.helpers, nb), n_pairs);
+    const uint32_t role = b - first - (nb - K);
+
+    // ---- the tile's verdict words, polled until they carry this launch's tag, transposed once:
+    //      VT[(t * max_cw + s) * 64 + bit] = 64-block mask of one term ----
+    uint64_t *VT = lds64;
+    const uint32_t g0 = tile * T, gt = min(T, ar.G - g0);
+    const uint64_t *V = a.V + ar.v_off * 2;
+    const uint32_t ncw = a.max_cw;
+    __syncthreads();                                                             // the probe phase is done with the LDS
+    for (uint32_t idx = wave; idx < gt * ncw; idx += kProbeWaves) {
+        const uint32_t tt = idx / ncw, s = idx - tt * ncw, g = g0 + tt;
+        const bool row_valid = g * 64u + lane < ar.n_blocks;
+        const uint64_t *e = V + (((uint64_t)g * a.Wt + s) * 64 + (row_valid ? lane : 0u)) * 2;
+        uint64_t x;
+        while (true) {
+            const bool ok = load_tagged(e, f.p.seq, x) || !row_valid;
+            if (__ballot(!ok) == 0ull || (f.lab & 2u)) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (!row_valid) x = 0ULL;
+        VT[(uint64_t)idx * 64 + lane] = wave_transpose64(x, (int)lane);
+    }
+    __syncthreads();
+
+    // ---- programs: a 512-thread workgroup is two 256-query halves; evaluator `role` takes chunk pairs role, role + K, ... ----
+    uint64_t *stk = lds64 + (uint64_t)T * ncw * 64 + tid;                       // per-lane stack, stride kProbeThreads
+    const uint32_t half = tid >> 8, htid = tid & 255u;
+    constexpr uint32_t kPre = kFoldPre;
+    for (uint32_t pair = role; pair < n_pairs; pair += K) {
+        const uint32_t c = pair * 2 + half;
+        uint32_t pre[kPre];
+#pragma unroll
+        for (uint32_t j = 0; j < kPre; ++j) pre[j] = pf.pre[j];
+        const uint32_t len = pf.len;
+        if (pair + K < n_pairs) fold_prefetch(a, pair + K, pf);                  // the next pair's words travel while this one runs
+        if (c >= n_chunks) continue;                                             // wave-uniform (a half is 4 whole waves)
+        const uint32_t *P = a.prog + (uint64_t)c * a.Lmax * kEvalThreads + htid;
+        const uint32_t q = c * kEvalThreads + htid;
+        uint64_t res[kFoldGroupTile];
+#pragma unroll
+        for (uint32_t tt = 0; tt < kFoldGroupTile; ++tt) {
+            if (tt < gt) {
+                const uint64_t *vt = VT + (uint64_t)tt * ncw * 64;
+                uint64_t top = ~0ULL;                                            // empty program == nil query == true
+                uint32_t sp = 0;
+                auto step = [&](uint32_t op) {
+                    const uint32_t opc = op >> 28;
+                    if (opc == 7u) return;
+                    if (opc == 1u || opc == 2u) {
+                        --sp;
+                        const uint64_t under = stk[(uint64_t)(sp - 1) * kProbeThreads];
+                        top = (opc == 1u) ? (under & top) : (under | top);
+                    } else {
+                        if (sp > 0) stk[(uint64_t)(sp - 1) * kProbeThreads] = top;
+                        ++sp;
+                        top = (opc == 0u) ? vt[op & 0x0FFFFFFFu] : (opc == 3u ? ~0ULL : 0ULL);
+                    }
+                };
+#pragma unroll
+                for (uint32_t j = 0; j < kPre; ++j) if (j < len) step(pre[j]);
+                for (uint32_t j = kPre; j < len; ++j) step(P[(uint64_t)j * kEvalThreads]);
+                const uint32_t nvalid = ar.n_blocks - (g0 + tt) * 64u;
+                res[tt] = top & (nvalid >= 64 ? ~0ULL : ((1ULL << nvalid) - 1));
+            }
+        }
+        if (q < a.n_queries && !(f.lab & 1u)) {
+            uint64_t *dst = a.out + ar.out_off + (uint64_t)q * ar.G + g0;
+            // (measured per 20 arenas, 119-122 us as written: non-temporal stores 172 us — 8-byte partial writes straight to HBM;
+            //  16-byte stores 125 us; tiles of 8 / 16 groups = 64 / 128-byte pieces per lane 128 / 147 us: the longer tail costs more
+            //  than the fuller lines save)
+#pragma unroll
+            for (uint32_t tt = 0; tt < kFoldGroupTile; ++tt) if (tt < gt) dst[tt] = res[tt];
+        }
+    }
+}
+
+// grid = (max_blocks, referenced kinds, arenas of the group), as k_probe_terms
+__global__ __launch_bounds__(kProbeThreads) __attribute__((amdgpu_num_sgpr(BSG_STREAM_SGPRS))) void k_probe_eval(const FoldArgs f, const ArenaTable<kMaxGroupArenas> t)
+{
+    extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
+    const ArenaRef &ar = t.ar[blockIdx.z];
+    const uint32_t b = blockIdx.x, y = blockIdx.y;
+    if (b >= ar.n_blocks) return;
+    // The evaluators of a tile are the workgroups of its LAST K blocks in the LAST kind's pass: every workgroup whose
+    // verdicts they wait for precedes them in the dispatch order (x fastest, then y), so it is resident or finished —
+    // the wait is bounded and cannot deadlock.  Everybody else runs the probe code on a path of its own, compiled as in
+    // k_probe_terms (sharing one path with the evaluators cost every workgroup 8%: 104 -> 112.6 us per 20 arenas).
+    const uint32_t T64 = f.tile_groups * 64u, first = b / T64 * T64, nb = min(ar.n_blocks - first, T64);
+    const uint32_t n_pairs = ((f.e.n_queries + kEvalThreads - 1) / kEvalThreads + 1) / 2;
+    const uint32_t K = min(min(f.helpers, nb), n_pairs);
+    const bool evaluator = y + 1u == f.n_kinds && b - first + K >= nb;          // workgroup-uniform
+    FoldPrefetch pf;
+    if (evaluator) fold_prefetch(f.e, b - first - (nb - K), pf);
+    probe_role<kProbeThreads, true, true>(f.p, ar, b, y, lds64);
+    if (evaluator) fold_tail(f, ar, b, y, lds64, pf);
 }
 
 // ---------------------------------------------------------------------------

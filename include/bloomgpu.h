@@ -99,11 +99,15 @@ typedef struct bsg_timing {
     double   ms_fused_kernel;
     uint64_t fused_stream_bytes; /* bitset bytes streamed by their probe role                               */
     uint64_t n_fused_arenas;
+    uint64_t n_folded;           /* timestamped k_probe_eval dispatches (probe + per-tile program evaluation in one) */
+    double   ms_folded_kernel;
+    uint64_t folded_stream_bytes;/* bitset bytes streamed by them                                           */
+    uint64_t n_folded_arenas;
 } bsg_timing;
 
 #define BSG_PROBE_ASYNC  1u  /* enqueue only; caller later calls bsg_sync                    */
 #define BSG_PROBE_TIMED  2u  /* timestamp the dispatches (see bsg_timing_read)               */
-#define BSG_PROBE_NOFUSE 4u  /* never fuse: every group runs as k_probe_terms + k_eval_programs */
+#define BSG_PROBE_NOFUSE 4u  /* never fuse or fold: every group runs as k_probe_terms + k_eval_programs */
 
 typedef struct bsg_ctx bsg_ctx;
 

@@ -40,9 +40,9 @@ def test_bench_gpus_2_launches_its_own_ranks_and_reports_c4_strong_scaling():
     assert out["config"]["blocks_total"] == 256
     assert out["value"] > 0 and out["ms_per_step"] > 0
     assert abs(out["value"] - out["config"]["probes_per_step"] * out["steps"] / (out["ms_per_step"] * 1e-3 * out["steps"])) < 1e-6 * out["value"]
-    assert out["roofline"]["kernel"] == "k_probe_terms" and out["roofline"]["frac"] > 0
+    assert out["roofline"]["kernel"] in ("k_probe_eval", "k_probe_terms") and out["roofline"]["frac"] > 0
     per_rank = out["c4"]["per_rank"]
-    assert [r["rank"] for r in per_rank] == [0, 1] and all(r["blocks"] == 128 and r["launches"] > 0 and r["k_probe_terms_ms"] > 0 for r in per_rank)
+    assert [r["rank"] for r in per_rank] == [0, 1] and all(r["blocks"] == 128 and r["launches"] > 0 and r["kernel_ms"] > 0 for r in per_rank)
     c2 = out["c2_weak"]
     assert c2["scaling"] == "weak" and c2["value"] > 0 and c2["config"]["workload"].startswith("C2")
     assert out["c4"]["host_gather"]["rank0_view"].startswith("file 0: 2 ranks")
@@ -54,4 +54,4 @@ def test_bench_gpus_1_keeps_c2_as_the_headline():
     assert "re-executing" not in err
     assert out["n_gpus"] == 1 and out["scaling"] == "weak" and out["config"]["workload"].startswith("C2")
     assert out["c4"]["scaling"] == "strong" and out["c4"]["n_gpus"] == 1 and "c2_weak" not in out
-    assert out["roofline"]["kernel"] == "k_probe_terms"
+    assert out["roofline"]["kernel"] in ("k_probe_eval", "k_probe_terms")

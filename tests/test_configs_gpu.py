@@ -233,14 +233,18 @@ def test_grouped_launches_equal_one_launch_per_arena(ctx):
             wants.append(np.zeros((cb.n_queries, 0), dtype=np.uint64))
             for limit in (1, 3, 32, 64):
                 ctx.set_probe_group(limit)
-                for flags in (0, _lib.PROBE_NOFUSE, _lib.PROBE_TIMED):
-                    got = ctx.probe_many([arenas[i] for i in order], bid, flags, cb.n_queries, [nbs[i] for i in order])
-                    for g, i in zip(got, order):
-                        assert np.array_equal(g, wants[i]), (len(terms), limit, flags, i)
+                for fold in (0, 8, 2):                      # lab key 11: k_probe_eval (evaluation folded into the probe dispatch) with 8 / 2 evaluators per tile
+                    ctx.set_lab(11, fold)
+                    for flags in (0, _lib.PROBE_NOFUSE, _lib.PROBE_TIMED):
+                        got = ctx.probe_many([arenas[i] for i in order], bid, flags, cb.n_queries, [nbs[i] for i in order])
+                        for g, i in zip(got, order):
+                            assert np.array_equal(g, wants[i]), (len(terms), limit, fold, flags, i)
     finally:
         ctx.set_probe_group(0)
+        ctx.set_lab(11, 0)
     t = ctx.timing_read()
-    assert t.n_fused > 0 and t.n_probes > 0 and t.n_eval > 0 and t.n_fused_arenas >= t.n_fused
+    # few-term batches: k_probe_fused for small groups, k_probe_eval when folding is on; the many-term batch and every NOFUSE call: the two kernels
+    assert t.n_fused > 0 and t.n_folded > 0 and t.n_probes > 0 and t.n_eval > 0 and t.n_fused_arenas >= t.n_fused and t.n_folded_arenas >= t.n_folded
     for a in arenas:
         ctx.arena_free(a)
     for b in batches:

@@ -2,7 +2,7 @@
 Per seed: a few random arenas (block counts around the 64-block groups, false-positive rates from 1e-5 to 0.5, nil
 filters, blocks without tokens), the device build compared with the oracle's bitsets, then random query batches — one
 query, a handful, hundreds; few distinct terms (one-dispatch and few-term kernels) or thousands (many-term kernel) —
-probed through every launch shape (group limit 1 / 3 / 32, fused or not, timed or not, sharded contexts) and through the one-call
+probed through every launch shape (group limit 1 / 3 / 32, fused, folded into one dispatch (k_probe_eval) or not, timed or not, sharded contexts) and through the one-call
 bsg_query (strings in; kernel-argument fast path or the batch path inside the call) and compared
 with the oracle's surviving-block sets bit for bit.  Exits non-zero on the first difference."""
 import os
@@ -53,6 +53,7 @@ def main():
             wants = [O.probe_batch(w, p.desc.view(O.DESC_DTYPE), terms.view(O.TERM_DTYPE), ops, poff) for w, p in zip(all_words, plans)]
             order = [int(i) for i in rng.integers(0, len(arenas), size=int(rng.integers(1, 40)))]
             ctx.set_probe_group(int(rng.choice([1, 3, 32])))
+            ctx.set_lab(11, int(rng.choice([0, 0, 1, 3, 8])))          # k_probe_eval: evaluation folded into the probe dispatch, 1 / 3 / 8 evaluators per tile
             flags = int(rng.choice([0, _lib.PROBE_NOFUSE, _lib.PROBE_TIMED]))
             got = ctx.probe_many([arenas[i] for i in order], bid, flags, cb.n_queries, [plans[i].n_blocks for i in order])
             for g, i in zip(got, order):
@@ -71,6 +72,7 @@ def main():
             n_cases += 1
             ctx.batch_free(bid)
         ctx.set_probe_group(0)
+        ctx.set_lab(11, 0)
         ctx.timing_read(reset=True)
         for a in arenas:
             ctx.arena_free(a)
