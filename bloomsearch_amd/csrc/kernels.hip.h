@@ -362,10 +362,20 @@ __device__ __forceinline__ void par_task_finish(const ParTask &p, BITS32 bits, l
 // padded tail of the last term word is probed like real terms (its verdict bits are never referenced) instead of being
 // masked per lane; the bitset image sits at LDS offset 0 so a bit address is two shifts; the 64x64 mul-high is spelled
 // out in 32-bit pieces.
-constexpr uint32_t kGroup = 4;
-constexpr uint32_t kTailBatch = 4;
+// Round 4, 4 054 terms x 64 arenas of 1 000 blocks (tools/fold_lab.py 64 needle), k_probe_terms_many per launch:
+//   kGroup 4 / rounds 2 (round 3's setting) 1 109 us; kGroup 8: 1 166 (wider groups do NOT help: the mode is not waiting on
+//   the hash loads); kGroup 1: 1 115; 3: 1 097; 2: 1 076; kGroup 2 with 1 / 3 compaction rounds: 1 059 / 1 156; tail batches
+//   of 2 / 7 locations: 1 109 / 1 115.
+#ifndef BSG_KGROUP
+#define BSG_KGROUP 2
+#endif
+#ifndef BSG_TAIL_BATCH
+#define BSG_TAIL_BATCH 4
+#endif
+constexpr uint32_t kGroup = BSG_KGROUP;          // chunks of 64 terms whose loads / reductions / LDS reads are in flight together (lab: -DBSG_KGROUP)
+constexpr uint32_t kTailBatch = BSG_TAIL_BATCH;
 #ifndef BSG_COMPACT_ROUNDS
-#define BSG_COMPACT_ROUNDS 2
+#define BSG_COMPACT_ROUNDS 1
 #endif
 
 // x mod m for m < 2^31 from the halves of x and of magic = floor(2^64 / m): only the low 32 bits of the quotient matter.
