@@ -466,6 +466,21 @@ def COLL_DEVICE():
     return "cuda" if dist.get_backend() == "nccl" else "cpu"
 
 
+class Ring:
+    """Hands out successive slices of a buffer, wrapping around: the output slots of successive calls (only the last ones are kept)."""
+
+    def __init__(self, buf):
+        self.buf, self.o, self.last = buf, 0, 0
+
+    def __getitem__(self, sl):
+        n = sl.stop - sl.start
+        if self.o + n > len(self.buf):
+            self.o = 0
+        self.last = self.o
+        self.o += n
+        return self.buf[self.last: self.last + n]
+
+
 class SharedHost:
     """One POSIX shared-memory segment mapped by every rank; rank r's survivors are DMA-ed into slice r
     (page-locked with bsg_host_register), so rank 0 reads every shard's bitsets from host memory after the
@@ -580,38 +595,45 @@ class Prober:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def plan(self, steps, per_call, out=None, words_per_step=0):
+    def plan(self, steps, per_call, out=None, words_per_step=0, hdr=None, hdr_per_step=0):
         """The calls of a run, arguments marshalled (arena id arrays, output slices): `per_call` consecutive steps share one
-        bsg_probe_many call.  Built before the clock starts: listing arena ids is the caller's bookkeeping, not the step."""
-        calls, o = [], 0
+        bsg_probe_many call.  Built before the clock starts: listing arena ids is the caller's bookkeeping, not the step.
+        hdr given: the calls are bsg_probe_many_rows (survivor rows: header + ids / words where needed, written by the device)."""
+        calls, o, ho = [], 0, 0
         for i in range(0, len(steps), per_call):
             ids = np.ascontiguousarray([a for st in steps[i: i + per_call] for a in st], dtype=np.uint64)
-            dst = None
+            dst = hd = None
             if out is not None:
                 n = words_per_step * len(steps[i: i + per_call])
                 dst = out[o: o + n]
                 o += n
-            calls.append((ids, dst))
+            if hdr is not None:
+                n = hdr_per_step * len(steps[i: i + per_call])
+                hd = hdr[ho: ho + n]
+                ho += n
+            calls.append((ids, dst, hd))
         return calls
 
     def run(self, calls, flags):
         """Enqueue every call of a plan."""
         from bloomsearch_amd import _lib
-        for ids, dst in calls:
+        for ids, dst, hd in calls:
             if dst is None:
                 self.ctx.probe_many(ids, self.bid, flags | _lib.PROBE_ASYNC)
-            else:
+            elif hd is None:
                 self.ctx.probe_many_into(ids, self.bid, dst, flags | _lib.PROBE_ASYNC)
+            else:
+                self.ctx.probe_many_rows(ids, self.bid, dst, hd, flags | _lib.PROBE_ASYNC)
 
-    def measure(self, make_step, steps, warmup, per_call, timed=True, out=None, words_per_step=0, nofuse=False):
+    def measure(self, make_step, steps, warmup, per_call, timed=True, out=None, words_per_step=0, nofuse=False, hdr=None, hdr_per_step=0):
         import torch
         from bloomsearch_amd import _lib
         flags = (_lib.PROBE_TIMED if timed else 0) | (_lib.PROBE_NOFUSE if nofuse else 0)
         self.ctx.set_timed_stride(1)
-        self.run(self.plan([make_step(i) for i in range(warmup)], per_call, out, words_per_step), flags)
+        self.run(self.plan([make_step(i) for i in range(warmup)], per_call, out, words_per_step, hdr, hdr_per_step), flags)
         self.ctx.sync()
         self.ctx.timing_read(reset=True)
-        calls = self.plan([make_step(i) for i in range(steps)], per_call, out, words_per_step)
+        calls = self.plan([make_step(i) for i in range(steps)], per_call, out, words_per_step, hdr, hdr_per_step)
         self.sync_all()
         t0 = time.perf_counter()
         self.run(calls, flags)
@@ -833,41 +855,64 @@ def c4_leg(ctx, args, rank, world, workers, log, headline=False):
     # the same steps with the host-side gather inside the timed region
     slot_words = words_per_step * per_call
     n_slots = 2
-    sh = SharedHost(ctx, slot_words * 8 * n_slots, rank, world, "c4")
-    ring = sh.mine
-
-    class RingOut:          # successive calls write successive slots of the shared segment (only the last ones survive)
-        def __init__(self):
-            self.i, self.last = 0, 0
-
-        def __getitem__(self, sl):
-            self.last = (self.i % n_slots) * slot_words
-            self.i += 1
-            return ring[self.last: self.last + (sl.stop - sl.start)]
-    ro = RingOut()
+    hdr_per_step = NQ * n_files
+    sh = SharedHost(ctx, slot_words * 8 * n_slots + hdr_per_step * per_call * 4 * n_slots, rank, world, "c4")
+    ring = sh.mine[: slot_words * n_slots]
+    ro = Ring(ring)          # successive calls write successive slots of the shared segment (only the last ones survive)
     dt2, _ = pr.measure(make, steps, 2, per_call, timed=False, out=ro, words_per_step=words_per_step)
     res["host_gather"] = {"ms_per_step": dt2 / steps * 1e3, "value": probes * steps / dt2,
                           "survivor_bytes_per_step_per_gpu": words_per_step * 8, "page_locked": sh.registered,
                           "note": "every rank's survivors DMA-ed into one shared page-locked host segment that rank 0 reads "
                                   "(copy stream, overlapped with the next dispatch)"}
+    dense_last = ro.last
+    if sh.registered:
+        # the same steps delivered as survivor ROWS: a 4-byte header per (file, query) + block ids / words only where the row needs
+        # them (bsg_probe_many_rows), written by the device into the same segment.  An 8-term Or keeps every block of a file for
+        # nearly every query: those rows are a header and nothing else.
+        from bloomsearch_amd.gpu import rows_to_dense
+        hdr_ring = sh.mine[slot_words * n_slots:].view(np.uint32)[: hdr_per_step * per_call * n_slots]
+        rr, hr = Ring(ring), Ring(hdr_ring)
+        dt3, _ = pr.measure(make, steps, 2, per_call, timed=False, out=rr, words_per_step=words_per_step, hdr=hr, hdr_per_step=hdr_per_step)
+        h_all = sh.part(rank)[slot_words * n_slots:].view(np.uint32)[hr.last: hr.last + hdr_per_step]
+        tags = np.bincount(h_all >> 30, minlength=4)
+        cnt = h_all & np.uint32(0x3FFFFFFF)
+        payload = int(4 * cnt[(h_all >> 30) == 2].sum() + 8 * sum(G[f] * int(((h_all[f * NQ: (f + 1) * NQ] >> 30) == 3).sum()) for f in range(n_files)))
+        o = 0
+        for f in range(n_files):                                   # the rows of the last call's first step expand to the direct probe's bitsets
+            if local_blocks[f] and not args.no_check:
+                back = rows_to_dense(h_all[f * NQ: (f + 1) * NQ], sh.part(rank)[rr.last + o: rr.last + o + NQ * G[f]], local_blocks[f])
+                if not np.array_equal(back, got[f]):
+                    sys.exit("c4: survivor rows of file %d do not expand to the direct probe's bitsets" % f)
+            o += NQ * G[f]
+        res["host_gather"]["rows"] = {"api": "bsg_probe_many_rows", "ms_per_step": dt3 / steps * 1e3, "value": probes * steps / dt3,
+                                      "bytes_per_step_per_gpu": int(4 * hdr_per_step + payload),
+                                      "rows_by_tag_none_all_list_dense": [int(x) for x in tags],
+                                      "vs_device_resident": dt3 / dt,
+                                      "note": "header + ids / words where needed, written by the device into the page-locked segment; "
+                                              "vs_device_resident = this step time over the step time with the survivors left on the device"}
+        # the dense pass is checked below: run it once more so that the segment holds bitsets again
+        ro = Ring(ring)
+        pr.measure(make, min(steps, per_call), 0, per_call, timed=False, out=ro, words_per_step=words_per_step)
+        dense_last = ro.last
     if rank == 0:
         # what the consumer does: rank 0 reads every rank's slice of the segment and interleaves global block order
         from bloomsearch_amd import parallel as P
-        mine = sh.part(0)[ro.last: ro.last + words_per_step]
+        mine = sh.part(0)[dense_last: dense_last + words_per_step]
         o = 0
         for f in range(n_files):
             if not np.array_equal(mine[o: o + NQ * G[f]].reshape(NQ, G[f]), got[f]):
                 sys.exit("c4: survivors delivered to the shared host segment differ from the direct probe")
             o += NQ * G[f]
         if per_file % world == 0 and n_files > 0:
-            parts = [sh.part(r)[ro.last: ro.last + NQ * G[0]].reshape(NQ, G[0]) for r in range(world)]
+            parts = [sh.part(r)[dense_last: dense_last + NQ * G[0]].reshape(NQ, G[0]) for r in range(world)]
             glob = P.interleave_survivors(parts, per_file)
             if not np.array_equal(np.ascontiguousarray(glob[:, : 1]) & np.uint64(1), got[0][:, :1] & np.uint64(1)):
                 sys.exit("c4: global block 0 of file 0 (held by rank 0) changed in the interleave")
             res["host_gather"]["rank0_view"] = "file 0: %d ranks' bitsets interleaved into [%d][%d] global words" % (world, NQ, glob.shape[1])
     sh.close()
-    log("c4: %.1f us/step = %.3g probes/s device-resident; %.1f us/step = %.3g probes/s with the host gather"
-        % (dt / steps * 1e6, res["value"], dt2 / steps * 1e6, res["host_gather"]["value"]))
+    log("c4: %.1f us/step = %.3g probes/s device-resident; %.1f us/step = %.3g probes/s with the host gather (dense bitsets); rows: %s"
+        % (dt / steps * 1e6, res["value"], dt2 / steps * 1e6, res["host_gather"]["value"],
+           ("%.1f us/step" % (res["host_gather"]["rows"]["ms_per_step"] * 1e3)) if "rows" in res["host_gather"] else "-"))
     for rep in reps:
         for a in rep:
             ctx.arena_free(a)
@@ -1136,24 +1181,27 @@ def main():
     # page-locked host segment (a ring: only the last calls' survivors are kept)
     wps = NQ * ((B + 63) // 64)
     ring_steps = min(max(args.steps, 1), 2 * per_call)
-    sh = SharedHost(ctx, wps * 8 * ring_steps, rank, world, "c2")
-    ring = sh.mine
-
-    class RingOut:
-        def __init__(self): self.o = 0
-        def __getitem__(self, sl):
-            n = sl.stop - sl.start
-            if self.o + n > len(ring):
-                self.o = 0
-            v = ring[self.o: self.o + n]
-            self.o += n
-            return v
-    h_elapsed, _ = pr.measure(make, args.steps, min(args.warmup, 4), per_call, timed=False, out=RingOut(), words_per_step=wps)
+    row_words = wps * ring_steps
+    sh = SharedHost(ctx, row_words * 8 + NQ * 4 * ring_steps, rank, world, "c2")
+    h_elapsed, _ = pr.measure(make, args.steps, min(args.warmup, 4), per_call, timed=False, out=Ring(sh.mine[:row_words]), words_per_step=wps)
     if rank == 0 and not args.no_check:
         # the ring's first slot holds some step's survivors of this rank: every replica holds the same filters
         if not np.array_equal(sh.part(0)[:wps].reshape(NQ, -1), got):
             sys.exit("survivors delivered to the shared host segment differ from the direct probe")
     page_locked = sh.registered
+    # ... and as survivor ROWS (bsg_probe_many_rows): a 4-byte header per query + block ids / words only where the row needs them,
+    # written by the device into the same page-locked segment
+    r_elapsed = rows_tags = None
+    if page_locked:
+        from bloomsearch_amd.gpu import rows_to_dense
+        hdr_ring = sh.mine[row_words:].view(np.uint32)[: NQ * ring_steps]
+        r_elapsed, _ = pr.measure(make, args.steps, min(args.warmup, 4), per_call, timed=False, out=Ring(sh.mine[:row_words]), words_per_step=wps,
+                                  hdr=Ring(hdr_ring), hdr_per_step=NQ)
+        if rank == 0:
+            h0 = sh.part(0)[row_words:].view(np.uint32)[:NQ]
+            if not args.no_check and not np.array_equal(rows_to_dense(h0, sh.part(0)[:wps], B), got):
+                sys.exit("survivor rows delivered to the shared host segment do not expand to the direct probe's bitsets")
+            rows_tags = [int(x) for x in np.bincount(h0 >> 30, minlength=4)]
     sh.close()
 
     # ---- kernel sampling beyond the timed region: the driver's --steps may cover a single dispatch, the number of record
@@ -1238,7 +1286,7 @@ def main():
             # `value` leaves the survivor bitsets on the device (inputs and outputs resident, nothing crosses PCIe in the timed
             # region); the north star's "host-side gather of surviving block IDs" costs what the next field says — the same steps
             # with every rank's survivors DMA-ed into host memory (details under host_gather)
-            "value_survivors_delivered_to_host": probes_per_step * args.steps / h_elapsed,
+            "value_survivors_delivered_to_host": probes_per_step * args.steps / min(h_elapsed, r_elapsed or h_elapsed),
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "ms_per_step_with_dispatch_timestamps": elapsed_ev / args.steps * 1e3,
             "timing_note": "value / ms_per_step: exactly K steps between barrier + synchronize, launches bare; the same K steps were then repeated "
@@ -1265,6 +1313,11 @@ def main():
                          "timed_region": timed_region, "sampling_passes": samples, "all": allk},
             "host_gather": {"ms_per_step": h_elapsed / args.steps * 1e3, "value": probes_per_step * args.steps / h_elapsed,
                             "survivor_bytes_per_step_per_gpu": wps * 8, "page_locked": page_locked,
+                            "rows": None if r_elapsed is None else {
+                                "api": "bsg_probe_many_rows", "ms_per_step": r_elapsed / args.steps * 1e3, "value": probes_per_step * args.steps / r_elapsed,
+                                "rows_by_tag_none_all_list_dense": rows_tags,
+                                "note": "per query a 4-byte header (tag, count) + block ids / words only where the row needs them, written by the device "
+                                        "straight into the page-locked segment: what crosses PCIe depends on what survives"},
                             "note": "same steps, every rank's survivors DMA-ed (copy stream, overlapped with the next dispatch) into one shared "
                                     "page-locked host segment that rank 0 reads: PCIe-inclusive, never `value`"},
         }
@@ -1277,7 +1330,7 @@ def main():
                                             "roofline", "host_gather")}
             out["c2_weak"] = c2
             out.update({
-                "value": c4["value"], "value_survivors_delivered_to_host": c4["host_gather"]["value"], "steps": c4["steps"],
+                "value": c4["value"], "value_survivors_delivered_to_host": (c4["host_gather"].get("rows") or c4["host_gather"])["value"], "steps": c4["steps"],
                 "warmup": c4["warmup"], "ms_per_step": c4["ms_per_step"], "scaling": "strong",
                 "config": {"workload": c4["workload"], "blocks_total": args.c4_files * args.c4_blocks_per_file, "queries": NQ,
                            "probes_per_step": c4["probes_per_step"], "sharding": "block b -> rank b % N, no collective; survivors left on the "

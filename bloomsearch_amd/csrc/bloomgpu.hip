@@ -1673,12 +1673,30 @@ void interleave_shard(const uint64_t *part, uint32_t Q, uint32_t n_local, uint32
 // enqueue on all of them before waiting on any, then interleave the shards' bitsets on the host.
 // out_dev != nullptr (single-device contexts): survivors are left at that device pointer instead, in the same layout.
 // (Measured on MI355X in round 1: per-arena cross-stream events cost the host 3-4 us each — per group they are noise.)
+// rows_hdr != nullptr (bsg_probe_many_rows; single-device contexts): out_survivors and rows_hdr are PAGE-LOCKED host memory that
+// k_survivor_rows writes itself — a header per (arena, query) and, only where needed, block ids or words in the row's dense slot.
 int32_t probe_arenas(bsg_ctx *ctx, const std::vector<std::shared_ptr<Arena>> &arenas, const Batch &B, uint32_t flags,
-                     uint64_t *out_survivors, uint64_t *out_dev)
+                     uint64_t *out_survivors, uint64_t *out_dev, uint32_t *rows_hdr = nullptr)
 {
     const uint32_t nd = (uint32_t)ctx->devs.size();
     const uint32_t n_arenas = (uint32_t)arenas.size();
     if (B.n_queries == 0 || n_arenas == 0) return BSG_OK;
+    uint64_t *d_rows = nullptr;
+    uint32_t *d_hdr = nullptr;
+    if (rows_hdr)      // arenas without blocks produce no launch: their rows are NONE
+        for (uint32_t i = 0; i < n_arenas; ++i)
+            if (arenas[i]->n_blocks == 0) memset(rows_hdr + (size_t)i * B.n_queries, 0, (size_t)B.n_queries * 4);
+    if (rows_hdr) {
+        if (nd != 1 || !B.subs.empty() || !out_survivors || out_dev)
+            return fail(BSG_E_UNSUPPORTED, "survivor rows need a single-device context and a batch within one launch's limits");
+        std::lock_guard<std::mutex> lk(ctx->devs[0]->mu);
+        if (int32_t rc = use_device(*ctx->devs[0])) return rc;
+        if (hipHostGetDevicePointer(reinterpret_cast<void **>(&d_rows), out_survivors, 0) != hipSuccess ||
+            hipHostGetDevicePointer(reinterpret_cast<void **>(&d_hdr), rows_hdr, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(BSG_E_INVALID, "survivor rows are written by the device: out_rows and out_hdr must be page-locked memory (bsg_pinned_alloc / bsg_host_register)");
+        }
+    }
     if (!B.subs.empty()) {
         // a composite batch: every run of queries probes on its own; its rows are scattered into the caller's layout
         // (arena i: [n_queries][G_i], the runs' rows [q0, q0 + nq) of it) on the host
@@ -1759,7 +1777,7 @@ int32_t probe_arenas(bsg_ctx *ctx, const std::vector<std::shared_ptr<Arena>> &ar
             // them (those produce no words), so the group's words are contiguous at out_off[first arena of the group]
             for (size_t gi = 0; gi < groups.size(); ++gi) goff[gi] = out_off[groups[gi].index[0]];
         }
-        const bool want_copy = out_survivors != nullptr || out_dev != nullptr;
+        const bool want_copy = (out_survivors != nullptr || out_dev != nullptr) && !rows_hdr;
         // latency path (a single interactive query): one group, a small synchronous result — the copy rides the compute
         // stream, no cross-stream events
         const bool inline_copy = want_copy && groups.size() == 1 && !(flags & BSG_PROBE_ASYNC) && groups[0].out_words * 8 <= (1u << 20);
@@ -1811,6 +1829,19 @@ int32_t probe_arenas(bsg_ctx *ctx, const std::vector<std::shared_ptr<Arena>> &ar
         std::vector<uint8_t> tflag(groups.size(), 0);
         auto after_eval = [&](size_t gi, uint32_t slot) -> int32_t {   // bookkeeping once K2(gi) is enqueued
             if (tflag[gi]) d.pending.push_back(evs[gi]);
+            if (rows_hdr) {
+                // the group's rows, tagged and compacted, straight into the caller's page-locked buffers (same stream: ordered
+                // behind the evaluation and ahead of the next use of out[slot])
+                const Group &g = groups[gi];
+                bsg::RowsArgs ra{d.out[slot].p, d_rows, d_hdr, B.n_queries};
+                bsg::ArenaTable<bsg::kMaxGroupArenas> t;
+                bsg::RowsTable<bsg::kMaxGroupArenas> dst;
+                fill_refs(g, B, t.ar);
+                for (size_t i = 0; i < g.shards.size(); ++i) dst.d[i] = bsg::RowsDst{out_off[g.index[i]], (uint64_t)g.index[i] * B.n_queries};
+                hipLaunchKernelGGL(bsg::k_survivor_rows, dim3((B.n_queries + 255) / 256, (uint32_t)g.shards.size()), dim3(256), 0, d.stream, ra, t, dst);
+                HIP_TRY(hipGetLastError());
+                return BSG_OK;
+            }
             if (!want_copy) return BSG_OK;
             const uint64_t bytes = groups[gi].out_words * 8;
             if (inline_copy) {
@@ -2010,6 +2041,33 @@ extern "C" int32_t bsg_probe_many(bsg_ctx *ctx, const uint64_t *arena_ids, uint3
     for (uint32_t i = 0; i < n_arenas; ++i) if (int32_t rc = get_arena(ctx, arena_ids[i], arenas[i])) return rc;
     // without an output pointer the call only enqueues (round-1 contract: pair with bsg_sync)
     return probe_arenas(ctx, arenas, *batch, out_survivors ? flags : (flags | BSG_PROBE_ASYNC), out_survivors, nullptr);
+}
+
+extern "C" int32_t bsg_probe_many_rows(bsg_ctx *ctx, const uint64_t *arena_ids, uint32_t n_arenas, uint64_t batch_id, uint32_t flags,
+                                       uint64_t *out_rows, uint32_t *out_hdr)
+{
+    BSG_ENTER(ctx);
+    if ((n_arenas && !arena_ids) || !out_rows || !out_hdr) return fail(BSG_E_INVALID, "null argument");
+    std::shared_ptr<Batch> batch;
+    if (int32_t rc = get_batch(ctx, batch_id, batch)) return rc;
+    std::vector<std::shared_ptr<Arena>> arenas(n_arenas);
+    for (uint32_t i = 0; i < n_arenas; ++i) if (int32_t rc = get_arena(ctx, arena_ids[i], arenas[i])) return rc;
+    return probe_arenas(ctx, arenas, *batch, flags, out_rows, nullptr, out_hdr);
+}
+
+extern "C" int32_t bsg_survivor_row_list(uint32_t hdr, const uint64_t *row, uint32_t n_blocks, uint32_t *out_blocks, uint32_t cap, uint32_t *out_n)
+{
+    if (!out_n || (cap && !out_blocks)) return fail(BSG_E_INVALID, "null argument");
+    const uint32_t tag = hdr >> 30, cnt = hdr & 0x3FFFFFFFu;
+    *out_n = cnt;
+    if (cnt > n_blocks) return fail(BSG_E_INVALID, "row header counts %u survivors of %u blocks", cnt, n_blocks);
+    if (cnt > cap) return fail(BSG_E_INVALID, "the row holds %u surviving blocks, the buffer %u", cnt, cap);
+    if (tag == bsg::kRowNone) return BSG_OK;
+    if (tag == bsg::kRowAll) { for (uint32_t b = 0; b < n_blocks; ++b) out_blocks[b] = b; return BSG_OK; }
+    if (!row) return fail(BSG_E_INVALID, "null row");
+    if (tag == bsg::kRowList) { memcpy(out_blocks, row, (size_t)cnt * 4); return BSG_OK; }
+    uint32_t n = 0;
+    return bsg_survivor_list(row, n_blocks, out_blocks, cap, &n);
 }
 
 extern "C" int32_t bsg_probe_many_dev(bsg_ctx *ctx, const uint64_t *arena_ids, uint32_t n_arenas, uint64_t batch_id, uint32_t flags,

@@ -1140,6 +1140,56 @@ __global__ __launch_bounds__(kProbeThreads) __attribute__((amdgpu_num_sgpr(BSG_S
 }
 
 // ---------------------------------------------------------------------------
+// Survivor ROWS for the host (round 4): what crosses PCIe is what the host needs, not Q x B / 8 bytes whatever they hold.
+// The reference's consumer wants the surviving block IDS of a query (blockScanCandidate order, query_exec.go:321,603);
+// a dense [Q][G] bitset over one PCIe link halved the delivered rate (C4: 5.2 MB per step).  One lane per query row
+// reads the row's G words from the device-side survivors, tags it
+//   NONE  no block survives              ALL   every block survives            (nothing but the 4-byte header travels)
+//   LIST  count <= 2 G survivors: their block indices, ascending, as u32 in the row's own slot
+//   DENSE the row's G words, as bsg_probe_many delivers them
+// and writes header + payload STRAIGHT into page-locked host memory (zero-copy: only the bytes written cross the link; the
+// row slots keep the dense layout, so addressing is fixed and nothing has to be sized before the copy).
+// ---------------------------------------------------------------------------
+constexpr uint32_t kRowNone = 0, kRowAll = 1, kRowList = 2, kRowDense = 3;
+struct RowsDst { uint64_t row_off; uint64_t hdr_off; };   // arena i of the group: first u64 of its rows / first u32 of its headers in the caller's buffers
+template <uint32_t N>
+struct RowsTable { RowsDst d[N]; };
+struct RowsArgs {
+    const uint64_t *out;      // the group's survivors on the device (arena i: [n_queries][G_i] at out + ar[i].out_off)
+    uint64_t *rows;           // host-mapped: the caller's row slots (dense layout)
+    uint32_t *hdr;            // host-mapped: tag << 30 | survivor count, per (arena, query)
+    uint32_t n_queries;
+};
+
+// grid = (ceil(n_queries / 256), arenas of the group)
+__global__ __launch_bounds__(256) void k_survivor_rows(const RowsArgs a, const ArenaTable<kMaxGroupArenas> t, const RowsTable<kMaxGroupArenas> dst)
+{
+    const ArenaRef &ar = t.ar[blockIdx.y];
+    const RowsDst d = dst.d[blockIdx.y];
+    const uint32_t q = blockIdx.x * 256u + threadIdx.x;
+    if (q >= a.n_queries) return;
+    const uint64_t *src = a.out + ar.out_off + (uint64_t)q * ar.G;
+    uint32_t cnt = 0;
+    for (uint32_t g = 0; g < ar.G; ++g) cnt += (uint32_t)__popcll(src[g]);
+    const uint32_t tag = cnt == 0u ? kRowNone : cnt == ar.n_blocks ? kRowAll : cnt <= 2u * ar.G ? kRowList : kRowDense;
+    a.hdr[d.hdr_off + q] = (tag << 30) | cnt;
+    uint64_t *row = a.rows + d.row_off + (uint64_t)q * ar.G;
+    if (tag == kRowList) {
+        uint32_t *ids = reinterpret_cast<uint32_t *>(row);
+        uint32_t n = 0;
+        for (uint32_t g = 0; g < ar.G; ++g) {
+            uint64_t w = src[g];
+            while (w) {
+                ids[n++] = g * 64u + (uint32_t)__builtin_ctzll(w);
+                w &= w - 1;
+            }
+        }
+    } else if (tag == kRowDense) {
+        for (uint32_t g = 0; g < ar.G; ++g) row[g] = src[g];
+    }
+}
+
+// ---------------------------------------------------------------------------
 // hash_entries: one lane per entry -> 4 x u64 base hashes.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_hash_entries(const uint8_t *bytes, const uint32_t *off, uint32_t n,

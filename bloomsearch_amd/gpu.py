@@ -35,6 +35,36 @@ def survivor_list(row: np.ndarray, n_blocks: int) -> np.ndarray:
     return out[: n.value].copy()
 
 
+def survivor_row_list(hdr: int, row: np.ndarray, n_blocks: int) -> np.ndarray:
+    """bsg_survivor_row_list: the surviving block indices of one row of bsg_probe_many_rows, whatever its tag."""
+    L = _lib.load()
+    row = np.ascontiguousarray(row, dtype=np.uint64)
+    n = C.c_uint32()
+    out = np.zeros(max(n_blocks, 1), dtype=np.uint32)
+    rc = L.bsg_survivor_row_list(int(hdr), _lib._ptr(row), n_blocks, _lib._ptr(out), len(out), C.byref(n))
+    if rc:
+        raise BloomGpuError(rc, L.bsg_last_error(None).decode())
+    return out[: n.value].copy()
+
+
+def rows_to_dense(hdr: np.ndarray, rows: np.ndarray, n_blocks: int) -> np.ndarray:
+    """[n_queries] headers + [n_queries][G] row slots of bsg_probe_many_rows -> the dense [n_queries][G] bitsets of bsg_probe_many
+    (numpy; tests and consumers that want the bitset form)."""
+    G = (n_blocks + 63) // 64
+    rows = np.asarray(rows, dtype=np.uint64).reshape(len(hdr), G)
+    out = np.zeros((len(hdr), G), dtype=np.uint64)
+    full = np.full(G, ~np.uint64(0), dtype=np.uint64)
+    if n_blocks & 63:
+        full[-1] = np.uint64((1 << (n_blocks & 63)) - 1)
+    tag, cnt = np.asarray(hdr, dtype=np.uint32) >> 30, np.asarray(hdr, dtype=np.uint32) & np.uint32(0x3FFFFFFF)
+    out[tag == 1] = full
+    out[tag == 3] = rows[tag == 3]
+    for q in np.nonzero(tag == 2)[0]:
+        ids = rows[q].view(np.uint32)[: int(cnt[q])].astype(np.int64)
+        np.bitwise_or.at(out[q], ids >> 6, np.uint64(1) << (ids & 63).astype(np.uint64))
+    return out
+
+
 def estimate_parameters(n: int, p: float):
     """bloom/v3 EstimateParameters with New()'s clamps (host arithmetic, no GPU needed)."""
     L = _lib.load()
@@ -194,6 +224,13 @@ class Context:
         """Synchronous probe of every arena; survivors written back to back into `out` (u64, e.g. pinned memory)."""
         ids = np.ascontiguousarray(arena_ids, dtype=np.uint64)
         self._check(self.L.bsg_probe_many(self.h, _lib._ptr(ids), len(ids), batch_id, flags, C.c_void_p(out.ctypes.data)))
+
+    def probe_many_rows(self, arena_ids, batch_id: int, rows: np.ndarray, hdr: np.ndarray, flags: int = 0):
+        """bsg_probe_many_rows: a header per (arena, query) into `hdr` (u32) and, only where the tag needs it, block ids or words into
+        the row's dense slot of `rows` (u64) — both PAGE-LOCKED arrays (pinned_array / host_register), written by the device."""
+        ids = np.ascontiguousarray(arena_ids, dtype=np.uint64)
+        self._check(self.L.bsg_probe_many_rows(self.h, _lib._ptr(ids), len(ids), batch_id, flags, C.c_void_p(rows.ctypes.data),
+                                               C.c_void_p(hdr.ctypes.data)))
 
     def set_probe_group(self, max_arenas_per_launch: int):
         self._check(self.L.bsg_set_probe_group(self.h, max_arenas_per_launch))

@@ -437,6 +437,95 @@ func SurvivorList(row []uint64, blocks uint32) ([]uint32, error) {
 	return out[:n], nil
 }
 
+// SurvivorRows is the result of ProbeManyRows for one arena: a header per query (tag << 30 | surviving-block count) and the
+// row slots in bsg_probe_many's dense layout; what a slot holds depends on the row's tag (see bsg_probe_many_rows).  Both
+// slices are views of page-locked C memory owned by the RowsBuffer they came from.
+type SurvivorRows struct {
+	Blocks uint32
+	Hdr    []uint32
+	Rows   []uint64
+}
+
+// Blocks of query q, ascending (blockScanCandidate order, query_exec.go:321,603), whatever the row's tag.
+func (s SurvivorRows) List(q int) ([]uint32, error) {
+	g := int((s.Blocks + 63) / 64)
+	hdr := s.Hdr[q]
+	n := hdr & 0x3FFFFFFF
+	if n == 0 {
+		return nil, nil
+	}
+	out := make([]uint32, n)
+	var got C.uint32_t
+	var row *C.uint64_t
+	if g > 0 {
+		row = (*C.uint64_t)(unsafe.Pointer(&s.Rows[q*g]))
+	}
+	if rc := C.bsg_survivor_row_list(C.uint32_t(hdr), row, C.uint32_t(s.Blocks), u32p(out), C.uint32_t(n), &got); rc != C.BSG_OK {
+		return nil, &Error{Code: int(rc), Message: C.GoString(C.bsg_last_error(nil))}
+	}
+	return out[:got], nil
+}
+
+// RowsBuffer is page-locked C memory (bsg_pinned_alloc) the device writes survivor rows into; reuse it across calls.
+type RowsBuffer struct {
+	g    *Context
+	rows unsafe.Pointer
+	hdr  unsafe.Pointer
+	nRow int // u64 capacity
+	nHdr int // u32 capacity
+}
+
+// NewRowsBuffer allocates room for `rowWords` u64 of row slots and `headers` u32 of headers.
+func (g *Context) NewRowsBuffer(rowWords, headers int) (*RowsBuffer, error) {
+	b := &RowsBuffer{g: g, nRow: rowWords, nHdr: headers}
+	if err := g.err(C.bsg_pinned_alloc(g.c, C.uint64_t(8*(rowWords+1)), &b.rows)); err != nil {
+		return nil, err
+	}
+	if err := g.err(C.bsg_pinned_alloc(g.c, C.uint64_t(4*(headers+1)), &b.hdr)); err != nil {
+		C.bsg_pinned_free(g.c, b.rows)
+		return nil, err
+	}
+	return b, nil
+}
+
+// Free returns the buffer's memory.
+func (b *RowsBuffer) Free() {
+	C.bsg_pinned_free(b.g.c, b.rows)
+	C.bsg_pinned_free(b.g.c, b.hdr)
+	b.rows, b.hdr = nil, nil
+}
+
+// ProbeManyRows is bsg_probe_many_rows: like ProbeMany, but what crosses PCIe is a 4-byte header per (arena, query) plus
+// block ids or words only for the rows that need them (single-device contexts).
+func (g *Context) ProbeManyRows(arenas []Arena, b Batch, buf *RowsBuffer) ([]SurvivorRows, error) {
+	if len(arenas) == 0 || b.Queries == 0 {
+		return nil, nil
+	}
+	ids := make([]uint64, len(arenas))
+	total := 0
+	for i, a := range arenas {
+		ids[i] = a.ID
+		total += int(b.Queries) * int((a.Blocks+63)/64)
+	}
+	if total > buf.nRow || len(arenas)*int(b.Queries) > buf.nHdr {
+		return nil, &Error{Code: int(C.BSG_E_INVALID), Message: "rows buffer too small"}
+	}
+	rc := C.bsg_probe_many_rows(g.c, u64p(ids), C.uint32_t(len(ids)), C.uint64_t(b.ID), 0, (*C.uint64_t)(buf.rows), (*C.uint32_t)(buf.hdr))
+	if err := g.err(rc); err != nil {
+		return nil, err
+	}
+	rows := unsafe.Slice((*uint64)(buf.rows), buf.nRow+1)
+	hdr := unsafe.Slice((*uint32)(buf.hdr), buf.nHdr+1)
+	out := make([]SurvivorRows, len(arenas))
+	o := 0
+	for i, a := range arenas {
+		n := int(b.Queries) * int((a.Blocks+63)/64)
+		out[i] = SurvivorRows{Blocks: a.Blocks, Hdr: hdr[i*int(b.Queries) : (i+1)*int(b.Queries)], Rows: rows[o : o+n : o+n]}
+		o += n
+	}
+	return out, nil
+}
+
 // DeviceCalls is bsg_device_calls: construct / match parts each device of the context has served so far.
 func (g *Context) DeviceCalls(nDevices int) ([]uint64, error) {
 	out := make([]uint64, nDevices)

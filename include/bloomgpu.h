@@ -252,6 +252,27 @@ BSG_API int32_t bsg_set_fuse_limit(bsg_ctx *ctx, uint32_t max_arenas);
  * terms * k * bytes_per_probe < its size (default 256; 0 = always stream). */
 BSG_API int32_t bsg_set_gather_cost(bsg_ctx *ctx, uint32_t bytes_per_probe);
 
+/* ---- survivor ROWS: surviving block ids for the host, not Q x B / 8 bytes whatever they hold ----
+ * bsg_probe_many with the host-side gather of the north star in mind (query_exec.go:321,603: the consumer walks the surviving
+ * block INDICES of a query).  Per (arena i, query q) a header out_hdr[i * n_queries + q] = tag << 30 | surviving-block count and
+ * the row's slot out_rows[row offset as in bsg_probe_many] whose content depends on the tag:
+ *   BSG_ROW_NONE   no block survives: slot untouched          BSG_ROW_ALL    every block survives: slot untouched
+ *   BSG_ROW_LIST   count <= 2 * ceil(n_blocks / 64): the slot starts with `count` ascending block indices (u32)
+ *   BSG_ROW_DENSE  the slot holds the row's words exactly as bsg_probe_many writes them
+ * Both buffers are written BY THE DEVICE (k_survivor_rows) and must be page-locked C memory (bsg_pinned_alloc /
+ * bsg_host_register): only the bytes written cross PCIe — a batch whose rows are mostly NONE / ALL / short lists costs 4 bytes
+ * per row instead of n_blocks / 8.  Single-device contexts (a context over several devices keeps bsg_probe_many: its shards'
+ * local block numbers are interleaved on the host); flags as bsg_probe_many (with BSG_PROBE_ASYNC both buffers must stay valid
+ * until bsg_sync).  bsg_survivor_row_list expands one row to its ascending block indices whatever its tag. */
+#define BSG_ROW_NONE  0u
+#define BSG_ROW_ALL   1u
+#define BSG_ROW_LIST  2u
+#define BSG_ROW_DENSE 3u
+BSG_API int32_t bsg_probe_many_rows(bsg_ctx *ctx, const uint64_t *arena_ids, uint32_t n_arenas, uint64_t batch_id, uint32_t flags,
+                                    uint64_t *out_rows, uint32_t *out_hdr);
+BSG_API int32_t bsg_survivor_row_list(uint32_t hdr, const uint64_t *row, uint32_t n_blocks, uint32_t *out_blocks, uint32_t cap,
+                                      uint32_t *out_n);
+
 /* One-shot convenience: batch_create + probe_batch + batch_free. */
 BSG_API int32_t bsg_probe(bsg_ctx *ctx, uint64_t arena_id, const bsg_term *terms, uint32_t n_terms,
                           const uint32_t *prog_ops, const uint32_t *prog_off, uint32_t n_queries,
