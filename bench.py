@@ -162,7 +162,7 @@ def ingest_leg(ctx, n_blocks, rows, seed, workers, plan, words, fpr, log, truste
             "check": "bitsets and (m, k) identical to bsg_build of the same blocks' entry sets"}
 
 
-def multi_device_context_leg(ctx, device_ids, plan, words, block_ids, rows, seed, fpr, terms, ops, poff, got, log):
+def multi_device_context_leg(ctx, device_ids, plan, words, block_ids, rows, seed, fpr, terms, ops, poff, got, log, res=None):
     """The OTHER way the library spans GPUs: ONE process, one context over several devices (what the Go engine opens:
     GPUDevices = [0 .. N-1]).  bench.py's contract is one process per GPU, so this in-process path is otherwise only ever run
     on one physical GPU (contexts that name device 0 several times).  Rank 0 runs it once, after every timed leg, when the
@@ -174,13 +174,22 @@ def multi_device_context_leg(ctx, device_ids, plan, words, block_ids, rows, seed
     from bloomsearch_amd import ingest as I, query as Q
     from bloomsearch_amd.gpu import Context
     B = len(block_ids)
-    res = {"devices": [int(d) for d in device_ids]}
+    res = {} if res is None else res           # filled stage by stage: if a stage never returns, the watchdog's line still holds the others
+    res.update({"devices": [int(d) for d in device_ids], "stages_done": [], "stage_running": "open"})
+
+    def stage(name):
+        if res["stage_running"] not in ("open",):
+            res["stages_done"].append(res["stage_running"])
+        res["stage_running"] = name
     with Context(tuple(device_ids)) as m:
+        res["peer_access"] = m.peer_access().tolist()        # 1: direct xGMI peer access; 0: copies between the pair are staged through the host
+        stage("probe")
         aid = m.arena_load(words, plan.desc)
         t0 = time.perf_counter()
         if not np.array_equal(m.probe(aid, B, terms, ops, poff), got):
             raise RuntimeError("survivors of the multi-device context differ from the single-device context's")
         res["probe_wall_ms"] = (time.perf_counter() - t0) * 1e3
+        stage("bsg_query")
         one = Q.compile_queries([Q.And(Q.FieldToken("level", "error"), Q.FieldToken("service", "payment"), Q.FieldToken("nested.region", "region-3"))])
         a1 = ctx.arena_load(words, plan.desc)
         same = np.array_equal(m.query([aid], [B], one)[0], ctx.query([a1], [B], one)[0])
@@ -189,6 +198,7 @@ def multi_device_context_leg(ctx, device_ids, plan, words, block_ids, rows, seed
         if not same:
             raise RuntimeError("bsg_query on the multi-device context differs")
         # the C3 build, one part per device
+        stage("build")
         t0 = time.perf_counter()
         w_m = m.build(plan.blob, plan.off, plan.fstart, plan.desc, plan.n_words)
         t_m = time.perf_counter() - t0
@@ -200,6 +210,7 @@ def multi_device_context_leg(ctx, device_ids, plan, words, block_ids, rows, seed
         res["build_wall_ms"] = {"one_device": t_s * 1e3, "sharded": t_m * 1e3,
                                 "note": "bsg_build of %d entries incl. the upload of the entry bytes and the bitsets' way back" % (len(plan.off) - 1)}
         # device ingest of the first blocks' rows: parts per device, parents merged across devices, sections + resident arenas
+        stage("ingest")
         nb = min(B, 64)
         parts = [_gen_rows((int(block_ids[b]), rows, seed)) for b in range(nb)]
         blob = np.frombuffer(b"".join(p[0] for p in parts), dtype=np.uint8)
@@ -223,6 +234,7 @@ def multi_device_context_leg(ctx, device_ids, plan, words, block_ids, rows, seed
         if nb == 64 and not np.array_equal(outs[0][3][:, 0], got[:, 0]):      # blocks 0..63 are the first survivor word of the loaded arena
             raise RuntimeError("the resident arena of the first blocks answers differently from the loaded arena")
         # fixed-geometry OR, partials device to device
+        stage("or_reduce")
         rng = np.random.default_rng(5)
         mm, nblk = 1000003, 96
         nw = (mm + 63) // 64
@@ -240,6 +252,9 @@ def multi_device_context_leg(ctx, device_ids, plan, words, block_ids, rows, seed
         if not np.array_equal(got_or, np.bitwise_or.reduce(w2.reshape(nblk, stride)[:, :nw], axis=0)):
             raise RuntimeError("bsg_or_reduce across the context's devices differs from numpy's OR")
         res["device_calls"] = [int(x) for x in m.device_calls()]
+        stage("close")
+    res["stages_done"].append("close")
+    res["stage_running"] = None
     res["check"] = ("probe (batch + one bsg_query), bsg_build, device ingest -> sections + resident arenas, bsg_or_reduce: identical to the "
                     "single-device context on %d devices in one process" % len(device_ids))
     log("multi-device context over devices %s: ok (build %.0f ms sharded vs %.0f ms on one device)" % (list(device_ids), t_m * 1e3, t_s * 1e3))
@@ -1392,17 +1407,18 @@ def main():
         if ids:
             finished = threading.Event()
 
+            mdc = out["multi_device_context"] = {"devices": ids}      # filled in place, stage by stage
+
             def giving_up():
-                if not finished.wait(float(os.environ.get("BSG_BENCH_MULTI_CTX_TIMEOUT", "300"))):
-                    out["multi_device_context"] = {"devices": ids, "error": "no answer within the watchdog's time; the leg was abandoned"}
+                if not finished.wait(float(os.environ.get("BSG_BENCH_MULTI_CTX_TIMEOUT", "240"))):
+                    mdc["error"] = "stage %r gave no answer within the watchdog's time; the leg was abandoned (stages_done lists what did finish)" % mdc.get("stage_running")
                     emit()
                     os._exit(0)
             threading.Thread(target=giving_up, daemon=True).start()
             try:
-                out["multi_device_context"] = multi_device_context_leg(ctx, ids, plan, words, block_ids, rows, 0xB100F5EA4C4, args.fpr,
-                                                                       terms, ops, poff, got, log)
+                multi_device_context_leg(ctx, ids, plan, words, block_ids, rows, 0xB100F5EA4C4, args.fpr, terms, ops, poff, got, log, res=mdc)
             except Exception as exc:  # noqa: BLE001 - reported in the line
-                out["multi_device_context"] = {"devices": ids, "error": repr(exc)}
+                mdc["error"] = "stage %r: %r" % (mdc.get("stage_running"), exc)
                 log("multi-device context leg failed: %r" % (exc,))
             finished.set()
         elif world > 1:

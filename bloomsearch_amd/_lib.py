@@ -52,7 +52,7 @@ def op(opcode: int, arg: int = 0) -> int:
 
 # every symbol include/bloomgpu.h declares (tests assert the .so exports all of them)
 EXPORTS = [
-    "bsg_device_count", "bsg_device_calls", "bsg_open", "bsg_open_err", "bsg_close", "bsg_last_error", "bsg_last_error_copy", "bsg_scope_open",
+    "bsg_device_count", "bsg_peer_access", "bsg_device_calls", "bsg_open", "bsg_open_err", "bsg_close", "bsg_last_error", "bsg_last_error_copy", "bsg_scope_open",
     "bsg_sync", "bsg_estimate_parameters", "bsg_probe_many_dev", "bsg_set_probe_group", "bsg_set_gather_cost", "bsg_set_fuse_limit", "bsg_set_spin_wait", "bsg_set_ingest_chunk", "bsg_set_lab",
     "bsg_hash_entries", "bsg_build", "bsg_build_hashed", "bsg_arena_load", "bsg_arena_load_sections", "bsg_arena_free",
     "bsg_arena_stream_begin", "bsg_arena_stream_append", "bsg_arena_stream_finish", "bsg_arena_stream_abort",
@@ -81,6 +81,7 @@ def load():
     L.bsg_device_count.restype = i32
     L.bsg_open.argtypes = [C.POINTER(i32), i32, C.POINTER(vp)]
     L.bsg_device_calls.argtypes = [vp, vp, u32]
+    L.bsg_peer_access.argtypes = [vp, vp, u32]
     L.bsg_open_err.argtypes = [C.POINTER(i32), i32, C.POINTER(vp), C.c_char_p, u64]
     L.bsg_last_error_copy.argtypes = [vp, C.c_char_p, u64]
     L.bsg_scope_open.argtypes = [vp, C.POINTER(vp)]

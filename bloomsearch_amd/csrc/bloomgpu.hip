@@ -271,6 +271,8 @@ struct bsg_ctx {
     uint32_t group_limit = bsg::kMaxGroupArenas;   // arenas one probe dispatch may cover (bsg_set_probe_group)
     uint32_t gather_cost = 256;  // a filter is gathered instead of staged when terms * k * gather_cost < its bytes
     bsg::FpKey fp_key{};         // secret key of the entries' fingerprints (drawn at bsg_open; never leaves the process)
+    std::vector<uint8_t> peer;   // [i * nd + j]: 1 = device i reaches device j's memory directly (xGMI peer access enabled, or the same device)
+    std::atomic<uint64_t> peer_warned{0};   // pairs (bit i * 8 + j, contexts of <= 8 devices) whose staged copies were announced
     std::vector<void *> comms;   // ncclComm_t per device (bsg_comm_init)
     uint32_t comm_world = 0, comm_rank = 0;
     uint64_t ingest_chunk_bytes = 64ull << 20;   // rows per upload chunk of bsg_ingest_rows (bsg_set_ingest_chunk)
@@ -323,6 +325,30 @@ int32_t use_device(Device &d)
     return BSG_OK;
 }
 
+// Device-to-device copy between two entries of the context, on `stream` (a stream of either device).  The same physical device:
+// a plain copy.  A pair with peer access: hipMemcpyPeerAsync over xGMI.  A pair WITHOUT it: the same call — the runtime stages
+// the bytes through host memory — announced on stderr once per pair (BSG_QUIET=1 silences it), because a multi-GPU flush or
+// merge that runs at PCIe speed should not look like a slow kernel.  bsg_peer_access reports the matrix.
+uint32_t dev_index(const bsg_ctx *ctx, const Device *d)
+{
+    for (uint32_t i = 0; i < ctx->devs.size(); ++i) if (ctx->devs[i].get() == d) return i;
+    return 0;
+}
+
+hipError_t peer_copy(bsg_ctx *ctx, uint32_t dst_i, void *dst, uint32_t src_i, const void *src, size_t bytes, hipStream_t stream)
+{
+    Device &D = *ctx->devs[dst_i], &S = *ctx->devs[src_i];
+    if (D.id == S.id) return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream);
+    const uint32_t nd = (uint32_t)ctx->devs.size();
+    const bool direct = ctx->peer.size() == (size_t)nd * nd && ctx->peer[(size_t)dst_i * nd + src_i] && ctx->peer[(size_t)src_i * nd + dst_i];
+    if (!direct && nd <= 8) {
+        const uint64_t bit = 1ull << (dst_i * 8 + src_i);
+        if (!(ctx->peer_warned.fetch_or(bit) & bit) && !getenv("BSG_QUIET"))
+            fprintf(stderr, "[bloomgpu] no peer access between devices %d and %d: copies between them are staged through host memory\n", S.id, D.id);
+    }
+    return hipMemcpyPeerAsync(dst, D.id, src, S.id, bytes, stream);
+}
+
 // The device for a call that stays on ONE device of the context: round-robin, preferring a device nobody holds right now
 // (the flush worker, a merge and the block workers of concurrent queries then land on different GPUs).  The answer is a
 // hint — the caller takes the device's lock the usual way.
@@ -346,14 +372,25 @@ int32_t run_parts(uint32_t n, F &&part)
     if (n == 0) return BSG_OK;
     if (n == 1) return part(0u);
     std::vector<int32_t> rc(n, BSG_OK);
+    std::vector<std::string> msg(n);          // a worker's message lives in ITS thread-local g_err: carried back by value
     bsg_ctx *scope = tl_scope;
     std::vector<std::thread> th;
     th.reserve(n - 1);
     for (uint32_t i = 1; i < n; ++i)
-        th.emplace_back([&rc, &part, scope, i]() { tl_scope = scope; rc[i] = part(i); tl_scope = nullptr; });
+        th.emplace_back([&rc, &msg, &part, scope, i]() {
+            tl_scope = scope;
+            g_err.clear();
+            rc[i] = part(i);
+            if (rc[i]) msg[i] = g_err;
+            tl_scope = nullptr;
+        });
+    g_err.clear();
     rc[0] = part(0u);
+    if (rc[0]) msg[0] = g_err;
     for (auto &t : th) t.join();
-    for (uint32_t i = 0; i < n; ++i) if (rc[i]) return rc[i];
+    // the first failing part's code AND message, re-issued on the caller's thread: bsg_last_error(NULL), the wrappers that save
+    // g_err around a nested call, and the scope's slot (which a later part may have overwritten) all name the same failure
+    for (uint32_t i = 0; i < n; ++i) if (rc[i]) return fail(rc[i], "%s", msg[i].empty() ? "a device part failed" : msg[i].c_str());
     return BSG_OK;
 }
 
@@ -576,21 +613,32 @@ int32_t bsg_open(const int32_t *device_ids, int32_t n_devices, bsg_ctx **out_ctx
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(bsg::k_probe_terms), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(bsg::k_probe_terms_many), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(bsg::k_probe_fused), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(bsg::k_probe_eval), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(bsg::k_build), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(bsg::k_build_sets), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget - bsg::kSetListBytes));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(bsg::k_union_partitions), hipFuncAttributeMaxDynamicSharedMemorySize, bsg::kPartLdsBytes));
 
         ctx->devs.push_back(std::move(d));
     }
-    // shards exchange partial bitsets device-to-device (bsg_or_reduce): enable xGMI peer access where the pair allows it
-    for (auto &a : ctx->devs)
-        for (auto &b : ctx->devs) {
-            if (a->id == b->id) continue;
+    // shards exchange partial bitsets, partial file-level sets and resident arenas device-to-device: enable xGMI peer access
+    // where the pair allows it and REMEMBER where it does not — a copy between such a pair still works (the runtime stages it
+    // through host memory) but at PCIe speed, and peer_copy says so once per pair instead of being silently slow
+    const uint32_t nd_open = (uint32_t)ctx->devs.size();
+    ctx->peer.assign((size_t)nd_open * nd_open, 1);
+    for (uint32_t i = 0; i < nd_open; ++i)
+        for (uint32_t j = 0; j < nd_open; ++j) {
+            Device &a = *ctx->devs[i], &b = *ctx->devs[j];
+            if (a.id == b.id) continue;
             int can = 0;
-            if (hipDeviceCanAccessPeer(&can, a->id, b->id) == hipSuccess && can) {
-                (void)hipSetDevice(a->id);
-                const hipError_t e = hipDeviceEnablePeerAccess(b->id, 0);
-                if (e != hipSuccess) (void)hipGetLastError();   // already enabled
+            hipError_t e = hipDeviceCanAccessPeer(&can, a.id, b.id);
+            if (e == hipSuccess && can) {
+                (void)hipSetDevice(a.id);
+                e = hipDeviceEnablePeerAccess(b.id, 0);
+                if (e == hipErrorPeerAccessAlreadyEnabled) { (void)hipGetLastError(); e = hipSuccess; }
+            }
+            if (e != hipSuccess || !can) {
+                (void)hipGetLastError();
+                ctx->peer[(size_t)i * nd_open + j] = 0;
             }
         }
     *out_ctx = ctx.release();
@@ -2285,6 +2333,15 @@ int32_t bsg_survivor_list(const uint64_t *survivor_row, uint32_t n_blocks, uint3
     return BSG_OK;
 }
 
+int32_t bsg_peer_access(bsg_ctx *ctx, uint8_t *out_matrix, uint32_t n)
+{
+    BSG_ENTER(ctx);
+    const uint32_t nd = (uint32_t)ctx->devs.size();
+    if (!out_matrix || n != nd) return fail(BSG_E_INVALID, "out_matrix must hold %u x %u entries", nd, nd);
+    for (uint32_t i = 0; i < nd * nd; ++i) out_matrix[i] = ctx->peer.size() == (size_t)nd * nd ? ctx->peer[i] : 0;
+    return BSG_OK;
+}
+
 int32_t bsg_device_calls(bsg_ctx *ctx, uint64_t *out_calls, uint32_t cap)
 {
     BSG_ENTER(ctx);
@@ -2432,8 +2489,7 @@ int32_t bsg_or_reduce(bsg_ctx *ctx, uint64_t arena_id, uint32_t kind, uint64_t *
         for (uint32_t di = 1; di < nd && e == hipSuccess; ++di) {
             e = hipStreamWaitEvent(d0.stream, done[di], 0);
             if (e == hipSuccess)
-                e = hipMemcpyPeerAsync(static_cast<uint64_t *>(gathered) + (uint64_t)(di - 1) * n_words, d0.id, partial[di],
-                                       ctx->devs[di]->id, n_words * 8, d0.stream);
+                e = peer_copy(ctx, 0, static_cast<uint64_t *>(gathered) + (uint64_t)(di - 1) * n_words, di, partial[di], n_words * 8, d0.stream);
         }
         if (e == hipSuccess && n_words) {
             const uint32_t grid = (uint32_t)std::min<uint64_t>((n_words + 255) / 256, 4096);

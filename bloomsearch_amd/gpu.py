@@ -329,6 +329,13 @@ class Context:
             buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
             self._check(self.L.bsg_comm_init(self.h, buf, rank, world))
 
+    def peer_access(self) -> np.ndarray:
+        """[n][n] u8: 1 where device i reaches device j's memory directly (bsg_peer_access)."""
+        n = self.n_devices
+        m = np.zeros((n, n), dtype=np.uint8)
+        self._check(self.L.bsg_peer_access(self.h, _lib._ptr(m), n))
+        return m
+
     def comm_info(self):
         """(ranks, this rank, asked_the_library) as the communicator library itself reports them (ncclCommCount / ncclCommUserRank)."""
         w, r, lib = C.c_int32(0), C.c_int32(0), C.c_int32(0)

@@ -39,18 +39,37 @@ type gpuEngine struct {
 	scopeMu   sync.Mutex
 	idle, all []*bloomgpu.Context // error scopes: one per goroutine-confined caller at a time (bsg_scope_open)
 
-	arenaMu sync.Mutex
-	arenas  map[string]*gpuFileArena // resident block filters by file pointer
+	arenaMu     sync.Mutex
+	arenas      map[string]*gpuFileArena // resident block filters by file pointer
+	arenaBytes  int64                    // Σ bytes of the cached arenas
+	arenaBudget int64                    // eviction starts above this (least recently used first, never one in use)
+	arenaTick   uint64
 }
 
 // gpuFileArena is one file's block filters decoded on the device.  Blocks are in ascending RowDataOffset order, the order
 // evaluateBlockFilters consults them in (blocksByAscendingRowDataOffset, query_exec.go:321).
 type gpuFileArena struct {
 	arena   bloomgpu.Arena
-	offsets []int   // RowDataOffset of arena block i
+	offsets []int    // RowDataOffset of arena block i
+	begin   []uint64 // its filter section's byte range in the file (what a later, wider load of the same file reads again)
+	end     []uint64
 	status  []int32 // parseFilterSection's verdict for block i (0 ok)
+	bytes   int64   // section bytes behind the arena (≈ the HBM it holds)
+	lastUse uint64  // tick of the most recent query that used it (LRU)
 	users   int
-	dead    bool // tombstoned while in use: freed by the last user
+	dead    bool // tombstoned, evicted or never cached while in use: freed by the last user
+}
+
+// defaultArenaBudget bounds the decoded block filters kept resident across queries (BLOOMSEARCH_GPU_ARENA_BYTES overrides it):
+// without a bound every file ever queried would hold HBM until it is merged away, and the build / ingest calls of the flush
+// worker would start failing with BSG_E_NOMEM on a large store.
+const defaultArenaBudget = int64(32) << 30
+
+func arenaBudgetFromEnv() int64 {
+	if v, err := strconv.ParseInt(strings.TrimSpace(os.Getenv("BLOOMSEARCH_GPU_ARENA_BYTES")), 10, 64); err == nil && v >= 0 {
+		return v
+	}
+	return defaultArenaBudget
 }
 
 // devicesFromEnv lets an UNCHANGED caller — the reference's own test suite above all — run with the GPU seams live:
@@ -81,7 +100,7 @@ func openGPUEngine(config BloomSearchEngineConfig, logger *slog.Logger) (*gpuEng
 		logger.Warn("GPUIngest needs the default tokenizer; rows stay on the host walker")
 		ingest = false
 	}
-	return &gpuEngine{g: g, ingest: ingest, logger: logger, arenas: map[string]*gpuFileArena{}}, nil
+	return &gpuEngine{g: g, ingest: ingest, logger: logger, arenas: map[string]*gpuFileArena{}, arenaBudget: arenaBudgetFromEnv()}, nil
 }
 
 func (e *gpuEngine) close() {
@@ -93,6 +112,7 @@ func (e *gpuEngine) close() {
 		e.g.ArenaFree(fa.arena)
 		delete(e.arenas, k)
 	}
+	e.arenaBytes = 0
 	e.arenaMu.Unlock()
 	e.scopeMu.Lock()
 	for _, s := range e.all {
@@ -242,12 +262,39 @@ func (e *gpuEngine) forget(filePointer []byte) {
 	e.arenaMu.Lock()
 	defer e.arenaMu.Unlock()
 	if fa := e.arenas[string(filePointer)]; fa != nil {
-		delete(e.arenas, string(filePointer))
-		if fa.users == 0 {
-			e.g.ArenaFree(fa.arena)
-		} else {
-			fa.dead = true
+		e.dropLocked(string(filePointer), fa)
+	}
+}
+
+// dropLocked takes a cached arena out of the table (arenaMu held): freed now, or by its last user.
+func (e *gpuEngine) dropLocked(key string, fa *gpuFileArena) {
+	delete(e.arenas, key)
+	e.arenaBytes -= fa.bytes
+	if fa.users == 0 {
+		e.g.ArenaFree(fa.arena)
+	} else {
+		fa.dead = true
+	}
+}
+
+// evictLocked frees least-recently-used arenas nobody is using until the cache fits its budget again (arenaMu held).  `keep`
+// is never evicted (the arena the caller is about to use).
+func (e *gpuEngine) evictLocked(keep *gpuFileArena) {
+	for e.arenaBytes > e.arenaBudget {
+		var victimKey string
+		var victim *gpuFileArena
+		for k, fa := range e.arenas {
+			if fa == keep || fa.users > 0 {
+				continue
+			}
+			if victim == nil || fa.lastUse < victim.lastUse {
+				victimKey, victim = k, fa
+			}
 		}
+		if victim == nil {
+			return // everything left is in use: the budget is exceeded until those queries finish
+		}
+		e.dropLocked(victimKey, victim)
 	}
 }
 
@@ -294,29 +341,51 @@ func (e *gpuEngine) arenaFor(s *bloomgpu.Context, file io.ReadSeeker, filePointe
 		}
 		if covered {
 			fa.users++
+			e.arenaTick++
+			fa.lastUse = e.arenaTick
 			e.arenaMu.Unlock()
 			return fa, false, nil
 		}
 	}
+	// what the cached arena of this file already holds is loaded again together with the new candidates: the result covers
+	// both candidate sets, so two queries that alternate over different blocks of one file stop replacing each other's arena
+	var haveOff []int
+	var haveBegin, haveEnd []uint64
+	if fa != nil {
+		haveOff, haveBegin, haveEnd = fa.offsets, fa.begin, fa.end
+	}
 	e.arenaMu.Unlock()
 
-	begin := make([]uint64, len(blocks))
-	end := make([]uint64, len(blocks))
-	offsets := make([]int, len(blocks))
+	begin := make([]uint64, 0, len(blocks)+len(haveOff))
+	end := make([]uint64, 0, len(blocks)+len(haveOff))
+	offsets := make([]int, 0, len(blocks)+len(haveOff))
 	for i := range blocks {
-		offsets[i] = blocks[i].RowDataOffset
-		begin[i] = uint64(blocks[i].BloomFilterOffset)
-		end[i] = begin[i] + uint64(blocks[i].BloomFilterSize) // size 0: a block without a section (nil filters)
+		if i > 0 && blocks[i].RowDataOffset <= blocks[i-1].RowDataOffset {
+			return nil, false, errors.New("bloomgpu: candidate blocks are not in ascending RowDataOffset order")
+		}
 	}
-	if !sort.IntsAreSorted(offsets) {
-		return nil, false, errors.New("bloomgpu: candidate blocks are not in ascending RowDataOffset order")
+	for i, j := 0, 0; i < len(blocks) || j < len(haveOff); { // merge by RowDataOffset; a block both lists name is taken once
+		if j == len(haveOff) || (i < len(blocks) && blocks[i].RowDataOffset <= haveOff[j]) {
+			if j < len(haveOff) && blocks[i].RowDataOffset == haveOff[j] {
+				j++
+			}
+			offsets = append(offsets, blocks[i].RowDataOffset)
+			begin = append(begin, uint64(blocks[i].BloomFilterOffset))
+			end = append(end, uint64(blocks[i].BloomFilterOffset)+uint64(blocks[i].BloomFilterSize)) // size 0: a block without a section (nil filters)
+			i++
+		} else {
+			offsets = append(offsets, haveOff[j])
+			begin = append(begin, haveBegin[j])
+			end = append(end, haveEnd[j])
+			j++
+		}
 	}
 	stream, err := s.ArenaStreamBegin(begin, end)
 	if err != nil {
 		return nil, false, err
 	}
-	order := make([]int, 0, len(blocks)) // sections in file order
-	for i := range blocks {
+	order := make([]int, 0, len(offsets)) // sections in file order
+	for i := range offsets {
 		if end[i] > begin[i] {
 			order = append(order, i)
 		}
@@ -350,22 +419,35 @@ func (e *gpuEngine) arenaFor(s *bloomgpu.Context, file io.ReadSeeker, filePointe
 	if err != nil {
 		return nil, false, err
 	}
-	fa = &gpuFileArena{arena: arena, offsets: offsets, status: status, users: 1}
-	e.arenaMu.Lock()
-	old := e.arenas[key]
-	if old == nil || len(old.offsets) <= len(offsets) {
-		e.arenas[key] = fa // keep the arena that covers more of the file
-		if old != nil {
-			if old.users == 0 {
-				defer e.g.ArenaFree(old.arena)
-			} else {
-				old.dead = true
-			}
+	fa = &gpuFileArena{arena: arena, offsets: offsets, begin: begin, end: end, status: status, users: 1}
+	clean := true
+	for i := range status {
+		fa.bytes += int64(end[i] - begin[i])
+		if status[i] != 0 {
+			clean = false
 		}
-	} else {
-		fa.dead = true // not cached: freed by done()
 	}
-	e.arenaMu.Unlock()
+	e.arenaMu.Lock()
+	defer e.arenaMu.Unlock()
+	// Only a clean decode becomes resident.  A section that failed its CRC or its structural checks may be a transient bad read
+	// (short or garbled bytes without an I/O error): the reference re-reads the sections on every query
+	// (query_exec.go:565-615) and recovers on the next one; a cached status would replay the failure until the file is merged.
+	if !clean || fa.bytes > e.arenaBudget {
+		fa.dead = true // serves this query, freed by done()
+		return fa, false, nil
+	}
+	if old := e.arenas[key]; old != nil {
+		if len(old.offsets) > len(offsets) {
+			fa.dead = true // a concurrent query cached a wider arena meanwhile: keep that one
+			return fa, false, nil
+		}
+		e.dropLocked(key, old)
+	}
+	e.arenaTick++
+	fa.lastUse = e.arenaTick
+	e.arenas[key] = fa
+	e.arenaBytes += fa.bytes
+	e.evictLocked(fa)
 	return fa, false, nil
 }
 

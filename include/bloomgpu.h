@@ -113,6 +113,10 @@ typedef struct bsg_ctx bsg_ctx;
 
 /* ---- lifecycle (engine construct / Stop) ---- */
 BSG_API int32_t bsg_device_count(void);
+/* out_matrix[i * n + j] (n = the context's devices) = 1 when device i reaches device j's memory directly (peer access over xGMI
+ * enabled at bsg_open, or the same device), 0 when copies between the two are staged through host memory by the runtime:
+ * still correct, at PCIe speed, and announced on stderr once per pair (BSG_QUIET=1 silences it). */
+BSG_API int32_t bsg_peer_access(bsg_ctx *ctx, uint8_t *out_matrix, uint32_t n);
 BSG_API int32_t bsg_open(const int32_t *device_ids, int32_t n_devices, bsg_ctx **out_ctx);
 BSG_API int32_t bsg_close(bsg_ctx *ctx);
 /* ---- errors ----

@@ -37,7 +37,7 @@ GO_PREDECLARED = set("bool byte complex64 complex128 error float32 float64 int i
 STD_NAMES = set("""
     Error Errorf Sprintf Printf Println Fprintf New Is As Join Unwrap Lock Unlock RLock RUnlock Add Done Wait Warn Debug Info Since Now Sub
     Duration Nanosecond Microsecond Millisecond Second Seconds Nanoseconds Milliseconds Search SearchInts Slice Ints IntsAreSorted Strings Split TrimSpace
-    Atoi Itoa Getenv Setenv ReadFile WriteFile Open Create Close Read Write Seek ReadFull SeekStart ReadSeeker ReadSeekCloser Reader Writer Mutex RWMutex
+    Atoi Itoa ParseInt Getenv Setenv ReadFile WriteFile Open Create Close Read Write Seek ReadFull SeekStart ReadSeeker ReadSeekCloser Reader Writer Mutex RWMutex
     WaitGroup Pool Get Put Logger Handler DiscardHandler Context Background WithCancel WithTimeout Err TODO Fatal Fatalf Skip Skipf Helper Run Logf Log
     Errorf Name Cleanup TempDir Setenv B N T TB ResetTimer StopTimer StartTimer ReportMetric ReportAllocs Loop Pointer Sizeof Slice SliceData String StringData
     BloomFilter EstimateParameters FromWithM NewWithEstimates AddString TestString Cap K BitSet Bytes Equal WriteTo ReadFrom NumCPU GOMAXPROCS
@@ -361,11 +361,11 @@ def check_patch(reference, problems, notes):
         # every hook the patch calls must exist, with that many arguments, in the real engine file AND in the stub
         real = hook_signatures(os.path.join(ROOT, "go", "overlay", "gpu_engine.go"))
         stub = hook_signatures(os.path.join(ROOT, "go", "overlay", "gpu_engine_stub.go"))
-        internal = {"gpuEngine.scope", "gpuEngine.release", "gpuEngine.done", "gpuEngine.arenaFor"}     # helpers the patch never calls
+        internal = {"gpuEngine.scope", "gpuEngine.release", "gpuEngine.done", "gpuEngine.arenaFor", "gpuEngine.dropLocked", "gpuEngine.evictLocked"}     # helpers the patch never calls
         if set(real) - internal != set(stub):
             problems.append("gpu_engine.go and gpu_engine_stub.go declare different hooks: %s" % sorted((set(real) - internal) ^ set(stub)))
         for name in set(real) & set(stub):
-            if real[name] != stub[name] and name.split(".")[1] not in ("scope", "release", "done", "arenaFor"):
+            if real[name] != stub[name] and name.split(".")[1] not in ("scope", "release", "done", "arenaFor", "dropLocked", "evictLocked"):
                 problems.append("hook %s takes %d parameters in gpu_engine.go and %d in the stub" % (name, real[name], stub[name]))
         added = "\n".join(line[1:] for line in open(patch).read().splitlines() if line.startswith("+") and not line.startswith("+++"))
         added = strip_go(added)
