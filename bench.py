@@ -1110,7 +1110,7 @@ def main():
                   "note": "CRC32C + BE->LE decode of %d filter sections on the device in one launch; bytes = sections read + words written" % B,
                   "pieces": {"launches": 4, "kernel_ms_sum": dec_ms, "end_to_end_s_incl_h2d": t2 - t1,
                              "note": "bsg_arena_load_sections as it runs by default: the decode of each quarter starts behind its part of the copy "
-                                     "(a launch of ~250 one-workgroup sections does not fill 256 CUs, hence the larger sum)"},
+                                     "(round 4: a section is cut into 16 KB slices, one workgroup each, so a quarter's ~250 sections are ~1 100 workgroups)"},
                   "end_to_end_s_incl_h2d": t2 - t1,
                   "stream": {"api": "bsg_arena_stream_begin / append (4 MiB chunks) / finish", "chunks": (len(blob_secs) + (4 << 20) - 1) // (4 << 20),
                              "end_to_end_s_incl_h2d": t4 - t3, "decode_kernels_ms_sum": stream_dec_ms,

@@ -1154,6 +1154,7 @@ const bsg::CrcConsts &crc_consts()
         t.skip = bsg::crc_x2nmodp((uint64_t)bsg::kCrcGranule * (bsg::kDecodeThreads - 1), 3, t.x2n);
         for (uint32_t i = 0; i < 256; ++i) t.gpow[i] = bsg::crc_x2nmodp((uint64_t)bsg::kCrcGranule * i, 3, t.x2n);
         for (uint32_t i = 0; i < bsg::kCrcGranule; ++i) t.bpow[i] = bsg::crc_x2nmodp(i, 3, t.x2n);
+        for (uint32_t i = 0; i < 64; ++i) t.upow[i] = bsg::crc_x2nmodp((uint64_t)BSG_DECODE_UNIT * i, 3, t.x2n);
         return t;
     }();
     return c;

@@ -1318,6 +1318,7 @@ struct CrcConsts {
     uint32_t pad[3];
     uint32_t gpow[256];       // x^(8 * kCrcGranule * t) mod P: thread t's last granule ends t granules before the tail
     uint32_t bpow[64];        // x^(8 * i) mod P: the tail's length (< kCrcGranule)
+    uint32_t upow[64];        // x^(8 * BSG_DECODE_UNIT * j) mod P: slice j's distance to the payload's end when the section takes the default unit
 };
 constexpr uint32_t kCrcGranule = 64;   // bytes one lane checksums per trip: a wave covers 4 KiB of contiguous payload
                                        // (measured per 1 000 block sections, decode: 64 -> 70.8 us, 128 -> 90.5 us, 256 -> 116.9 us)
@@ -1406,8 +1407,15 @@ struct SectionSlot {
     uint32_t len;            // section bytes incl. the 4-byte CRC trailer (0 => block without a section)
     uint32_t slot_cap_words; // words the slot holds (section bytes + room for the per-filter alignment)
     uint32_t block;          // local block index: where desc / status of this section live
-    uint32_t pad;
+    uint32_t init_image;     // 0xFFFFFFFF shifted over the payload, xor the final 0xFFFFFFFF (crc_init_image(len - 4)): a function of the
+                             // length alone, computed by the host — on the device it was ~17 serial 32-step multiplies per workgroup
 };
+
+// what the 0xFFFFFFFF initial value and the final xor contribute to the CRC-32C of a payload of P bytes
+__host__ __device__ inline uint32_t crc_init_image(uint64_t P, const uint32_t *x2n)
+{
+    return crc_multmodp(crc_x2nmodp(P, 3, x2n), 0xFFFFFFFFu) ^ 0xFFFFFFFFu;
+}
 
 constexpr uint32_t kMaxHashCountDev = 1024;   // same bound as the host side (kMaxHashCount)
 
@@ -1444,63 +1452,125 @@ __device__ inline int32_t parse_section_header(const uint8_t *sec, uint32_t plen
     return pos == plen ? 0 : -6;
 }
 
-// grid.x = sections [first, first + gridDim.x) of the slot table.  CRC32C of the payload (crc32c_payload), then — in one
-// thread — the header chain, then every present filter's big-endian words byte-swapped into the section's slot and its
-// DevDesc (word offset, m, k, Barrett magic) written.  A CRC mismatch (-2 = ErrInvalidHash) or a structural error marks
-// the block and leaves its filters nil (m = 0): a corrupt section cannot poison the batch (query_exec.go:580-590).
+// Several workgroups per section (round 4).  One workgroup per section left a 1 000-section launch at 4 workgroups per CU, each
+// walking ~70 KB behind one chain of dependent loads: 76 us = 0.23 of the HBM roofline, and a run of ~55 sections (one 4 MiB
+// chunk of the region cursor) did not fill a quarter of the chip.  CRC-32C is linear over GF(2), so a section's payload is cut
+// into SLICES counted from its END — slice j = bytes [P - (j + 1) U, P - j U), U = decode_unit(P) — one workgroup each:
+//   * the slice's checksum (crc32c_payload, zero initial value) times x^(8 U j) is its contribution to the payload's checksum;
+//     slice 0 also carries the 0xFFFFFFFF initial value shifted over the payload and the final xor;
+//   * every workgroup walks the header chain itself (flags, lengths, m, k: <= 3 dependent reads, bounds-checked against the
+//     payload because nothing is trusted before the checksum) and byte-swaps the words that START inside its slice into
+//     the section's slot — before the checksum is known: a block whose checksum fails keeps nil descriptors (m = 0), so
+//     its words are never looked at;
+//   * contributions are published with write-through stores, an arrival counter tells the last workgroup of the section,
+//     which XORs them, compares with the stored checksum and writes status + descriptors.
+// grid = (most slices of any section of the run, sections [first, first + gridDim.y)).
+constexpr uint32_t kDecodeMaxSplits = 64;
+#ifndef BSG_DECODE_UNIT
+#define BSG_DECODE_UNIT 16384
+#endif
+__host__ __device__ inline uint32_t decode_unit(uint32_t P)
+{
+    const uint32_t u = (uint32_t)((((uint64_t)P + kDecodeMaxSplits - 1) / kDecodeMaxSplits + 63) / 64 * 64);
+    return u > (uint32_t)BSG_DECODE_UNIT ? u : (uint32_t)BSG_DECODE_UNIT;
+}
+__host__ __device__ inline uint32_t decode_splits(uint32_t len)      // workgroups a section of `len` bytes (CRC trailer incl.) takes
+{
+    if (len < 5) return 1;
+    const uint32_t P = len - 4, U = decode_unit(P);
+    return P == 0 ? 1u : (P + U - 1) / U;
+}
+
+struct DecodeScratch {
+    uint32_t *part;     // [slot][kDecodeMaxSplits] contributions to the section's checksum
+    uint32_t *done;     // [slot] arrivals (0 before the section's launch)
+};
+
 __global__ __launch_bounds__(kDecodeThreads) void k_decode_sections(const uint8_t *region, const SectionSlot *slots, uint32_t first,
                                                                    const CrcConsts *consts, uint64_t *arena, DevDesc *desc,
-                                                                   int32_t *status)
+                                                                   int32_t *status, const DecodeScratch scratch)
 {
     __shared__ uint32_t tab[8][256];
     __shared__ uint32_t part[kDecodeThreads];
     __shared__ int32_t st;
-    __shared__ uint32_t s_present, s_woff[3], s_nw[3];
-    __shared__ uint64_t s_dst[3];
+    __shared__ uint32_t s_present, s_woff[3], s_nw[3], s_k[3], s_last;
+    __shared__ uint64_t s_dst[3], s_m[3];
     const uint32_t tid = threadIdx.x;
-    const SectionSlot sl = slots[first + blockIdx.x];
+    const uint32_t slot = first + blockIdx.y, j = blockIdx.x;
+    const SectionSlot sl = slots[slot];
     const uint32_t b = sl.block;
     if (sl.len == 0) return;                                       // block without a section: filters stay nil, status 0
-    if (sl.len < 5) { if (tid == 0) status[b] = -1; return; }      // parseFilterSection: too small
+    if (sl.len < 5) { if (tid == 0 && j == 0) status[b] = -1; return; }      // parseFilterSection: too small
+    const uint32_t P = sl.len - 4, U = decode_unit(P), n_split = P == 0 ? 1u : (P + U - 1) / U;
+    if (j >= n_split) return;
     for (uint32_t i = tid; i < 8 * 256; i += kDecodeThreads) (&tab[0][0])[i] = (&consts->table[0][0])[i];
-    __syncthreads();
     const uint8_t *sec = region + sl.begin;
-    const uint32_t P = sl.len - 4;
-    const uint32_t raw = crc32c_payload(sec, P, tab, consts, part, tid);
-    if (tid == 0) {
-        // fold in the 0xFFFFFFFF initial value (shifted over the whole payload) and the final xor
-        const uint32_t total = raw ^ crc_multmodp(crc_x2nmodp(P, 3, consts->x2n), 0xFFFFFFFFu) ^ 0xFFFFFFFFu;
-        int32_t r = total != rd_le32_dev(sec + P) ? -2 : 0;
+    const uint32_t hi = P - j * U, lo = hi > U ? hi - U : 0u;       // this workgroup's slice [lo, hi) of the payload
+    if (tid == kDecodeThreads - 1) {
+        // the header chain (untrusted until the checksum is known: every step is checked against the payload's length).  Every
+        // workgroup of the section walks it itself, while its other waves are already at their granules — a launch of its own
+        // for the headers (one thread per section, a parsed-header table) was measured and dropped: 68 -> 73 us in one launch,
+        // 107 -> 134 us as four launches behind the copy.
         uint64_t m[3];
         uint32_t k[3];
-        if (r == 0) r = parse_section_header(sec, P, s_present, s_woff, s_nw, m, k);
+        int32_t r = parse_section_header(sec, P, s_present, s_woff, s_nw, m, k);
         if (r == 0) {
             uint64_t cursor = sl.slot_words;
             for (uint32_t c = 0; c < 3; ++c) {
+                s_m[c] = m[c]; s_k[c] = k[c];
                 if (!((s_present >> c) & 1u)) continue;
                 s_dst[c] = cursor;
                 cursor += ((uint64_t)s_nw[c] + 15) / 16 * 16;
             }
             if (cursor - sl.slot_words > sl.slot_cap_words) r = -5;   // cannot happen for a slot sized from the section length
         }
-        if (r == 0) {
-            for (uint32_t c = 0; c < 3; ++c) {
-                if (!((s_present >> c) & 1u)) continue;
-                uint64_t magic = m[c] <= 1 ? ~0ULL : ~0ULL / m[c];
-                if (m[c] > 1 && (m[c] & (m[c] - 1)) == 0) magic += 1;
-                desc[(uint64_t)b * 3 + c] = DevDesc{s_dst[c], m[c], magic, k[c], 0};
-            }
-        }
-        status[b] = r;
         st = r;
     }
+    if (tid == kDecodeThreads - 2) {
+        // this slice's distance to the payload's end: a table entry for sections of the default unit (the usual case), a
+        // square-and-multiply chain for the few sections large enough to take a wider one
+        s_last = j == 0 ? (1u << 31) : U == (uint32_t)BSG_DECODE_UNIT ? consts->upow[j] : crc_x2nmodp((uint64_t)U * j, 3, consts->x2n);
+    }
     __syncthreads();
-    if (st != 0) return;
-    for (uint32_t c = 0; c < 3; ++c) {
-        if (!((s_present >> c) & 1u)) continue;
-        const uint8_t *src = sec + s_woff[c];
-        uint64_t *dst = arena + s_dst[c];
-        for (uint32_t w = tid; w < s_nw[c]; w += kDecodeThreads) dst[w] = __builtin_bswap64(load_u64_unaligned(src + 8ull * w));
+    uint32_t raw = crc32c_payload(sec + lo, hi - lo, tab, consts, part, tid);      // valid in thread 0; ends with a barrier
+    // the words that start inside [lo, hi), byte-swapped into the slot (speculative: see above)
+    if (st == 0) {
+        for (uint32_t c = 0; c < 3; ++c) {
+            if (!((s_present >> c) & 1u)) continue;
+            const uint32_t w0 = s_woff[c];
+            const uint32_t a = lo > w0 ? (lo - w0 + 7) / 8 : 0u;
+            const uint32_t e = hi > w0 ? min(s_nw[c], (hi - w0 + 7) / 8) : 0u;
+            const uint8_t *src = sec + w0;
+            uint64_t *dst = arena + s_dst[c];
+            for (uint32_t w = a + tid; w < e; w += kDecodeThreads) dst[w] = __builtin_bswap64(load_u64_unaligned(src + 8ull * w));
+        }
+    }
+    if (tid == 0) {
+        uint32_t contrib = j ? crc_multmodp(s_last, raw) : raw ^ sl.init_image;     // slice 0 carries the initial value's image and the final xor
+        uint32_t *mine = scratch.part + (uint64_t)slot * kDecodeMaxSplits;
+        uint32_t arrived = n_split;
+        if (n_split > 1) {
+            __hip_atomic_store(mine + j, contrib, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // write-through
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            arrived = __hip_atomic_fetch_add(scratch.done + slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+        }
+        if (arrived == n_split) {                                   // the section's last workgroup: every contribution is published
+            uint32_t total = contrib;
+            if (n_split > 1) {
+                total = 0;
+                for (uint32_t i = 0; i < n_split; ++i) total ^= __hip_atomic_load(mine + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            int32_t r = total != rd_le32_dev(sec + P) ? -2 : st;
+            if (r == 0) {
+                for (uint32_t c = 0; c < 3; ++c) {
+                    if (!((s_present >> c) & 1u)) continue;
+                    uint64_t magic = s_m[c] <= 1 ? ~0ULL : ~0ULL / s_m[c];
+                    if (s_m[c] > 1 && (s_m[c] & (s_m[c] - 1)) == 0) magic += 1;
+                    desc[(uint64_t)b * 3 + c] = DevDesc{s_dst[c], s_m[c], magic, s_k[c], 0};
+                }
+            }
+            status[b] = r;
+        }
     }
 }
 
@@ -1519,6 +1589,8 @@ struct EncodeInfo {
     uint64_t m[3];
     uint32_t k[3];
     uint32_t nw[3];
+    uint32_t init_image;     // crc_init_image(len - 4): the initial value's and the final xor's share of the checksum (host)
+    uint32_t pad;
 };
 
 __device__ __forceinline__ void store_u64_unaligned(uint8_t *p, uint64_t v) { __builtin_memcpy(p, &v, 8); }
@@ -1560,8 +1632,7 @@ __global__ __launch_bounds__(kDecodeThreads) void k_crc_sections(uint8_t *region
     const uint32_t P = e.len - 4;
     const uint32_t raw = crc32c_payload(sec, P, tab, consts, part, tid);
     if (tid == 0) {
-        const uint32_t total = raw ^ crc_multmodp(crc_x2nmodp(P, 3, consts->x2n), 0xFFFFFFFFu) ^ 0xFFFFFFFFu;
-        store_u32_unaligned(sec + P, total);
+        store_u32_unaligned(sec + P, raw ^ e.init_image);
     }
 }
 
