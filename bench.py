@@ -773,6 +773,87 @@ def q1_latency(ctx, arena, B, n_terms_hash, log):
             "survivors": int(sum(bin(int(x)).count("1") for x in first.ravel())), **res}
 
 
+def big_filter_leg(ctx, args, log):
+    """Block filters BEYOND the LDS budget (VERDICT r03 missing 4): the reference's defaults (10 000 rows / 10 MiB per block,
+    engine.go:127-128) give ~1 MB token filters once a row holds ~60 distinct tokens — 8.3 Mbit, seven times what a workgroup can
+    stage (144 KiB).  Such a filter is never streamed into LDS: every (term, location) is a sector read from L2 / HBM, with the
+    many-term mode's early termination (~3.3 of k = 10 locations per absent term).  64 blocks x 580 000 distinct 8-byte tokens
+    (fill ~50 % as a right-sized filter has), a 29-term and a 4 054-term batch of single-Token queries; the kernel time is set
+    against BOTH regimes' algorithmic bytes: every bitset once (what a windowed stream would move) and k x 8 B per
+    (block, term) probe (what the gathers need)."""
+    from bloomsearch_amd import _lib
+    from bloomsearch_amd._lib import DESC_DTYPE
+    from bloomsearch_amd.gpu import estimate_parameters
+    from oracle import oracle as O
+    n_blocks, per_block = 64, 580_000
+    rng = np.random.default_rng(20260927)
+    m, k = estimate_parameters(per_block, args.fpr)
+    nw = (m + 63) // 64
+    stride = (nw + 15) // 16 * 16
+    t0 = time.time()
+    toks = rng.integers(1, 1 << 62, size=n_blocks * per_block, dtype=np.uint64)          # 8 raw bytes per token (distinct with overwhelming odds)
+    blob = toks.view(np.uint8)
+    off = (np.arange(n_blocks * per_block + 1, dtype=np.uint64) * 8).astype(np.uint32)
+    desc = np.zeros(n_blocks * 3, dtype=DESC_DTYPE)
+    fstart = [0]
+    for b in range(n_blocks):
+        fstart.append(b * per_block)                    # field: absent
+        desc[b * 3 + 1] = (b * stride, m, k, 0)
+        fstart += [(b + 1) * per_block, (b + 1) * per_block]
+    words = ctx.build(blob, off, np.asarray(fstart, dtype=np.uint32), desc, n_blocks * stride)
+    R = 4
+    arenas = [ctx.arena_load(words, desc) for _ in range(R)]
+    t_setup = time.time() - t0
+    res = {"workload": "%d blocks x %d distinct tokens -> token filters of m = %d bits (%.2f MB, k = %d): %.1fx the LDS staging budget"
+                       % (n_blocks, per_block, m, nw * 8 / 1e6, k, nw * 8 / (144 * 1024)),
+           "bitset_bytes_per_arena": int(n_blocks * nw * 8)}
+    for name, n_terms in (("few_terms", 29), ("many_terms", 4054)):
+        n_present = max(1, n_terms // 10)
+        present = toks[rng.integers(0, len(toks), size=n_present)]
+        absent = rng.integers(1 << 62, 1 << 63, size=n_terms - n_present, dtype=np.uint64)
+        tv = np.concatenate([present, absent])
+        terms = np.zeros(n_terms, dtype=_lib.TERM_DTYPE)
+        terms["h"] = ctx.hash_entries(tv.view(np.uint8), (np.arange(n_terms + 1, dtype=np.uint64) * 8).astype(np.uint32))
+        terms["kind"] = 1
+        ops = np.asarray([_lib.op(_lib.OP_TERM, i) for i in range(n_terms)], dtype=np.uint32)
+        poff = np.arange(n_terms + 1, dtype=np.uint32)
+        bid = ctx.batch_create(terms, ops, poff)
+        got = ctx.probe_batch(arenas[0], bid, n_terms, n_blocks)
+        if not args.no_check:
+            want = O.probe_batch(words, desc.view(O.DESC_DTYPE), terms.view(O.TERM_DTYPE), ops, poff)
+            if not np.array_equal(got, want):
+                sys.exit("big filters (%s): survivors differ from the oracle" % name)
+        ids = np.ascontiguousarray([arenas[i % R] for i in range(8)], dtype=np.uint64)
+        for _ in range(3):
+            ctx.probe_many(ids, bid, _lib.PROBE_ASYNC | _lib.PROBE_NOFUSE)
+        ctx.sync()
+        ctx.timing_read(reset=True)
+        n = 10
+        for _ in range(n):
+            ctx.probe_many(ids, bid, _lib.PROBE_ASYNC | _lib.PROBE_NOFUSE | _lib.PROBE_TIMED)
+        ctx.sync()
+        tm = ctx.timing_read()
+        ms = tm.ms_terms_kernel / max(tm.n_probes, 1)
+        stream_bytes = len(ids) * n_blocks * nw * 8
+        gather_bytes = len(ids) * n_blocks * n_terms * k * 8
+        survive = sum(bin(int(x)).count("1") for x in got.ravel()) / (n_terms * n_blocks)
+        res[name] = {"terms": n_terms, "arenas_per_launch": len(ids), "kernel": "k_probe_terms_many" if n_terms > 128 else "k_probe_terms",
+                     "kernel_ms": ms, "pairs_surviving": survive,
+                     "stream_regime": {"algorithmic_bytes": stream_bytes, "achieved": stream_bytes / ms / 1e6, "frac": stream_bytes / ms / 1e6 / HBM_PEAK_GBPS},
+                     "gather_regime": {"algorithmic_bytes": gather_bytes, "achieved": gather_bytes / ms / 1e6, "frac": gather_bytes / ms / 1e6 / HBM_PEAK_GBPS,
+                                       "note": "k x 8 B per (block, term); 8-byte words out of 64-byte sectors: 12.5% of peak is this regime's ceiling"},
+                     "probes_per_s": len(ids) * n_blocks * n_terms / (ms * 1e-3)}
+        ctx.batch_free(bid)
+        log("big filters, %d terms: %.1f us per %d arenas of %d x %.2f MB = %.0f GB/s of bitsets (%.3f of peak if they were streamed), %.3g probes/s"
+            % (n_terms, ms * 1e3, len(ids), n_blocks, nw * 8 / 1e6, res[name]["stream_regime"]["achieved"], res[name]["stream_regime"]["frac"],
+               res[name]["probes_per_s"]))
+    for a in arenas:
+        ctx.arena_free(a)
+    res["setup_s"] = t_setup
+    res["check"] = "survivors of both batches bit-exact vs the oracle"
+    return res
+
+
 def c4_leg(ctx, args, rank, world, workers, log, headline=False):
     """BASELINE configs[3] / SURVEY C4: 100 M rows / 10 000 blocks as 10 files of 1 000 blocks, block b on rank b % N
     (strong scaling: the total is fixed), Q = 4096 8-term Or(FieldToken) queries.  One step probes the whole set once;
@@ -834,9 +915,13 @@ def c4_leg(ctx, args, rank, world, workers, log, headline=False):
     # as the line's headline (N > 1) the leg times EXACTLY --steps steps after --warmup untimed ones, like the contract says;
     # as a side leg (N = 1) it is bounded
     steps = max(1, args.steps) if headline else max(4, min(args.steps, 60))
-    per_call = max(1, 64 // max(n_files, 1))           # steps handed to one bsg_probe_many call (<= 64 arenas per dispatch)
+    per_call = max(1, args.group // max(n_files, 1))   # steps handed to one bsg_probe_many call (<= --group arenas per dispatch)
     make = lambda i: reps[i % R]
     c4_warm = max(0, args.warmup) if headline else max(2, min(args.warmup, 8))
+    # untimed setup: one call of the timed region's shape sizes the library's verdict / survivor scratch (the warmup steps may be
+    # fewer than one call covers, and a first call that grows the scratch calls hipMalloc inside the region: +8 us per step, measured)
+    pr.run(pr.plan([make(i) for i in range(min(per_call, steps))], per_call), 0)
+    ctx.sync()
     if args.events_in_headline:
         dt, tm = pr.measure(make, steps, c4_warm, per_call)
         dt_ev = dt
@@ -981,7 +1066,7 @@ def main():
                          "10 M rows (2.5 GB of JSON); 0 = skip")
     ap.add_argument("--scaled", type=int, default=64,
                     help="also time C2': the arena replicated this many times inside one launch (0/1 = skip)")
-    ap.add_argument("--group", type=int, default=64, help="arenas one probe dispatch may cover (bsg_set_probe_group, <= 64)")
+    ap.add_argument("--group", type=int, default=128, help="arenas one probe dispatch may cover (bsg_set_probe_group, <= 128)")
     ap.add_argument("--samples", type=int, default=16, help="timestamped dispatches of each kernel beyond the timed region")
     ap.add_argument("--c4-files", type=int, default=10, help="files of the c4 leg (0 = skip the leg)")
     ap.add_argument("--c4-blocks-per-file", type=int, default=1000)
@@ -990,7 +1075,9 @@ def main():
     ap.add_argument("--events-in-headline", action="store_true",
                     help="carry the per-dispatch HIP timestamps inside the headline region too (they cost ~17 us per 2-dispatch call: the default "
                          "times the K steps bare, then repeats them with the timestamps on and reports both)")
+    ap.add_argument("--fold", type=int, default=-1, help="lab: evaluators per tile of k_probe_eval (bsg_set_lab key 11; 0 = two dispatches, the default)")
     ap.add_argument("--no-q1", action="store_true", help="skip the Q = 1 latency leg")
+    ap.add_argument("--no-big-filters", action="store_true", help="skip the leg with block filters beyond the LDS budget (~1 MB each)")
     ap.add_argument("--no-single", action="store_true", help="skip the one-arena-per-launch sampling pass")
     args = ap.parse_args()
     self_launch(args)
@@ -1037,6 +1124,8 @@ def main():
         ctx.set_lab(1, args.compact_rounds)
     if args.fuse_limit >= 0:
         ctx.set_fuse_limit(args.fuse_limit)
+    if args.fold >= 0:
+        ctx.set_lab(11, args.fold)
     B, rows, NQ = args.blocks, args.rows_per_block, args.queries
 
     # ---- untimed setup: this rank's shard = global blocks rank, rank + world, ... (round-robin) ----
@@ -1174,7 +1263,7 @@ def main():
     # (BSG_PROBE_TIMED: the dispatch's own begin/end, i.e. what a rocprofv3 kernel trace reports for it).
     pr = Prober(ctx, bid, world, log)
     G0 = max(1, min(args.steps, args.group))          # arenas per dispatch in the timed region
-    per_call = max(G0, (64 // G0) * G0)
+    per_call = max(G0, (args.group // G0) * G0)
     make = lambda i: [arenas[i % R]]
     # untimed setup: one call of the timed region's shape sizes the library's verdict / survivor scratch (the warmup steps
     # may be fewer than one dispatch covers)
@@ -1268,6 +1357,10 @@ def main():
     for a in arenas:
         ctx.arena_free(a)
     arenas = []
+
+    big = None
+    if rank == 0 and world == 1 and not args.no_big_filters:
+        big = big_filter_leg(ctx, args, log)
 
     c4 = None
     if args.c4_files > 0:
@@ -1365,6 +1458,8 @@ def main():
                                                  note="one 1 000-block arena (35 MB) per dispatch: ~half of such a launch is dispatch ramp + completion")
         if q1:
             out["q1"] = q1
+        if big:
+            out["big_filters"] = big
         if c4:
             out["c4"] = c4
         out["build"] = {"workload": "C3 flush-side build: %d blocks x %d rows -> %d filters, %d distinct entries"

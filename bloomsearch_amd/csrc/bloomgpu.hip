@@ -1437,15 +1437,14 @@ struct Group {
     uint32_t max_blocks = 0, max_G = 0, total_G = 0;
 };
 
-void fill_refs(const Group &g, const Batch &B, bsg::ArenaRef *refs)
+// the group's arena records from position i0 on (at most `cap` of them); g_prefix counts from the group's first arena
+void fill_refs(const Group &g, const Batch &, bsg::ArenaRef *refs, size_t i0 = 0, size_t cap = ~size_t(0))
 {
-    uint64_t v = 0, o = 0;
-    for (size_t i = 0; i < g.shards.size(); ++i) {
+    uint32_t gp = 0;
+    for (size_t i = 0; i < g.shards.size() && i < i0 + cap; ++i) {
         const ArenaShard &s = *g.shards[i];
-        const uint32_t G = (s.n_blocks + 63) / 64;
-        refs[i] = bsg::ArenaRef{s.d_words, s.d_desc, v, o, s.n_blocks, G};
-        v += (uint64_t)G * std::max(B.Wt, 1u) * 64;
-        o += (uint64_t)B.n_queries * G;
+        if (i >= i0) refs[i - i0] = bsg::ArenaRef{s.d_words, s.d_desc, s.n_blocks, gp};
+        gp += (s.n_blocks + 63) / 64;
     }
 }
 
@@ -1569,9 +1568,9 @@ int32_t enqueue_eval(Device &d, const Group &g, const BatchDev &bd, const Batch 
     // batches with the identity word list transpose a whole tile's words at once (eval_role_all) when that fits 64 KB of LDS
     static const bool lab_serial = getenv("BSG_LAB_EVAL_SERIAL") != nullptr;   // lab only: the per-group walk for every batch
     uint32_t lds = bsg::eval_lds_bytes(B.max_cw, B.max_depth);
-    if (B.identity_cw && !lab_serial && bsg::eval_lds_bytes(B.max_cw * bsg::kEvalGroupTile, B.max_depth) <= 64 * 1024) {
+    if (B.identity_cw && !lab_serial && bsg::eval_lds_bytes(B.max_cw * bsg::kEvalGroupTile, B.max_depth * bsg::kEvalGroupTile) <= 64 * 1024) {
         a.identity_cw |= 2u;
-        lds = bsg::eval_lds_bytes(B.max_cw * bsg::kEvalGroupTile, B.max_depth);
+        lds = bsg::eval_lds_bytes(B.max_cw * bsg::kEvalGroupTile, B.max_depth * bsg::kEvalGroupTile);
     }
     const uint32_t nx = (g.max_G + tile - 1) / tile;
     const uint64_t n_wg = (uint64_t)(B.n_chunks * (uint64_t)a.n_arenas + 7) / 8 * 8 * nx;
@@ -1883,12 +1882,15 @@ int32_t probe_arenas(bsg_ctx *ctx, const std::vector<std::shared_ptr<Arena>> &ar
                 // behind the evaluation and ahead of the next use of out[slot])
                 const Group &g = groups[gi];
                 bsg::RowsArgs ra{d.out[slot].p, d_rows, d_hdr, B.n_queries};
-                bsg::ArenaTable<bsg::kMaxGroupArenas> t;
-                bsg::RowsTable<bsg::kMaxGroupArenas> dst;
-                fill_refs(g, B, t.ar);
-                for (size_t i = 0; i < g.shards.size(); ++i) dst.d[i] = bsg::RowsDst{out_off[g.index[i]], (uint64_t)g.index[i] * B.n_queries};
-                hipLaunchKernelGGL(bsg::k_survivor_rows, dim3((B.n_queries + 255) / 256, (uint32_t)g.shards.size()), dim3(256), 0, d.stream, ra, t, dst);
-                HIP_TRY(hipGetLastError());
+                for (size_t i0 = 0; i0 < g.shards.size(); i0 += bsg::kMaxRowsArenas) {      // (two tables ride in the kernel arguments: runs of 64 arenas)
+                    const size_t n = std::min<size_t>(bsg::kMaxRowsArenas, g.shards.size() - i0);
+                    bsg::ArenaTable<bsg::kMaxRowsArenas> t;
+                    bsg::RowsTable<bsg::kMaxRowsArenas> dst;
+                    fill_refs(g, B, t.ar, i0, n);
+                    for (size_t i = 0; i < n; ++i) dst.d[i] = bsg::RowsDst{out_off[g.index[i0 + i]], (uint64_t)g.index[i0 + i] * B.n_queries};
+                    hipLaunchKernelGGL(bsg::k_survivor_rows, dim3((B.n_queries + 255) / 256, (uint32_t)n), dim3(256), 0, d.stream, ra, t, dst);
+                    HIP_TRY(hipGetLastError());
+                }
                 return BSG_OK;
             }
             if (!want_copy) return BSG_OK;

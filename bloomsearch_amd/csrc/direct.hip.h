@@ -40,7 +40,7 @@ __device__ __forceinline__ void direct_body(const DirectArgs &a, const uint64_t 
 {
     const uint32_t g = blockIdx.x;
     const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
-    if (g < ar.G) {                                              // (arenas of a group may differ in size)
+    if (g < ar.G()) {                                              // (arenas of a group may differ in size)
     constexpr uint32_t n_waves = kEvalThreads / kWave;
     uint64_t *VT = lds64;                                        // VT[position]: 64-block mask of one term
     uint64_t *stk = lds64 + (uint64_t)a.Wt * 64 + tid;           // per-lane stack, stride kEvalThreads
@@ -119,7 +119,7 @@ __device__ __forceinline__ void direct_body(const DirectArgs &a, const uint64_t 
     }
     const uint32_t nvalid = ar.n_blocks - g * 64;
     if (tid < a.n_queries)
-        a.out[ar.out_off + (uint64_t)tid * ar.G + g] = top & (nvalid >= 64 ? ~0ULL : ((1ULL << nvalid) - 1));
+        a.out[ar.out_off(a.n_queries) + (uint64_t)tid * ar.G() + g] = top & (nvalid >= 64 ? ~0ULL : ((1ULL << nvalid) - 1));
     }
     if (a.flag) {
         __threadfence_system();                                  // this workgroup's survivor words reach the host before the count moves

@@ -250,17 +250,25 @@ __device__ __forceinline__ uint64_t wave_transpose64(uint64_t x, int lane)
 // One launch probes a GROUP of arenas (the candidate files of one query stage, bsg_probe_many): the per-arena
 // pointers ride in the kernel arguments, so a group costs one dispatch ramp instead of one per arena — at 35 MB
 // per arena the ~3-4 us ramp + completion of a dispatch is as long as the streaming itself.
-constexpr uint32_t kMaxGroupArenas = 64;      // 64 x 40 B of per-arena records + the scalar arguments stay inside the 4 KB of kernel arguments
+// 128 x 24 B of per-arena records + the scalar arguments stay inside the 4 KB of kernel arguments (round 4: the records were 40 B
+// and a dispatch held 64 arenas; where the arenas are small — a file's shard on one of 8 GPUs is 125 blocks — twice as many
+// per dispatch halve the dispatch ramps and boundaries per step).
+constexpr uint32_t kMaxGroupArenas = 128;
 constexpr uint32_t kMaxFusedArenas = 8;       // k_probe_fused carries TWO tables (the group it streams, the group it evaluates)
+constexpr uint32_t kMaxRowsArenas = 64;       // k_survivor_rows carries a destination table as well: it takes a group in runs of 64
 
+// An arena of a dispatch group.  Where its verdict words and its survivors lie in the group's scratch follows from ONE number,
+// the 64-block groups of the arenas in front of it: v_off = g_prefix x max(Wt, 1) x 64 words, out_off = g_prefix x n_queries words.
 struct ArenaRef {
     const uint64_t *words;
     const DevDesc *desc;          // [n_blocks * 3]
-    uint64_t v_off;               // u64 offset of this arena's verdict words inside V
-    uint64_t out_off;             // u64 offset of this arena's survivors inside out ([n_queries][G])
     uint32_t n_blocks;
-    uint32_t G;                   // ceil(n_blocks / 64)
+    uint32_t g_prefix;            // 64-block groups of the group's arenas before this one
+    __host__ __device__ uint32_t G() const { return (n_blocks + 63u) >> 6; }
+    __host__ __device__ uint64_t v_off(uint32_t Wt) const { return (uint64_t)g_prefix * (Wt ? Wt : 1u) * 64u; }
+    __host__ __device__ uint64_t out_off(uint32_t n_queries) const { return (uint64_t)g_prefix * n_queries; }
 };
+static_assert(sizeof(ArenaRef) == 24, "ArenaRef must stay 24 bytes: 128 of them ride in the kernel arguments");
 
 // the per-arena records of a dispatch group: a kernel argument of its own, next to the scalars
 template <uint32_t N>
@@ -656,7 +664,7 @@ __device__ __forceinline__ void probe_role(const ProbeArgs &a, const ArenaRef &a
     const uint32_t n_real = a.term_count[y];
     const uint32_t n_tw = (n_real + 63) >> 6;
     // (k_probe_eval's verdict entries are 16 bytes: word + tag)
-    uint64_t *vout = a.V + (ar.v_off + ((uint64_t)(b >> 6) * a.Wt + (t0 >> 6)) * 64 + (b & 63)) * (VSC1 ? 2 : 1);
+    uint64_t *vout = a.V + (ar.v_off(a.Wt) + ((uint64_t)(b >> 6) * a.Wt + (t0 >> 6)) * 64 + (b & 63)) * (VSC1 ? 2 : 1);
 
     if (d.m == 0) {  // nil filter: cannot disqualify (query_exec.go:137-151)
         for (uint32_t w = tid; w < n_tw; w += kProbeThreads) store_verdict<VSC1>(vout, w, ~0ULL, a.seq);
@@ -761,7 +769,7 @@ constexpr uint32_t kEvalGroupTile = BSG_EVAL_GROUP_TILE;   // block groups one e
 __device__ __forceinline__ void eval_role(const EvalArgs &a, const ArenaRef &ar, uint32_t g0, uint32_t gt, uint32_t c, uint32_t htid,
                                           uint64_t *lds, bool active)
 {
-    const uint64_t *V = a.V + ar.v_off;
+    const uint64_t *V = a.V + ar.v_off(a.Wt);
     const int lane = htid & (kWave - 1);
     const uint32_t wave = htid / kWave;
     constexpr uint32_t n_waves = kEvalThreads / kWave;
@@ -833,7 +841,7 @@ __device__ __forceinline__ void eval_role(const EvalArgs &a, const ArenaRef &ar,
         }
     }
     if (active && q < a.n_queries) {
-        uint64_t *dst = a.out + ar.out_off + (uint64_t)q * ar.G + g0;
+        uint64_t *dst = a.out + ar.out_off(a.n_queries) + (uint64_t)q * ar.G() + g0;
 #pragma unroll
         for (uint32_t t = 0; t < kEvalGroupTile; ++t) if (t < gt) dst[t] = res[t];
     }
@@ -843,16 +851,16 @@ __device__ __forceinline__ void eval_role(const EvalArgs &a, const ArenaRef &ar,
 // interactive batches): the words of ALL gt groups are requested at once, transposed by the waves in parallel and parked in
 // LDS behind ONE barrier, then the programs of the gt groups run back to back.  eval_role pays a dependent global round trip,
 // two barriers and a serial transpose per group (round 4: 15.5 -> see profiles/r04 per 20 arenas of C2).
-// LDS: gt x max_cw transposed words + the per-lane stacks (eval_lds_bytes(max_cw * tile, depth)).
+// LDS: gt x max_cw transposed words + the per-lane stacks of tile-mask entries (eval_lds_bytes(max_cw * tile, depth * tile)).
 __device__ __forceinline__ void eval_role_all(const EvalArgs &a, const ArenaRef &ar, uint32_t g0, uint32_t gt, uint32_t c, uint32_t tid, uint64_t *lds)
 {
-    const uint64_t *V = a.V + ar.v_off;
+    const uint64_t *V = a.V + ar.v_off(a.Wt);
     const uint32_t lane = tid & (kWave - 1);
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid / kWave);
     constexpr uint32_t n_waves = kEvalThreads / kWave;
     const uint32_t ncw = a.max_cw;
     uint64_t *VT = lds;                                                          // VT[(t * ncw + s) * 64 + bit]
-    uint64_t *stk = lds + (uint64_t)kEvalGroupTile * ncw * 64 + tid;             // per-lane stack, stride kEvalThreads
+    uint64_t *stk = lds + (uint64_t)kEvalGroupTile * ncw * 64 + tid;             // per-lane stack of kEvalGroupTile-mask entries, stride kEvalThreads
     constexpr uint32_t kPre = 8;
     uint32_t pre[kPre];
     const uint32_t *P = a.prog + (uint64_t)c * a.Lmax * kEvalThreads + tid;
@@ -881,35 +889,53 @@ __device__ __forceinline__ void eval_role_all(const EvalArgs &a, const ArenaRef 
     }
     __syncthreads();
     const uint32_t q = c * kEvalThreads + tid;
+    // every op is decoded ONCE and applied to the masks of all the tile's groups (the groups past gt hold zeros: harmless)
     uint64_t res[kEvalGroupTile];
+#pragma unroll
+    for (uint32_t tt = 0; tt < kEvalGroupTile; ++tt) res[tt] = ~0ULL;            // empty program == nil query == true
+    uint32_t sp = 0;
+    const uint32_t gstride = ncw * 64;
+    auto step = [&](uint32_t op) {
+        const uint32_t opc = op >> 28;
+        if (opc == 7u) return;
+        if (opc == 1u || opc == 2u) {
+            --sp;
+            const uint64_t *u = stk + (uint64_t)(sp - 1) * kEvalGroupTile * kEvalThreads;
+#pragma unroll
+            for (uint32_t tt = 0; tt < kEvalGroupTile; ++tt) {
+                const uint64_t under = u[(uint64_t)tt * kEvalThreads];
+                res[tt] = (opc == 1u) ? (under & res[tt]) : (under | res[tt]);
+            }
+        } else {
+            if (sp > 0) {
+                uint64_t *u = stk + (uint64_t)(sp - 1) * kEvalGroupTile * kEvalThreads;
+#pragma unroll
+                for (uint32_t tt = 0; tt < kEvalGroupTile; ++tt) u[(uint64_t)tt * kEvalThreads] = res[tt];
+            }
+            ++sp;
+            if (opc == 0u) {
+                const uint64_t *vt = VT + (op & 0x0FFFFFFFu);
+#pragma unroll
+                for (uint32_t tt = 0; tt < kEvalGroupTile; ++tt) res[tt] = tt < gt ? vt[(uint64_t)tt * gstride] : 0ULL;
+            } else {
+                const uint64_t v = opc == 3u ? ~0ULL : 0ULL;
+#pragma unroll
+                for (uint32_t tt = 0; tt < kEvalGroupTile; ++tt) res[tt] = v;
+            }
+        }
+    };
+#pragma unroll
+    for (uint32_t j = 0; j < kPre; ++j) if (j < len) step(pre[j]);
+    for (uint32_t j = kPre; j < len; ++j) step(P[(uint64_t)j * kEvalThreads]);
 #pragma unroll
     for (uint32_t tt = 0; tt < kEvalGroupTile; ++tt) {
         if (tt < gt) {
-            const uint64_t *vt = VT + (uint64_t)tt * ncw * 64;
-            uint64_t top = ~0ULL;                                                // empty program == nil query == true
-            uint32_t sp = 0;
-            auto step = [&](uint32_t op) {
-                const uint32_t opc = op >> 28;
-                if (opc == 7u) return;
-                if (opc == 1u || opc == 2u) {
-                    --sp;
-                    const uint64_t under = stk[(uint64_t)(sp - 1) * kEvalThreads];
-                    top = (opc == 1u) ? (under & top) : (under | top);
-                } else {
-                    if (sp > 0) stk[(uint64_t)(sp - 1) * kEvalThreads] = top;
-                    ++sp;
-                    top = (opc == 0u) ? vt[op & 0x0FFFFFFFu] : (opc == 3u ? ~0ULL : 0ULL);
-                }
-            };
-#pragma unroll
-            for (uint32_t j = 0; j < kPre; ++j) if (j < len) step(pre[j]);
-            for (uint32_t j = kPre; j < len; ++j) step(P[(uint64_t)j * kEvalThreads]);
             const uint32_t nvalid = ar.n_blocks - (g0 + tt) * 64u;
-            res[tt] = top & (nvalid >= 64 ? ~0ULL : ((1ULL << nvalid) - 1));
+            res[tt] &= nvalid >= 64 ? ~0ULL : ((1ULL << nvalid) - 1);
         }
     }
     if (q < a.n_queries) {
-        uint64_t *dst = a.out + ar.out_off + (uint64_t)q * ar.G + g0;
+        uint64_t *dst = a.out + ar.out_off(a.n_queries) + (uint64_t)q * ar.G() + g0;
 #pragma unroll
         for (uint32_t tt = 0; tt < kEvalGroupTile; ++tt) if (tt < gt) dst[tt] = res[tt];
     }
@@ -935,9 +961,9 @@ __global__ __launch_bounds__(kEvalThreads) void k_eval_programs(const EvalArgs a
     const uint32_t c = combo % n_chunks;
     const ArenaRef &ar = t.ar[combo / n_chunks];
     const uint32_t g0 = tx * tile;
-    if (g0 >= ar.G) return;
-    if (a.identity_cw & 2u) eval_role_all(a, ar, g0, min(tile, ar.G - g0), c, threadIdx.x, lds64);
-    else eval_role(a, ar, g0, min(tile, ar.G - g0), c, threadIdx.x, lds64, true);
+    if (g0 >= ar.G()) return;
+    if (a.identity_cw & 2u) eval_role_all(a, ar, g0, min(tile, ar.G() - g0), c, threadIdx.x, lds64);
+    else eval_role(a, ar, g0, min(tile, ar.G() - g0), c, threadIdx.x, lds64, true);
 }
 
 // ---------------------------------------------------------------------------
@@ -975,11 +1001,11 @@ __global__ __launch_bounds__(kProbeThreads) void k_probe_fused(const FusedArgs f
         const uint32_t gtile = r / f.eval_pairs, pair = r - gtile * f.eval_pairs;
         const ArenaRef &ar = te.ar[ai];
         const uint32_t g0 = gtile * f.eval_tile;
-        if (g0 >= ar.G) return;
+        if (g0 >= ar.G()) return;
         const uint32_t half = threadIdx.x >> 8, htid = threadIdx.x & 255u;
         const uint32_t c = pair * 2 + half;
         const uint32_t n_chunks = (f.e.n_queries + kEvalThreads - 1) / kEvalThreads;
-        eval_role(f.e, ar, g0, min(f.eval_tile, ar.G - g0), c, htid, lds64 + (uint64_t)half * (f.eval_lds_half / 8), c < n_chunks);
+        eval_role(f.e, ar, g0, min(f.eval_tile, ar.G() - g0), c, htid, lds64 + (uint64_t)half * (f.eval_lds_half / 8), c < n_chunks);
     }
 }
 
@@ -1047,8 +1073,8 @@ __device__ __forceinline__ void fold_tail(const FoldArgs &f, const ArenaRef &ar,
     // ---- the tile's verdict words, polled until they carry this launch's tag, transposed once:
     //      VT[(t * max_cw + s) * 64 + bit] = 64-block mask of one term ----
     uint64_t *VT = lds64;
-    const uint32_t g0 = tile * T, gt = min(T, ar.G - g0);
-    const uint64_t *V = a.V + ar.v_off * 2;
+    const uint32_t g0 = tile * T, gt = min(T, ar.G() - g0);
+    const uint64_t *V = a.V + ar.v_off(a.Wt) * 2;
     const uint32_t ncw = a.max_cw;
     __syncthreads();                                                             // the probe phase is done with the LDS
     for (uint32_t idx = wave; idx < gt * ncw; idx += kProbeWaves) {
@@ -1108,7 +1134,7 @@ __device__ __forceinline__ void fold_tail(const FoldArgs &f, const ArenaRef &ar,
             }
         }
         if (q < a.n_queries && !(f.lab & 1u)) {
-            uint64_t *dst = a.out + ar.out_off + (uint64_t)q * ar.G + g0;
+            uint64_t *dst = a.out + ar.out_off(a.n_queries) + (uint64_t)q * ar.G() + g0;
             // (measured per 20 arenas, 119-122 us as written: non-temporal stores 172 us — 8-byte partial writes straight to HBM;
             //  16-byte stores 125 us; tiles of 8 / 16 groups = 64 / 128-byte pieces per lane 128 / 147 us: the longer tail costs more
             //  than the fuller lines save)
@@ -1162,22 +1188,23 @@ struct RowsArgs {
 };
 
 // grid = (ceil(n_queries / 256), arenas of the group)
-__global__ __launch_bounds__(256) void k_survivor_rows(const RowsArgs a, const ArenaTable<kMaxGroupArenas> t, const RowsTable<kMaxGroupArenas> dst)
+__global__ __launch_bounds__(256) void k_survivor_rows(const RowsArgs a, const ArenaTable<kMaxRowsArenas> t, const RowsTable<kMaxRowsArenas> dst)
 {
     const ArenaRef &ar = t.ar[blockIdx.y];
     const RowsDst d = dst.d[blockIdx.y];
     const uint32_t q = blockIdx.x * 256u + threadIdx.x;
     if (q >= a.n_queries) return;
-    const uint64_t *src = a.out + ar.out_off + (uint64_t)q * ar.G;
+    const uint32_t G = ar.G();
+    const uint64_t *src = a.out + ar.out_off(a.n_queries) + (uint64_t)q * G;
     uint32_t cnt = 0;
-    for (uint32_t g = 0; g < ar.G; ++g) cnt += (uint32_t)__popcll(src[g]);
-    const uint32_t tag = cnt == 0u ? kRowNone : cnt == ar.n_blocks ? kRowAll : cnt <= 2u * ar.G ? kRowList : kRowDense;
+    for (uint32_t g = 0; g < G; ++g) cnt += (uint32_t)__popcll(src[g]);
+    const uint32_t tag = cnt == 0u ? kRowNone : cnt == ar.n_blocks ? kRowAll : cnt <= 2u * G ? kRowList : kRowDense;
     a.hdr[d.hdr_off + q] = (tag << 30) | cnt;
-    uint64_t *row = a.rows + d.row_off + (uint64_t)q * ar.G;
+    uint64_t *row = a.rows + d.row_off + (uint64_t)q * G;
     if (tag == kRowList) {
         uint32_t *ids = reinterpret_cast<uint32_t *>(row);
         uint32_t n = 0;
-        for (uint32_t g = 0; g < ar.G; ++g) {
+        for (uint32_t g = 0; g < G; ++g) {
             uint64_t w = src[g];
             while (w) {
                 ids[n++] = g * 64u + (uint32_t)__builtin_ctzll(w);
@@ -1185,7 +1212,7 @@ __global__ __launch_bounds__(256) void k_survivor_rows(const RowsArgs a, const A
             }
         }
     } else if (tag == kRowDense) {
-        for (uint32_t g = 0; g < ar.G; ++g) row[g] = src[g];
+        for (uint32_t g = 0; g < G; ++g) row[g] = src[g];
     }
 }
 
