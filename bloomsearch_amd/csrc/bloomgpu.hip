@@ -1188,1119 +1188,9 @@ int32_t bsg_arena_free(bsg_ctx *ctx, uint64_t arena_id)
 
 }  // extern "C"
 
-namespace {
-
-// One batch that fits one launch's limits.  *too_big: the failure (BSG_E_UNSUPPORTED) is one a smaller run of queries may not have.
-int32_t create_simple_batch(bsg_ctx *ctx, const bsg_term *terms, uint32_t n_terms, const uint32_t *prog_ops, const uint32_t *prog_off,
-                            uint32_t n_queries, std::shared_ptr<Batch> &out, bool *too_big)
-{
-    *too_big = false;
-    auto batch = std::make_shared<Batch>();
-    Batch &B = *batch;
-    B.n_queries = n_queries;
-    // group terms by kind; each kind's segment starts on a 64-term boundary
-    uint32_t count[3] = {0, 0, 0};
-    for (uint32_t t = 0; t < n_terms; ++t) {
-        if (terms[t].kind > 2) return fail(BSG_E_INVALID, "term %u has unknown kind %u", t, terms[t].kind);
-        count[terms[t].kind]++;
-    }
-    uint32_t begin_of_kind[3] = {0, 0, 0};
-    uint32_t cursor = 0;
-    for (uint32_t c = 0; c < 3; ++c) {
-        if (count[c] == 0) continue;
-        B.kind[B.n_kinds] = c;
-        B.term_begin[B.n_kinds] = cursor;
-        B.term_count[B.n_kinds] = count[c];
-        begin_of_kind[c] = cursor;
-        cursor += (count[c] + 63) / 64 * 64;
-        B.n_kinds++;
-    }
-    B.Tp = cursor;
-    B.Wt = cursor / 64;
-    std::vector<uint32_t> term_pos(n_terms);
-    std::vector<uint64_t> th((size_t)4 * std::max(B.Tp, 1u), 0);
-    uint32_t fill[3] = {0, 0, 0};
-    for (uint32_t t = 0; t < n_terms; ++t) {
-        const uint32_t c = terms[t].kind;
-        const uint32_t pos = begin_of_kind[c] + fill[c]++;
-        term_pos[t] = pos;
-        for (int j = 0; j < 4; ++j) th[(size_t)j * B.Tp + pos] = terms[t].h[j];
-    }
-    // lower programs; pack per 256-query chunk in lane-interleaved (coalesced) order with ONE stride for all
-    // chunks (Lmax ops, NOP padded) and one stride for the per-chunk verdict-word lists (max_cw)
-    B.n_chunks = (n_queries + bsg::kEvalThreads - 1) / bsg::kEvalThreads;
-    std::vector<std::vector<uint32_t>> lowered(n_queries);
-    for (uint32_t q = 0; q < n_queries; ++q) {
-        if (prog_off[q + 1] < prog_off[q]) return fail(BSG_E_INVALID, "prog_off not monotone at %u", q);
-        const uint32_t n_ops = prog_off[q + 1] - prog_off[q];
-        if (n_ops && !prog_ops) return fail(BSG_E_INVALID, "prog_ops is null");
-        uint32_t depth = 1;
-        if (int32_t rc = lower_program(prog_ops + prog_off[q], n_ops, n_terms, term_pos, lowered[q], depth)) return rc;
-        B.max_depth = std::max(B.max_depth, depth);
-        B.Lmax = std::max<uint32_t>(B.Lmax, (uint32_t)lowered[q].size());
-    }
-    B.identity_cw = B.Wt >= 1 && B.Wt <= 8;
-    for (uint32_t y = 0; y < B.n_kinds; ++y) if ((B.term_count[y] + 63) / 64 > bsg::kParallelKMaxWords) B.many_terms = true;
-    std::vector<uint32_t> chunk_len(std::max(B.n_chunks, 1u), 0), cw_cnt(std::max(B.n_chunks, 1u), 0);
-    std::vector<std::vector<uint32_t>> chunk_words(B.n_chunks);
-    for (uint32_t c = 0; c < B.n_chunks; ++c) {
-        const uint32_t q0 = c * bsg::kEvalThreads;
-        const uint32_t nq = std::min<uint32_t>(bsg::kEvalThreads, n_queries - q0);
-        std::vector<uint32_t> &words = chunk_words[c];   // verdict words this chunk references -> slots
-        for (uint32_t i = 0; i < nq; ++i) {
-            chunk_len[c] = std::max<uint32_t>(chunk_len[c], (uint32_t)lowered[q0 + i].size());
-            for (uint32_t op : lowered[q0 + i])
-                if ((op >> 28) == 0u) words.push_back((op & 0x0FFFFFFFu) >> 6);
-        }
-        std::sort(words.begin(), words.end());
-        words.erase(std::unique(words.begin(), words.end()), words.end());
-        if (B.identity_cw) { words.resize(B.Wt); for (uint32_t w = 0; w < B.Wt; ++w) words[w] = w; }
-        cw_cnt[c] = (uint32_t)words.size();
-        B.max_cw = std::max<uint32_t>(B.max_cw, (uint32_t)words.size());
-    }
-    std::vector<uint32_t> packed((size_t)std::max(B.n_chunks, 1u) * B.Lmax * bsg::kEvalThreads, 7u << 28);
-    std::vector<uint32_t> cw((size_t)std::max(B.n_chunks, 1u) * B.max_cw, 0);
-    for (uint32_t c = 0; c < B.n_chunks; ++c) {
-        const uint32_t q0 = c * bsg::kEvalThreads;
-        const uint32_t nq = std::min<uint32_t>(bsg::kEvalThreads, n_queries - q0);
-        const std::vector<uint32_t> &words = chunk_words[c];
-        std::copy(words.begin(), words.end(), cw.begin() + (size_t)c * B.max_cw);
-        for (uint32_t i = 0; i < nq; ++i)
-            for (size_t j = 0; j < lowered[q0 + i].size(); ++j) {
-                uint32_t op = lowered[q0 + i][j];
-                if ((op >> 28) == 0u) {   // TERM args become slot * 64 + bit
-                    const uint32_t pos = op & 0x0FFFFFFFu;
-                    const uint32_t slot = (uint32_t)(std::lower_bound(words.begin(), words.end(), pos >> 6) - words.begin());
-                    op = slot * 64 + (pos & 63);
-                }
-                packed[((size_t)c * B.Lmax + j) * bsg::kEvalThreads + i] = op;
-            }
-    }
-    if (packed.size() > (1ull << 30)) {
-        *too_big = true;
-        return fail(BSG_E_UNSUPPORTED, "padded program table of %zu ops is too large for one launch", packed.size());
-    }
-    const size_t lds_need = ((size_t)B.max_cw * 64 + (size_t)B.max_depth * bsg::kEvalThreads) * 8;
-    if (lds_need > 64 * 1024) {
-        *too_big = true;
-        return fail(BSG_E_UNSUPPORTED, "a 256-query chunk needs %zu B of LDS (%u verdict words, stack depth %u)", lds_need,
-                    B.max_cw, B.max_depth);
-    }
-    {
-        // k_probe_terms keeps per-kind verdict words + wave queues in LDS beside the bitset image
-        uint32_t max_tw = 0;
-        for (uint32_t y = 0; y < B.n_kinds; ++y) max_tw = std::max(max_tw, (B.term_count[y] + 63) / 64);
-        if (bsg::probe_lds_head_bytes(max_tw) > 48 * 1024) {
-            *too_big = true;
-            return fail(BSG_E_UNSUPPORTED, "%u distinct terms of one kind exceed what one probe launch holds", max_tw * 64);
-        }
-    }
-    B.dev.resize(ctx->devs.size());
-    for (size_t di = 0; di < ctx->devs.size(); ++di) {
-        Device &d = *ctx->devs[di];
-        BatchDev &bd = B.dev[di];
-        std::lock_guard<std::mutex> lk(d.mu);
-        if (int32_t rc = use_device(d)) { free_batch(ctx, B); return rc; }
-        hipError_t e = hipMalloc(reinterpret_cast<void **>(&bd.d_th), th.size() * 8);
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&bd.d_prog), std::max<size_t>(packed.size(), 1) * 4);
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&bd.d_chunk_len), chunk_len.size() * 4);
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&bd.d_cw_cnt), cw_cnt.size() * 4);
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&bd.d_cw), std::max<size_t>(cw.size(), 1) * 4);
-        if (e == hipSuccess) e = hipMemcpyAsync(bd.d_cw_cnt, cw_cnt.data(), cw_cnt.size() * 4, hipMemcpyHostToDevice, d.stream);
-        if (e == hipSuccess && !cw.empty()) e = hipMemcpyAsync(bd.d_cw, cw.data(), cw.size() * 4, hipMemcpyHostToDevice, d.stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(bd.d_th, th.data(), th.size() * 8, hipMemcpyHostToDevice, d.stream);
-        if (e == hipSuccess && !packed.empty())
-            e = hipMemcpyAsync(bd.d_prog, packed.data(), packed.size() * 4, hipMemcpyHostToDevice, d.stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(bd.d_chunk_len, chunk_len.data(), chunk_len.size() * 4, hipMemcpyHostToDevice, d.stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(d.stream);
-        if (e != hipSuccess) {
-            free_batch(ctx, B);
-            return fail(e == hipErrorOutOfMemory ? BSG_E_NOMEM : BSG_E_HIP, "batch upload failed: %s", hipGetErrorString(e));
-        }
-    }
-    out = batch;
-    return BSG_OK;
-}
-
-// A batch of any size: one simple batch when it fits a launch, otherwise runs of queries (halved until they fit), each with the
-// terms its own queries reference.  A single query beyond the limits stays unsupported.
-int32_t create_batch_tree(bsg_ctx *ctx, const bsg_term *terms, uint32_t n_terms, const uint32_t *prog_ops, const uint32_t *prog_off,
-                          uint32_t q0, uint32_t q1, std::vector<std::shared_ptr<Batch>> &subs, std::vector<uint32_t> &sub_q0)
-{
-    // the run's own terms and programs (term indices renumbered densely in order of first use)
-    std::vector<uint32_t> remap(n_terms, 0xFFFFFFFFu), ops, off{0};
-    std::vector<bsg_term> used;
-    for (uint32_t q = q0; q < q1; ++q) {
-        for (uint32_t j = prog_off[q]; j < prog_off[q + 1]; ++j) {
-            uint32_t op = prog_ops[j];
-            if ((op >> 28) == BSG_OP_TERM) {
-                const uint32_t t = op & 0x0FFFFFFFu;
-                if (t >= n_terms) return fail(BSG_E_INVALID, "program references term %u of %u", t, n_terms);
-                if (remap[t] == 0xFFFFFFFFu) { remap[t] = (uint32_t)used.size(); used.push_back(terms[t]); }
-                op = BSG_OP(BSG_OP_TERM, remap[t]);
-            }
-            ops.push_back(op);
-        }
-        off.push_back((uint32_t)ops.size());
-    }
-    std::shared_ptr<Batch> b;
-    bool too_big = false;
-    const int32_t rc = create_simple_batch(ctx, used.data(), (uint32_t)used.size(), ops.data(), off.data(), q1 - q0, b, &too_big);
-    if (rc == BSG_OK) { subs.push_back(b); sub_q0.push_back(q0); return BSG_OK; }
-    if (!too_big || q1 - q0 <= 1) return rc;
-    // halves on 256-query (chunk) boundaries where the run is long enough
-    uint32_t mid = q0 + (q1 - q0) / 2;
-    if (q1 - q0 > 2 * bsg::kEvalThreads) mid = q0 + (mid - q0 + bsg::kEvalThreads - 1) / bsg::kEvalThreads * bsg::kEvalThreads;
-    if (int32_t rc2 = create_batch_tree(ctx, terms, n_terms, prog_ops, prog_off, q0, mid, subs, sub_q0)) return rc2;
-    return create_batch_tree(ctx, terms, n_terms, prog_ops, prog_off, mid, q1, subs, sub_q0);
-}
-
-}  // namespace
+#include "probe_api.inc"
 
 extern "C" {
-
-int32_t bsg_batch_create(bsg_ctx *ctx, const bsg_term *terms, uint32_t n_terms, const uint32_t *prog_ops,
-                         const uint32_t *prog_off, uint32_t n_queries, uint64_t *out_batch_id)
-{
-    BSG_ENTER(ctx);
-    if (!ctx || !out_batch_id) return fail(BSG_E_INVALID, "null argument");
-    if (n_terms && !terms) return fail(BSG_E_INVALID, "terms is null");
-    if (n_queries && !prog_off) return fail(BSG_E_INVALID, "prog_off is null");
-    for (uint32_t q = 0; q < n_queries; ++q) {
-        if (prog_off[q + 1] < prog_off[q]) return fail(BSG_E_INVALID, "prog_off not monotone at %u", q);
-        if (prog_off[q + 1] > prog_off[q] && !prog_ops) return fail(BSG_E_INVALID, "prog_ops is null");
-    }
-    std::shared_ptr<Batch> batch;
-    bool too_big = false;
-    int32_t rc = create_simple_batch(ctx, terms, n_terms, prog_ops, prog_off, n_queries, batch, &too_big);
-    if (rc && too_big && n_queries > 1) {
-        // beyond one launch: a composite of runs of queries (the caller sees one batch; the evaluator it replaces has no limit)
-        auto comp = std::make_shared<Batch>();
-        comp->n_queries = n_queries;
-        rc = create_batch_tree(ctx, terms, n_terms, prog_ops, prog_off, 0, n_queries, comp->subs, comp->sub_q0);
-        if (rc) { const std::string saved = g_err; free_batch(ctx, *comp); return fail(rc, "%s", saved.c_str()); }
-        batch = comp;
-    }
-    if (rc) return rc;
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    const uint64_t id = ctx->next_id++;
-    ctx->batches[id] = batch;
-    *out_batch_id = id;
-    return BSG_OK;
-}
-
-int32_t bsg_batch_free(bsg_ctx *ctx, uint64_t batch_id)
-{
-    BSG_ENTER(ctx);
-    if (!ctx) return fail(BSG_E_INVALID, "ctx is null");
-    std::shared_ptr<Batch> b;
-    {
-        std::lock_guard<std::mutex> lk(ctx->mu);
-        auto it = ctx->batches.find(batch_id);
-        if (it == ctx->batches.end()) return fail(BSG_E_NOTFOUND, "unknown batch id %llu", (unsigned long long)batch_id);
-        b = it->second;
-        ctx->batches.erase(it);
-    }
-    for (auto &dp : ctx->devs) {
-        std::lock_guard<std::mutex> lk(dp->mu);
-        (void)hipSetDevice(dp->id);
-        (void)hipStreamSynchronize(dp->stream);
-    }
-    free_batch(ctx, *b);
-    return BSG_OK;
-}
-
-}  // extern "C"
-
-namespace {
-
-int32_t take_events(bsg_ctx *ctx, Device &d, EventTriple &ev)
-{
-    if (d.pending.size() >= 4096) if (int32_t rc = drain_timing(ctx, d)) return rc;
-    if (!d.free_events.empty()) { ev = d.free_events.back(); d.free_events.pop_back(); }
-    else {
-        HIP_TRY(hipEventCreate(&ev.k1s)); HIP_TRY(hipEventCreate(&ev.k1e));
-        HIP_TRY(hipEventCreate(&ev.k2s)); HIP_TRY(hipEventCreate(&ev.k2e));
-    }
-    ev.bytes = 0;
-    ev.has_k1 = ev.has_k2 = ev.fused = ev.folded = false;
-    ev.n_arenas = 0;
-    return BSG_OK;
-}
-
-// A launch group: the shards (on one device) of up to kMaxGroupArenas arenas, probed by ONE dispatch.
-struct Group {
-    std::vector<const ArenaShard *> shards;
-    std::vector<uint32_t> index;     // position of each shard's arena in the caller's list
-    uint64_t v_words = 0;            // verdict scratch the group needs (u64)
-    uint64_t out_words = 0;          // survivors the group produces (u64)
-    uint32_t max_blocks = 0, max_G = 0, total_G = 0;
-};
-
-// the group's arena records from position i0 on (at most `cap` of them); g_prefix counts from the group's first arena
-void fill_refs(const Group &g, const Batch &, bsg::ArenaRef *refs, size_t i0 = 0, size_t cap = ~size_t(0))
-{
-    uint32_t gp = 0;
-    for (size_t i = 0; i < g.shards.size() && i < i0 + cap; ++i) {
-        const ArenaShard &s = *g.shards[i];
-        if (i >= i0) refs[i - i0] = bsg::ArenaRef{s.d_words, s.d_desc, s.n_blocks, gp};
-        gp += (s.n_blocks + 63) / 64;
-    }
-}
-
-void group_add(Group &g, const Batch &B, const ArenaShard &s, uint32_t idx)
-{
-    const uint32_t G = (s.n_blocks + 63) / 64;
-    g.shards.push_back(&s);
-    g.index.push_back(idx);
-    g.v_words += (uint64_t)G * std::max(B.Wt, 1u) * 64;
-    g.out_words += (uint64_t)B.n_queries * G;
-    g.max_blocks = std::max(g.max_blocks, s.n_blocks);
-    g.max_G = std::max(g.max_G, G);
-    g.total_G += G;
-}
-
-// K1 arguments: stream every referenced bitset of the group once, one verdict word per (block, 64 terms) into V[slot].
-int32_t make_probe_args(bsg_ctx *ctx, Device &d, const Group &g, const BatchDev &bd, const Batch &B, uint32_t slot, EventTriple *ev,
-                        bsg::ProbeArgs &a, uint32_t &lds_bytes)
-{
-    HIP_TRY(d.V[slot].reserve(std::max<uint64_t>(g.v_words, 1)));
-    a = bsg::ProbeArgs{};
-    a.th = bd.d_th; a.V = d.V[slot].p;
-    a.Tp = B.Tp; a.Wt = B.Wt;
-    a.n_arenas = (uint32_t)g.shards.size();
-    a.max_blocks = g.max_blocks;
-    a.gather_cost = ctx->gather_cost;
-    uint32_t max_tw = 0;
-    for (uint32_t y = 0; y < B.n_kinds; ++y) max_tw = std::max(max_tw, (B.term_count[y] + 63) / 64);
-    const size_t head = bsg::probe_lds_head_bytes(max_tw);
-    // staged-filter cap for this launch: what is left of the LDS budget after the head
-    const uint64_t cap_words = head + 32 < kLdsBudget ? (kLdsBudget - head) / 16 * 2 : 0;
-    a.lds_cap_words = (uint32_t)std::min<uint64_t>(kLdsCapWords, cap_words);
-    uint64_t lds_words = 2;
-    for (uint32_t y = 0; y < B.n_kinds; ++y) {
-        a.kind[y] = B.kind[y]; a.term_begin[y] = B.term_begin[y]; a.term_count[y] = B.term_count[y];
-        for (const ArenaShard *s : g.shards) {
-            lds_words = std::max(lds_words, std::min<uint64_t>(s->max_staged_words[B.kind[y]], a.lds_cap_words));
-            if (ev) ev->bytes += s->sum_words[B.kind[y]] * 8;
-        }
-    }
-    if (ev) ev->n_arenas = a.n_arenas;
-    lds_words = (lds_words + 1) / 2 * 2;
-    a.lds_image_bytes = (uint32_t)(lds_words * 8);
-    a.compact_rounds = ctx->compact_rounds;
-    lds_bytes = (uint32_t)(head + lds_words * 8);
-    return BSG_OK;
-}
-
-int32_t make_eval_args(Device &d, const Group &g, const BatchDev &bd, const Batch &B, uint32_t slot, bsg::EvalArgs &a)
-{
-    HIP_TRY(d.out[slot].reserve(std::max<uint64_t>(g.out_words, 1)));
-    a = bsg::EvalArgs{};
-    a.V = d.V[slot].p; a.prog = bd.d_prog; a.chunk_len = bd.d_chunk_len;
-    a.out = d.out[slot].p; a.Wt = B.Wt; a.n_queries = B.n_queries;
-    a.cw_cnt = bd.d_cw_cnt; a.cw = bd.d_cw; a.max_cw = B.max_cw; a.Lmax = B.Lmax; a.identity_cw = B.identity_cw ? 1u : 0u;
-    a.n_arenas = (uint32_t)g.shards.size();
-    a.max_G = g.max_G;
-    return BSG_OK;
-}
-
-// Small launches keep one block group per eval workgroup (latency); large ones tile kEvalGroupTile groups so a
-// query's survivor words leave as one 32-byte store instead of four strided 8-byte stores.
-// (A 32-arena group of 1 000-block arenas with one group per workgroup wrote 66.7 MB for 16.8 MB of survivors: 8-byte
-// stores at a 128-byte stride cost a 32-byte sector each.)
-uint32_t eval_tile_for(const Group &g)
-{
-    static const char *force = getenv("BSG_LAB_EVAL_TILE");   // lab only
-    if (force) return std::max(1, atoi(force));
-    return (g.max_G >= 64 || g.total_G >= 64) ? bsg::kEvalGroupTile : 1u;
-}
-
-int32_t enqueue_terms(bsg_ctx *ctx, Device &d, const Group &g, const BatchDev &bd, const Batch &B, uint32_t slot, EventTriple *ev)
-{
-    bsg::ProbeArgs a;
-    uint32_t lds = 0;
-    if (int32_t rc = make_probe_args(ctx, d, g, bd, B, slot, ev, a, lds)) return rc;
-    if (B.n_kinds == 0) return BSG_OK;
-    bsg::ArenaTable<bsg::kMaxGroupArenas> t;
-    fill_refs(g, B, t.ar);
-    if (B.many_terms)
-        hipExtLaunchKernelGGL(bsg::k_probe_terms_many, dim3(g.max_blocks, B.n_kinds, a.n_arenas), dim3(bsg::kProbeThreads), lds, d.stream,
-                              ev ? ev->k1s : nullptr, ev ? ev->k1e : nullptr, 0, a, t);
-    else
-        hipExtLaunchKernelGGL(bsg::k_probe_terms, dim3(g.max_blocks, B.n_kinds, a.n_arenas), dim3(bsg::kProbeThreads), lds, d.stream,
-                              ev ? ev->k1s : nullptr, ev ? ev->k1e : nullptr, 0, a, t);
-    HIP_TRY(hipGetLastError());
-    if (ev) ev->has_k1 = true;
-    return BSG_OK;
-}
-
-// One dispatch for a small batch: bit tests + programs of every 64-block group (direct.hip.h); survivors to `out`.
-int32_t enqueue_direct(Device &d, const Group &g, const BatchDev &bd, const Batch &B, uint64_t *out, uint64_t *flag, uint64_t seq, EventTriple *ev)
-{
-    bsg::DirectArgs a{};
-    a.done_count = d.d_direct_count; a.flag = flag; a.seq = seq;
-    a.th = bd.d_th; a.prog = bd.d_prog; a.chunk_len = bd.d_chunk_len; a.out = out;
-    a.Tp = B.Tp; a.Wt = std::max(B.Wt, 1u); a.n_queries = B.n_queries; a.Lmax = B.Lmax; a.max_depth = B.max_depth; a.n_kinds = B.n_kinds;
-    for (uint32_t y = 0; y < B.n_kinds; ++y) { a.kind[y] = B.kind[y]; a.term_begin[y] = B.term_begin[y]; a.term_count[y] = B.term_count[y]; }
-    a.n_arenas = (uint32_t)g.shards.size();
-    bsg::ArenaTable<bsg::kMaxGroupArenas> t;
-    fill_refs(g, B, t.ar);
-    hipExtLaunchKernelGGL(bsg::k_probe_direct, dim3(g.max_G, 1, a.n_arenas), dim3(bsg::kEvalThreads), bsg::direct_lds_bytes(a.Wt, B.max_depth),
-                          d.stream, ev ? ev->k1s : nullptr, ev ? ev->k1e : nullptr, 0, a, t);
-    HIP_TRY(hipGetLastError());
-    if (ev) {
-        ev->has_k1 = true; ev->fused = true; ev->n_arenas = a.n_arenas;
-        for (uint32_t y = 0; y < B.n_kinds; ++y)       // algorithmic bytes of the gather regime: k words of 8 bytes per (block, term)
-            for (const ArenaShard *s : g.shards) ev->bytes += (uint64_t)s->n_blocks * B.term_count[y] * 10 * 8;
-    }
-    return BSG_OK;
-}
-
-// K2: programs over V[slot] -> out[slot].
-int32_t enqueue_eval(Device &d, const Group &g, const BatchDev &bd, const Batch &B, uint32_t slot, EventTriple *ev)
-{
-    bsg::EvalArgs a;
-    if (int32_t rc = make_eval_args(d, g, bd, B, slot, a)) return rc;
-    const uint32_t tile = eval_tile_for(g);
-    bsg::ArenaTable<bsg::kMaxGroupArenas> t;
-    fill_refs(g, B, t.ar);
-    // batches with the identity word list transpose a whole tile's words at once (eval_role_all) when that fits 64 KB of LDS
-    static const bool lab_serial = getenv("BSG_LAB_EVAL_SERIAL") != nullptr;   // lab only: the per-group walk for every batch
-    uint32_t lds = bsg::eval_lds_bytes(B.max_cw, B.max_depth);
-    if (B.identity_cw && !lab_serial && bsg::eval_lds_bytes(B.max_cw * bsg::kEvalGroupTile, B.max_depth * bsg::kEvalGroupTile) <= 64 * 1024) {
-        a.identity_cw |= 2u;
-        lds = bsg::eval_lds_bytes(B.max_cw * bsg::kEvalGroupTile, B.max_depth * bsg::kEvalGroupTile);
-    }
-    const uint32_t nx = (g.max_G + tile - 1) / tile;
-    const uint64_t n_wg = (uint64_t)(B.n_chunks * (uint64_t)a.n_arenas + 7) / 8 * 8 * nx;
-    if (n_wg > 0x7FFFFFFFull) return fail(BSG_E_UNSUPPORTED, "evaluation launch of %llu workgroups", (unsigned long long)n_wg);
-    hipExtLaunchKernelGGL(bsg::k_eval_programs, dim3((uint32_t)n_wg), dim3(bsg::kEvalThreads),
-                          lds, d.stream, ev ? ev->k2s : nullptr,
-                          ev ? ev->k2e : nullptr, 0, a, t, tile, nx, B.n_chunks);
-    HIP_TRY(hipGetLastError());
-    if (ev) ev->has_k2 = true;
-    return BSG_OK;
-}
-
-// One launch per group, evaluation folded in per tile of 64 x tile_groups blocks (k_probe_eval): verdicts into V[slot],
-// survivors into out[slot] by the last arrivals of every tile.
-bool fold_applies(const bsg_ctx *ctx, const Batch &B, uint32_t flags)
-{
-    return ctx->fold_helpers > 0 && !(flags & BSG_PROBE_NOFUSE) && !B.many_terms && B.n_kinds > 0 && B.identity_cw && B.max_cw == std::max(B.Wt, 1u) &&
-           bsg::fold_eval_lds_bytes(bsg::kFoldGroupTile, B.max_cw, B.max_depth) <= 64 * 1024;
-}
-
-int32_t enqueue_fold(bsg_ctx *ctx, Device &d, const Group &g, const BatchDev &bd, const Batch &B, uint32_t slot, EventTriple *ev)
-{
-    bsg::FoldArgs f{};
-    uint32_t lds = 0;
-    if (int32_t rc = make_probe_args(ctx, d, g, bd, B, slot, ev, f.p, lds)) return rc;
-    if (int32_t rc = make_eval_args(d, g, bd, B, slot, f.e)) return rc;
-    // verdict entries are 16 bytes here (word + tag): twice the words of the plain layout, zeroed when (re)allocated so that no
-    // entry can carry a tag by accident
-    const uint64_t v_need = 2 * std::max<uint64_t>(g.v_words, 1);
-    if (v_need > d.V[slot].cap) {
-        HIP_TRY(hipStreamSynchronize(d.stream));
-        HIP_TRY(d.V[slot].reserve(v_need));
-        HIP_TRY(hipMemsetAsync(d.V[slot].p, 0, d.V[slot].cap * sizeof(uint64_t), d.stream));
-    }
-    f.p.V = d.V[slot].p;
-    f.e.V = d.V[slot].p;
-    f.p.seq = ++d.fold_seq;
-    f.tile_groups = eval_tile_for(g) > 1 ? bsg::kFoldGroupTile : 1u;
-    f.helpers = ctx->fold_helpers;
-    static const bool lab_skip = getenv("BSG_LAB_FOLD_SKIP") != nullptr;   // lab only: nobody evaluates (what the probe side of the fold costs by itself)
-    if (lab_skip) f.helpers = 0;
-    static const uint32_t lab_fold = getenv("BSG_LAB_FOLD") ? (uint32_t)atoi(getenv("BSG_LAB_FOLD")) : 0u;
-    f.lab = lab_fold;
-    f.n_kinds = B.n_kinds;
-    lds = std::max(lds, bsg::fold_eval_lds_bytes(f.tile_groups, B.max_cw, B.max_depth));
-    bsg::ArenaTable<bsg::kMaxGroupArenas> t;
-    fill_refs(g, B, t.ar);
-    hipExtLaunchKernelGGL(bsg::k_probe_eval, dim3(g.max_blocks, B.n_kinds, f.p.n_arenas), dim3(bsg::kProbeThreads), lds, d.stream,
-                          ev ? ev->k1s : nullptr, ev ? ev->k1e : nullptr, 0, f, t);
-    HIP_TRY(hipGetLastError());
-    if (ev) { ev->has_k1 = true; ev->folded = true; }
-    return BSG_OK;
-}
-
-// One launch: K1 of the current group (slot) + K2 of the previous group (pslot).  See k_probe_fused.
-int32_t enqueue_fused(bsg_ctx *ctx, Device &d, const Group &g, uint32_t slot, const Group &pg, uint32_t pslot, const BatchDev &bd,
-                      const Batch &B, EventTriple *ev)
-{
-    bsg::FusedArgs f{};
-    uint32_t lds = 0;
-    if (int32_t rc = make_probe_args(ctx, d, g, bd, B, slot, ev, f.p, lds)) return rc;
-    if (int32_t rc = make_eval_args(d, pg, bd, B, pslot, f.e)) return rc;
-    f.n_kinds = B.n_kinds;
-    f.n_probe = g.max_blocks * B.n_kinds * f.p.n_arenas;
-    f.eval_pairs = (B.n_chunks + 1) / 2;
-    f.eval_lds_half = bsg::eval_lds_bytes(B.max_cw, B.max_depth);
-    lds = std::max(lds, 2 * f.eval_lds_half);
-    f.eval_tile = eval_tile_for(pg);
-    const uint64_t grid = (uint64_t)f.n_probe + (uint64_t)(pg.max_G + f.eval_tile - 1) / f.eval_tile * f.eval_pairs * f.e.n_arenas;
-    if (grid > 0x7FFFFFFFull) return fail(BSG_E_UNSUPPORTED, "fused launch of %llu workgroups", (unsigned long long)grid);
-    bsg::ArenaTable<bsg::kMaxFusedArenas> tp, te;              // (the caller keeps fused groups within kMaxFusedArenas)
-    fill_refs(g, B, tp.ar);
-    fill_refs(pg, B, te.ar);
-    hipExtLaunchKernelGGL(bsg::k_probe_fused, dim3((uint32_t)grid), dim3(bsg::kProbeThreads), lds, d.stream, ev ? ev->k1s : nullptr,
-                          ev ? ev->k1e : nullptr, 0, f, tp, te);
-    HIP_TRY(hipGetLastError());
-    if (ev) { ev->has_k1 = true; ev->fused = true; }
-    return BSG_OK;
-}
-
-// survivors of device di's shard (local block lb == global block lb * nd + di) -> the caller's global bitset.
-// An output word holds, from device di, the local bits lo..hi at the positions p0, p0 + nd, ...: one bit-field extract and
-// one parallel deposit (BMI2 pdep) per (word, device) instead of a loop over the set bits — a 10 000-block, 4 096-query
-// result has 17 M of them.  Hosts without BMI2 take the loop.
-static void interleave_shard_loop(const uint64_t *part, uint32_t Q, uint32_t n_local, uint32_t di, uint32_t nd, uint64_t *dst, uint64_t Gglobal)
-{
-    const uint32_t G = (n_local + 63) / 64;
-    for (uint32_t q = 0; q < Q; ++q) {
-        const uint64_t *row = part + (size_t)q * G;
-        uint64_t *o = dst + (size_t)q * Gglobal;
-        for (uint32_t g = 0; g < G; ++g) {
-            uint64_t w = row[g];
-            while (w) {
-                const uint32_t bit = (uint32_t)__builtin_ctzll(w);
-                w &= w - 1;
-                const uint64_t b = ((uint64_t)g * 64 + bit) * nd + di;
-                o[b >> 6] |= 1ULL << (b & 63);
-            }
-        }
-    }
-}
-
-__attribute__((target("bmi2"))) static void interleave_shard_pdep(const uint64_t *part, uint32_t Q, uint32_t n_local, uint32_t di, uint32_t nd,
-                                                                   uint64_t *dst, uint64_t Gglobal)
-{
-    const uint32_t G = (n_local + 63) / 64;
-    // deposit masks by first position p0 < nd: bits p0, p0 + nd, ... below 64
-    std::vector<uint64_t> masks(nd, 0);
-    for (uint32_t p0 = 0; p0 < nd; ++p0)
-        for (uint32_t p = p0; p < 64; p += nd) masks[p0] |= 1ULL << p;
-    const uint64_t n_global = (uint64_t)(n_local - 1) * nd + di + 1;      // one past this shard's last global block
-    const uint64_t n_words = (n_global + 63) / 64;
-    // per output word: first local bit and first position (the same for every query)
-    std::vector<uint32_t> lo_of(n_words), p0_of(n_words);
-    for (uint64_t ow = 0; ow < n_words; ++ow) {
-        const uint64_t first = ow * 64;                                   // lo = ceil((first - di) / nd), clamped at 0
-        const uint64_t lo = first > di ? (first - di + nd - 1) / nd : 0;
-        lo_of[ow] = (uint32_t)lo;
-        p0_of[ow] = (uint32_t)(lo * nd + di - first);
-    }
-    for (uint32_t q = 0; q < Q; ++q) {
-        const uint64_t *row = part + (size_t)q * G;
-        uint64_t *o = dst + (size_t)q * Gglobal;
-        for (uint64_t ow = 0; ow < n_words; ++ow) {
-            const uint32_t lo = lo_of[ow], p0 = p0_of[ow];
-            if (lo >= n_local || p0 >= 64) continue;
-            const uint32_t wi = lo >> 6, sh = lo & 63u;
-            uint64_t src = row[wi] >> sh;
-            if (sh && wi + 1 < G) src |= row[wi + 1] << (64 - sh);       // (bits past n_local are zero in the survivors)
-            o[ow] |= __builtin_ia32_pdep_di(src, masks[p0]);
-        }
-    }
-}
-
-void interleave_shard(const uint64_t *part, uint32_t Q, uint32_t n_local, uint32_t di, uint32_t nd, uint64_t *dst, uint64_t Gglobal)
-{
-    if (n_local == 0) return;
-    static const bool has_bmi2 = __builtin_cpu_supports("bmi2");
-    if (has_bmi2 && nd <= 64) interleave_shard_pdep(part, Q, n_local, di, nd, dst, Gglobal);
-    else interleave_shard_loop(part, Q, n_local, di, nd, dst, Gglobal);
-}
-
-// Probes batch B against every arena of the list.  Per device the launches are software-pipelined on one in-order stream
-//   K1(g0) | F(g1) = K1(g1) + K2(g0) | F(g2) = K1(g2) + K2(g1) | ... | K2(g_last)
-// where a group g_i is up to ctx->group_limit arenas probed by ONE dispatch and F = k_probe_fused: the program evaluation
-// of group i-1 rides in the grid that streams group i's bitsets.  V/out are double-buffered by group parity.  Survivors
-// leave through the device's copy stream (D2H of group i overlaps the kernels of group i+1); contexts on several devices
-// enqueue on all of them before waiting on any, then interleave the shards' bitsets on the host.
-// out_dev != nullptr (single-device contexts): survivors are left at that device pointer instead, in the same layout.
-// (Measured on MI355X in round 1: per-arena cross-stream events cost the host 3-4 us each — per group they are noise.)
-// rows_hdr != nullptr (bsg_probe_many_rows; single-device contexts): out_survivors and rows_hdr are PAGE-LOCKED host memory that
-// k_survivor_rows writes itself — a header per (arena, query) and, only where needed, block ids or words in the row's dense slot.
-int32_t probe_arenas(bsg_ctx *ctx, const std::vector<std::shared_ptr<Arena>> &arenas, const Batch &B, uint32_t flags,
-                     uint64_t *out_survivors, uint64_t *out_dev, uint32_t *rows_hdr = nullptr)
-{
-    const uint32_t nd = (uint32_t)ctx->devs.size();
-    const uint32_t n_arenas = (uint32_t)arenas.size();
-    if (B.n_queries == 0 || n_arenas == 0) return BSG_OK;
-    uint64_t *d_rows = nullptr;
-    uint32_t *d_hdr = nullptr;
-    if (rows_hdr)      // arenas without blocks produce no launch: their rows are NONE
-        for (uint32_t i = 0; i < n_arenas; ++i)
-            if (arenas[i]->n_blocks == 0) memset(rows_hdr + (size_t)i * B.n_queries, 0, (size_t)B.n_queries * 4);
-    if (rows_hdr) {
-        if (nd != 1 || !B.subs.empty() || !out_survivors || out_dev)
-            return fail(BSG_E_UNSUPPORTED, "survivor rows need a single-device context and a batch within one launch's limits");
-        std::lock_guard<std::mutex> lk(ctx->devs[0]->mu);
-        if (int32_t rc = use_device(*ctx->devs[0])) return rc;
-        if (hipHostGetDevicePointer(reinterpret_cast<void **>(&d_rows), out_survivors, 0) != hipSuccess ||
-            hipHostGetDevicePointer(reinterpret_cast<void **>(&d_hdr), rows_hdr, 0) != hipSuccess) {
-            (void)hipGetLastError();
-            return fail(BSG_E_INVALID, "survivor rows are written by the device: out_rows and out_hdr must be page-locked memory (bsg_pinned_alloc / bsg_host_register)");
-        }
-    }
-    if (!B.subs.empty()) {
-        // a composite batch: every run of queries probes on its own; its rows are scattered into the caller's layout
-        // (arena i: [n_queries][G_i], the runs' rows [q0, q0 + nq) of it) on the host
-        if (out_dev) return fail(BSG_E_UNSUPPORTED, "a batch beyond one launch's limits cannot leave its survivors at a device pointer");
-        if (!out_survivors) {
-            for (auto &sub : B.subs) if (int32_t rc = probe_arenas(ctx, arenas, *sub, flags, nullptr, nullptr)) return rc;
-            return BSG_OK;
-        }
-        if (flags & BSG_PROBE_ASYNC) return fail(BSG_E_UNSUPPORTED, "a batch beyond one launch's limits needs a synchronous probe");
-        std::vector<uint64_t> G(n_arenas), aoff(n_arenas + 1, 0);
-        for (uint32_t i = 0; i < n_arenas; ++i) { G[i] = ((uint64_t)arenas[i]->n_blocks + 63) / 64; aoff[i + 1] = aoff[i] + (uint64_t)B.n_queries * G[i]; }
-        std::vector<uint64_t> tmp;
-        for (size_t si = 0; si < B.subs.size(); ++si) {
-            const Batch &S = *B.subs[si];
-            tmp.assign(std::max<uint64_t>(1, (uint64_t)S.n_queries * (aoff[n_arenas] / std::max(B.n_queries, 1u))), 0);
-            if (int32_t rc = probe_arenas(ctx, arenas, S, flags, tmp.data(), nullptr)) return rc;
-            uint64_t o = 0;
-            for (uint32_t i = 0; i < n_arenas; ++i) {
-                memcpy(out_survivors + aoff[i] + (uint64_t)B.sub_q0[si] * G[i], tmp.data() + o, (uint64_t)S.n_queries * G[i] * 8);
-                o += (uint64_t)S.n_queries * G[i];
-            }
-        }
-        return BSG_OK;
-    }
-    const bool timed = flags & BSG_PROBE_TIMED;
-    // Fusing pays while a dispatch is short enough for its ramp + completion to matter (a few arenas); behind a large
-    // group the evaluation workgroups only take LDS and issue slots from the streaming (measured at 20-32 arenas of
-    // 35 MB per dispatch: fused 5.9 us per arena, k_probe_terms + k_eval_programs 5.2 + 1.0 us with the evaluation
-    // costing no HBM time of its own).
-    const bool fuse = !(flags & BSG_PROBE_NOFUSE) && !B.many_terms && B.n_kinds > 0 && 2 * bsg::eval_lds_bytes(B.max_cw, B.max_depth) <= 64 * 1024;
-    const uint32_t fuse_max_arenas = std::min(ctx->fuse_max_arenas, bsg::kMaxFusedArenas);
-    const uint32_t limit = std::max(1u, std::min(ctx->group_limit, bsg::kMaxGroupArenas));
-    std::vector<uint64_t> out_off(n_arenas + 1, 0);   // arena i's survivors start at out_survivors + out_off[i]
-    for (uint32_t i = 0; i < n_arenas; ++i)
-        out_off[i + 1] = out_off[i] + (uint64_t)B.n_queries * (((uint64_t)arenas[i]->n_blocks + 63) / 64);
-    // multi-device: every device's shard bitsets land in a host buffer of its own and are interleaved afterwards
-    std::vector<std::vector<uint64_t>> parts(nd > 1 && out_survivors ? nd : 0);
-    std::vector<std::vector<uint64_t>> part_off(parts.size());
-    struct DirectPending { uint64_t *buf; size_t cap; uint64_t *dst; size_t bytes; Device *dev; uint64_t *flag; uint64_t seq; };
-    std::vector<DirectPending> direct_pending;     // k_probe_direct results waiting in page-locked buffers for the stream to drain
-    struct DirectGuard {                           // the buffers go back to their device whatever way this call ends
-        std::vector<DirectPending> &v;
-        bool drained = false;                      // the kernels that write them are known to be over
-        ~DirectGuard()
-        {
-            for (auto &p : v) {
-                std::lock_guard<std::mutex> lk(p.dev->mu);
-                if (!drained) (void)hipStreamSynchronize(p.dev->stream);
-                p.dev->direct_bufs.emplace_back(p.buf, p.cap);
-            }
-        }
-    } direct_guard{direct_pending};
-    for (uint32_t di = 0; di < nd; ++di) {
-        Device &d = *ctx->devs[di];
-        const BatchDev &bd = B.dev[di];
-        std::lock_guard<std::mutex> lk(d.mu);
-        if (int32_t rc = use_device(d)) return rc;
-        // groups of this device
-        std::vector<Group> groups;
-        for (uint32_t i = 0; i < n_arenas; ++i) {
-            const ArenaShard &s = arenas[i]->shards[di];
-            if (s.n_blocks == 0) continue;
-            if (groups.empty() || groups.back().shards.size() >= limit) groups.push_back(Group{});
-            group_add(groups.back(), B, s, i);
-        }
-        if (groups.empty()) continue;
-        uint64_t *host_base = out_survivors;
-        std::vector<uint64_t> goff(groups.size() + 1, 0);   // where each group's survivors go (u64 offset)
-        if (!parts.empty()) {
-            uint64_t total = 0;
-            for (size_t gi = 0; gi < groups.size(); ++gi) { goff[gi] = total; total += groups[gi].out_words; }
-            goff[groups.size()] = total;
-            parts[di].resize(total);
-            part_off[di] = goff;
-            host_base = parts[di].data();
-        } else {
-            // single device: a group's arenas are consecutive in the caller's list unless empty arenas sit between
-            // them (those produce no words), so the group's words are contiguous at out_off[first arena of the group]
-            for (size_t gi = 0; gi < groups.size(); ++gi) goff[gi] = out_off[groups[gi].index[0]];
-        }
-        const bool want_copy = (out_survivors != nullptr || out_dev != nullptr) && !rows_hdr;
-        // latency path (a single interactive query): one group, a small synchronous result — the copy rides the compute
-        // stream, no cross-stream events
-        const bool inline_copy = want_copy && groups.size() == 1 && !(flags & BSG_PROBE_ASYNC) && groups[0].out_words * 8 <= (1u << 20);
-        if (want_copy && !inline_copy && !d.copy_stream) {
-            HIP_TRY(hipStreamCreateWithFlags(&d.copy_stream, hipStreamNonBlocking));
-            for (int s2 = 0; s2 < 2; ++s2) {
-                HIP_TRY(hipEventCreateWithFlags(&d.ev_eval[s2], hipEventDisableTiming));
-                HIP_TRY(hipEventCreateWithFlags(&d.ev_copy[s2], hipEventDisableTiming));
-            }
-        }
-        // one interactive query (a small synchronous batch with a few terms against one group): one dispatch, and the
-        // survivors are written straight into page-locked host memory — one launch and one wait instead of three enqueues
-        uint32_t real_terms = 0;
-        for (uint32_t y = 0; y < B.n_kinds; ++y) real_terms += B.term_count[y];
-        const bool direct = inline_copy && !(flags & BSG_PROBE_NOFUSE) && B.n_chunks == 1 && B.identity_cw && !B.many_terms &&
-                            real_terms <= ctx->direct_max_terms && bsg::direct_lds_bytes(std::max(B.Wt, 1u), B.max_depth) <= 64 * 1024;
-        if (direct) {
-            EventTriple ev0;
-            const bool t0 = timed;
-            if (t0) if (int32_t rc = take_events(ctx, d, ev0)) return rc;
-            const uint64_t bytes = groups[0].out_words * 8;
-            uint64_t *target = out_dev ? out_dev + goff[0] : nullptr;
-            uint64_t *flag = nullptr;
-            if (!out_dev) {
-                DirectPending p{};
-                const size_t need = bytes + 64;                  // the doorbell word sits behind the survivors
-                for (size_t i = 0; i < d.direct_bufs.size(); ++i)
-                    if (d.direct_bufs[i].second >= need) { p.buf = d.direct_bufs[i].first; p.cap = d.direct_bufs[i].second; d.direct_bufs.erase(d.direct_bufs.begin() + i); break; }
-                if (!p.buf) {
-                    p.cap = std::max<size_t>(64 * 1024, need);
-                    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&p.buf), p.cap, hipHostMallocDefault));
-                }
-                if (!d.d_direct_count) {
-                    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d.d_direct_count), 64));
-                    HIP_TRY(hipMemsetAsync(d.d_direct_count, 0, 64, d.stream));
-                }
-                p.dst = host_base + goff[0]; p.bytes = bytes; p.dev = &d;
-                p.flag = p.buf + (bytes + 7) / 8; p.seq = ++d.direct_seq;
-                *reinterpret_cast<volatile uint64_t *>(p.flag) = 0;
-                flag = p.flag;
-                direct_pending.push_back(p);
-                target = p.buf;
-            }
-            if (int32_t rc = enqueue_direct(d, groups[0], bd, B, target, flag, d.direct_seq, t0 ? &ev0 : nullptr)) return rc;
-            if (t0) d.pending.push_back(ev0);
-            continue;
-        }
-        std::vector<EventTriple> evs(groups.size());
-        std::vector<uint8_t> tflag(groups.size(), 0);
-        auto after_eval = [&](size_t gi, uint32_t slot) -> int32_t {   // bookkeeping once K2(gi) is enqueued
-            if (tflag[gi]) d.pending.push_back(evs[gi]);
-            if (rows_hdr) {
-                // the group's rows, tagged and compacted, straight into the caller's page-locked buffers (same stream: ordered
-                // behind the evaluation and ahead of the next use of out[slot])
-                const Group &g = groups[gi];
-                bsg::RowsArgs ra{d.out[slot].p, d_rows, d_hdr, B.n_queries};
-                for (size_t i0 = 0; i0 < g.shards.size(); i0 += bsg::kMaxRowsArenas) {      // (two tables ride in the kernel arguments: runs of 64 arenas)
-                    const size_t n = std::min<size_t>(bsg::kMaxRowsArenas, g.shards.size() - i0);
-                    bsg::ArenaTable<bsg::kMaxRowsArenas> t;
-                    bsg::RowsTable<bsg::kMaxRowsArenas> dst;
-                    fill_refs(g, B, t.ar, i0, n);
-                    for (size_t i = 0; i < n; ++i) dst.d[i] = bsg::RowsDst{out_off[g.index[i0 + i]], (uint64_t)g.index[i0 + i] * B.n_queries};
-                    hipLaunchKernelGGL(bsg::k_survivor_rows, dim3((B.n_queries + 255) / 256, (uint32_t)n), dim3(256), 0, d.stream, ra, t, dst);
-                    HIP_TRY(hipGetLastError());
-                }
-                return BSG_OK;
-            }
-            if (!want_copy) return BSG_OK;
-            const uint64_t bytes = groups[gi].out_words * 8;
-            if (inline_copy) {
-                HIP_TRY(hipMemcpyAsync(out_dev ? (void *)(out_dev + goff[gi]) : (void *)(host_base + goff[gi]), d.out[slot].p, bytes,
-                                       out_dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, d.stream));
-                return BSG_OK;
-            }
-            HIP_TRY(hipEventRecord(d.ev_eval[slot], d.stream));
-            HIP_TRY(hipStreamWaitEvent(d.copy_stream, d.ev_eval[slot], 0));
-            if (out_dev) HIP_TRY(hipMemcpyAsync(out_dev + goff[gi], d.out[slot].p, bytes, hipMemcpyDeviceToDevice, d.copy_stream));
-            else HIP_TRY(hipMemcpyAsync(host_base + goff[gi], d.out[slot].p, bytes, hipMemcpyDeviceToHost, d.copy_stream));
-            HIP_TRY(hipEventRecord(d.ev_copy[slot], d.copy_stream));
-            d.copy_busy[slot] = true;
-            return BSG_OK;
-        };
-        auto before_eval = [&](uint32_t slot) -> int32_t {           // out[slot] is about to be overwritten
-            if (d.copy_busy[slot]) { HIP_TRY(hipStreamWaitEvent(d.stream, d.ev_copy[slot], 0)); d.copy_busy[slot] = false; }
-            return BSG_OK;
-        };
-        const bool fold = fold_applies(ctx, B, flags);
-        for (size_t gi = 0; gi < groups.size(); ++gi) {
-            const uint32_t slot = (uint32_t)(gi & 1);
-            tflag[gi] = timed && (ctx->timed_stride <= 1 || (ctx->timed_counter++ % ctx->timed_stride) == ctx->timed_stride / 2);
-            if (tflag[gi]) if (int32_t rc = take_events(ctx, d, evs[gi])) return rc;
-            EventTriple *ev = tflag[gi] ? &evs[gi] : nullptr;
-            if (fold) {
-                // one dispatch per group: the survivors of group gi are complete when its kernel is
-                if (int32_t rc = before_eval(slot)) return rc;
-                if (int32_t rc = enqueue_fold(ctx, d, groups[gi], bd, B, slot, ev)) return rc;
-                if (int32_t rc = after_eval(gi, slot)) return rc;
-                continue;
-            }
-            if (gi > 0 && fuse && groups[gi].shards.size() <= fuse_max_arenas && groups[gi - 1].shards.size() <= fuse_max_arenas) {
-                // a fused launch's own timestamps cover the streaming of group gi AND the evaluation of group gi-1
-                if (int32_t rc = before_eval(slot ^ 1)) return rc;
-                if (int32_t rc = enqueue_fused(ctx, d, groups[gi], slot, groups[gi - 1], slot ^ 1, bd, B, ev)) return rc;
-                if (int32_t rc = after_eval(gi - 1, slot ^ 1)) return rc;
-            } else {
-                if (gi > 0) {
-                    if (int32_t rc = before_eval(slot ^ 1)) return rc;
-                    if (int32_t rc = enqueue_eval(d, groups[gi - 1], bd, B, slot ^ 1, tflag[gi - 1] ? &evs[gi - 1] : nullptr)) return rc;
-                    if (int32_t rc = after_eval(gi - 1, slot ^ 1)) return rc;
-                }
-                if (int32_t rc = enqueue_terms(ctx, d, groups[gi], bd, B, slot, ev)) return rc;
-            }
-        }
-        if (!fold) {
-            const size_t gl = groups.size() - 1;
-            const uint32_t slot = (uint32_t)(gl & 1);
-            if (int32_t rc = before_eval(slot)) return rc;
-            if (int32_t rc = enqueue_eval(d, groups[gl], bd, B, slot, tflag[gl] ? &evs[gl] : nullptr)) return rc;
-            if (int32_t rc = after_eval(gl, slot)) return rc;
-        }
-    }
-    if (flags & BSG_PROBE_ASYNC) return BSG_OK;
-    // k_probe_direct rings a doorbell in page-locked memory when its last workgroup is done: reading our own memory is
-    // cheaper than asking the runtime.  Completion is tracked PER DEVICE: eligibility for the one-dispatch path is decided
-    // per device (one group, a small result), so on a context over several devices some shards may have gone direct and
-    // others through the streaming kernels + an asynchronous copy — a device is only excused from the stream wait when
-    // every doorbell it owes has rung (a bell that stays silent for a millisecond falls back to the wait as well).
-    std::vector<uint8_t> rang(nd, 0);
-    for (auto &p : direct_pending) {
-        uint32_t di = 0;
-        while (di < nd && ctx->devs[di].get() != p.dev) ++di;
-        const auto t0 = std::chrono::steady_clock::now();
-        bool ok = true;
-        while (__atomic_load_n(p.flag, __ATOMIC_ACQUIRE) != p.seq) {
-            if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(1000)) { ok = false; break; }
-        }
-        if (di < nd) rang[di] = ok ? std::max<uint8_t>(rang[di], 1) : 2;     // 2: a bell of this device stayed silent
-    }
-    for (uint32_t di = 0; di < nd; ++di) {
-        if (rang[di] == 1) continue;                                          // every result of this device is in host memory
-        Device &d = *ctx->devs[di];
-        std::lock_guard<std::mutex> lk(d.mu);
-        if (int32_t rc = use_device(d)) return rc;
-        if (ctx->spin_wait_us) {   // a short busy-wait first: waking from a blocking wait costs more than a single query's kernels run
-            const auto t0 = std::chrono::steady_clock::now();
-            while (hipStreamQuery(d.stream) == hipErrorNotReady &&
-                   std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(ctx->spin_wait_us)) {}
-        }
-        HIP_TRY(hipStreamSynchronize(d.stream));
-        if (d.copy_stream) HIP_TRY(hipStreamSynchronize(d.copy_stream));
-        d.copy_busy[0] = d.copy_busy[1] = false;
-    }
-    for (auto &p : direct_pending) memcpy(p.dst, p.buf, p.bytes);
-    direct_guard.drained = true;                   // the doorbell rang, or the stream was waited for
-    if (!parts.empty()) {
-        memset(out_survivors, 0, out_off[n_arenas] * 8);
-        for (uint32_t di = 0; di < nd; ++di) {
-            uint64_t o = 0;
-            for (uint32_t i = 0; i < n_arenas; ++i) {
-                const ArenaShard &s = arenas[i]->shards[di];
-                if (s.n_blocks == 0) continue;
-                const uint32_t G = (s.n_blocks + 63) / 64;
-                interleave_shard(parts[di].data() + o, B.n_queries, s.n_blocks, di, nd, out_survivors + out_off[i],
-                                 ((uint64_t)arenas[i]->n_blocks + 63) / 64);
-                o += (uint64_t)B.n_queries * G;
-            }
-        }
-    }
-    return BSG_OK;
-}
-
-}  // namespace
-
-extern "C" int32_t bsg_set_timed_stride(bsg_ctx *ctx, uint32_t stride)
-{
-    BSG_ENTER(ctx);
-    ctx->timed_stride = stride ? stride : 1;
-    ctx->timed_counter = 0;
-    return BSG_OK;
-}
-
-extern "C" int32_t bsg_set_probe_group(bsg_ctx *ctx, uint32_t max_arenas_per_launch)
-{
-    BSG_ENTER(ctx);
-    ctx->group_limit = max_arenas_per_launch ? std::min(max_arenas_per_launch, bsg::kMaxGroupArenas) : bsg::kMaxGroupArenas;
-    return BSG_OK;
-}
-
-// lab knobs (tools/, bench sweeps, tests of the paths the defaults no longer take): key 1 = compaction rounds of the
-// many-term probe mode; key 2 = bytes of HBM a binned build of a large bitset may use for its locations (0: global atomics);
-// key 3 = most distinct terms of a small batch that takes the one-dispatch path k_probe_direct (0: never);
-// key 4 = pieces bsg_arena_load_sections decodes a region in (1: one launch after the whole copy);
-// key 6 = fewest locations (entries x k) for which a bitset beyond LDS is built from binned locations (default 4 M);
-// key 7 = fewest entries of a bsg_hash_entries / bsg_build* call that is cut into one part per device (default 256 K);
-// key 8 = fewest row bytes of a bsg_ingest_rows / bsg_match_rows call that is cut into one part per device (default 8 MiB);
-// key 9 = 1: the file-level union goes through global hash tables (round 2's path) instead of LDS partitions; key 10 = start the
-// partitioned union with 2^value x too few partitions (exercises its retry and its fallback; 32 + v: 2^v x too many — runs of a few, one, less than one home slot)
-extern "C" int32_t bsg_set_lab(bsg_ctx *ctx, uint32_t key, uint64_t value)
-{
-    BSG_ENTER(ctx);
-    if (key == 1) { ctx->compact_rounds = (uint32_t)std::min<uint64_t>(value, 16); return BSG_OK; }
-    if (key == 2) { ctx->bin_scratch_bytes = value; return BSG_OK; }
-    if (key == 6) { ctx->bin_min_locs = value; return BSG_OK; }
-    if (key == 3) { ctx->direct_max_terms = (uint32_t)std::min<uint64_t>(value, 192); return BSG_OK; }
-    if (key == 4) { ctx->load_pieces = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(value, 1), 64); return BSG_OK; }
-    if (key == 7) { ctx->shard_min_entries = value; return BSG_OK; }
-    if (key == 8) { ctx->shard_min_row_bytes = value; return BSG_OK; }
-    if (key == 9) { ctx->union_mode = (uint32_t)std::min<uint64_t>(value, 1); return BSG_OK; }
-    if (key == 11) { ctx->fold_helpers = (uint32_t)std::min<uint64_t>(value, 64); return BSG_OK; }
-    if (key == 10) { ctx->union_coarsen = (uint32_t)std::min<uint64_t>(value, 56); return BSG_OK; }
-    return fail(BSG_E_INVALID, "unknown lab key %u", key);
-}
-
-extern "C" int32_t bsg_set_ingest_chunk(bsg_ctx *ctx, uint64_t bytes)
-{
-    BSG_ENTER(ctx);
-    ctx->ingest_chunk_bytes = bytes ? std::max<uint64_t>(bytes, 1u << 16) : (64ull << 20);
-    return BSG_OK;
-}
-
-extern "C" int32_t bsg_set_spin_wait(bsg_ctx *ctx, uint32_t microseconds)
-{
-    BSG_ENTER(ctx);
-    ctx->spin_wait_us = microseconds;
-    return BSG_OK;
-}
-
-extern "C" int32_t bsg_set_fuse_limit(bsg_ctx *ctx, uint32_t max_arenas)
-{
-    BSG_ENTER(ctx);
-    ctx->fuse_max_arenas = max_arenas;
-    return BSG_OK;
-}
-
-extern "C" int32_t bsg_set_gather_cost(bsg_ctx *ctx, uint32_t bytes_per_probe)
-{
-    BSG_ENTER(ctx);
-    ctx->gather_cost = bytes_per_probe;
-    return BSG_OK;
-}
-
-extern "C" int32_t bsg_probe_batch(bsg_ctx *ctx, uint64_t arena_id, uint64_t batch_id, uint32_t flags, uint64_t *out_survivors)
-{
-    BSG_ENTER(ctx);
-    std::vector<std::shared_ptr<Arena>> arenas(1);
-    std::shared_ptr<Batch> batch;
-    if (int32_t rc = get_arena(ctx, arena_id, arenas[0])) return rc;
-    if (int32_t rc = get_batch(ctx, batch_id, batch)) return rc;
-    if ((flags & BSG_PROBE_ASYNC) && out_survivors)
-        return fail(BSG_E_INVALID, "BSG_PROBE_ASYNC cannot return survivors to the host");
-    return probe_arenas(ctx, arenas, *batch, flags, out_survivors, nullptr);
-}
-
-extern "C" int32_t bsg_probe_many(bsg_ctx *ctx, const uint64_t *arena_ids, uint32_t n_arenas, uint64_t batch_id, uint32_t flags,
-                                  uint64_t *out_survivors)
-{
-    BSG_ENTER(ctx);
-    if (n_arenas && !arena_ids) return fail(BSG_E_INVALID, "null argument");
-    if ((flags & BSG_PROBE_ASYNC) && out_survivors && ctx->devs.size() != 1)
-        return fail(BSG_E_INVALID, "BSG_PROBE_ASYNC with a host output needs a single-device context (shards are interleaved on the host)");
-    std::shared_ptr<Batch> batch;
-    if (int32_t rc = get_batch(ctx, batch_id, batch)) return rc;
-    std::vector<std::shared_ptr<Arena>> arenas(n_arenas);
-    for (uint32_t i = 0; i < n_arenas; ++i) if (int32_t rc = get_arena(ctx, arena_ids[i], arenas[i])) return rc;
-    // without an output pointer the call only enqueues (round-1 contract: pair with bsg_sync)
-    return probe_arenas(ctx, arenas, *batch, out_survivors ? flags : (flags | BSG_PROBE_ASYNC), out_survivors, nullptr);
-}
-
-extern "C" int32_t bsg_probe_many_rows(bsg_ctx *ctx, const uint64_t *arena_ids, uint32_t n_arenas, uint64_t batch_id, uint32_t flags,
-                                       uint64_t *out_rows, uint32_t *out_hdr)
-{
-    BSG_ENTER(ctx);
-    if ((n_arenas && !arena_ids) || !out_rows || !out_hdr) return fail(BSG_E_INVALID, "null argument");
-    std::shared_ptr<Batch> batch;
-    if (int32_t rc = get_batch(ctx, batch_id, batch)) return rc;
-    std::vector<std::shared_ptr<Arena>> arenas(n_arenas);
-    for (uint32_t i = 0; i < n_arenas; ++i) if (int32_t rc = get_arena(ctx, arena_ids[i], arenas[i])) return rc;
-    return probe_arenas(ctx, arenas, *batch, flags, out_rows, nullptr, out_hdr);
-}
-
-extern "C" int32_t bsg_survivor_row_list(uint32_t hdr, const uint64_t *row, uint32_t n_blocks, uint32_t *out_blocks, uint32_t cap, uint32_t *out_n)
-{
-    if (!out_n || (cap && !out_blocks)) return fail(BSG_E_INVALID, "null argument");
-    const uint32_t tag = hdr >> 30, cnt = hdr & 0x3FFFFFFFu;
-    *out_n = cnt;
-    if (cnt > n_blocks) return fail(BSG_E_INVALID, "row header counts %u survivors of %u blocks", cnt, n_blocks);
-    if (cnt > cap) return fail(BSG_E_INVALID, "the row holds %u surviving blocks, the buffer %u", cnt, cap);
-    if (tag == bsg::kRowNone) return BSG_OK;
-    if (tag == bsg::kRowAll) { for (uint32_t b = 0; b < n_blocks; ++b) out_blocks[b] = b; return BSG_OK; }
-    if (!row) return fail(BSG_E_INVALID, "null row");
-    if (tag == bsg::kRowList) { memcpy(out_blocks, row, (size_t)cnt * 4); return BSG_OK; }
-    uint32_t n = 0;
-    return bsg_survivor_list(row, n_blocks, out_blocks, cap, &n);
-}
-
-extern "C" int32_t bsg_probe_many_dev(bsg_ctx *ctx, const uint64_t *arena_ids, uint32_t n_arenas, uint64_t batch_id, uint32_t flags,
-                                      void *d_out_survivors)
-{
-    BSG_ENTER(ctx);
-    if ((n_arenas && !arena_ids) || !d_out_survivors) return fail(BSG_E_INVALID, "null argument");
-    if (ctx->devs.size() != 1) return fail(BSG_E_UNSUPPORTED, "bsg_probe_many_dev needs a single-device context");
-    std::shared_ptr<Batch> batch;
-    if (int32_t rc = get_batch(ctx, batch_id, batch)) return rc;
-    std::vector<std::shared_ptr<Arena>> arenas(n_arenas);
-    for (uint32_t i = 0; i < n_arenas; ++i) if (int32_t rc = get_arena(ctx, arena_ids[i], arenas[i])) return rc;
-    return probe_arenas(ctx, arenas, *batch, flags, nullptr, static_cast<uint64_t *>(d_out_survivors));
-}
-
-extern "C" {
-
-int32_t bsg_probe(bsg_ctx *ctx, uint64_t arena_id, const bsg_term *terms, uint32_t n_terms, const uint32_t *prog_ops,
-                  const uint32_t *prog_off, uint32_t n_queries, uint64_t *out_survivors)
-{
-    BSG_ENTER(ctx);
-    if (n_queries && !out_survivors) return fail(BSG_E_INVALID, "out_survivors is null");
-    uint64_t bid = 0;
-    if (int32_t rc = bsg_batch_create(ctx, terms, n_terms, prog_ops, prog_off, n_queries, &bid)) return rc;
-    const int32_t rc = bsg_probe_batch(ctx, arena_id, bid, 0, out_survivors);
-    const std::string saved = rc ? g_err : std::string();
-    (void)bsg_batch_free(ctx, bid);
-    if (rc) fail(rc, "%s", saved.c_str());   // the probe's message, not the free's
-    return rc;
-}
-
-// ---- one interactive Query() in ONE call: strings in, survivors out (direct.hip.h: k_query_direct) ----
-int32_t bsg_query(bsg_ctx *ctx, const uint64_t *arena_ids, uint32_t n_arenas, const uint8_t *term_bytes, const uint32_t *term_off,
-                  const uint32_t *term_kinds, uint32_t n_terms, const uint32_t *prog_ops, const uint32_t *prog_off, uint32_t n_queries,
-                  uint64_t *out_survivors)
-{
-    BSG_ENTER(ctx);
-    if (n_arenas && !arena_ids) return fail(BSG_E_INVALID, "arena_ids is null");
-    if (n_queries && (!prog_off || !out_survivors)) return fail(BSG_E_INVALID, "null argument");
-    if (n_terms && (!term_off || !term_kinds)) return fail(BSG_E_INVALID, "terms are null");
-    for (uint32_t t = 0; t < n_terms; ++t) {
-        if (term_off[t + 1] < term_off[t]) return fail(BSG_E_INVALID, "term_off not monotone at %u", t);
-        if (term_kinds[t] > 2) return fail(BSG_E_INVALID, "term %u has unknown kind %u", t, term_kinds[t]);
-    }
-    if (n_terms && term_off[n_terms] && !term_bytes) return fail(BSG_E_INVALID, "term_bytes is null");
-    if (n_queries == 0 || n_arenas == 0) return BSG_OK;
-    // the probed strings are hashed HERE, on the host, by the function the kernels hash entries with (TestString hashes
-    // inside the call too, query_exec.go:141-154): no device launch for a handful of strings
-    std::vector<bsg_term> terms(n_terms);
-    for (uint32_t t = 0; t < n_terms; ++t) {
-        bsg::base_hashes(term_bytes + term_off[t], term_off[t + 1] - term_off[t], terms[t].h);
-        terms[t].kind = term_kinds[t];
-        terms[t].reserved = 0;
-    }
-    std::vector<std::shared_ptr<Arena>> arenas(n_arenas);
-    for (uint32_t i = 0; i < n_arenas; ++i) if (int32_t rc = get_arena(ctx, arena_ids[i], arenas[i])) return rc;
-    const uint32_t nd = (uint32_t)ctx->devs.size();
-    // ---- does the call fit one dispatch per device with everything in the kernel arguments? ----
-    bool fast = n_terms <= bsg::kQueryMaxTerms && n_queries <= bsg::kEvalThreads;
-    for (uint32_t di = 0; di < nd && fast; ++di) {
-        uint32_t n = 0;
-        for (auto &a : arenas) n += a->shards[di].n_blocks ? 1u : 0u;
-        if (n > bsg::kQueryMaxArenas) fast = false;
-    }
-    bsg::QueryKernArgs q{};
-    Batch B;                                            // host-only stand-in: geometry for fill_refs, nothing on a device
-    uint32_t max_depth = 1, Lmax = 1;
-    if (fast) {
-        // compact term layout: grouped by kind, no padding (<= 16 terms: one verdict word)
-        uint32_t count[3] = {0, 0, 0}, begin[3] = {0, 0, 0}, fill[3] = {0, 0, 0};
-        for (uint32_t t = 0; t < n_terms; ++t) count[terms[t].kind]++;
-        uint32_t cursor = 0;
-        for (uint32_t c = 0; c < 3; ++c) {
-            if (!count[c]) continue;
-            q.a.kind[q.a.n_kinds] = c; q.a.term_begin[q.a.n_kinds] = cursor; q.a.term_count[q.a.n_kinds] = count[c];
-            begin[c] = cursor; cursor += count[c]; q.a.n_kinds++;
-        }
-        std::vector<uint32_t> term_pos(n_terms);
-        for (uint32_t t = 0; t < n_terms; ++t) {
-            const uint32_t pos = begin[terms[t].kind] + fill[terms[t].kind]++;
-            term_pos[t] = pos;
-            for (int j = 0; j < 4; ++j) q.th[(size_t)j * bsg::kQueryMaxTerms + pos] = terms[t].h[j];
-        }
-        std::vector<std::vector<uint32_t>> lowered(n_queries);
-        for (uint32_t i = 0; i < n_queries; ++i) {
-            if (prog_off[i + 1] < prog_off[i]) return fail(BSG_E_INVALID, "prog_off not monotone at %u", i);
-            const uint32_t n_ops = prog_off[i + 1] - prog_off[i];
-            if (n_ops && !prog_ops) return fail(BSG_E_INVALID, "prog_ops is null");
-            uint32_t depth = 1;
-            if (int32_t rc = lower_program(prog_ops + prog_off[i], n_ops, n_terms, term_pos, lowered[i], depth)) return rc;
-            max_depth = std::max(max_depth, depth);
-            Lmax = std::max<uint32_t>(Lmax, (uint32_t)lowered[i].size());
-        }
-        if ((uint64_t)Lmax * n_queries > bsg::kQueryMaxProgWords || bsg::direct_lds_bytes(1, max_depth) > 64 * 1024) fast = false;
-        else {
-            for (uint32_t w = 0; w < bsg::kQueryMaxProgWords; ++w) q.prog[w] = 7u << 28;
-            for (uint32_t i = 0; i < n_queries; ++i)
-                for (size_t j = 0; j < lowered[i].size(); ++j) q.prog[j * n_queries + i] = lowered[i][j];      // TERM arg = position = verdict slot
-            q.len = Lmax; q.stride = n_queries;
-            q.a.Tp = bsg::kQueryMaxTerms; q.a.Wt = 1; q.a.n_queries = n_queries; q.a.Lmax = Lmax; q.a.max_depth = max_depth;
-            B.n_queries = n_queries; B.Wt = 1;
-        }
-    }
-    if (!fast) {                                        // a larger batch: the batch object after all (hashes still from the host)
-        uint64_t bid = 0;
-        if (int32_t rc = bsg_batch_create(ctx, terms.data(), n_terms, prog_ops, prog_off, n_queries, &bid)) return rc;
-        std::shared_ptr<Batch> batch;
-        int32_t rc = get_batch(ctx, bid, batch);
-        if (!rc) rc = probe_arenas(ctx, arenas, *batch, 0, out_survivors, nullptr);
-        const std::string saved = rc ? g_err : std::string();
-        (void)bsg_batch_free(ctx, bid);
-        if (rc) fail(rc, "%s", saved.c_str());
-        return rc;
-    }
-    // ---- one k_query_direct per device that holds blocks; survivors land in page-locked memory, a doorbell says when ----
-    std::vector<uint64_t> out_off(n_arenas + 1, 0);
-    for (uint32_t i = 0; i < n_arenas; ++i) out_off[i + 1] = out_off[i] + (uint64_t)n_queries * (((uint64_t)arenas[i]->n_blocks + 63) / 64);
-    struct Pending { uint64_t *buf; size_t cap; size_t words; Device *dev; uint64_t *flag; uint64_t seq; uint32_t di; };
-    std::vector<Pending> pend;
-    struct Guard {
-        std::vector<Pending> &v; bool drained = false;
-        ~Guard() { for (auto &p : v) { std::lock_guard<std::mutex> lk(p.dev->mu); if (!drained) (void)hipStreamSynchronize(p.dev->stream); p.dev->direct_bufs.emplace_back(p.buf, p.cap); } }
-    } guard{pend};
-    for (uint32_t di = 0; di < nd; ++di) {
-        Device &d = *ctx->devs[di];
-        Group g;
-        for (uint32_t i = 0; i < n_arenas; ++i) if (arenas[i]->shards[di].n_blocks) group_add(g, B, arenas[i]->shards[di], i);
-        if (g.shards.empty()) continue;
-        std::lock_guard<std::mutex> lk(d.mu);
-        if (int32_t rc = use_device(d)) return rc;
-        Pending p{};
-        const size_t bytes = g.out_words * 8, need = bytes + 64;
-        for (size_t i = 0; i < d.direct_bufs.size(); ++i)
-            if (d.direct_bufs[i].second >= need) { p.buf = d.direct_bufs[i].first; p.cap = d.direct_bufs[i].second; d.direct_bufs.erase(d.direct_bufs.begin() + i); break; }
-        if (!p.buf) {
-            p.cap = std::max<size_t>(64 * 1024, need);
-            HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&p.buf), p.cap, hipHostMallocDefault));
-        }
-        p.words = g.out_words; p.dev = &d; p.di = di;
-        p.flag = p.buf + g.out_words; p.seq = ++d.direct_seq;
-        *reinterpret_cast<volatile uint64_t *>(p.flag) = 0;
-        pend.push_back(p);
-        if (!d.d_direct_count) {
-            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d.d_direct_count), 64));
-            HIP_TRY(hipMemsetAsync(d.d_direct_count, 0, 64, d.stream));
-        }
-        bsg::QueryKernArgs k = q;
-        k.a.done_count = d.d_direct_count; k.a.flag = p.flag; k.a.seq = p.seq; k.a.out = p.buf;
-        k.a.n_arenas = (uint32_t)g.shards.size();
-        fill_refs(g, B, k.t.ar);
-        hipLaunchKernelGGL(bsg::k_query_direct, dim3(g.max_G, 1, k.a.n_arenas), dim3(bsg::kEvalThreads), bsg::direct_lds_bytes(1, max_depth), d.stream, k);
-        HIP_TRY(hipGetLastError());
-    }
-    for (auto &p : pend) {
-        const auto t0 = std::chrono::steady_clock::now();
-        bool ok = true;
-        while (__atomic_load_n(p.flag, __ATOMIC_ACQUIRE) != p.seq)
-            if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(1000)) { ok = false; break; }
-        if (!ok) {                                      // the bell did not ring within a millisecond: ask the runtime
-            std::lock_guard<std::mutex> lk(p.dev->mu);
-            if (int32_t rc = use_device(*p.dev)) return rc;
-            HIP_TRY(hipStreamSynchronize(p.dev->stream));
-        }
-    }
-    guard.drained = true;
-    if (nd == 1) {
-        // one device: a group's arenas are the caller's non-empty arenas in order, their words back to back — as out_survivors wants them
-        if (!pend.empty()) memcpy(out_survivors, pend[0].buf, pend[0].words * 8);
-        return BSG_OK;
-    }
-    memset(out_survivors, 0, out_off[n_arenas] * 8);
-    for (auto &p : pend) {
-        uint64_t o = 0;
-        for (uint32_t i = 0; i < n_arenas; ++i) {
-            const ArenaShard &s = arenas[i]->shards[p.di];
-            if (s.n_blocks == 0) continue;
-            interleave_shard(p.buf + o, n_queries, s.n_blocks, p.di, nd, out_survivors + out_off[i], ((uint64_t)arenas[i]->n_blocks + 63) / 64);
-            o += (uint64_t)n_queries * ((s.n_blocks + 63) / 64);
-        }
-    }
-    return BSG_OK;
-}
 
 int32_t bsg_last_kernel_ms(bsg_ctx *ctx, float *build_ms, float *hash_ms, float *decode_ms)
 {
