@@ -1380,7 +1380,7 @@ def main():
         # coalesced reads on gfx950, + WRITE_SIZE), committed under profiles/.
         traffic = traffic_src = None
         try:
-            tname = "r03_traffic.json" if os.path.exists(os.path.join(ROOT, "profiles", "r03_traffic.json")) else "r02_traffic.json"
+            tname = next(n for n in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", n)))
             rec = json.load(open(os.path.join(ROOT, "profiles", tname)))
             per_arena = rec[dom]["hbm_bytes_corrected_per_arena"]
             if args.workload == "c2" and B == 1000 and k:

@@ -526,6 +526,23 @@ func (g *Context) ProbeManyRows(arenas []Arena, b Batch, buf *RowsBuffer) ([]Sur
 	return out, nil
 }
 
+// PeerAccess is bsg_peer_access: m[i][j] is true when device i of the context reaches device j's memory directly (xGMI peer
+// access); copies between the other pairs are staged through host memory by the runtime.
+func (g *Context) PeerAccess(nDevices int) ([][]bool, error) {
+	flat := make([]byte, nDevices*nDevices)
+	if err := g.err(C.bsg_peer_access(g.c, (*C.uint8_t)(unsafe.Pointer(&flat[0])), C.uint32_t(nDevices))); err != nil {
+		return nil, err
+	}
+	m := make([][]bool, nDevices)
+	for i := range m {
+		m[i] = make([]bool, nDevices)
+		for j := range m[i] {
+			m[i][j] = flat[i*nDevices+j] != 0
+		}
+	}
+	return m, nil
+}
+
 // DeviceCalls is bsg_device_calls: construct / match parts each device of the context has served so far.
 func (g *Context) DeviceCalls(nDevices int) ([]uint64, error) {
 	out := make([]uint64, nDevices)
