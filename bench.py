@@ -1066,7 +1066,7 @@ def main():
                          "10 M rows (2.5 GB of JSON); 0 = skip")
     ap.add_argument("--scaled", type=int, default=64,
                     help="also time C2': the arena replicated this many times inside one launch (0/1 = skip)")
-    ap.add_argument("--group", type=int, default=128, help="arenas one probe dispatch may cover (bsg_set_probe_group, <= 128)")
+    ap.add_argument("--group", type=int, default=256, help="arenas one probe dispatch may cover (bsg_set_probe_group; beyond 128 the arena records travel in device memory)")
     ap.add_argument("--samples", type=int, default=16, help="timestamped dispatches of each kernel beyond the timed region")
     ap.add_argument("--c4-files", type=int, default=10, help="files of the c4 leg (0 = skip the leg)")
     ap.add_argument("--c4-blocks-per-file", type=int, default=1000)

@@ -180,6 +180,8 @@ struct Device {
     std::mutex mu;                 // serialises enqueue + scratch reuse on this device
     DevBuf<uint64_t> V[2];         // verdict scratch (two slots: bsg_probe_many software-pipelines launches)
     DevBuf<uint64_t> out[2];       // survivors scratch
+    DevBuf<bsg::ArenaRef> ar_ext[2];            // arena records of a dispatch group beyond kMaxGroupArenas (device copy, per scratch slot)
+    std::vector<bsg::ArenaRef> ar_ext_host[2];  // ... and the host copy its upload reads (kept until the slot's next use)
     uint64_t fold_seq = 0;         // k_probe_eval: number of the last launch = the tag of its verdict entries
     DevBuf<uint8_t> stage_a;       // build/hash staging
     DevBuf<uint32_t> stage_off;
@@ -268,7 +270,7 @@ struct bsg_ctx {
     bsg_timing timing{};
     uint32_t timed_stride = 1;   // with BSG_PROBE_TIMED, timestamp every timed_stride-th launch
     uint64_t timed_counter = 0;
-    uint32_t group_limit = bsg::kMaxGroupArenas;   // arenas one probe dispatch may cover (bsg_set_probe_group)
+    uint32_t group_limit = 1024;   // arenas one probe dispatch may cover (bsg_set_probe_group; beyond kMaxGroupArenas the records travel in device memory)
     uint32_t gather_cost = 256;  // a filter is gathered instead of staged when terms * k * gather_cost < its bytes
     bsg::FpKey fp_key{};         // secret key of the entries' fingerprints (drawn at bsg_open; never leaves the process)
     std::vector<uint8_t> peer;   // [i * nd + j]: 1 = device i reaches device j's memory directly (xGMI peer access enabled, or the same device)
@@ -612,6 +614,8 @@ int32_t bsg_open(const int32_t *device_ids, int32_t n_devices, bsg_ctx **out_ctx
         // more than 64 KiB of dynamic LDS per workgroup is opt-in per kernel
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(bsg::k_probe_terms), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(bsg::k_probe_terms_many), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(bsg::k_probe_terms_ext), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(bsg::k_probe_terms_many_ext), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(bsg::k_probe_fused), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(bsg::k_probe_eval), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(bsg::k_build), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));

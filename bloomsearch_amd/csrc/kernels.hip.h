@@ -273,6 +273,12 @@ static_assert(sizeof(ArenaRef) == 24, "ArenaRef must stay 24 bytes: 128 of them 
 // the per-arena records of a dispatch group: a kernel argument of its own, next to the scalars
 template <uint32_t N>
 struct ArenaTable { ArenaRef ar[N]; };
+// Groups beyond kMaxGroupArenas (many small arenas: the candidate files of a wide query, a file's shards on one of 8 GPUs) carry
+// their records in DEVICE memory instead (`ext`, uploaded in front of the dispatch on the same stream): one dispatch then
+// covers up to kMaxExtGroupArenas arenas and its ramp is paid once.  ext == nullptr: the records in the kernel arguments.
+// The two forms are separate KERNELS: a select between the kernel-argument table and a global pointer inside one kernel turned
+// the record's scalar loads into vector loads (generic pointers) and cost k_probe_terms 10-14 % at every group size.
+constexpr uint32_t kMaxExtGroupArenas = 4096;
 
 struct ProbeArgs {
     const uint64_t *th;           // SoA term hashes: th[j * Tp + t], j < 4
@@ -322,6 +328,20 @@ __device__ __forceinline__ bool test_bit(BITS32 bits, uint64_t loc)
 // hashes feeding location(h, i) for a wave-uniform i: (h[i%2], h[2 + (((i + i%2) % 4) / 2)])
 __device__ __forceinline__ uint32_t ha_row(uint32_t i) { return i & 1u; }
 __device__ __forceinline__ uint32_t hb_row(uint32_t i) { const uint32_t r = i & 3u; return (r == 1u || r == 2u) ? 3u : 2u; }
+
+// A filter descriptor at a workgroup-uniform address, through the CONSTANT address space (descriptors are written by the arena
+// load / section decode, never by a probe): scalar loads into SGPRs whatever the pointer's provenance — a descriptor pointer that
+// itself came out of memory (the device-memory arena table) would otherwise be chased with vector loads.
+__device__ __forceinline__ DevDesc load_desc_uniform(const DevDesc *p)
+{
+    typedef const __attribute__((address_space(4))) uint64_t c64;
+    c64 *q = (c64 *)(uintptr_t)p;
+    DevDesc d;
+    d.word_off = q[0]; d.m = q[1]; d.magic = q[2];
+    const uint64_t kp = q[3];
+    d.k = (uint32_t)kp; d.pad = (uint32_t)(kp >> 32);
+    return d;
+}
 
 constexpr uint32_t kProbeWaves = kProbeThreads / kWave;
 constexpr uint32_t kParallelKMaxWords = 2;  // term words (x64 terms) up to which mode A is used
@@ -659,7 +679,7 @@ __device__ __forceinline__ void probe_role(const ProbeArgs &a, const ArenaRef &a
     const uint32_t wave = tid / kWave;
 
     if (b >= ar.n_blocks) return;   // arenas of a group may differ in size
-    const DevDesc d = ar.desc[(uint64_t)b * 3 + a.kind[y]];
+    const DevDesc d = load_desc_uniform(ar.desc + ((uint64_t)b * 3 + a.kind[y]));
     const uint32_t t0 = a.term_begin[y];
     const uint32_t n_real = a.term_count[y];
     const uint32_t n_tw = (n_real + 63) >> 6;
@@ -715,6 +735,34 @@ __global__ __launch_bounds__(kProbeThreads) void k_probe_terms_many(const ProbeA
 {
     extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
     probe_role<kProbeThreads, false>(a, t.ar[blockIdx.z], blockIdx.x, blockIdx.y, lds64);
+}
+// One record of a device-memory table, fetched through the CONSTANT address space: the table is written before the dispatch and
+// never during it, the index is workgroup-uniform — so the fields arrive by scalar loads into SGPRs, as they do from the kernel
+// arguments (a plain global load put them into VGPRs: the LDS-DMA lost its scalar base and the probe 10 %).
+__device__ __forceinline__ ArenaRef load_arena_ref(const ArenaRef *ext, uint32_t i)
+{
+    typedef const __attribute__((address_space(4))) uint64_t c64;
+    c64 *p = (c64 *)(uintptr_t)(ext + i);
+    ArenaRef r;
+    r.words = (const uint64_t *)p[0];
+    r.desc = (const DevDesc *)p[1];
+    const uint64_t nb_gp = p[2];
+    r.n_blocks = (uint32_t)nb_gp;
+    r.g_prefix = (uint32_t)(nb_gp >> 32);
+    return r;
+}
+// the same two kernels for groups whose arena records lie in device memory
+__global__ __launch_bounds__(kProbeThreads) void k_probe_terms_ext(const ProbeArgs a, const ArenaRef *__restrict__ ext)
+{
+    extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
+    const ArenaRef ar = load_arena_ref(ext, blockIdx.z);
+    probe_role<kProbeThreads, true>(a, ar, blockIdx.x, blockIdx.y, lds64);
+}
+__global__ __launch_bounds__(kProbeThreads) void k_probe_terms_many_ext(const ProbeArgs a, const ArenaRef *__restrict__ ext)
+{
+    extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
+    const ArenaRef ar = load_arena_ref(ext, blockIdx.z);
+    probe_role<kProbeThreads, false>(a, ar, blockIdx.x, blockIdx.y, lds64);
 }
 
 // (Measured and dropped, twice now: the same kernel with 1 024 threads per block — 16 waves sharing one block's image, 32
@@ -951,19 +999,37 @@ __host__ __device__ inline uint32_t eval_grid_blocks(uint32_t nx, uint32_t n_chu
 {
     return (n_chunks * n_arenas + 7u) / 8u * 8u * nx;
 }
-__global__ __launch_bounds__(kEvalThreads) void k_eval_programs(const EvalArgs a, const ArenaTable<kMaxGroupArenas> t, const uint32_t tile, const uint32_t nx,
-                                                                const uint32_t n_chunks)
+__device__ __forceinline__ bool eval_block_of(const EvalArgs &a, uint32_t nx, uint32_t n_chunks, uint32_t &combo, uint32_t &tx)
 {
-    extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
     const uint32_t L = blockIdx.x, span = 8u * nx;
-    const uint32_t r = L % span, combo = L / span * 8u + (r & 7u), tx = r >> 3;
-    if (combo >= n_chunks * a.n_arenas) return;
-    const uint32_t c = combo % n_chunks;
-    const ArenaRef &ar = t.ar[combo / n_chunks];
+    const uint32_t r = L % span;
+    combo = L / span * 8u + (r & 7u);
+    tx = r >> 3;
+    return combo < n_chunks * a.n_arenas;
+}
+__device__ __forceinline__ void eval_block(const EvalArgs &a, const ArenaRef &ar, uint32_t tile, uint32_t tx, uint32_t c, uint64_t *lds64)
+{
     const uint32_t g0 = tx * tile;
     if (g0 >= ar.G()) return;
     if (a.identity_cw & 2u) eval_role_all(a, ar, g0, min(tile, ar.G() - g0), c, threadIdx.x, lds64);
     else eval_role(a, ar, g0, min(tile, ar.G() - g0), c, threadIdx.x, lds64, true);
+}
+__global__ __launch_bounds__(kEvalThreads) void k_eval_programs(const EvalArgs a, const ArenaTable<kMaxGroupArenas> t, const uint32_t tile, const uint32_t nx,
+                                                                const uint32_t n_chunks)
+{
+    extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
+    uint32_t combo, tx;
+    if (!eval_block_of(a, nx, n_chunks, combo, tx)) return;
+    eval_block(a, t.ar[combo / n_chunks], tile, tx, combo % n_chunks, lds64);
+}
+__global__ __launch_bounds__(kEvalThreads) void k_eval_programs_ext(const EvalArgs a, const ArenaRef *__restrict__ ext, const uint32_t tile, const uint32_t nx,
+                                                                    const uint32_t n_chunks)
+{
+    extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
+    uint32_t combo, tx;
+    if (!eval_block_of(a, nx, n_chunks, combo, tx)) return;
+    const ArenaRef ar = load_arena_ref(ext, combo / n_chunks);
+    eval_block(a, ar, tile, tx, combo % n_chunks, lds64);
 }
 
 // ---------------------------------------------------------------------------

@@ -222,7 +222,7 @@ BSG_API int32_t bsg_probe_batch(bsg_ctx *ctx, uint64_t arena_id, uint64_t batch_
                                 uint64_t *out_survivors);
 
 /* Probe the same batch against each of n_arenas arenas (e.g. the candidate files of one query
- * stage) in one call.  Up to 128 arenas (bsg_set_probe_group) are covered by ONE dispatch — a 35 MB arena streams in
+ * stage) in one call.  Up to 1 024 arenas (bsg_set_probe_group; at most 4 096) are covered by ONE dispatch — a 35 MB arena streams in
  * about the time a dispatch takes to ramp up and complete, so per-arena launches cap the HBM roofline fraction near
  * one half — and dispatches are software-pipelined: the program evaluation of group i rides inside the launch that
  * streams group i+1's bitsets (k_probe_fused).  out_survivors == NULL: enqueue only (results stay on the device; pair

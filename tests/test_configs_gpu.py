@@ -251,6 +251,55 @@ def test_grouped_launches_equal_one_launch_per_arena(ctx):
         ctx.batch_free(b[4])
 
 
+def test_groups_beyond_the_kernel_arguments_carry_their_arena_records_in_device_memory(ctx):
+    """Up to 128 arenas ride in a dispatch's kernel arguments; a larger group (many small arenas: the candidate files of a wide
+    query, a file's shards on one of 8 GPUs) uploads its records in front of the dispatch and is still ONE dispatch.  300 arenas
+    through groups of 1 024 (the default), 129 and 200, few-term and many-term batches, dense and row outputs: the same bits as
+    the oracle's."""
+    rng = np.random.default_rng(15)
+    plans, vocab = [], None
+    for n_blocks in (70, 3, 129, 1, 65):
+        plan, _, vocab = H.make_random_arena(rng, n_blocks, absent_frac=0.02)
+        plans.append((plan, ctx.build(plan.blob, plan.off, plan.fstart, plan.desc, plan.n_words)))
+    arenas = [ctx.arena_load(w, p.desc) for p, w in plans]
+    nbs = [p.n_blocks for p, _ in plans]
+    order = [int(i) for i in rng.integers(0, len(arenas), size=300)]
+    try:
+        for n_queries, words in ((300, vocab), (40, vocab[:10])):
+            cb = Q.compile_queries([None] + [H.random_expression(rng, words, None) for _ in range(n_queries)])
+            ops, poff, _ = cb.arrays()
+            terms = H.gpu_terms(ctx, cb)
+            bid = ctx.batch_create(terms, ops, poff)
+            wants = [O.probe_batch(w, p.desc.view(O.DESC_DTYPE), terms.view(O.TERM_DTYPE), ops, poff) for p, w in plans]
+            for limit in (0, 129, 200):
+                ctx.set_probe_group(limit)
+                ctx.timing_read(reset=True)
+                got = ctx.probe_many([arenas[i] for i in order], bid, _lib.PROBE_TIMED, cb.n_queries, [nbs[i] for i in order])
+                for g, i in zip(got, order):
+                    assert np.array_equal(g, wants[i]), (len(terms), limit, i)
+                t = ctx.timing_read()
+                assert t.n_probes == {0: 1, 129: 3, 200: 2}[limit] and t.n_probe_arenas == 300      # one dispatch per group, whatever its size
+            # and as survivor rows
+            from bloomsearch_amd.gpu import rows_to_dense
+            NQ = cb.n_queries
+            Gs = [(nbs[i] + 63) // 64 for i in order]
+            rows = ctx.pinned_array(NQ * sum(Gs) * 8).view(np.uint64)
+            hdr = ctx.pinned_array(NQ * len(order) * 4).view(np.uint32)
+            ctx.set_probe_group(0)
+            ctx.probe_many_rows([arenas[i] for i in order], bid, rows, hdr)
+            o = 0
+            for j, i in enumerate(order):
+                assert np.array_equal(rows_to_dense(hdr[j * NQ: (j + 1) * NQ], rows[o: o + NQ * Gs[j]], nbs[i]), wants[i]), (j, i)
+                o += NQ * Gs[j]
+            ctx.pinned_free(rows.view(np.uint8))
+            ctx.pinned_free(hdr.view(np.uint8))
+            ctx.batch_free(bid)
+    finally:
+        ctx.set_probe_group(0)
+    for a in arenas:
+        ctx.arena_free(a)
+
+
 def test_survivors_to_device_pointer_and_async_host_output(ctx):
     rng = np.random.default_rng(6)
     plan, _, vocab = H.make_random_arena(rng, 150, absent_frac=0.0)

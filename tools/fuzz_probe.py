@@ -51,8 +51,8 @@ def main():
             terms = H.gpu_terms(ctx, cb)
             bid = ctx.batch_create(terms, ops, poff)
             wants = [O.probe_batch(w, p.desc.view(O.DESC_DTYPE), terms.view(O.TERM_DTYPE), ops, poff) for w, p in zip(all_words, plans)]
-            order = [int(i) for i in rng.integers(0, len(arenas), size=int(rng.integers(1, 40)))]
-            ctx.set_probe_group(int(rng.choice([1, 3, 32])))
+            order = [int(i) for i in rng.integers(0, len(arenas), size=int(rng.integers(1, 40)) if rng.random() > 0.1 else int(rng.integers(129, 400)))]
+            ctx.set_probe_group(int(rng.choice([1, 3, 32, 0])))          # 0: the default — up to 1 024 arenas per dispatch, records in device memory beyond 128
             ctx.set_lab(11, int(rng.choice([0, 0, 1, 3, 8])))          # k_probe_eval: evaluation folded into the probe dispatch, 1 / 3 / 8 evaluators per tile
             flags = int(rng.choice([0, _lib.PROBE_NOFUSE, _lib.PROBE_TIMED]))
             got = ctx.probe_many([arenas[i] for i in order], bid, flags, cb.n_queries, [plans[i].n_blocks for i in order])
