@@ -179,3 +179,30 @@ def test_survivor_list_is_the_ascending_bit_positions():
         padded[:n_blocks] = bits
         row = np.packbits(padded, bitorder="little").view(np.uint64) if n_blocks else np.zeros(0, dtype=np.uint64)
         assert survivor_list(row, n_blocks).tolist() == np.flatnonzero(bits).tolist()
+
+
+def test_survivor_row_list_expands_every_tag_on_the_host():
+    """bsg_survivor_row_list is host arithmetic (no device): a row of bsg_probe_many_rows, whatever its tag, becomes the ascending
+    block indices blockScanCandidate walks (query_exec.go:321,603); rows_to_dense is its numpy twin."""
+    import numpy as np
+    from bloomsearch_amd.gpu import BloomGpuError, rows_to_dense, survivor_list, survivor_row_list
+    n_blocks = 150
+    G = (n_blocks + 63) // 64
+    rng = np.random.default_rng(3)
+    dense = rng.integers(0, 1 << 63, size=G, dtype=np.uint64)
+    dense[-1] &= np.uint64((1 << (n_blocks & 63)) - 1)
+    want_dense = survivor_list(dense, n_blocks)
+    ids = np.asarray([0, 63, 64, 149], dtype=np.uint32)
+    slot = np.zeros(G, dtype=np.uint64)
+    slot.view(np.uint32)[: len(ids)] = ids
+    cases = [((0 << 30) | 0, np.zeros(G, dtype=np.uint64), np.zeros(0, dtype=np.uint32)),
+             ((1 << 30) | n_blocks, np.zeros(G, dtype=np.uint64), np.arange(n_blocks, dtype=np.uint32)),
+             ((2 << 30) | len(ids), slot, ids),
+             ((3 << 30) | len(want_dense), dense, want_dense)]
+    for hdr, row, want in cases:
+        assert np.array_equal(survivor_row_list(hdr, row, n_blocks), want), hdr >> 30
+    back = rows_to_dense(np.asarray([c[0] for c in cases], dtype=np.uint32), np.concatenate([c[1] for c in cases]), n_blocks)
+    for i, (_, _, want) in enumerate(cases):
+        assert np.array_equal(survivor_list(back[i], n_blocks), want), i
+    with pytest.raises(BloomGpuError):
+        survivor_row_list((2 << 30) | (n_blocks + 1), slot, n_blocks)          # a count beyond the arena's blocks
