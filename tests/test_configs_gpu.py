@@ -708,3 +708,35 @@ def test_batches_beyond_one_launch_are_split_inside_the_library(ctx):
     assert survivor_list(row, 70).tolist() == [b for b in range(70) if (int(row[b >> 6]) >> (b & 63)) & 1]
     ctx.arena_free(aid)
     ctx.arena_free(aid2)
+
+
+def test_a_batch_without_terms_against_a_group_beyond_the_kernel_arguments(ctx):
+    """Queries that reference no term (nil queries, nil conditions: always true — query_exec.go:81-83, 101-104) launch no probe
+    kernel; their evaluation must still find the records of a group of more than 128 arenas (device-memory table), whatever a
+    previous, larger call left in that table."""
+    rng = np.random.default_rng(25)
+    plans = []
+    for n_blocks in (200, 3, 65, 130):
+        plan, _, vocab = H.make_random_arena(rng, n_blocks, absent_frac=0.0)
+        plans.append((plan, ctx.build(plan.blob, plan.off, plan.fstart, plan.desc, plan.n_words)))
+    arenas = [ctx.arena_load(w, p.desc) for p, w in plans]
+    nbs = [p.n_blocks for p, _ in plans]
+    # a larger call first: its records stay in the slot's table
+    cb0 = Q.compile_queries([H.random_expression(rng, vocab, None) for _ in range(20)])
+    ops0, poff0, _ = cb0.arrays()
+    bid0 = ctx.batch_create(H.gpu_terms(ctx, cb0), ops0, poff0)
+    ctx.probe_many([arenas[0]] * 400, bid0, 0, cb0.n_queries, [nbs[0]] * 400)
+    ctx.batch_free(bid0)
+    cb = Q.compile_queries([None, None, {"ExpressionType": "CONDITION", "Condition": None}])
+    ops, poff, _ = cb.arrays()
+    bid = ctx.batch_create(H.gpu_terms(ctx, cb), ops, poff)
+    order = [int(i) for i in rng.integers(1, len(arenas), size=150)]
+    got = ctx.probe_many([arenas[i] for i in order], bid, 0, cb.n_queries, [nbs[i] for i in order])
+    for g, i in zip(got, order):
+        want = np.full((3, (nbs[i] + 63) // 64), ~np.uint64(0), dtype=np.uint64)
+        if nbs[i] & 63:
+            want[:, -1] = np.uint64((1 << (nbs[i] & 63)) - 1)
+        assert np.array_equal(g, want), i
+    ctx.batch_free(bid)
+    for a in arenas:
+        ctx.arena_free(a)
