@@ -3,7 +3,7 @@ Per seed: a few random arenas (block counts around the 64-block groups, false-po
 filters, blocks without tokens), the device build compared with the oracle's bitsets, then random query batches — one
 query, a handful, hundreds; few distinct terms (one-dispatch and few-term kernels) or thousands (many-term kernel) —
 probed through every launch shape (group limit 1 / 3 / 32, fused, folded into one dispatch (k_probe_eval) or not, timed or not, sharded contexts) and through the one-call
-bsg_query (strings in; kernel-argument fast path or the batch path inside the call) and compared
+bsg_query (strings in; kernel-argument fast path or the batch path inside the call), and as survivor rows (bsg_probe_many_rows), and compared
 with the oracle's surviving-block sets bit for bit.  Exits non-zero on the first difference."""
 import os
 import sys
@@ -61,6 +61,24 @@ def main():
                     sys.exit("seed %d: survivors differ (nq %d, %d terms, group order %s, flags %d, %d-entry context, arena %d)"
                              % (seed, nq, len(terms), order[:8], flags, nd, i))
                 n_bits += g.size * 64
+            # the same call as survivor ROWS (single-device contexts): whatever the tags, the rows expand to the same bitsets
+            if nd == 1 and rng.random() < 0.5:
+                from bloomsearch_amd.gpu import rows_to_dense
+                NQ = cb.n_queries
+                Gs = [(plans[i].n_blocks + 63) // 64 for i in order]
+                rows = ctx.pinned_array(max(NQ * sum(Gs), 1) * 8).view(np.uint64)
+                hdr = ctx.pinned_array(NQ * len(order) * 4).view(np.uint32)
+                rows[:] = np.iinfo(np.uint64).max
+                hdr[:] = np.iinfo(np.uint32).max
+                ctx.probe_many_rows([arenas[i] for i in order], bid, rows, hdr, flags)
+                o = 0
+                for j, i in enumerate(order):
+                    if not np.array_equal(rows_to_dense(hdr[j * NQ: (j + 1) * NQ], rows[o: o + NQ * Gs[j]], plans[i].n_blocks), wants[i]):
+                        sys.exit("seed %d: survivor rows differ (nq %d, %d terms, %d arenas, flags %d, arena %d)" % (seed, nq, len(terms), len(order), flags, i))
+                    o += NQ * Gs[j]
+                    n_bits += NQ * Gs[j] * 64
+                ctx.pinned_free(rows.view(np.uint8))
+                ctx.pinned_free(hdr.view(np.uint8))
             # the same batch through the one-call path (bsg_query: strings in, hashed on the host; one k_query_direct dispatch per
             # device when <= 16 terms / 128 program words / 32 arenas fit the kernel arguments, the batch path inside the call otherwise)
             sub = [int(i) for i in rng.integers(0, len(arenas), size=int(rng.choice([1, 2, 5, 33])))]
