@@ -26,6 +26,13 @@ for a in "20" "128" "20 c4" "64 needle"; do echo "== tools/fold_lab.py $a"; pyth
 python tools/decode_lab.py > gpurun_out/${R}_decode_lab.txt 2>&1
 for bpf in 1000 500 250 125; do python bench.py --steps 20 --warmup 5 --ingest-blocks 0 --no-decode --or-union 0 --cpu-budget 0 --no-q1 --no-single --scaled 0 --no-big-filters --c4-blocks-per-file $bpf 2>/dev/null | python -c "import json,sys; o=json.loads(sys.stdin.read()); c=o['c4']; print('$bpf blocks per file held by this GPU (= N = %d ranks): %.2f us per step bare, %.2f with dispatch timestamps; rows to host %.2f; kernels %s' % (1000 // $bpf, c['ms_per_step']*1e3, c['ms_per_step_with_dispatch_timestamps']*1e3, c['host_gather']['rows']['ms_per_step']*1e3, {k:(round(v['kernel_ms']*1e3,1), v.get('arenas_per_launch')) for k,v in c['kernels'].items()}))"; done > gpurun_out/${R}_c4_shard_sweep.txt 2>&1
 BSG_BENCH_SHARE_GPU=1 python bench.py --gpus 2 --steps 20 --warmup 5 --ingest-blocks 0 --no-decode --cpu-budget 0 --no-q1 --no-single --scaled 0 --no-big-filters > gpurun_out/${R}_bench_gpus2_shared_gpu.json 2> gpurun_out/${R}_bench_gpus2_shared_gpu.err
+# the fuzzers' closing sweep (bounded: ~3 minutes in all); each line is the tool's own last line
+(echo "== tools/fuzz_probe.py 7000 600"; timeout 200 python tools/fuzz_probe.py 7000 600 2>&1 | tail -1
+ echo "== tools/fuzz_sections.py 7000 400"; timeout 120 python tools/fuzz_sections.py 7000 400 2>&1 | tail -1
+ echo "== tools/fuzz_ingest_layout.py 700 150"; timeout 120 python tools/fuzz_ingest_layout.py 700 150 2>&1 | tail -1
+ echo "== tools/fuzz_build.py 700 150"; timeout 100 python tools/fuzz_build.py 700 150 2>&1 | tail -1
+ echo "== tools/fuzz_walker.py 700 50"; timeout 120 python tools/fuzz_walker.py 700 50 2>&1 | tail -1) > gpurun_out/${R}_fuzz.txt 2>&1
+cp gpurun_out/${R}_fuzz.txt gpurun_out/keep/ 2>/dev/null
 cp gpurun_out/${R}_fold_lab.txt gpurun_out/${R}_decode_lab.txt gpurun_out/${R}_c4_shard_sweep.txt gpurun_out/${R}_bench_gpus2_shared_gpu.json gpurun_out/keep/ 2>/dev/null
 # what to keep: the summaries and the bench lines (the rocprofv3 databases stay in gpurun_out/)
 mkdir -p gpurun_out/keep
