@@ -236,7 +236,8 @@ BSG_API int32_t bsg_probe_many(bsg_ctx *ctx, const uint64_t *arena_ids, uint32_t
 /* Same, survivors left at a DEVICE pointer (single-device contexts; one-process-per-GPU layers that forward them). */
 BSG_API int32_t bsg_probe_many_dev(bsg_ctx *ctx, const uint64_t *arena_ids, uint32_t n_arenas, uint64_t batch_id,
                                    uint32_t flags, void *d_out_survivors);
-/* Arenas one probe dispatch may cover (1..64; 0 = default 64). */
+/* Arenas one probe dispatch may cover (1..4096; 0 = the default, 1 024).  Up to 128 arena records ride in the dispatch's kernel
+ * arguments; a larger group uploads its records into device memory in front of the dispatch (same stream). */
 BSG_API int32_t bsg_set_probe_group(bsg_ctx *ctx, uint32_t max_arenas_per_launch);
 /* Lab knobs for tools/, bench sweeps and tests (key 1: compaction rounds of the many-term probe mode; key 2: HBM bytes a
  * binned build of a bitset beyond LDS may park its locations in, 0 = build it with global atomics; key 3: most distinct terms
@@ -244,7 +245,9 @@ BSG_API int32_t bsg_set_probe_group(bsg_ctx *ctx, uint32_t max_arenas_per_launch
  * bsg_arena_load_sections is split into, 1 = one launch after the whole copy; key 6: fewest locations (entries x k) from
  * which a bitset beyond LDS is built from binned locations instead of global atomics; keys 7 / 8: fewest entries / row bytes from
  * which a construct or match call on a context over several devices is cut into one part per device; key 9: 1 = file-level unions
- * through global hash tables instead of LDS partitions, key 10: start that partitioning 2^value x too coarse); not part of the seam. */
+ * through global hash tables instead of LDS partitions, key 10: start that partitioning 2^value x too coarse; key 11: evaluators per
+ * tile of k_probe_eval — probe and program evaluation of few-term batches in ONE dispatch —, 0 = two dispatches, the default);
+ * not part of the seam. */
 BSG_API int32_t bsg_set_lab(bsg_ctx *ctx, uint32_t key, uint64_t value);
 /* Synchronous probes poll their stream for up to this long before they block (default 0: block at once).  A single
  * query's kernels finish in ~10 us; being woken from a blocking wait costs more than that. */
