@@ -180,8 +180,7 @@ struct Device {
     std::mutex mu;                 // serialises enqueue + scratch reuse on this device
     DevBuf<uint64_t> V[2];         // verdict scratch (two slots: bsg_probe_many software-pipelines launches)
     DevBuf<uint64_t> out[2];       // survivors scratch
-    DevBuf<bsg::ArenaRef> ar_ext[2];            // arena records of a dispatch group beyond kMaxGroupArenas (device copy, per scratch slot)
-    std::vector<bsg::ArenaRef> ar_ext_host[2];  // ... and the host copy its upload reads (kept until the slot's next use)
+    DevBuf<bsg::ArenaRef> ar_ext[2];            // arena records of a dispatch group beyond kMaxGroupArenas (per scratch slot; written by k_write_arena_table)
     uint64_t fold_seq = 0;         // k_probe_eval: number of the last launch = the tag of its verdict entries
     DevBuf<uint8_t> stage_a;       // build/hash staging
     DevBuf<uint32_t> stage_off;

@@ -736,6 +736,13 @@ __global__ __launch_bounds__(kProbeThreads) void k_probe_terms_many(const ProbeA
     extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
     probe_role<kProbeThreads, false>(a, t.ar[blockIdx.z], blockIdx.x, blockIdx.y, lds64);
 }
+// Writes up to kMaxGroupArenas records of a device-memory table from the KERNEL ARGUMENTS: the records are captured when the
+// launch is enqueued, so no host buffer has to outlive an asynchronous call (a hipMemcpyAsync would read its source later).
+__global__ __launch_bounds__(kMaxGroupArenas) void k_write_arena_table(ArenaRef *dst, const ArenaTable<kMaxGroupArenas> t, uint32_t n)
+{
+    if (threadIdx.x < n) dst[threadIdx.x] = t.ar[threadIdx.x];
+}
+
 // One record of a device-memory table, fetched through the CONSTANT address space: the table is written before the dispatch and
 // never during it, the index is workgroup-uniform — so the fields arrive by scalar loads into SGPRs, as they do from the kernel
 // arguments (a plain global load put them into VGPRs: the LDS-DMA lost its scalar base and the probe 10 %).
