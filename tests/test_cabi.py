@@ -206,3 +206,7 @@ def test_survivor_row_list_expands_every_tag_on_the_host():
         assert np.array_equal(survivor_list(back[i], n_blocks), want), i
     with pytest.raises(BloomGpuError):
         survivor_row_list((2 << 30) | (n_blocks + 1), slot, n_blocks)          # a count beyond the arena's blocks
+    with pytest.raises(BloomGpuError):
+        survivor_row_list((1 << 30) | 3, slot, n_blocks)                       # ALL with a count that is not the arena's
+    with pytest.raises(BloomGpuError):
+        survivor_row_list((3 << 30) | (len(want_dense) - 1), dense, n_blocks)  # DENSE whose words disagree with the header
