@@ -11,6 +11,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "crc_slices.h"
+
 namespace bsg {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -1416,7 +1418,6 @@ __global__ __launch_bounds__(kBuildThreads) void k_build(const BuildArgs a)
 // A CRC mismatch marks the block (status -2 = ErrInvalidHash) and turns its filters into nil filters
 // (m = 0) so a corrupt section cannot poison the batch (query_exec.go:580-590 isolates it per block).
 // ---------------------------------------------------------------------------
-constexpr uint32_t kCrc32cPoly = 0x82F63B78u;
 
 constexpr int kDecodeThreads = 256;
 
@@ -1434,32 +1435,6 @@ struct CrcConsts {
 };
 constexpr uint32_t kCrcGranule = 64;   // bytes one lane checksums per trip: a wave covers 4 KiB of contiguous payload
                                        // (measured per 1 000 block sections, decode: 64 -> 70.8 us, 128 -> 90.5 us, 256 -> 116.9 us)
-
-__host__ __device__ inline uint32_t crc_multmodp(uint32_t a, uint32_t b)
-{
-    uint32_t m = 1u << 31, p = 0;
-    for (;;) {
-        if (a & m) {
-            p ^= b;
-            if ((a & (m - 1)) == 0) break;
-        }
-        m >>= 1;
-        b = (b & 1u) ? (b >> 1) ^ kCrc32cPoly : b >> 1;
-    }
-    return p;
-}
-
-// x^(n * 2^k) mod P
-__host__ __device__ inline uint32_t crc_x2nmodp(uint64_t n, uint32_t k, const uint32_t *x2n)
-{
-    uint32_t p = 1u << 31;   // x^0
-    while (n) {
-        if (n & 1) p = crc_multmodp(x2n[k & 63], p);   // k < 64 for every n < 2^61 at the k = 3 this file starts from
-        n >>= 1;
-        ++k;
-    }
-    return p;
-}
 
 // CRC32C (zero initial value, no final xor) of sec[0, P) by one workgroup of kDecodeThreads threads.
 // CRC is linear over GF(2): the payload is cut into kCrcGranule-byte granules dealt to the threads round-robin, so a wave
@@ -1523,12 +1498,6 @@ struct SectionSlot {
                              // length alone, computed by the host — on the device it was ~17 serial 32-step multiplies per workgroup
 };
 
-// what the 0xFFFFFFFF initial value and the final xor contribute to the CRC-32C of a payload of P bytes
-__host__ __device__ inline uint32_t crc_init_image(uint64_t P, const uint32_t *x2n)
-{
-    return crc_multmodp(crc_x2nmodp(P, 3, x2n), 0xFFFFFFFFu) ^ 0xFFFFFFFFu;
-}
-
 constexpr uint32_t kMaxHashCountDev = 1024;   // same bound as the host side (kMaxHashCount)
 
 __device__ __forceinline__ uint64_t rd_be64_dev(const uint8_t *p) { return __builtin_bswap64(load_u64_unaligned(p)); }
@@ -1577,22 +1546,8 @@ __device__ inline int32_t parse_section_header(const uint8_t *sec, uint32_t plen
 //   * contributions are published with write-through stores, an arrival counter tells the last workgroup of the section,
 //     which XORs them, compares with the stored checksum and writes status + descriptors.
 // grid = (most slices of any section of the run, sections [first, first + gridDim.y)).
-constexpr uint32_t kDecodeMaxSplits = 64;
-#ifndef BSG_DECODE_UNIT
-#define BSG_DECODE_UNIT 16384
-#endif
-__host__ __device__ inline uint32_t decode_unit(uint32_t P)
-{
-    const uint32_t u = (uint32_t)((((uint64_t)P + kDecodeMaxSplits - 1) / kDecodeMaxSplits + 63) / 64 * 64);
-    return u > (uint32_t)BSG_DECODE_UNIT ? u : (uint32_t)BSG_DECODE_UNIT;
-}
-__host__ __device__ inline uint32_t decode_splits(uint32_t len)      // workgroups a section of `len` bytes (CRC trailer incl.) takes
-{
-    if (len < 5) return 1;
-    const uint32_t P = len - 4, U = decode_unit(P);
-    return P == 0 ? 1u : (P + U - 1) / U;
-}
-
+// (decode_unit / decode_splits / kDecodeMaxSplits and the GF(2) arithmetic live in crc_slices.h: tests/crc_slices_check.cpp walks the
+//  same slices on the host)
 struct DecodeScratch {
     uint32_t *part;     // [slot][kDecodeMaxSplits] contributions to the section's checksum
     uint32_t *done;     // [slot] arrivals (0 before the section's launch)
