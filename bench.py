@@ -297,6 +297,18 @@ def or_reduce_leg(ctx, plan, B, fpr, n_union, world, log):
         desc[b * 3 + 1] = (b * stride, m, k, 0)        # token filters only; field / field::token left nil
     t0 = time.time()
     words = ctx.build(plan.blob, plan.off, plan.fstart, desc, B * stride)
+    # BASELINE configs[4] reduces 10 000 block filters in all: at N > 1 this rank holds its 10 000 / N of them (1 250 at N = 8) —
+    # the B built ones, then address-distinct copies of them in order (a copy adds no bit to the OR; every byte is still read from
+    # an address of its own).  N = 1 keeps the B filters of its own blocks.
+    n_f = B
+    if world > 1:
+        import torch.distributed as dist
+        n_f = C5_TOTAL_FILTERS // world + (1 if dist.get_rank() < C5_TOTAL_FILTERS % world else 0)
+        reps = (n_f + B - 1) // B
+        words = np.concatenate([words[: B * stride]] * reps)[: n_f * stride]
+        desc = np.zeros(n_f * 3, dtype=DESC_DTYPE)
+        for b in range(n_f):
+            desc[b * 3 + 1] = (b * stride, m, k, 0)
     aid = ctx.arena_load(words, desc)
     t_setup = time.time() - t0
     out = torch.zeros(nw, dtype=torch.int64, device="cuda")
@@ -324,17 +336,18 @@ def or_reduce_leg(ctx, plan, B, fpr, n_union, world, log):
     got = out.cpu().numpy().view(np.uint64)
     if not np.array_equal(got, want):
         sys.exit("OR-reduce of the block filters differs from the build of the union at the same geometry")
-    res = {"workload": "C5 OR-reduce: %d fixed-geometry token filters per GPU (m = %d bits, k = %d; %d entries) -> one partial bitset"
-                       % (B, m, k, len(idx)),
-           "kernel": "k_or_reduce_blocks", "kernel_ms": local_ms, "algorithmic_bytes": B * nw * 8 + nw * 8,
-           "achieved": (B * nw * 8 + nw * 8) / max(local_ms, 1e-6) / 1e6, "unit": "GB/s", "bound": "hbm",
+    res = {"workload": "C5 OR-reduce: %d fixed-geometry token filters on this GPU%s (m = %d bits, k = %d; %d distinct entries) -> one partial bitset"
+                       % (n_f, " of %d over %d ranks" % (C5_TOTAL_FILTERS, world) if world > 1 else "", m, k, len(idx)),
+           "filters_this_rank": n_f, "filters_total": C5_TOTAL_FILTERS if world > 1 else n_f,
+           "kernel": "k_or_reduce_blocks", "kernel_ms": local_ms, "algorithmic_bytes": n_f * nw * 8 + nw * 8,
+           "achieved": (n_f * nw * 8 + nw * 8) / max(local_ms, 1e-6) / 1e6, "unit": "GB/s", "bound": "hbm",
            "check": "equals bsg_build(union of the blocks' entries, m, k) bit for bit"}
     res["frac"] = res["achieved"] / HBM_PEAK_GBPS
     state = {"aid": aid, "out": out, "got": got, "nw": nw} if world > 1 and COLL_DEVICE() == "cuda" else None
     if state is None:
         ctx.arena_free(aid)
     log("OR-reduce: %d filters x %.0f KB in %.1f us = %.0f GB/s (%.0f%% of peak); setup %.1fs"
-        % (B, nw * 8 / 1e3, local_ms * 1e3, res["achieved"], 100 * res["frac"], t_setup))
+        % (n_f, nw * 8 / 1e3, local_ms * 1e3, res["achieved"], 100 * res["frac"], t_setup))
     return res, state
 
 
@@ -568,6 +581,10 @@ class SharedHost:
                 pass
 
 
+C5_TOTAL_FILTERS = 10000     # BASELINE configs[4]: "OR-reduce of 10 000 block bloom filters", shared over the ranks at N > 1
+CLOCK_NOTE = ("ms_per_step / value: barrier + synchronize open the region on every rank, a rank's clock stops after its own device-wide "
+              "synchronize, the job's time is the MAX over ranks (the same clock at every N); ms_per_step_closing_barrier_inside: the same "
+              "region with the closing dist.barrier() (an all-reduce kernel + stream wait under nccl) counted in")
 PROBE_KERNEL = "k_probe_terms"      # "k_probe_terms_many" for batches with more than 128 distinct terms of one kind
 
 
@@ -659,6 +676,13 @@ class Prober:
                 self.ctx._check(rc)
 
     def measure(self, make_step, steps, warmup, per_call, timed=True, out=None, words_per_step=0, nofuse=False, hdr=None, hdr_per_step=0):
+        """The same clock at every world size: a barrier + device synchronize OPENS the region on every rank; a rank's clock stops
+        after its OWN torch.cuda.synchronize() (its K steps are complete in HBM); the job's time is the MAX over ranks of those.  The
+        closing barrier of the contract still runs — after the rank's clock — and the time with it inside is kept beside the figure
+        (self.last_closing): at N > 1 a `nccl` dist.barrier() is an all-reduce kernel plus a stream wait, tens of microseconds that
+        the N = 1 clock never contains, against a timed region of ~200 us at the 8-rank shard.
+        The rotation index runs on from the warm-up into the timed steps (step i of the region is make_step(warmup + i)): the timed
+        region never starts on the arenas the warm-up just left in the 256 MiB Infinity Cache."""
         import torch
         from bloomsearch_amd import _lib
         flags = (_lib.PROBE_TIMED if timed else 0) | (_lib.PROBE_NOFUSE if nofuse else 0)
@@ -666,21 +690,31 @@ class Prober:
         self.run(self.plan([make_step(i) for i in range(warmup)], per_call, out, words_per_step, hdr, hdr_per_step), flags)
         self.ctx.sync()
         self.ctx.timing_read(reset=True)
-        calls = self.plan([make_step(i) for i in range(steps)], per_call, out, words_per_step, hdr, hdr_per_step)
+        calls = self.plan([make_step(warmup + i) for i in range(steps)], per_call, out, words_per_step, hdr, hdr_per_step)
         self.sync_all()
         t0 = time.perf_counter()
         self.run(calls, flags)
         t_enq = time.perf_counter() - t0
-        self.sync_all()                    # barrier + torch.cuda.synchronize(): the device-wide wait covers the library's streams
+        torch.cuda.synchronize()           # this rank's K steps are done: the device-wide wait covers the library's streams
         dt = time.perf_counter() - t0
-        self.ctx.sync()                    # (the library's own bookkeeping of finished copies, outside the clock)
+        dt_closing = dt
         if self.world > 1:
             import torch.distributed as dist
-            t = torch.tensor([dt], dtype=torch.float64, device=COLL_DEVICE())
+            dist.barrier()                 # the contract's closing barrier, outside the rank's clock; timed beside it
+            torch.cuda.synchronize()
+            dt_closing = time.perf_counter() - t0
+        self.ctx.sync()                    # (the library's own bookkeeping of finished copies, outside the clock)
+        dt_local = dt
+        if self.world > 1:
+            t = torch.tensor([dt, dt_closing], dtype=torch.float64, device=COLL_DEVICE())
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        self.log("%d steps: host enqueue %.2f us/step, wall %.2f us/step%s"
-                 % (steps, t_enq / steps * 1e6, dt / steps * 1e6, " (survivors delivered to host memory)" if out is not None else ""))
+            dt, dt_closing = float(t[0].item()), float(t[1].item())
+        self.last_closing = {"ms_per_step_closing_barrier_inside": dt_closing / steps * 1e3,
+                             "ms_per_step_this_rank": dt_local / steps * 1e3,
+                             "closing_barrier_us": (dt_closing - dt) * 1e6}
+        self.log("%d steps: host enqueue %.2f us/step, wall %.2f us/step (max over ranks; %.2f with the closing barrier inside)%s"
+                 % (steps, t_enq / steps * 1e6, dt / steps * 1e6, dt_closing / steps * 1e6,
+                    " (survivors delivered to host memory)" if out is not None else ""))
         return dt, self.ctx.timing_read()
 
 
@@ -942,9 +976,11 @@ def c4_leg(ctx, args, rank, world, workers, log, headline=False):
     ctx.sync()
     if args.events_in_headline:
         dt, tm = pr.measure(make, steps, c4_warm, per_call)
+        c4_clock = dict(pr.last_closing)
         dt_ev = dt
     else:                                                # bare first (the number), then the same steps with dispatch timestamps (the kernel durations)
         dt, _ = pr.measure(make, steps, c4_warm, per_call, timed=False)
+        c4_clock = dict(pr.last_closing)
         dt_ev, tm = pr.measure(make, steps, 2, per_call)
     global PROBE_KERNEL
     saved_kernel, PROBE_KERNEL = PROBE_KERNEL, "k_probe_terms"      # 77 distinct terms: the few-term kernel
@@ -955,7 +991,7 @@ def c4_leg(ctx, args, rank, world, workers, log, headline=False):
     res = {"workload": "C4: %d rows/block x %d blocks in %d files, block b on rank b %% %d, Q=%d 8-term Or(FieldToken), %d distinct terms; "
                        "%d address-distinct replicas rotated per step" % (rows, total_blocks, n_files, world, NQ, len(terms), R),
            "scaling": "strong", "n_gpus": world, "steps": steps, "ms_per_step": dt / steps * 1e3, "value": probes * steps / dt,
-           "ms_per_step_with_dispatch_timestamps": dt_ev / steps * 1e3,
+           "ms_per_step_with_dispatch_timestamps": dt_ev / steps * 1e3, "clock": dict(c4_clock, note=CLOCK_NOTE),
            "unit": "probes/s", "probes_per_step": probes, "stream_bytes_per_step_per_gpu": ft_bytes,
            "kernels": c4_kernels, "dominant_kernel": c4_dom, "warmup": c4_warm,
            "blocks_held_by_rank0": int(sum(local_blocks)),
@@ -1294,9 +1330,11 @@ def main():
     # completion signal per profiled command), which at 20 steps = one call of two dispatches is 10% of the region.
     if args.events_in_headline:
         elapsed, tm = pr.measure(make, args.steps, args.warmup, per_call, timed=True)
+        clock = dict(pr.last_closing)
         elapsed_ev = elapsed
     else:
         elapsed, _ = pr.measure(make, args.steps, args.warmup, per_call, timed=False)
+        clock = dict(pr.last_closing)
         elapsed_ev, tm = pr.measure(make, args.steps, min(args.warmup, 4), per_call, timed=True)
     timed_region = kernel_stats(tm, len(terms))
 
@@ -1415,7 +1453,7 @@ def main():
             # with every rank's survivors DMA-ed into host memory (details under host_gather)
             "value_survivors_delivered_to_host": probes_per_step * args.steps / min(h_elapsed, r_elapsed or h_elapsed),
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "ms_per_step_with_dispatch_timestamps": elapsed_ev / args.steps * 1e3,
+            "ms_per_step_with_dispatch_timestamps": elapsed_ev / args.steps * 1e3, "clock": dict(clock, note=CLOCK_NOTE),
             "timing_note": "value / ms_per_step: exactly K steps between barrier + synchronize, launches bare; the same K steps were then repeated "
                            "with HIP timestamps on every dispatch (hipExtLaunchKernelGGL start/stop events on the library's stream): "
                            "ms_per_step_with_dispatch_timestamps, and roofline.timed_region holds those dispatches' durations"
@@ -1453,12 +1491,12 @@ def main():
             # b % N, the 8-term Or batch, exactly --steps timed steps) — and the weak-scaling C2 run above moves to `c2_weak`.
             # The C4 curve over N reads: this line's `value` at N > 1, and the `c4.value` of the N = 1 line.
             ck = (c4.get("kernels") or {}).get(c4.get("dominant_kernel")) or {}
-            c2 = {key: out[key] for key in ("value", "value_survivors_delivered_to_host", "steps", "warmup", "ms_per_step", "scaling", "config",
+            c2 = {key: out[key] for key in ("value", "value_survivors_delivered_to_host", "steps", "warmup", "ms_per_step", "clock", "scaling", "config",
                                             "roofline", "host_gather")}
             out["c2_weak"] = c2
             out.update({
                 "value": c4["value"], "value_survivors_delivered_to_host": (c4["host_gather"].get("rows") or c4["host_gather"])["value"], "steps": c4["steps"],
-                "warmup": c4["warmup"], "ms_per_step": c4["ms_per_step"], "scaling": "strong",
+                "warmup": c4["warmup"], "ms_per_step": c4["ms_per_step"], "clock": c4["clock"], "scaling": "strong",
                 "config": {"workload": c4["workload"], "blocks_total": args.c4_files * args.c4_blocks_per_file, "queries": NQ,
                            "probes_per_step": c4["probes_per_step"], "sharding": "block b -> rank b % N, no collective; survivors left on the "
                            "device (host_gather: delivered to one shared page-locked host segment)",
