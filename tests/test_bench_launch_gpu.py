@@ -46,6 +46,15 @@ def test_bench_gpus_2_launches_its_own_ranks_and_reports_c4_strong_scaling():
     c2 = out["c2_weak"]
     assert c2["scaling"] == "weak" and c2["value"] > 0 and c2["config"]["workload"].startswith("C2")
     assert out["c4"]["host_gather"]["rank0_view"].startswith("file 0: 2 ranks")
+    # the N > 1 clock is the N = 1 clock: a rank's clock stops after its own synchronize and the job time is the MAX over ranks;
+    # the closing barrier is timed BESIDE it (never less, and reported as its own field)
+    ck = out["clock"]
+    assert ck == out["c4"]["clock"]
+    assert ck["ms_per_step_closing_barrier_inside"] >= out["ms_per_step"] > 0 and ck["closing_barrier_us"] >= 0
+    assert 0 < ck["ms_per_step_this_rank"] <= out["ms_per_step"] * (1 + 1e-9)
+    assert c2["clock"]["ms_per_step_closing_barrier_inside"] >= c2["ms_per_step"]
+    # BASELINE configs[4]: 10 000 block filters in all, shared over the ranks
+    assert out["or_reduce"]["filters_total"] == 10000 and out["or_reduce"]["filters_this_rank"] == 5000
 
 
 @pytest.mark.gpu
@@ -55,3 +64,5 @@ def test_bench_gpus_1_keeps_c2_as_the_headline():
     assert out["n_gpus"] == 1 and out["scaling"] == "weak" and out["config"]["workload"].startswith("C2")
     assert out["c4"]["scaling"] == "strong" and out["c4"]["n_gpus"] == 1 and "c2_weak" not in out
     assert out["roofline"]["kernel"] in ("k_probe_eval", "k_probe_terms")
+    # one rank: no closing barrier to time, both figures are the same clock
+    assert out["clock"]["ms_per_step_closing_barrier_inside"] == out["ms_per_step"] and out["clock"]["closing_barrier_us"] == 0
