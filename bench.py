@@ -825,6 +825,46 @@ def q1_latency(ctx, arena, B, n_terms_hash, log):
             "survivors": int(sum(bin(int(x)).count("1") for x in first.ravel())), **res}
 
 
+def concurrent_queries_leg(ctx, arenas, B, exprs, got, log, seconds=0.25):
+    """The Go surface's call pattern: T host threads, each calling bsg_query with ONE query (a 3-term And(FieldToken) of the C2 batch)
+    against 1 or 10 arenas — what the reference's file workers do (query_exec.go:303-357, 427-431: a goroutine per candidate file,
+    several Query() calls at once).  Native threads (tools/native/conc_driver.cpp; Python threads would measure the interpreter
+    lock).  Twice: with every call going alone (bsg_set_lab key 12 = 0: one k_query_direct dispatch per call, serialised on the
+    device's stream — the round-4 behaviour) and with the combiner on (calls that meet share dispatches).  Every result of every call
+    is compared with the batch probe's rows inside the driver."""
+    from bloomsearch_amd import conc
+    nq = min(256, len(exprs))
+    expected = np.ascontiguousarray(got[:nq])
+    n_ar = min(len(arenas), 12)
+    res = {"queries": "%d distinct 3-term And(FieldToken) queries of the C2 batch, one per call" % nq, "seconds_per_point": seconds,
+           "check": "every call's survivors compared with the batch probe's rows (bit-exact) inside the driver", "points": []}
+    for apc in (1, 10):
+        if apc > n_ar:
+            continue
+        for T in (1, 16, 64, 256):
+            row = {"threads": T, "arenas_per_call": apc}
+            for mode, name in ((0, "alone"), (1, "combined")):
+                ctx.set_lab(12, mode)
+                ctx.query_stats(reset=True)
+                r = conc.run(ctx, exprs[:nq], arenas[:n_ar], B, expected, n_threads=T, seconds=seconds, arenas_per_call=apc)
+                st = ctx.query_stats()
+                if r["mismatches"] or r["errors"]:
+                    sys.exit("concurrent_queries: %d mismatches, %d errors at T=%d, %d arenas per call, mode %s" % (r["mismatches"], r["errors"], T, apc, name))
+                row[name] = {"queries_per_s": r["queries_per_s"], "probes_per_s": r["queries_per_s"] * apc * B * 3, "p50_us": r["p50_us"], "p99_us": r["p99_us"],
+                             "calls": r["calls"]}
+                if mode:
+                    row[name].update({"cycles": st["cycles"], "calls_per_cycle": st["cycle_calls"] / max(st["cycles"], 1),
+                                      "max_calls_per_cycle": st["max_calls_per_cycle"], "dispatches": st["dispatches"]})
+            row["speedup"] = row["combined"]["queries_per_s"] / max(row["alone"]["queries_per_s"], 1e-9)
+            res["points"].append(row)
+            log("concurrent queries: T=%3d x %2d arena(s) per call: alone %.3g q/s (p50 %.0f us, p99 %.0f us), combined %.3g q/s (p50 %.0f us, p99 %.0f us, "
+                "%.1f calls per cycle) = %.1fx" % (T, apc, row["alone"]["queries_per_s"], row["alone"]["p50_us"], row["alone"]["p99_us"],
+                                                    row["combined"]["queries_per_s"], row["combined"]["p50_us"], row["combined"]["p99_us"],
+                                                    row["combined"]["calls_per_cycle"], row["speedup"]))
+    ctx.set_lab(12, 1)
+    return res
+
+
 def big_filter_leg(ctx, args, log):
     """Block filters BEYOND the LDS budget (VERDICT r03 missing 4): the reference's defaults (10 000 rows / 10 MiB per block,
     engine.go:127-128) give ~1 MB token filters once a row holds ~60 distinct tokens — 8.3 Mbit, seven times what a workgroup can
@@ -1131,6 +1171,7 @@ def main():
                          "times the K steps bare, then repeats them with the timestamps on and reports both)")
     ap.add_argument("--fold", type=int, default=-1, help="lab: evaluators per tile of k_probe_eval (bsg_set_lab key 11; 0 = two dispatches, the default)")
     ap.add_argument("--no-q1", action="store_true", help="skip the Q = 1 latency leg")
+    ap.add_argument("--no-concurrent", action="store_true", help="skip the concurrent_queries leg (T host threads x bsg_query)")
     ap.add_argument("--no-big-filters", action="store_true", help="skip the leg with block filters beyond the LDS budget (~1 MB each)")
     ap.add_argument("--no-single", action="store_true", help="skip the one-arena-per-launch sampling pass")
     args = ap.parse_args()
@@ -1387,6 +1428,9 @@ def main():
     q1 = None
     if not args.no_q1 and rank == 0 and world == 1:
         q1 = q1_latency(ctx, arenas[0], B, None, log)
+    conc_q = None
+    if not args.no_concurrent and rank == 0 and world == 1:
+        conc_q = concurrent_queries_leg(ctx, arenas, B, exprs, got, log)
 
     # ---- C2' (SURVEY 8d): the same arena replicated x S inside ONE arena so steady-state streaming
     # bandwidth is visible next to the launch-latency-bound 35 MB case (N=1 only) ----
@@ -1515,6 +1559,8 @@ def main():
                                                  note="one 1 000-block arena (35 MB) per dispatch: ~half of such a launch is dispatch ramp + completion")
         if q1:
             out["q1"] = q1
+        if conc_q:
+            out["concurrent_queries"] = conc_q
         if big:
             out["big_filters"] = big
         if c4:

@@ -21,6 +21,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <deque>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -192,6 +193,7 @@ struct Device {
     DevBuf<uint8_t> stage_region;  // encoded filter sections
     std::vector<uint8_t *> idle_staging;   // pinned 4 MiB chunk buffers of finished arena streams
     std::vector<std::pair<uint64_t *, size_t>> direct_bufs;   // idle page-locked result buffers of k_probe_direct (pointer, bytes)
+    std::vector<hipEvent_t> idle_events;      // completion events of combined query dispatches (combine_api.inc)
     uint32_t *d_direct_count = nullptr;       // finished-workgroup counter of k_probe_direct (0 between launches)
     uint64_t direct_seq = 0;                  // doorbell value of the last k_probe_direct launch
     std::vector<EventTriple> pending;
@@ -253,6 +255,19 @@ struct Batch {
 struct Ingest;   // ingest_api.inc
 struct ArenaStream;   // stream_api.inc
 
+// concurrent bsg_query callers share dispatches (combine_api.inc)
+struct QReq;
+struct Combiner {
+    std::mutex mu;
+    std::deque<QReq *> queue;     // calls waiting to be collected (the head is the next collector)
+    bool collecting = false;      // a caller is collecting / preparing / enqueueing a cycle (or going alone)
+    uint32_t inflight = 0;        // cycles handed to the devices and not yet dealt out
+    uint32_t mode = 1;            // 0: every call goes alone (bsg_set_lab key 12)
+    uint32_t max_inflight = 2;    // cycles in flight (bsg_set_lab key 13): one running, one being prepared behind it
+    uint32_t max_calls = 256;     // calls one cycle collects (bsg_set_lab key 14)
+    uint64_t n_calls = 0, n_solo = 0, n_cycles = 0, n_cycle_calls = 0, n_dispatches = 0, max_cycle_calls = 0;
+};
+
 }  // namespace
 
 struct bsg_ctx {
@@ -289,6 +304,7 @@ struct bsg_ctx {
     // 322 + 39 us as two dispatches; wall 134.8 vs 133.2 us.  The survivor words written under the stream leave L2 as partial lines
     // before the other tiles complete them, which costs what the second dispatch's ramp would (bsg_set_lab key 11 turns it on)
     uint32_t fold_helpers = 0;
+    Combiner cmb;                // concurrent bsg_query calls merged into shared dispatches (combine_api.inc)
     // write side / matcher over several devices: a call large enough is cut into one part per device (contiguous runs of
     // filters / sets / rows), each part on a thread of its own; smaller calls take ONE device, chosen round-robin among
     // the ones whose lock is free, so independent callers (flush worker, merge, block workers) spread over the context
@@ -428,11 +444,8 @@ void free_batch(bsg_ctx *ctx, Batch &b)
     b.subs.clear();
     for (size_t i = 0; i < b.dev.size(); ++i) {
         (void)hipSetDevice(ctx->devs[i]->id);
-        if (b.dev[i].d_th) (void)hipFree(b.dev[i].d_th);
-        if (b.dev[i].d_prog) (void)hipFree(b.dev[i].d_prog);
-        if (b.dev[i].d_chunk_len) (void)hipFree(b.dev[i].d_chunk_len);
-        if (b.dev[i].d_cw_cnt) (void)hipFree(b.dev[i].d_cw_cnt);
-        if (b.dev[i].d_cw) (void)hipFree(b.dev[i].d_cw);
+        if (b.dev[i].d_th) (void)hipFree(b.dev[i].d_th);       // one block holds the five tables (probe_api.inc: BatchTables), d_th is its base
+        b.dev[i] = BatchDev{};
     }
 }
 
@@ -1192,6 +1205,7 @@ int32_t bsg_arena_free(bsg_ctx *ctx, uint64_t arena_id)
 }  // extern "C"
 
 #include "probe_api.inc"
+#include "combine_api.inc"
 
 extern "C" {
 

@@ -289,6 +289,12 @@ class Context:
             o += sz
         return res
 
+    def query_stats(self, reset: bool = True) -> dict:
+        """How the eligible bsg_query calls were served since the last reset (the combiner of concurrent callers)."""
+        t = _lib.QueryStats()
+        self._check(self.L.bsg_query_stats_read(self.h, C.byref(t), 1 if reset else 0))
+        return {f: int(getattr(t, f)) for f, _ in _lib.QueryStats._fields_}
+
     def timing_read(self, reset: bool = True) -> Timing:
         t = Timing()
         self._check(self.L.bsg_timing_read(self.h, C.byref(t), 1 if reset else 0))

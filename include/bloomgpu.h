@@ -297,6 +297,26 @@ BSG_API int32_t bsg_query(bsg_ctx *ctx, const uint64_t *arena_ids, uint32_t n_ar
                           const uint8_t *term_bytes, const uint32_t *term_off, const uint32_t *term_kinds, uint32_t n_terms,
                           const uint32_t *prog_ops, const uint32_t *prog_off, uint32_t n_queries, uint64_t *out_survivors);
 
+/* Concurrent bsg_query calls on one context SHARE dispatches (the reference consults every candidate file of a Query() from a worker
+ * goroutine of its own, query_exec.go:303-357, 427-431, and runs several Query() calls at once — mirrored call by call that is one
+ * ~8 us dispatch per (query, file), serialised on the device's stream).  A call that finds the device idle goes alone, at once, as
+ * described above.  Calls that arrive while another is collecting or in flight queue inside the library; the head of the queue
+ * collects everything queued (<= 256 queries / 128 arena references), merges calls on the same arena list into one batch (each
+ * distinct term probed once) and arena lists asked the same queries into one dispatch — the reference's own pattern: one query, one
+ * call per candidate file — enqueues one dispatch per merged group, hands the collector role on (two cycles in flight) and deals
+ * every caller its rows.  Nobody waits for a window to fill; results equal the solo path's bit for bit.  Calls with more than 64
+ * queries / 64 terms / 32 arenas always go alone.  bsg_set_lab key 12 = 0 turns combining off (13: cycles in flight, 14: calls per
+ * cycle).  bsg_query_stats_read: how calls were served since the last reset. */
+typedef struct bsg_query_stats {
+    uint64_t calls;                /* bsg_query calls that were eligible for combining                      */
+    uint64_t solo_calls;           /* ... served by a dispatch of their own                                */
+    uint64_t cycles;               /* collector cycles (a solo call is a cycle of one)                      */
+    uint64_t cycle_calls;          /* calls served by those cycles                                          */
+    uint64_t dispatches;           /* merged-group dispatches (per device) the combined cycles enqueued     */
+    uint64_t max_calls_per_cycle;
+} bsg_query_stats;
+BSG_API int32_t bsg_query_stats_read(bsg_ctx *ctx, bsg_query_stats *out, int32_t reset);
+
 /* The surviving blocks of ONE query as the reference's probe hands them on: blockScanCandidate{index} per survivor in the order
  * the blocks were consulted (ascending RowDataOffset, query_exec.go:321, 603) = the ascending bit positions of the query's row
  * survivor_row[ceil(n_blocks / 64)] of a bsg_probe* / bsg_query result, for an arena loaded in that block order.  out_blocks may be

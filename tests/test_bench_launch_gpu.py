@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 SMALL = ["--blocks", "128", "--rows-per-block", "1000", "--queries", "512", "--c4-files", "2", "--c4-blocks-per-file", "128",
          "--ingest-blocks", "0", "--scaled", "0", "--no-decode", "--cpu-budget", "0", "--or-union", "20000", "--no-q1", "--no-single",
-         "--samples", "2", "--no-big-filters"]
+         "--samples", "2", "--no-big-filters", "--no-concurrent"]
 
 
 def run_bench(extra, env_extra=None, timeout=600):

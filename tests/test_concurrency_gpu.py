@@ -138,3 +138,91 @@ def test_many_threads_one_sharded_context():
         assert not errors, errors
         assert all(results)
         assert (m.device_calls() > 0).all()
+
+
+# ---- concurrent bsg_query callers share dispatches (csrc/combine_api.inc) ----
+
+def _combiner_case(ctx, seed, n_threads, rounds):
+    """Python threads, each issuing bsg_query calls of random queries over random arena subsets — the same few arenas and a small
+    pool of queries, so calls meet on arena lists and on query sets, while others differ in both — every result against the oracle's
+    tree-walking evaluator."""
+    rng = np.random.default_rng(seed)
+    plans, words, aids = [], [], []
+    vocab = None
+    for nb in (1, 63, 64, 130, 257, 1000):
+        plan, _, vocab = H.make_random_arena(rng, nb, absent_frac=0.03, max_tokens=120, vocab_size=40)
+        w = ctx.build(plan.blob, plan.off, plan.fstart, plan.desc, plan.n_words)
+        plans.append(plan); words.append(w); aids.append(ctx.arena_load(w, plan.desc))
+    pool = [Q.And(Q.Token(vocab[i % 40]), Q.Or(Q.FieldToken("f%d" % (i % 9), vocab[(i * 7) % 40]), Q.Field("f%d" % (i % 45)))) for i in range(12)]
+    pool += [H.random_expression(rng, vocab[:12], None) for _ in range(12)] + [None]
+    want = [[O.survivors_tree(w, p.desc.view(O.DESC_DTYPE), [e])[0] for e in pool] for w, p in zip(words, plans)]
+    lists = [[0], [5], [2, 3], [5, 4], [1, 0, 5], [3]]
+    errors = []
+    gate = threading.Barrier(n_threads)
+
+    def run(t):
+        r = np.random.default_rng(seed * 1000 + t)
+        try:
+            gate.wait(timeout=60)
+            for _ in range(rounds):
+                sub = lists[int(r.integers(0, len(lists)))]
+                qs = [int(x) for x in r.integers(0, len(pool), size=int(r.choice([1, 1, 1, 2, 5])))]
+                got = ctx.query([aids[i] for i in sub], [plans[i].n_blocks for i in sub], Q.compile_queries([pool[q] for q in qs]))
+                for g, i in zip(got, sub):
+                    for row, q in zip(g, qs):
+                        assert np.array_equal(row, want[i][q]), "thread %d: arena %d query %d differs from the oracle" % (t, i, q)
+        except BaseException as exc:  # noqa: BLE001
+            errors.append((t, repr(exc)))
+
+    ths = [threading.Thread(target=run, args=(t,)) for t in range(n_threads)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    for a in aids:
+        ctx.arena_free(a)
+    assert not errors, errors[:3]
+
+
+def test_concurrent_queries_equal_the_oracle_whatever_they_are_merged_with(ctx):
+    ctx.query_stats(reset=True)
+    _combiner_case(ctx, 11, 24, ROUNDS * 25)
+    st = ctx.query_stats()
+    assert st["calls"] == 24 * ROUNDS * 25 and st["cycle_calls"] == st["calls"]
+    assert st["max_calls_per_cycle"] > 1, "no two calls ever shared a cycle: %r" % (st,)
+
+
+def test_concurrent_queries_on_a_sharded_context():
+    from bloomsearch_amd.gpu import Context
+    with Context((0, 0, 0)) as m:
+        _combiner_case(m, 12, 12, ROUNDS * 10)
+        assert m.query_stats()["max_calls_per_cycle"] > 1
+
+
+def test_native_callers_share_dispatches_bit_exactly(ctx):
+    """T native threads (no interpreter lock between them) x bsg_query of one 3-term query against 1 and 3 arenas: every result
+    compared inside the driver with the rows the solo path returned — which are checked against the oracle here."""
+    from bloomsearch_amd import conc
+    blocks = [synth.block_entry_sets(b * 400, 400) for b in range(200)]
+    from bloomsearch_amd.arena import plan_blocks
+    plan = plan_blocks(blocks, 0.001)
+    words = ctx.build(plan.blob, plan.off, plan.fstart, plan.desc, plan.n_words)
+    aids = [ctx.arena_load(words, plan.desc) for _ in range(6)]
+    exprs = synth.make_queries(48, "c2", seed=77)
+    ctx.set_lab(12, 0)
+    expected = np.stack([ctx.query([aids[0]], [200], Q.compile_queries([e]))[0][0] for e in exprs])
+    assert np.array_equal(expected, O.survivors_tree(words, plan.desc.view(O.DESC_DTYPE), exprs))
+    ctx.query_stats(reset=True)
+    off = conc.run(ctx, exprs, aids, 200, expected, n_threads=32, seconds=0.3)
+    st_off = ctx.query_stats()
+    assert off["mismatches"] == 0 and off["errors"] == 0 and off["calls"] > 0
+    assert st_off["calls"] == 0                                     # combining off: no call ever reaches the combiner
+    ctx.set_lab(12, 1)
+    for apc in (1, 3):
+        on = conc.run(ctx, exprs, aids, 200, expected, n_threads=32, seconds=0.3, arenas_per_call=apc)
+        st = ctx.query_stats()
+        assert on["mismatches"] == 0 and on["errors"] == 0 and on["calls"] > 0
+        assert st["calls"] == on["calls"] == st["cycle_calls"]
+        assert st["max_calls_per_cycle"] > 4 and st["cycles"] < st["calls"], st
+    for a in aids:
+        ctx.arena_free(a)
