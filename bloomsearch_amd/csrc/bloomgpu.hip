@@ -265,7 +265,11 @@ struct Combiner {
     uint32_t mode = 1;            // 0: every call goes alone (bsg_set_lab key 12)
     uint32_t max_inflight = 2;    // cycles in flight (bsg_set_lab key 13): one running, one being prepared behind it
     uint32_t max_calls = 256;     // calls one cycle collects (bsg_set_lab key 14)
-    uint64_t n_calls = 0, n_solo = 0, n_cycles = 0, n_cycle_calls = 0, n_dispatches = 0, max_cycle_calls = 0;
+    uint32_t linger_us = 0, linger_calls = 0;   // lab (bsg_set_lab key 15): a collector waits this long / for this many queued calls
+    uint32_t hot_min_queries = 24;              // an arena asked at least this many queries in a cycle is streamed once for all of them (key 16; 0: never)
+    uint32_t spin_us = 400;                     // a queued caller polls this long before it sleeps in a futex (key 17)
+    uint64_t n_calls = 0, n_solo = 0, n_cycles = 0, n_cycle_calls = 0, n_dispatches = 0, n_hot = 0, max_cycle_calls = 0;
+    uint64_t ns_prepare = 0, ns_enqueue = 0, ns_wait = 0, ns_deal = 0, ns_wake = 0;   // the combined cycles' phases, summed (collector's clock)
 };
 
 }  // namespace

@@ -35,10 +35,10 @@ __host__ __device__ inline uint32_t direct_lds_bytes(uint32_t Wt, uint32_t max_d
 
 // The shared body: th = SoA term hashes th[j * a.Tp + pos]; prog = the chunk's programs, op j of lane l at prog[j * prog_stride + l];
 // len = ops of the longest program.  A kind's terms sit at positions term_begin .. term_begin + term_count of th AND of VT.
+// g = the workgroup's 64-block group of the arena; n_wg = workgroups of the launch (the doorbell rings when all are done).
 __device__ __forceinline__ void direct_body(const DirectArgs &a, const uint64_t *th, const uint32_t *prog, uint32_t prog_stride, uint32_t len,
-                                            const ArenaRef &ar, uint64_t *lds64)
+                                            const ArenaRef &ar, uint64_t *lds64, const uint32_t g, const uint32_t n_wg)
 {
-    const uint32_t g = blockIdx.x;
     const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
     if (g < ar.G()) {                                              // (arenas of a group may differ in size)
     constexpr uint32_t n_waves = kEvalThreads / kWave;
@@ -125,7 +125,6 @@ __device__ __forceinline__ void direct_body(const DirectArgs &a, const uint64_t 
         __threadfence_system();                                  // this workgroup's survivor words reach the host before the count moves
         __syncthreads();
         if (tid == 0) {
-            const uint32_t n_wg = gridDim.x * gridDim.z;
             if (__hip_atomic_fetch_add(a.done_count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u == n_wg) {
                 __hip_atomic_store(a.done_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(a.flag, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -138,7 +137,7 @@ __device__ __forceinline__ void direct_body(const DirectArgs &a, const uint64_t 
 __global__ __launch_bounds__(kEvalThreads) void k_probe_direct(const DirectArgs a, const ArenaTable<kMaxGroupArenas> t)
 {
     extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
-    direct_body(a, a.th, a.prog, kEvalThreads, a.chunk_len[0], t.ar[blockIdx.z], lds64);
+    direct_body(a, a.th, a.prog, kEvalThreads, a.chunk_len[0], t.ar[blockIdx.z], lds64, blockIdx.x, gridDim.x * gridDim.z);
 }
 
 // ---- the same dispatch with NOTHING uploaded beforehand: bsg_query ----
@@ -168,7 +167,56 @@ __global__ __launch_bounds__(kEvalThreads) void k_query_direct(const QueryKernAr
     const uint64_t *th = reinterpret_cast<const uint64_t *>(ka + offsetof(QueryKernArgs, th));
     const uint32_t *prog = reinterpret_cast<const uint32_t *>(ka + offsetof(QueryKernArgs, prog));
     const ArenaRef *ar = reinterpret_cast<const ArenaRef *>(ka + offsetof(QueryKernArgs, t)) + blockIdx.z;
-    direct_body(q.a, th, prog, q.stride, q.len, *ar, lds64);
+    direct_body(q.a, th, prog, q.stride, q.len, *ar, lds64, blockIdx.x, gridDim.x * gridDim.z);
+}
+
+// ---- MANY such calls in one dispatch: the job list of a combiner cycle (combine_api.inc) ----
+// Concurrent bsg_query callers (the reference's file workers: one goroutine per candidate file, several Query() calls at once,
+// query_exec.go:303-357, 427-431) each ask for one small query set against a few arenas.  A JOB is one (call, arena) pair; a
+// workgroup is one 64-block group of one job and runs the body above unchanged — its term hashes and programs lie in a table
+// uploaded once per cycle (a call's jobs share them), its rows go to the job's own place in page-locked memory, and ONE doorbell
+// rings for the whole list.  Cost follows the pairs asked for, not the product of all queries and all arenas of the cycle.
+struct QJob {
+    const uint64_t *words;       // the arena shard
+    const DevDesc *desc;
+    uint32_t n_blocks;
+    uint32_t wg0;                // first workgroup of the job (jobs ascending; a job owns ceil(n_blocks / 64) workgroups)
+    uint64_t out_off;            // first word of the job's rows [n_queries][G] in the result
+    uint32_t th_off;             // u64 index into the table: th[j * kQueryMaxTerms + pos], j < 4
+    uint32_t prog_off;           // u32 index into the table (as u32): prog[j * n_queries + q]
+    uint16_t n_queries, len, max_depth, n_kinds;
+    uint8_t kind[4], term_begin[4], term_count[4];
+    uint32_t pad;
+};
+static_assert(sizeof(QJob) == 64, "one job record per 64-byte line");
+
+struct JobsArgs {
+    const QJob *jobs;            // device memory (the cycle's table; hashes and programs behind the records)
+    const uint64_t *tab;         // the same table, as u64 / u32 words
+    uint64_t *out;               // page-locked host memory
+    uint32_t n_jobs, n_wg;
+    uint32_t *done_count; uint64_t *flag; uint64_t seq;
+};
+
+__global__ __launch_bounds__(kEvalThreads) void k_query_jobs(const JobsArgs j)
+{
+    extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
+    // the job of this workgroup: the last record whose first workgroup is <= blockIdx.x (wave-uniform: scalar loads)
+    uint32_t lo = 0, hi = j.n_jobs;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (j.jobs[mid].wg0 <= blockIdx.x) lo = mid; else hi = mid;
+    }
+    const QJob &J = j.jobs[lo];
+    DirectArgs a{};
+    a.out = j.out + J.out_off;
+    a.Tp = kQueryMaxTerms; a.Wt = 1; a.n_queries = J.n_queries; a.Lmax = J.len; a.max_depth = J.max_depth; a.n_kinds = J.n_kinds;
+#pragma unroll
+    for (uint32_t y = 0; y < 3; ++y) { a.kind[y] = J.kind[y]; a.term_begin[y] = J.term_begin[y]; a.term_count[y] = J.term_count[y]; }
+    a.n_arenas = 1;
+    a.done_count = j.done_count; a.flag = j.flag; a.seq = j.seq;
+    const ArenaRef ar{J.words, J.desc, J.n_blocks, 0u};
+    direct_body(a, j.tab + J.th_off, reinterpret_cast<const uint32_t *>(j.tab) + J.prog_off, J.n_queries, J.len, ar, lds64, blockIdx.x - J.wg0, j.n_wg);
 }
 
 }  // namespace bsg

@@ -301,19 +301,24 @@ BSG_API int32_t bsg_query(bsg_ctx *ctx, const uint64_t *arena_ids, uint32_t n_ar
  * goroutine of its own, query_exec.go:303-357, 427-431, and runs several Query() calls at once — mirrored call by call that is one
  * ~8 us dispatch per (query, file), serialised on the device's stream).  A call that finds the device idle goes alone, at once, as
  * described above.  Calls that arrive while another is collecting or in flight queue inside the library; the head of the queue
- * collects everything queued (<= 256 queries / 128 arena references), merges calls on the same arena list into one batch (each
- * distinct term probed once) and arena lists asked the same queries into one dispatch — the reference's own pattern: one query, one
- * call per candidate file — enqueues one dispatch per merged group, hands the collector role on (two cycles in flight) and deals
- * every caller its rows.  Nobody waits for a window to fill; results equal the solo path's bit for bit.  Calls with more than 64
- * queries / 64 terms / 32 arenas always go alone.  bsg_set_lab key 12 = 0 turns combining off (13: cycles in flight, 14: calls per
- * cycle).  bsg_query_stats_read: how calls were served since the last reset. */
+ * collects everything queued (<= 256 calls) as (call, arena) pairs: an arena asked >= 24 queries in the cycle is STREAMED once for
+ * all of them (their query sets merged into one batch, each distinct term probed once: k_probe_terms + k_eval_programs), every other
+ * pair is a job of ONE k_query_jobs dispatch (gather regime: cost follows the pairs asked for — one query, one call per candidate
+ * file is a list of such jobs).  The collector hands its role on (two cycles in flight) and deals every caller its rows.  Nobody
+ * waits for a window to fill; results equal the solo path's bit for bit.  Calls beyond 16 terms / 128 program words / 64 queries /
+ * 32 arenas always go alone.  bsg_set_lab key 12 = 0 turns combining off (13: cycles in flight, 14: calls per cycle, 16: the
+ * hot-arena threshold, 17: microseconds a queued caller polls before it sleeps).  bsg_query_stats_read: how calls were served. */
 typedef struct bsg_query_stats {
     uint64_t calls;                /* bsg_query calls that were eligible for combining                      */
     uint64_t solo_calls;           /* ... served by a dispatch of their own                                */
     uint64_t cycles;               /* collector cycles (a solo call is a cycle of one)                      */
     uint64_t cycle_calls;          /* calls served by those cycles                                          */
-    uint64_t dispatches;           /* merged-group dispatches (per device) the combined cycles enqueued     */
+    uint64_t dispatches;           /* dispatches (per device) the combined cycles enqueued: hot arenas + job lists */
+    uint64_t hot_arenas;           /* ... of which arenas streamed once for all their callers               */
     uint64_t max_calls_per_cycle;
+    /* the combined cycles' phases on their collectors' clocks, summed (ns): merging + planning the batches; enqueueing (tables up,
+     * dispatches); waiting for the device; dealing the rows out + releasing the callers (ns_wake: the releasing part of that) */
+    uint64_t ns_prepare, ns_enqueue, ns_wait, ns_deal, ns_wake;
 } bsg_query_stats;
 BSG_API int32_t bsg_query_stats_read(bsg_ctx *ctx, bsg_query_stats *out, int32_t reset);
 
