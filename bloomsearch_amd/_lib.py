@@ -37,7 +37,8 @@ class Timing(C.Structure):
 class QueryStats(C.Structure):
     _fields_ = [("calls", C.c_uint64), ("solo_calls", C.c_uint64), ("cycles", C.c_uint64), ("cycle_calls", C.c_uint64),
                 ("dispatches", C.c_uint64), ("hot_arenas", C.c_uint64), ("max_calls_per_cycle", C.c_uint64),
-                ("ns_prepare", C.c_uint64), ("ns_enqueue", C.c_uint64), ("ns_wait", C.c_uint64), ("ns_deal", C.c_uint64), ("ns_wake", C.c_uint64)]
+                ("ns_prepare", C.c_uint64), ("ns_enqueue", C.c_uint64), ("ns_wait", C.c_uint64), ("ns_deal", C.c_uint64), ("ns_wake", C.c_uint64),
+                ("ns_scatter", C.c_uint64), ("ns_free", C.c_uint64), ("ns_retire", C.c_uint64)]
 
 
 class IngestStats(C.Structure):

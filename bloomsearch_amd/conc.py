@@ -26,7 +26,7 @@ class ConcQuery(C.Structure):
 
 
 class ConcResult(C.Structure):
-    _fields_ = [("calls", C.c_uint64), ("mismatches", C.c_uint64), ("errors", C.c_uint64), ("seconds", C.c_double), ("n_lat", C.c_uint64)]
+    _fields_ = [("calls", C.c_uint64), ("mismatches", C.c_uint64), ("errors", C.c_uint64), ("seconds", C.c_double), ("n_lat", C.c_uint64), ("cpu_seconds", C.c_double)]
 
 
 def build(force: bool = False) -> str:
@@ -83,4 +83,5 @@ def run(ctx, exprs, arena_ids, n_blocks, expected, n_threads, seconds, arenas_pe
     l = np.sort(lat[: int(res.n_lat)]) / 1e3
     return {"threads": n_threads, "arenas_per_call": arenas_per_call, "calls": int(res.calls), "seconds": float(res.seconds),
             "queries_per_s": res.calls / max(res.seconds, 1e-9), "mismatches": int(res.mismatches), "errors": int(res.errors),
+            "cpu_us_per_call": res.cpu_seconds / max(res.calls, 1) * 1e6, "cpus_busy": res.cpu_seconds / max(res.seconds, 1e-9),
             "p50_us": float(l[len(l) // 2]) if len(l) else None, "p99_us": float(l[min(len(l) - 1, int(len(l) * 0.99))]) if len(l) else None}

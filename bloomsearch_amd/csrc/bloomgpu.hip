@@ -25,6 +25,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <shared_mutex>
 #include <random>
 #include <string>
 #include <thread>
@@ -169,6 +170,9 @@ struct DevPool {
     }
 };
 
+// scratch of one combined query dispatch (combine_api.inc): the table's device block, its page-locked stage, the page-locked result
+struct CmbSet { void *d_block = nullptr; size_t d_cap = 0; std::pair<uint64_t *, size_t> stage{nullptr, 0}, result{nullptr, 0}; };
+
 struct Device {
     int id = 0;
     uint32_t n_cus = 256;
@@ -193,7 +197,8 @@ struct Device {
     DevBuf<uint8_t> stage_region;  // encoded filter sections
     std::vector<uint8_t *> idle_staging;   // pinned 4 MiB chunk buffers of finished arena streams
     std::vector<std::pair<uint64_t *, size_t>> direct_bufs;   // idle page-locked result buffers of k_probe_direct (pointer, bytes)
-    std::vector<hipEvent_t> idle_events;      // completion events of combined query dispatches (combine_api.inc)
+    std::mutex cmb_mu;                        // guards cmb_sets only
+    std::vector<CmbSet> cmb_sets;             // idle scratch sets of combined query dispatches
     uint32_t *d_direct_count = nullptr;       // finished-workgroup counter of k_probe_direct (0 between launches)
     uint64_t direct_seq = 0;                  // doorbell value of the last k_probe_direct launch
     std::vector<EventTriple> pending;
@@ -255,21 +260,21 @@ struct Batch {
 struct Ingest;   // ingest_api.inc
 struct ArenaStream;   // stream_api.inc
 
-// concurrent bsg_query callers share dispatches (combine_api.inc)
+// concurrent bsg_query callers share dispatches (combine_api.inc).  No mutex on the way in: with hundreds of callers a contended
+// lock hands over at ~5-10 us a time (its waiters sleep), which by itself bounds the context at ~10^5 calls a second.
 struct QReq;
 struct Combiner {
-    std::mutex mu;
-    std::deque<QReq *> queue;     // calls waiting to be collected (the head is the next collector)
-    bool collecting = false;      // a caller is collecting / preparing / enqueueing a cycle (or going alone)
-    uint32_t inflight = 0;        // cycles handed to the devices and not yet dealt out
+    std::atomic<QReq *> head{nullptr};          // calls waiting to be collected: a lock-free stack (callers push; only the collector takes)
+    std::atomic<uint32_t> gate{0};              // bit 31: a caller is collecting / preparing / enqueueing a cycle; low bits: cycles in flight
+    std::atomic<uint32_t> n_queued{0};
     uint32_t mode = 1;            // 0: every call goes alone (bsg_set_lab key 12)
     uint32_t max_inflight = 2;    // cycles in flight (bsg_set_lab key 13): one running, one being prepared behind it
-    uint32_t max_calls = 256;     // calls one cycle collects (bsg_set_lab key 14)
     uint32_t linger_us = 0, linger_calls = 0;   // lab (bsg_set_lab key 15): a collector waits this long / for this many queued calls
     uint32_t hot_min_queries = 24;              // an arena asked at least this many queries in a cycle is streamed once for all of them (key 16; 0: never)
-    uint32_t spin_us = 400;                     // a queued caller polls this long before it sleeps in a futex (key 17)
-    uint64_t n_calls = 0, n_solo = 0, n_cycles = 0, n_cycle_calls = 0, n_dispatches = 0, n_hot = 0, max_cycle_calls = 0;
-    uint64_t ns_prepare = 0, ns_enqueue = 0, ns_wait = 0, ns_deal = 0, ns_wake = 0;   // the combined cycles' phases, summed (collector's clock)
+    uint32_t spin_us = 60;                      // a queued caller polls this long before it sleeps in a futex (key 17)
+    std::atomic<uint64_t> n_calls{0}, n_solo{0}, n_cycles{0}, n_cycle_calls{0}, n_dispatches{0}, n_hot{0}, max_cycle_calls{0};
+    std::atomic<uint64_t> ns_scatter{0}, ns_free{0}, ns_retire{0};   // parts of ns_deal
+    std::atomic<uint64_t> ns_prepare{0}, ns_enqueue{0}, ns_wait{0}, ns_deal{0}, ns_wake{0};   // the combined cycles' phases, summed (collector's clock)
 };
 
 }  // namespace
@@ -279,7 +284,7 @@ struct bsg_ctx {
     std::mutex err_mu;
     std::string err;             // last failure recorded on this scope / context
     std::vector<std::unique_ptr<Device>> devs;
-    std::mutex mu;  // handle tables
+    std::shared_mutex mu;  // handle tables (looked up under a shared lock by every probe / query call, changed under an exclusive one)
     std::map<uint64_t, std::shared_ptr<Arena>> arenas;
     std::map<uint64_t, std::shared_ptr<Batch>> batches;
     std::map<uint64_t, std::shared_ptr<Ingest>> ingests;
@@ -461,7 +466,7 @@ int32_t drain_timing(bsg_ctx *ctx, Device &d)
         float a = 0, b = 0;
         if (t.has_k1) HIP_TRY(hipEventElapsedTime(&a, t.k1s, t.k1e));
         if (t.has_k2) HIP_TRY(hipEventElapsedTime(&b, t.k2s, t.k2e));
-        std::lock_guard<std::mutex> lk(ctx->mu);
+        std::lock_guard<std::shared_mutex> lk(ctx->mu);
         if (t.has_k1 && t.folded) {
             ctx->timing.n_folded += 1;
             ctx->timing.ms_folded_kernel += a;
@@ -558,7 +563,7 @@ int32_t lower_program(const uint32_t *ops, uint32_t n_ops, uint32_t n_terms, con
 
 int32_t get_arena(bsg_ctx *ctx, uint64_t id, std::shared_ptr<Arena> &out)
 {
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::shared_lock<std::shared_mutex> lk(ctx->mu);
     auto it = ctx->arenas.find(id);
     if (it == ctx->arenas.end()) return fail(BSG_E_NOTFOUND, "unknown arena id %llu", (unsigned long long)id);
     out = it->second;
@@ -567,7 +572,7 @@ int32_t get_arena(bsg_ctx *ctx, uint64_t id, std::shared_ptr<Arena> &out)
 
 int32_t get_batch(bsg_ctx *ctx, uint64_t id, std::shared_ptr<Batch> &out)
 {
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::shared_lock<std::shared_mutex> lk(ctx->mu);
     auto it = ctx->batches.find(id);
     if (it == ctx->batches.end()) return fail(BSG_E_NOTFOUND, "unknown batch id %llu", (unsigned long long)id);
     out = it->second;
@@ -699,6 +704,11 @@ int32_t bsg_close(bsg_ctx *ctx)
         d.pool.trim(0);
         for (uint8_t *p : d.idle_staging) (void)hipHostFree(p);
         for (auto &p : d.direct_bufs) (void)hipHostFree(p.first);
+        for (auto &cs : d.cmb_sets) {
+            if (cs.d_block) (void)hipFree(cs.d_block);
+            if (cs.stage.first) (void)hipHostFree(cs.stage.first);
+            if (cs.result.first) (void)hipHostFree(cs.result.first);
+        }
         if (d.d_direct_count) (void)hipFree(d.d_direct_count);
         if (d.d_crc) (void)hipFree(d.d_crc);
         if (d.d_lower) (void)hipFree(d.d_lower);
@@ -819,7 +829,7 @@ int32_t bsg_hash_entries(bsg_ctx *ctx, const uint8_t *bytes, const uint32_t *off
         return hash_entries_on(*ctx->devs[(first + i) % nd], bytes, offsets, e0, e1, out_h, &ms[i]);
     });
     if (rc) return rc;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::shared_mutex> lk(ctx->mu);
     ctx->last_hash_ms = *std::max_element(ms.begin(), ms.end());
     return BSG_OK;
 }
@@ -1054,7 +1064,7 @@ static int32_t build_common(bsg_ctx *ctx, const uint8_t *bytes, const uint32_t *
         for (const BuildPart &P : parts)
             for (uint32_t b = P.f0 / 3; b <= P.f1 / 3; ++b) sections->sec_off[b] = P.region_off + P.sec_off_local[b - P.f0 / 3];
     }
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::shared_mutex> lk(ctx->mu);
     ctx->last_build_ms = ms;
     if (sections) ctx->last_encode_ms = ems;
     return BSG_OK;
@@ -1147,7 +1157,7 @@ int32_t bsg_arena_load(bsg_ctx *ctx, const uint64_t *words, uint64_t n_words, co
         free_arena(ctx, *arena);
         return fail(e == hipErrorOutOfMemory ? BSG_E_NOMEM : BSG_E_HIP, "arena upload failed: %s", hipGetErrorString(e));
     }
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::shared_mutex> lk(ctx->mu);
     const uint64_t id = ctx->next_id++;
     ctx->arenas[id] = arena;
     *out_arena_id = id;
@@ -1191,7 +1201,7 @@ int32_t bsg_arena_free(bsg_ctx *ctx, uint64_t arena_id)
     if (!ctx) return fail(BSG_E_INVALID, "ctx is null");
     std::shared_ptr<Arena> a;
     {
-        std::lock_guard<std::mutex> lk(ctx->mu);
+        std::lock_guard<std::shared_mutex> lk(ctx->mu);
         auto it = ctx->arenas.find(arena_id);
         if (it == ctx->arenas.end()) return fail(BSG_E_NOTFOUND, "unknown arena id %llu", (unsigned long long)arena_id);
         a = it->second;
@@ -1217,7 +1227,7 @@ int32_t bsg_last_kernel_ms(bsg_ctx *ctx, float *build_ms, float *hash_ms, float 
 {
     BSG_ENTER(ctx);
     if (!ctx) return fail(BSG_E_INVALID, "ctx is null");
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::shared_mutex> lk(ctx->mu);
     if (build_ms) *build_ms = ctx->last_build_ms;
     if (hash_ms) *hash_ms = ctx->last_hash_ms;
     if (decode_ms) *decode_ms = ctx->last_decode_ms;
@@ -1268,7 +1278,7 @@ int32_t bsg_last_or_ms(bsg_ctx *ctx, float *or_ms)
 {
     BSG_ENTER(ctx);
     if (!ctx || !or_ms) return fail(BSG_E_INVALID, "null argument");
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::shared_mutex> lk(ctx->mu);
     *or_ms = ctx->last_or_ms;
     return BSG_OK;
 }
@@ -1282,7 +1292,7 @@ int32_t bsg_timing_read(bsg_ctx *ctx, bsg_timing *out, int32_t reset)
         if (int32_t rc = use_device(*dp)) return rc;
         if (int32_t rc = drain_timing(ctx, *dp)) return rc;
     }
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::shared_mutex> lk(ctx->mu);
     *out = ctx->timing;
     if (reset) ctx->timing = bsg_timing{};
     return BSG_OK;
@@ -1329,7 +1339,7 @@ int32_t bsg_or_reduce_dev(bsg_ctx *ctx, uint64_t arena_id, uint32_t kind, void *
     if (int32_t rc = or_reduce_shard(ctx, *arena, 0, kind, n_words, static_cast<uint64_t *>(d_out))) return rc;
     HIP_TRY(hipStreamSynchronize(d.stream));
     if (d.or_pending) { HIP_TRY(hipEventElapsedTime(&d.last_or_ms, d.kb0, d.kb1)); d.or_pending = false; }
-    { std::lock_guard<std::mutex> lk2(ctx->mu); ctx->last_or_ms = d.last_or_ms; }
+    { std::lock_guard<std::shared_mutex> lk2(ctx->mu); ctx->last_or_ms = d.last_or_ms; }
     return BSG_OK;
 }
 
@@ -1429,7 +1439,7 @@ int32_t bsg_or_reduce(bsg_ctx *ctx, uint64_t arena_id, uint32_t kind, uint64_t *
             d.or_pending = false;
             slowest = std::max(slowest, d.last_or_ms);
         }
-        std::lock_guard<std::mutex> lk2(ctx->mu);
+        std::lock_guard<std::shared_mutex> lk2(ctx->mu);
         ctx->last_or_ms = slowest;
     } else
         for (uint32_t di = 0; di < nd; ++di) { (void)hipSetDevice(ctx->devs[di]->id); (void)hipStreamSynchronize(ctx->devs[di]->stream); }

@@ -219,4 +219,12 @@ __global__ __launch_bounds__(kEvalThreads) void k_query_jobs(const JobsArgs j)
     direct_body(a, j.tab + J.th_off, reinterpret_cast<const uint32_t *>(j.tab) + J.prog_off, J.n_queries, J.len, ar, lds64, blockIdx.x - J.wg0, j.n_wg);
 }
 
+// The completion doorbell of a combiner cycle: ONE system-scope store behind the cycle's last dispatch (same stream, in order) into
+// page-locked memory the collector polls — no runtime call while waiting (an event polled with hipEventQuery takes the runtime's
+// locks the next collector's enqueue needs), and one fence per cycle instead of one per workgroup.
+__global__ void k_ring(uint64_t *flag, uint64_t seq)
+{
+    __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 }  // namespace bsg

@@ -301,12 +301,12 @@ BSG_API int32_t bsg_query(bsg_ctx *ctx, const uint64_t *arena_ids, uint32_t n_ar
  * goroutine of its own, query_exec.go:303-357, 427-431, and runs several Query() calls at once — mirrored call by call that is one
  * ~8 us dispatch per (query, file), serialised on the device's stream).  A call that finds the device idle goes alone, at once, as
  * described above.  Calls that arrive while another is collecting or in flight queue inside the library; the head of the queue
- * collects everything queued (<= 256 calls) as (call, arena) pairs: an arena asked >= 24 queries in the cycle is STREAMED once for
+ * collects everything queued as (call, arena) pairs: an arena asked >= 24 queries in the cycle is STREAMED once for
  * all of them (their query sets merged into one batch, each distinct term probed once: k_probe_terms + k_eval_programs), every other
  * pair is a job of ONE k_query_jobs dispatch (gather regime: cost follows the pairs asked for — one query, one call per candidate
  * file is a list of such jobs).  The collector hands its role on (two cycles in flight) and deals every caller its rows.  Nobody
  * waits for a window to fill; results equal the solo path's bit for bit.  Calls beyond 16 terms / 128 program words / 64 queries /
- * 32 arenas always go alone.  bsg_set_lab key 12 = 0 turns combining off (13: cycles in flight, 14: calls per cycle, 16: the
+ * 32 arenas always go alone.  bsg_set_lab key 12 = 0 turns combining off (13: cycles in flight, 16: the
  * hot-arena threshold, 17: microseconds a queued caller polls before it sleeps).  bsg_query_stats_read: how calls were served. */
 typedef struct bsg_query_stats {
     uint64_t calls;                /* bsg_query calls that were eligible for combining                      */
@@ -319,6 +319,7 @@ typedef struct bsg_query_stats {
     /* the combined cycles' phases on their collectors' clocks, summed (ns): merging + planning the batches; enqueueing (tables up,
      * dispatches); waiting for the device; dealing the rows out + releasing the callers (ns_wake: the releasing part of that) */
     uint64_t ns_prepare, ns_enqueue, ns_wait, ns_deal, ns_wake;
+    uint64_t ns_scatter, ns_free, ns_retire;   /* parts of ns_deal: rows copied out; scratch given back (device lock); slot released + next collector appointed */
 } bsg_query_stats;
 BSG_API int32_t bsg_query_stats_read(bsg_ctx *ctx, bsg_query_stats *out, int32_t reset);
 

@@ -35,20 +35,22 @@ def main():
             for T in (1, 16, 64, 256):
                 ctx.set_lab(12, 0)
                 a = conc.run(ctx, exprs, pool, B, expected, T, seconds, apc)
-                line = "T=%3d x %2d arena(s) of %2d: alone %.3g q/s p50 %.0f p99 %.0f |" % (T, apc, len(pool), a["queries_per_s"], a["p50_us"], a["p99_us"])
+                line = "T=%3d x %2d arena(s) of %2d: alone %.3g q/s p50 %.0f p99 %.0f cpu %.1f us/call (%.1f busy) |" % (T, apc, len(pool), a["queries_per_s"], a["p50_us"], a["p99_us"], a["cpu_us_per_call"], a["cpus_busy"])
                 ctx.set_lab(12, 1)
                 for inf in inflights:
                     for hm in hot:
                         ctx.set_lab(13, inf)
                         ctx.set_lab(16, hm)
+                        if "SPIN" in os.environ:
+                            ctx.set_lab(17, int(os.environ["SPIN"]))
                         ctx.query_stats(reset=True)
                         r = conc.run(ctx, exprs, pool, B, expected, T, seconds, apc)
                         st = ctx.query_stats()
                         assert not (a["mismatches"] or a["errors"] or r["mismatches"] or r["errors"]), (a, r)
                         cyc = max(st["cycles"] - st["solo_calls"], 1)
-                        line += " inflight %d hot>=%d: %.3g q/s (%.1fx) p50 %.0f p99 %.0f, %.1f calls/cycle, %d solo; per combined cycle: prepare %.1f enqueue %.1f wait %.1f deal %.1f (wake %.1f) us, %.2f dispatches (%.2f hot) |" % (
-                            inf, hm, r["queries_per_s"], r["queries_per_s"] / a["queries_per_s"], r["p50_us"], r["p99_us"], st["cycle_calls"] / max(st["cycles"], 1), st["solo_calls"],
-                            st["ns_prepare"] / cyc / 1e3, st["ns_enqueue"] / cyc / 1e3, st["ns_wait"] / cyc / 1e3, st["ns_deal"] / cyc / 1e3, st["ns_wake"] / cyc / 1e3,
+                        line += " inflight %d hot>=%d: %.3g q/s (%.1fx) p50 %.0f p99 %.0f cpu %.1f us/call (%.1f busy), %.1f calls/cycle, %d solo; per combined cycle: prepare %.1f enqueue %.1f wait %.1f deal %.1f (scatter %.1f free %.1f retire %.1f wake %.1f) us, %.2f dispatches (%.2f hot) |" % (
+                            inf, hm, r["queries_per_s"], r["queries_per_s"] / a["queries_per_s"], r["p50_us"], r["p99_us"], r["cpu_us_per_call"], r["cpus_busy"], st["cycle_calls"] / max(st["cycles"], 1), st["solo_calls"],
+                            st["ns_prepare"] / cyc / 1e3, st["ns_enqueue"] / cyc / 1e3, st["ns_wait"] / cyc / 1e3, st["ns_deal"] / cyc / 1e3, st["ns_scatter"] / cyc / 1e3, st["ns_free"] / cyc / 1e3, st["ns_retire"] / cyc / 1e3, st["ns_wake"] / cyc / 1e3,
                             st["dispatches"] / cyc, st["hot_arenas"] / cyc)
                 print(line, flush=True)
 
