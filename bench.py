@@ -825,42 +825,55 @@ def q1_latency(ctx, arena, B, n_terms_hash, log):
             "survivors": int(sum(bin(int(x)).count("1") for x in first.ravel())), **res}
 
 
-def concurrent_queries_leg(ctx, arenas, B, exprs, got, log, seconds=0.25):
+def concurrent_queries_leg(ctx, arenas, B, exprs, got, log, seconds=0.4):
     """The Go surface's call pattern: T host threads, each calling bsg_query with ONE query (a 3-term And(FieldToken) of the C2 batch)
     against 1 or 10 arenas — what the reference's file workers do (query_exec.go:303-357, 427-431: a goroutine per candidate file,
     several Query() calls at once).  Native threads (tools/native/conc_driver.cpp; Python threads would measure the interpreter
     lock).  Twice: with every call going alone (bsg_set_lab key 12 = 0: one k_query_direct dispatch per call, serialised on the
-    device's stream — the round-4 behaviour) and with the combiner on (calls that meet share dispatches).  Every result of every call
-    is compared with the batch probe's rows inside the driver."""
+    device's stream — the round-4 behaviour) and with the combiner on (calls that meet share dispatches: a hot arena streamed once for
+    all its callers, everything else one k_query_jobs dispatch).  `same arena`: every call names C2's arena; `12 arenas`: the calls
+    rotate over 12 address-distinct replicas of it (distinct files).  Every result of every call is compared with the batch probe's
+    rows inside the driver.  cpu_us_per_call = processor time of the whole process per call: the box's cgroup quota (cpu.max, quoted
+    below) is what bounds the combined rate once hundreds of callers sleep and wake per call."""
     from bloomsearch_amd import conc
     nq = min(256, len(exprs))
     expected = np.ascontiguousarray(got[:nq])
     n_ar = min(len(arenas), 12)
+    try:
+        quota = open("/sys/fs/cgroup/cpu.max").read().split()
+        cpus_quota = None if quota[0] == "max" else float(quota[0]) / float(quota[1])
+    except Exception:  # noqa: BLE001
+        cpus_quota = None
     res = {"queries": "%d distinct 3-term And(FieldToken) queries of the C2 batch, one per call" % nq, "seconds_per_point": seconds,
+           "host_cpus": os.cpu_count(), "cgroup_cpu_quota_cpus": cpus_quota,
            "check": "every call's survivors compared with the batch probe's rows (bit-exact) inside the driver", "points": []}
-    for apc in (1, 10):
-        if apc > n_ar:
+    for apc, pool, name in ((1, arenas[:1], "same arena"), (1, arenas[:n_ar], "%d arenas" % n_ar), (10, arenas[:n_ar], "%d arenas" % n_ar)):
+        if apc > len(pool):
             continue
         for T in (1, 16, 64, 256):
-            row = {"threads": T, "arenas_per_call": apc}
-            for mode, name in ((0, "alone"), (1, "combined")):
+            row = {"threads": T, "arenas_per_call": apc, "arena_pool": name}
+            for mode, mname in ((0, "alone"), (1, "combined")):
                 ctx.set_lab(12, mode)
                 ctx.query_stats(reset=True)
-                r = conc.run(ctx, exprs[:nq], arenas[:n_ar], B, expected, n_threads=T, seconds=seconds, arenas_per_call=apc)
+                r = conc.run(ctx, exprs[:nq], pool, B, expected, n_threads=T, seconds=seconds, arenas_per_call=apc)
                 st = ctx.query_stats()
                 if r["mismatches"] or r["errors"]:
-                    sys.exit("concurrent_queries: %d mismatches, %d errors at T=%d, %d arenas per call, mode %s" % (r["mismatches"], r["errors"], T, apc, name))
-                row[name] = {"queries_per_s": r["queries_per_s"], "probes_per_s": r["queries_per_s"] * apc * B * 3, "p50_us": r["p50_us"], "p99_us": r["p99_us"],
-                             "calls": r["calls"]}
+                    sys.exit("concurrent_queries: %d mismatches, %d errors at T=%d, %d arenas per call, mode %s" % (r["mismatches"], r["errors"], T, apc, mname))
+                row[mname] = {"queries_per_s": r["queries_per_s"], "probes_per_s": r["queries_per_s"] * apc * B * 3, "p50_us": r["p50_us"], "p99_us": r["p99_us"],
+                              "calls": r["calls"], "cpu_us_per_call": r["cpu_us_per_call"], "cpus_busy": r["cpus_busy"]}
                 if mode:
-                    row[name].update({"cycles": st["cycles"], "calls_per_cycle": st["cycle_calls"] / max(st["cycles"], 1),
-                                      "max_calls_per_cycle": st["max_calls_per_cycle"], "dispatches": st["dispatches"]})
+                    cyc = max(st["cycles"] - st["solo_calls"], 1)
+                    row[mname].update({"cycles": st["cycles"], "calls_per_cycle": st["cycle_calls"] / max(st["cycles"], 1), "solo_cycles": st["solo_calls"],
+                                       "max_calls_per_cycle": st["max_calls_per_cycle"], "dispatches_per_combined_cycle": st["dispatches"] / cyc,
+                                       "hot_arenas_per_combined_cycle": st["hot_arenas"] / cyc,
+                                       "collector_us_per_combined_cycle": {k[3:]: st[k] / cyc / 1e3 for k in ("ns_prepare", "ns_enqueue", "ns_wait", "ns_deal")}})
             row["speedup"] = row["combined"]["queries_per_s"] / max(row["alone"]["queries_per_s"], 1e-9)
             res["points"].append(row)
-            log("concurrent queries: T=%3d x %2d arena(s) per call: alone %.3g q/s (p50 %.0f us, p99 %.0f us), combined %.3g q/s (p50 %.0f us, p99 %.0f us, "
-                "%.1f calls per cycle) = %.1fx" % (T, apc, row["alone"]["queries_per_s"], row["alone"]["p50_us"], row["alone"]["p99_us"],
-                                                    row["combined"]["queries_per_s"], row["combined"]["p50_us"], row["combined"]["p99_us"],
-                                                    row["combined"]["calls_per_cycle"], row["speedup"]))
+            log("concurrent queries: T=%3d x %2d arena(s) per call (%s): alone %.3g q/s (p50 %.0f us, p99 %.0f us, %.1f us cpu/call), combined %.3g q/s "
+                "(p50 %.0f us, p99 %.0f us, %.1f us cpu/call, %.1f calls per cycle) = %.1fx"
+                % (T, apc, name, row["alone"]["queries_per_s"], row["alone"]["p50_us"], row["alone"]["p99_us"], row["alone"]["cpu_us_per_call"],
+                   row["combined"]["queries_per_s"], row["combined"]["p50_us"], row["combined"]["p99_us"], row["combined"]["cpu_us_per_call"],
+                   row["combined"]["calls_per_cycle"], row["speedup"]))
     ctx.set_lab(12, 1)
     return res
 

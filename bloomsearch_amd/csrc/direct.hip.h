@@ -182,11 +182,11 @@ struct QJob {
     uint32_t n_blocks;
     uint32_t wg0;                // first workgroup of the job (jobs ascending; a job owns ceil(n_blocks / 64) workgroups)
     uint64_t out_off;            // first word of the job's rows [n_queries][G] in the result
-    uint32_t th_off;             // u64 index into the table: th[j * kQueryMaxTerms + pos], j < 4
+    uint32_t th_off;             // u64 index into the table: th[j * th_stride + pos], j < 4
     uint32_t prog_off;           // u32 index into the table (as u32): prog[j * n_queries + q]
     uint16_t n_queries, len, max_depth, n_kinds;
     uint8_t kind[4], term_begin[4], term_count[4];
-    uint32_t pad;
+    uint32_t th_stride;          // the call's terms (its hashes lie packed: 4 rows of th_stride words)
 };
 static_assert(sizeof(QJob) == 64, "one job record per 64-byte line");
 
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(kEvalThreads) void k_query_jobs(const JobsArgs j)
     const QJob &J = j.jobs[lo];
     DirectArgs a{};
     a.out = j.out + J.out_off;
-    a.Tp = kQueryMaxTerms; a.Wt = 1; a.n_queries = J.n_queries; a.Lmax = J.len; a.max_depth = J.max_depth; a.n_kinds = J.n_kinds;
+    a.Tp = J.th_stride; a.Wt = 1; a.n_queries = J.n_queries; a.Lmax = J.len; a.max_depth = J.max_depth; a.n_kinds = J.n_kinds;
 #pragma unroll
     for (uint32_t y = 0; y < 3; ++y) { a.kind[y] = J.kind[y]; a.term_begin[y] = J.term_begin[y]; a.term_count[y] = J.term_count[y]; }
     a.n_arenas = 1;

@@ -46,7 +46,8 @@ def main():
         for _ in range(3):
             nq = int(rng.choice([1, 1, 2, 3, 7, 12, 64, 256, 257, 600]))
             words_pool = vocab[: int(rng.choice([2, 6, len(vocab)]))]
-            cb = Q.compile_queries([H.random_expression(rng, words_pool, None) if rng.random() > 0.03 else None for _ in range(nq)])
+            exprs_of_batch = [H.random_expression(rng, words_pool, None) if rng.random() > 0.03 else None for _ in range(nq)]
+            cb = Q.compile_queries(exprs_of_batch)
             ops, poff, _ = cb.arrays()
             terms = H.gpu_terms(ctx, cb)
             bid = ctx.batch_create(terms, ops, poff)
@@ -87,6 +88,38 @@ def main():
                 if not np.array_equal(g, wants[i]):
                     sys.exit("seed %d: bsg_query differs (nq %d, %d terms, %d arenas, %d-entry context, arena %d)" % (seed, nq, len(terms), len(sub), nd, i))
                 n_bits += g.size * 64
+            # ... and from several threads at once, every thread its own handful of the batch's queries over its own arena subset, the
+            # collector told to wait for company (lab key 15): calls are merged — hot arenas as one batch, the rest as jobs of one
+            # dispatch — and every call must still get exactly its rows
+            if cb.n_queries >= 2 and rng.random() < 0.5:
+                import threading
+                ctx.set_lab(15, (3000 << 16) | 5)
+                ctx.set_lab(16, int(rng.choice([0, 2, 24])))
+                errs = []
+
+                def one(t, seed2):
+                    r2 = np.random.default_rng(seed2)
+                    try:
+                        for _ in range(3):
+                            qs = [int(x) for x in r2.integers(0, cb.n_queries, size=int(r2.choice([1, 1, 2, 4])))]
+                            sub2 = [int(i) for i in r2.integers(0, len(arenas), size=int(r2.choice([1, 1, 2, 5])))]
+                            small = Q.compile_queries([exprs_of_batch[q] for q in qs])
+                            g2 = ctx.query([arenas[i] for i in sub2], [plans[i].n_blocks for i in sub2], small)
+                            for g, i in zip(g2, sub2):
+                                if not np.array_equal(g, wants[i][qs]):
+                                    errs.append("thread %d: queries %s on arena %d" % (t, qs, i))
+                    except BaseException as exc:  # noqa: BLE001
+                        errs.append(repr(exc))
+                ths = [threading.Thread(target=one, args=(t, seed * 100 + t)) for t in range(6)]
+                for t in ths:
+                    t.start()
+                for t in ths:
+                    t.join()
+                ctx.set_lab(15, 0)
+                ctx.set_lab(16, 24)
+                if errs:
+                    sys.exit("seed %d: concurrent bsg_query differs (%d-entry context): %s" % (seed, nd, errs[:3]))
+                n_bits += 6 * 3 * 64
             n_cases += 1
             ctx.batch_free(bid)
         ctx.set_probe_group(0)

@@ -43,10 +43,12 @@ int32_t conc_run(bsg_ctx *ctx, uint32_t n_threads, double seconds, const conc_qu
                  uint64_t *lat_ns, uint64_t lat_cap, conc_result *out)
 {
     const uint32_t G = (n_blocks + 63) / 64;
-    std::atomic<uint64_t> calls{0}, mismatches{0}, errors{0}, lat_n{0};
+    std::atomic<uint64_t> calls{0}, mismatches{0}, errors{0};
     std::atomic<uint32_t> ready{0};
     std::atomic<int> go{0};
     std::vector<std::thread> th;
+    const uint64_t per_thread = lat_cap / n_threads;
+    std::vector<uint64_t> recorded(n_threads, 0);
     auto body = [&](uint32_t tid) {
         bsg_ctx *scope = nullptr;
         if (bsg_scope_open(ctx, &scope) != BSG_OK) { errors++; scope = ctx; }
@@ -73,13 +75,14 @@ int32_t conc_run(bsg_ctx *ctx, uint32_t n_threads, double seconds, const conc_qu
             else
                 for (uint32_t j = 0; j < arenas_per_call; ++j)
                     if (memcmp(got.data() + (size_t)j * G, expected + (size_t)qi * G, (size_t)G * 8) != 0) { mismatches++; break; }
-            const uint64_t slot = lat_n.fetch_add(1, std::memory_order_relaxed);
-            if (slot < lat_cap) lat_ns[slot] = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count();
+            // (a thread's own slice of the latency buffer: a shared cursor would be one more cache line all threads write)
+            if (mine < per_thread) lat_ns[(uint64_t)tid * per_thread + mine] = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count();
             ++mine;
             qi = (qi + 1) % n_queries;
             ai = (ai + arenas_per_call) % n_arena_ids;
         }
         calls += mine;
+        recorded[tid] = std::min<uint64_t>(mine, per_thread);
         if (scope != ctx) bsg_close(scope);
     };
     for (uint32_t t = 0; t < n_threads; ++t) th.emplace_back(body, t);
@@ -97,7 +100,10 @@ int32_t conc_run(bsg_ctx *ctx, uint32_t n_threads, double seconds, const conc_qu
     out->mismatches = mismatches.load();
     out->errors = errors.load();
     out->seconds = std::chrono::duration<double>(t1 - t0).count();
-    out->n_lat = std::min<uint64_t>(lat_n.load(), lat_cap);
+    uint64_t w = 0;                                   // pack the threads' slices to the front
+    for (uint32_t t = 0; t < n_threads; ++t)
+        for (uint64_t i = 0; i < recorded[t]; ++i) lat_ns[w++] = lat_ns[(uint64_t)t * per_thread + i];
+    out->n_lat = w;
     return 0;
 }
 
