@@ -208,6 +208,42 @@ def multi_device_context_leg(ctx, device_ids, plan, words, block_ids, rows, seed
         if not np.array_equal(m.probe(aid, B, terms, ops, poff), got):
             raise RuntimeError("survivors of the multi-device context differ from the single-device context's")
         res["probe_wall_ms"] = (time.perf_counter() - t0) * 1e3
+        # the host-side gather as survivor ROWS: every device writes its shards' rows into its slice of one page-locked buffer, the
+        # host merges a (file, query)'s rows into global block ids (bsg_survivor_rows_list) — against the dense bitsets + interleave
+        stage("rows")
+        bid_m = m.batch_create(terms, ops, poff)
+        NQ = len(poff) - 1
+        rw, hw = m.survivor_rows_size([aid], bid_m)
+        r_buf = m.pinned_array(max(rw, 1) * 8).view(np.uint64)
+        h_buf = m.pinned_array(hw * 4).view(np.uint32)
+        dense_buf = m.pinned_array(NQ * ((B + 63) // 64) * 8).view(np.uint64)
+        t_rows, t_dense = [], []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            m.probe_many_rows([aid], bid_m, r_buf, h_buf)
+            t_rows.append(time.perf_counter() - t0)
+            t0 = time.perf_counter()
+            m.probe_many_into([aid], bid_m, dense_buf)
+            t_dense.append(time.perf_counter() - t0)
+        sel = np.sort(np.random.default_rng(99).choice(NQ, size=min(NQ, 64), replace=False))
+        for q in sel:
+            ids = m.survivor_rows_list([aid], bid_m, r_buf, h_buf, 0, int(q), B).astype(np.int64)
+            bits = np.zeros_like(got[q])
+            np.bitwise_or.at(bits, ids >> 6, np.uint64(1) << (ids & 63).astype(np.uint64))
+            if not np.array_equal(bits, got[q]):
+                raise RuntimeError("survivor rows of the multi-device context do not merge to the single-device context's survivors (query %d)" % q)
+        if not np.array_equal(dense_buf.reshape(NQ, -1), got):
+            raise RuntimeError("dense survivors of the multi-device context differ")
+        tags = np.bincount(h_buf >> 30, minlength=4)
+        cnt = h_buf & np.uint32(0x3FFFFFFF)
+        nd_m = len(device_ids)
+        res["rows"] = {"api": "bsg_probe_many_rows on the %d-device context + bsg_survivor_rows_list" % nd_m,
+                       "wall_ms_rows": float(np.median(t_rows[1:])) * 1e3, "wall_ms_dense_bitsets_interleaved_on_host": float(np.median(t_dense[1:])) * 1e3,
+                       "bytes_written_by_the_devices": int(4 * hw + 4 * cnt[(h_buf >> 30) == 2].sum() + 8 * ((B // nd_m + 63) // 64) * int(((h_buf >> 30) == 3).sum())),
+                       "dense_bytes": int(NQ * ((B + 63) // 64) * 8), "rows_by_tag_none_all_list_dense": [int(x) for x in tags],
+                       "check": "%d randomly chosen queries: the %d shards' rows merge to the single-device survivors" % (len(sel), nd_m)}
+        m.pinned_free(r_buf.view(np.uint8)); m.pinned_free(h_buf.view(np.uint8)); m.pinned_free(dense_buf.view(np.uint8))
+        m.batch_free(bid_m)
         stage("bsg_query")
         one = Q.compile_queries([Q.And(Q.FieldToken("level", "error"), Q.FieldToken("service", "payment"), Q.FieldToken("nested.region", "region-3"))])
         a1 = ctx.arena_load(words, plan.desc)

@@ -232,6 +232,23 @@ class Context:
         self._check(self.L.bsg_probe_many_rows(self.h, _lib._ptr(ids), len(ids), batch_id, flags, C.c_void_p(rows.ctypes.data),
                                                C.c_void_p(hdr.ctypes.data)))
 
+    def survivor_rows_size(self, arena_ids, batch_id: int):
+        """bsg_survivor_rows_size: (row words, headers) bsg_probe_many_rows writes for these arenas and this batch on this context."""
+        ids = np.ascontiguousarray(arena_ids, dtype=np.uint64)
+        rw, hw = C.c_uint64(), C.c_uint64()
+        self._check(self.L.bsg_survivor_rows_size(self.h, _lib._ptr(ids), len(ids), batch_id, C.byref(rw), C.byref(hw)))
+        return int(rw.value), int(hw.value)
+
+    def survivor_rows_list(self, arena_ids, batch_id: int, rows: np.ndarray, hdr: np.ndarray, arena_index: int, query: int, n_blocks: int) -> np.ndarray:
+        """bsg_survivor_rows_list: the ascending GLOBAL block indices of (arena, query) from the rows bsg_probe_many_rows left — on a
+        context of several devices the shards' rows merged (global = local * n_devices + device)."""
+        ids = np.ascontiguousarray(arena_ids, dtype=np.uint64)
+        out = np.zeros(max(n_blocks, 1), dtype=np.uint32)
+        n = C.c_uint32()
+        self._check(self.L.bsg_survivor_rows_list(self.h, _lib._ptr(ids), len(ids), batch_id, C.c_void_p(rows.ctypes.data), C.c_void_p(hdr.ctypes.data),
+                                                  arena_index, query, C.c_void_p(out.ctypes.data), len(out), C.byref(n)))
+        return out[: int(n.value)]
+
     def set_probe_group(self, max_arenas_per_launch: int):
         self._check(self.L.bsg_set_probe_group(self.h, max_arenas_per_launch))
 

@@ -526,6 +526,56 @@ func (g *Context) ProbeManyRows(arenas []Arena, b Batch, buf *RowsBuffer) ([]Sur
 	return out, nil
 }
 
+// RowsOnDevices is the result of ProbeManyRowsOnDevices: the rows every device of the context wrote for its shards (local block
+// numbers, a slice of the buffer per device).  List merges the shards' rows of one (arena, query) into GLOBAL block order.
+type RowsOnDevices struct {
+	g      *Context
+	ids    []uint64
+	batch  Batch
+	buf    *RowsBuffer
+	blocks []uint32
+}
+
+// ProbeManyRowsOnDevices is bsg_probe_many_rows on a context opened over several GPUs (the Go host's shape: one process, all 8
+// GPUs): block b of every arena lives on device b % n, every device writes its shards' rows into its own slice of buf, and the
+// host-side gather of surviving block ids (query_exec.go:603) is RowsOnDevices.List.  Works on a single-device context too.
+func (g *Context) ProbeManyRowsOnDevices(arenas []Arena, b Batch, buf *RowsBuffer) (*RowsOnDevices, error) {
+	if len(arenas) == 0 || b.Queries == 0 {
+		return nil, nil
+	}
+	r := &RowsOnDevices{g: g, ids: make([]uint64, len(arenas)), batch: b, buf: buf, blocks: make([]uint32, len(arenas))}
+	for i, a := range arenas {
+		r.ids[i], r.blocks[i] = a.ID, a.Blocks
+	}
+	var rowWords, hdrWords C.uint64_t
+	if err := g.err(C.bsg_survivor_rows_size(g.c, u64p(r.ids), C.uint32_t(len(r.ids)), C.uint64_t(b.ID), &rowWords, &hdrWords)); err != nil {
+		return nil, err
+	}
+	if int(rowWords) > buf.nRow || int(hdrWords) > buf.nHdr {
+		return nil, &Error{Code: int(C.BSG_E_INVALID), Message: "rows buffer too small"}
+	}
+	rc := C.bsg_probe_many_rows(g.c, u64p(r.ids), C.uint32_t(len(r.ids)), C.uint64_t(b.ID), 0, (*C.uint64_t)(buf.rows), (*C.uint32_t)(buf.hdr))
+	if err := g.err(rc); err != nil {
+		return nil, err
+	}
+	return r, nil
+}
+
+// List returns the surviving blocks of query q in arena i, ascending global block indices (blockScanCandidate order).
+func (r *RowsOnDevices) List(i, q int) ([]uint32, error) {
+	if r.blocks[i] == 0 {
+		return nil, nil
+	}
+	out := make([]uint32, r.blocks[i])
+	var n C.uint32_t
+	rc := C.bsg_survivor_rows_list(r.g.c, u64p(r.ids), C.uint32_t(len(r.ids)), C.uint64_t(r.batch.ID), (*C.uint64_t)(r.buf.rows), (*C.uint32_t)(r.buf.hdr),
+		C.uint32_t(i), C.uint32_t(q), u32p(out), C.uint32_t(len(out)), &n)
+	if err := r.g.err(rc); err != nil {
+		return nil, err
+	}
+	return out[:n], nil
+}
+
 // PeerAccess is bsg_peer_access: m[i][j] is true when device i of the context reaches device j's memory directly (xGMI peer
 // access); copies between the other pairs are staged through host memory by the runtime.
 func (g *Context) PeerAccess(nDevices int) ([][]bool, error) {

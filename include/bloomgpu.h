@@ -268,8 +268,7 @@ BSG_API int32_t bsg_set_gather_cost(bsg_ctx *ctx, uint32_t bytes_per_probe);
  *   BSG_ROW_DENSE  the slot holds the row's words exactly as bsg_probe_many writes them
  * Both buffers are written BY THE DEVICE (k_survivor_rows) and must be page-locked C memory (bsg_pinned_alloc /
  * bsg_host_register): only the bytes written cross PCIe — a batch whose rows are mostly NONE / ALL / short lists costs 4 bytes
- * per row instead of n_blocks / 8.  Single-device contexts (a context over several devices keeps bsg_probe_many: its shards'
- * local block numbers are interleaved on the host); flags as bsg_probe_many (with BSG_PROBE_ASYNC both buffers must stay valid
+ * per row instead of n_blocks / 8.  Flags as bsg_probe_many (with BSG_PROBE_ASYNC both buffers must stay valid
  * until bsg_sync).  bsg_survivor_row_list expands one row to its ascending block indices whatever its tag. */
 #define BSG_ROW_NONE  0u
 #define BSG_ROW_ALL   1u
@@ -279,6 +278,19 @@ BSG_API int32_t bsg_probe_many_rows(bsg_ctx *ctx, const uint64_t *arena_ids, uin
                                     uint64_t *out_rows, uint32_t *out_hdr);
 BSG_API int32_t bsg_survivor_row_list(uint32_t hdr, const uint64_t *row, uint32_t n_blocks, uint32_t *out_blocks, uint32_t cap,
                                       uint32_t *out_n);
+/* On a context of nd > 1 devices — the Go host's shape: ONE process that opens all 8 GPUs — every device writes the rows of ITS shards
+ * (local block numbers: local l on device d is global block l * nd + d) into a slice of its own of the same two buffers:
+ *   headers: out_hdr + d * n_arenas * n_queries, [arena][query] (count = the shard's surviving blocks)
+ *   rows   : device d's slice behind the slices of the devices before it; in it arena i's [n_queries][ceil(local blocks / 64)] slots
+ * bsg_survivor_rows_size gives the words / headers the two buffers must hold (nd == 1: the layout described above), and
+ * bsg_survivor_rows_list — the north star's "host-side gather of surviving block IDs" (query_exec.go:603) — merges the nd shards'
+ * rows of one (arena, query) into the ascending GLOBAL block indices: NONE shards contribute nothing, ALL shards every block they
+ * hold, neither touches the rows' payload.  (Single-row, single-device: bsg_survivor_row_list above.) */
+BSG_API int32_t bsg_survivor_rows_size(bsg_ctx *ctx, const uint64_t *arena_ids, uint32_t n_arenas, uint64_t batch_id,
+                                       uint64_t *out_row_words, uint64_t *out_hdr_words);
+BSG_API int32_t bsg_survivor_rows_list(bsg_ctx *ctx, const uint64_t *arena_ids, uint32_t n_arenas, uint64_t batch_id, const uint64_t *rows,
+                                       const uint32_t *hdr, uint32_t arena_index, uint32_t query, uint32_t *out_blocks, uint32_t cap,
+                                       uint32_t *out_n);
 
 /* One-shot convenience: batch_create + probe_batch + batch_free. */
 BSG_API int32_t bsg_probe(bsg_ctx *ctx, uint64_t arena_id, const bsg_term *terms, uint32_t n_terms,

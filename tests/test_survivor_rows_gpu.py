@@ -91,3 +91,67 @@ def test_pageable_output_memory_is_refused_not_staged(ctx):
     assert "page-locked" in str(ei.value)
     ctx.batch_free(bid)
     ctx.arena_free(aid)
+
+
+def test_rows_on_a_context_of_several_devices_merge_to_the_global_block_order():
+    """The Go host's shape — ONE process, one context over all 8 GPUs: every device writes its shards' rows (local block numbers) into
+    its own slice of the page-locked buffers, and bsg_survivor_rows_list merges a (file, query)'s 8 rows into the surviving GLOBAL
+    block indices (query_exec.go:603: the consumer walks surviving block ids).  Against the oracle's survivors, whatever the tags."""
+    from bloomsearch_amd.gpu import Context
+    rng = np.random.default_rng(77)
+    for nd in (8, 3):
+        with Context((0,) * nd) as m:
+            plans, words, aids = [], [], []
+            for nb in (1000, 5, 64 * nd + 1, 1, 130):
+                plan, _, vocab = H.make_random_arena(rng, nb, absent_frac=0.02, max_tokens=60, vocab_size=30)
+                w = m.build(plan.blob, plan.off, plan.fstart, plan.desc, plan.n_words)
+                plans.append(plan); words.append(w); aids.append(m.arena_load(w, plan.desc))
+            exprs = [None, Q.Token("absent-everywhere"), Q.Or(Q.Token("absent-everywhere"), Q.Field("f1")), Q.Token(vocab[0]),
+                     Q.And(Q.Token(vocab[1]), Q.Token(vocab[2]))] + [H.random_expression(rng, vocab[:10], None) for _ in range(40)]
+            cb = Q.compile_queries(exprs)
+            ops, poff, _ = cb.arrays()
+            bid = m.batch_create(H.gpu_terms(m, cb), ops, poff)
+            order = [0, 1, 2, 3, 4, 0]
+            ids = [aids[i] for i in order]
+            rw, hw = m.survivor_rows_size(ids, bid)
+            assert hw == nd * len(order) * len(exprs)
+            rows = m.pinned_array(max(rw, 1) * 8).view(np.uint64)
+            hdr = m.pinned_array(hw * 4).view(np.uint32)
+            rows[:] = np.iinfo(np.uint64).max
+            hdr[:] = np.iinfo(np.uint32).max
+            m.probe_many_rows(ids, bid, rows, hdr)
+            tags = np.bincount(hdr >> 30, minlength=4)
+            assert tags[0] > 0 and tags[1] > 0 and tags[2] + tags[3] > 0, tags        # every kind of row took part
+            for j, i in enumerate(order):
+                want = O.survivors_tree(words[i], plans[i].desc.view(O.DESC_DTYPE), exprs)
+                for q in range(len(exprs)):
+                    got = m.survivor_rows_list(ids, bid, rows, hdr, j, q, plans[i].n_blocks)
+                    bits = np.zeros_like(want[q])
+                    np.bitwise_or.at(bits, got.astype(np.int64) >> 6, np.uint64(1) << (got & 63).astype(np.uint64))
+                    assert np.all(np.diff(got.astype(np.int64)) > 0) and np.array_equal(bits, want[q]), (nd, i, q)
+            # the dense path of the same context agrees
+            dense = m.probe_many(ids, bid, 0, len(exprs), [plans[i].n_blocks for i in order])
+            for j, i in enumerate(order):
+                assert np.array_equal(dense[j], O.survivors_tree(words[i], plans[i].desc.view(O.DESC_DTYPE), exprs))
+            m.pinned_free(rows.view(np.uint8))
+            m.pinned_free(hdr.view(np.uint8))
+            m.batch_free(bid)
+
+
+def test_a_corrupt_list_header_is_rejected():
+    """bsg_survivor_row_list never reads past a row's slot: a LIST header that counts more ids than the slot holds, or ids that are
+    not ascending block numbers, is an error."""
+    from bloomsearch_amd import _lib
+    import ctypes as C
+    L = _lib.load()
+    n_blocks = 130                                            # G = 3: the slot holds 6 ids
+    row = np.zeros(3, dtype=np.uint64)
+    row.view(np.uint32)[:6] = [1, 5, 9, 64, 100, 129]
+    out = np.zeros(n_blocks, dtype=np.uint32)
+    n = C.c_uint32()
+    assert L.bsg_survivor_row_list((2 << 30) | 6, row.ctypes.data, n_blocks, out.ctypes.data, n_blocks, C.byref(n)) == 0 and n.value == 6
+    assert L.bsg_survivor_row_list((2 << 30) | 7, row.ctypes.data, n_blocks, out.ctypes.data, n_blocks, C.byref(n)) == _lib.BSG_E_INVALID
+    row.view(np.uint32)[2] = 5                                # not ascending
+    assert L.bsg_survivor_row_list((2 << 30) | 6, row.ctypes.data, n_blocks, out.ctypes.data, n_blocks, C.byref(n)) == _lib.BSG_E_INVALID
+    row.view(np.uint32)[:6] = [1, 5, 9, 64, 100, 130]         # an id past the arena
+    assert L.bsg_survivor_row_list((2 << 30) | 6, row.ctypes.data, n_blocks, out.ctypes.data, n_blocks, C.byref(n)) == _lib.BSG_E_INVALID
