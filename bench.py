@@ -1219,6 +1219,7 @@ def main():
                     help="carry the per-dispatch HIP timestamps inside the headline region too (they cost ~17 us per 2-dispatch call: the default "
                          "times the K steps bare, then repeats them with the timestamps on and reports both)")
     ap.add_argument("--fold", type=int, default=-1, help="lab: evaluators per tile of k_probe_eval (bsg_set_lab key 11; 0 = two dispatches, the default)")
+    ap.add_argument("--tail-split", type=int, default=-1, help="lab: percent of a single-group run evaluated on a second stream beside the rest's probe (bsg_set_lab key 19)")
     ap.add_argument("--no-q1", action="store_true", help="skip the Q = 1 latency leg")
     ap.add_argument("--no-concurrent", action="store_true", help="skip the concurrent_queries leg (T host threads x bsg_query)")
     ap.add_argument("--no-big-filters", action="store_true", help="skip the leg with block filters beyond the LDS budget (~1 MB each)")
@@ -1271,6 +1272,8 @@ def main():
         ctx.set_fuse_limit(args.fuse_limit)
     if args.fold >= 0:
         ctx.set_lab(11, args.fold)
+    if args.tail_split >= 0:
+        ctx.set_lab(19, args.tail_split)
     B, rows, NQ = args.blocks, args.rows_per_block, args.queries
 
     # ---- untimed setup: this rank's shard = global blocks rank, rank + world, ... (round-robin) ----

@@ -179,6 +179,8 @@ struct Device {
     DevPool pool;
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;          // survivors leave here so the D2H of group i overlaps the kernels of group i+1
+    hipStream_t aux_stream = nullptr;           // tail split: the evaluation of a run's first part beside the probe of its second
+    hipEvent_t ev_aux[2] = {nullptr, nullptr};
     hipEvent_t ev_eval[2] = {nullptr, nullptr}; // out[slot] written (compute stream)
     hipEvent_t ev_copy[2] = {nullptr, nullptr}; // out[slot] copied out (copy stream)
     bool copy_busy[2] = {false, false};
@@ -315,6 +317,7 @@ struct bsg_ctx {
     // 322 + 39 us as two dispatches; wall 134.8 vs 133.2 us.  The survivor words written under the stream leave L2 as partial lines
     // before the other tiles complete them, which costs what the second dispatch's ramp would (bsg_set_lab key 11 turns it on)
     uint32_t fold_helpers = 0;
+    uint32_t tail_split_pct = 0;   // bsg_set_lab key 19
     Combiner cmb;                // concurrent bsg_query calls merged into shared dispatches (combine_api.inc)
     // write side / matcher over several devices: a call large enough is cut into one part per device (contiguous runs of
     // filters / sets / rows), each part on a thread of its own; smaller calls take ONE device, chosen round-robin among
@@ -733,6 +736,7 @@ int32_t bsg_close(bsg_ctx *ctx)
             (void)hipStreamDestroy(d.copy_stream);
         }
         if (d.kb0) { (void)hipEventDestroy(d.kb0); (void)hipEventDestroy(d.kb1); }
+        if (d.aux_stream) { (void)hipEventDestroy(d.ev_aux[0]); (void)hipEventDestroy(d.ev_aux[1]); (void)hipStreamDestroy(d.aux_stream); }
         d.pool.trim(0);
         for (uint8_t *p : d.idle_staging) (void)hipHostFree(p);
         for (auto &p : d.direct_bufs) (void)hipHostFree(p.first);
