@@ -1519,6 +1519,8 @@ struct SectionSlot {
     uint32_t len;            // section bytes incl. the 4-byte CRC trailer (0 => block without a section)
     uint32_t slot_cap_words; // words the slot holds (section bytes + room for the per-filter alignment)
     uint32_t block;          // local block index: where desc / status of this section live
+    uint32_t first_item;     // (section, slice) items of the sections before this one (the device's sections in file order): the persistent decode grid's numbering
+    uint32_t pad;
     uint32_t init_image;     // 0xFFFFFFFF shifted over the payload, xor the final 0xFFFFFFFF (crc_init_image(len - 4)): a function of the
                              // length alone, computed by the host — on the device it was ~17 serial 32-step multiplies per workgroup
 };
@@ -1558,19 +1560,23 @@ __device__ inline int32_t parse_section_header(const uint8_t *sec, uint32_t plen
     return pos == plen ? 0 : -6;
 }
 
-// Several workgroups per section (round 4).  One workgroup per section left a 1 000-section launch at 4 workgroups per CU, each
-// walking ~70 KB behind one chain of dependent loads: 76 us = 0.23 of the HBM roofline, and a run of ~55 sections (one 4 MiB
-// chunk of the region cursor) did not fill a quarter of the chip.  CRC-32C is linear over GF(2), so a section's payload is cut
-// into SLICES counted from its END — slice j = bytes [P - (j + 1) U, P - j U), U = decode_unit(P) — one workgroup each:
-//   * the slice's checksum (crc32c_payload, zero initial value) times x^(8 U j) is its contribution to the payload's checksum;
-//     slice 0 also carries the 0xFFFFFFFF initial value shifted over the payload and the final xor;
-//   * every workgroup walks the header chain itself (flags, lengths, m, k: <= 3 dependent reads, bounds-checked against the
-//     payload because nothing is trusted before the checksum) and byte-swaps the words that START inside its slice into
-//     the section's slot — before the checksum is known: a block whose checksum fails keeps nil descriptors (m = 0), so
-//     its words are never looked at;
-//   * contributions are published with write-through stores, an arrival counter tells the last workgroup of the section,
-//     which XORs them, compares with the stored checksum and writes status + descriptors.
-// grid = (most slices of any section of the run, sections [first, first + gridDim.y)).
+// A section's decode is cut into SLICES (round 4): CRC-32C is linear over GF(2), so a section's payload is cut into slices counted
+// from its END — slice j = bytes [P - (j + 1) U, P - j U), U = decode_unit(P) —
+//   * the slice's checksum (zero initial value) times x^(8 U j) is its contribution to the payload's checksum; slice 0 also carries
+//     the 0xFFFFFFFF initial value shifted over the payload and the final xor;
+//   * contributions are published with write-through stores, an arrival counter tells the last arrival of the section, which XORs
+//     them, compares with the stored checksum and writes status + descriptors (a block whose checksum fails keeps nil descriptors
+//     (m = 0), so the words written for it are never looked at).
+// Round 5: the launch is a PERSISTENT grid — a few workgroups per CU, each walking a contiguous run of the launch's (section, slice)
+// items — instead of one workgroup per slice:
+//   * the 8 KB of CRC tables are copied into LDS once per workgroup, not once per 16 KB slice (that was half as many LDS bytes
+//     written as payload bytes read);
+//   * a run's slices mostly belong to one section: the header chain (flags, lengths, m, k: <= 3 dependent reads, bounds-checked
+//     because nothing is trusted before the checksum) is walked once per section and run, not once per slice;
+//   * the payload is read ONCE: the lane that checksums a 64-byte granule also byte-swaps the words that START inside it (the words
+//     are not aligned to the granules — a filter's first word sits 29 bytes into the section — so the lane takes 8 more bytes and
+//     funnel-shifts) and stores them into the section's slot: 64 contiguous bytes per lane, a wave 4 KB.  Round 4 re-read the
+//     slice for a separate byte-swap pass (13.6 of 68.5 us).
 // (decode_unit / decode_splits / kDecodeMaxSplits and the GF(2) arithmetic live in crc_slices.h: tests/crc_slices_check.cpp walks the
 //  same slices on the host)
 struct DecodeScratch {
@@ -1578,90 +1584,173 @@ struct DecodeScratch {
     uint32_t *done;     // [slot] arrivals (0 before the section's launch)
 };
 
-__global__ __launch_bounds__(kDecodeThreads) void k_decode_sections(const uint8_t *region, const SectionSlot *slots, uint32_t first,
+struct DecodeHeader {            // a section's parsed header, kept in LDS while the workgroup's items stay inside the section
+    uint32_t present, woff[3], nw[3], k[3];
+    int32_t st;
+    uint64_t dst[3], m[3];
+};
+
+// the words of the section's filters that start inside the 64-byte granule at byte `p` (of the section), byte-swapped into the slot.
+// v[0..7] = the granule, v[8] = the 8 bytes behind it.
+__device__ __forceinline__ void swap_granule_words(const DecodeHeader &H, uint64_t *arena, uint32_t p, const uint64_t (&v)[9])
+{
+#pragma unroll
+    for (uint32_t c = 0; c < 3; ++c) {
+        if (!((H.present >> c) & 1u)) continue;
+        const uint32_t w0 = H.woff[c], wend = w0 + 8u * H.nw[c];
+        if (p + 64u <= w0 || p >= wend) continue;                    // (most granules lie inside exactly one filter)
+        const uint32_t d = (w0 - p) & 7u;                            // where in every 8 bytes of the granule a word starts
+        uint64_t *dst = arena + H.dst[c];
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k) {
+            const uint32_t at = p + d + 8u * k;                      // the word's first byte
+            if (at < w0 || at >= wend) continue;
+            const uint64_t x = d == 0 ? v[k] : (v[k] >> (8u * d)) | (v[k + 1] << (64u - 8u * d));
+            dst[(at - w0) >> 3] = __builtin_bswap64(x);
+        }
+    }
+}
+
+// CRC32C (zero initial value) of the slice [lo, hi) of the section at `sec`, with the byte-swap of its words folded in.  The scheme
+// of crc32c_payload: 64-byte granules dealt to the threads from the slice's END, partials aligned to the end and XOR-ed.  Result
+// valid in thread 0; ends with a barrier.
+__device__ __forceinline__ uint32_t crc_and_swap_slice(const uint8_t *sec, uint32_t lo, uint32_t hi, uint32_t P, const DecodeHeader &H, bool do_swap,
+                                                       uint64_t *arena, const uint32_t (*tab)[256], const CrcConsts *consts, uint32_t *part, uint32_t tid)
+{
+    const uint32_t n = hi - lo, G = n / kCrcGranule, tail = n % kCrcGranule;
+    const uint32_t skip = consts->skip;
+    uint32_t crc = 0;
+    if (tid < G) {
+        const uint32_t g_last = G - 1 - tid;
+        bool any = false;
+        for (uint32_t g = g_last % kDecodeThreads; g <= g_last; g += kDecodeThreads) {
+            uint64_t v[9];
+            const uint32_t p = lo + g * kCrcGranule;
+            const uint8_t *src = sec + p;
+#pragma unroll
+            for (int u = 0; u < 9; ++u) v[u] = load_u64_unaligned(src + 8 * u);      // (the region image is allocated 64 bytes longer than the file bytes it holds)
+            if (any) crc = crc_multmodp(skip, crc);
+            any = true;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const uint32_t l = (uint32_t)v[u] ^ crc, h = (uint32_t)(v[u] >> 32);
+                crc = tab[7][l & 0xFF] ^ tab[6][(l >> 8) & 0xFF] ^ tab[5][(l >> 16) & 0xFF] ^ tab[4][l >> 24] ^
+                      tab[3][h & 0xFF] ^ tab[2][(h >> 8) & 0xFF] ^ tab[1][(h >> 16) & 0xFF] ^ tab[0][h >> 24];
+            }
+            if (do_swap) swap_granule_words(H, arena, p, v);
+        }
+        if (tid) crc = crc_multmodp(consts->gpow[tid], crc);
+        if (tail) crc = crc_multmodp(consts->bpow[tail], crc);
+    }
+    if (tid == kDecodeThreads - 1 && tail) {                            // trailing bytes: already aligned to the end
+        uint32_t t = 0;
+        for (uint32_t i = hi - tail; i < hi; ++i) t = tab[0][(t ^ sec[i]) & 0xFF] ^ (t >> 8);
+        crc ^= t;
+        if (do_swap)                                                    // ... and the (<= 8) words that start among them
+            for (uint32_t c = 0; c < 3; ++c) {
+                if (!((H.present >> c) & 1u)) continue;
+                const uint32_t w0 = H.woff[c];
+                for (uint32_t w = hi - tail > w0 ? (hi - tail - w0 + 7) / 8 : 0u; w < H.nw[c] && w0 + 8u * w < hi; ++w)
+                    arena[H.dst[c] + w] = __builtin_bswap64(load_u64_unaligned(sec + w0 + 8ull * w));
+            }
+    }
+    (void)P;
+    part[tid] = crc;
+    __syncthreads();
+    for (uint32_t step = kDecodeThreads / 2; step > 0; step >>= 1) {
+        if (tid < step) part[tid] ^= part[tid + step];
+        __syncthreads();
+    }
+    return part[0];
+}
+
+// grid = (workgroups, 1): workgroup w walks the items [I0 + n w / W, I0 + n (w + 1) / W) of the run's sections [first, first + n_sec),
+// an item = (section, slice), numbered section by section (SectionSlot::first_item).
+__global__ __launch_bounds__(kDecodeThreads) void k_decode_sections(const uint8_t *region, const SectionSlot *slots, uint32_t first, uint32_t n_sec,
                                                                    const CrcConsts *consts, uint64_t *arena, DevDesc *desc,
                                                                    int32_t *status, const DecodeScratch scratch)
 {
     __shared__ uint32_t tab[8][256];
     __shared__ uint32_t part[kDecodeThreads];
-    __shared__ int32_t st;
-    __shared__ uint32_t s_present, s_woff[3], s_nw[3], s_k[3], s_last;
-    __shared__ uint64_t s_dst[3], s_m[3];
+    __shared__ DecodeHeader H;
+    __shared__ uint32_t s_last;
     const uint32_t tid = threadIdx.x;
-    const uint32_t slot = first + blockIdx.y, j = blockIdx.x;
-    const SectionSlot sl = slots[slot];
-    const uint32_t b = sl.block;
-    if (sl.len == 0) return;                                       // block without a section: filters stay nil, status 0
-    if (sl.len < 5) { if (tid == 0 && j == 0) status[b] = -1; return; }      // parseFilterSection: too small
-    const uint32_t P = sl.len - 4, U = decode_unit(P), n_split = P == 0 ? 1u : (P + U - 1) / U;
-    if (j >= n_split) return;
+    const uint32_t I0 = slots[first].first_item;
+    const SectionSlot last_sl = slots[first + n_sec - 1];
+    const uint32_t n_items = last_sl.first_item + decode_splits(last_sl.len) - I0;
+    const uint32_t it0 = I0 + (uint32_t)((uint64_t)n_items * blockIdx.x / gridDim.x), it1 = I0 + (uint32_t)((uint64_t)n_items * (blockIdx.x + 1) / gridDim.x);
+    if (it0 >= it1) return;
     for (uint32_t i = tid; i < 8 * 256; i += kDecodeThreads) (&tab[0][0])[i] = (&consts->table[0][0])[i];
-    const uint8_t *sec = region + sl.begin;
-    const uint32_t hi = P - j * U, lo = hi > U ? hi - U : 0u;       // this workgroup's slice [lo, hi) of the payload
-    if (tid == kDecodeThreads - 1) {
-        // the header chain (untrusted until the checksum is known: every step is checked against the payload's length).  Every
-        // workgroup of the section walks it itself, while its other waves are already at their granules — a launch of its own
-        // for the headers (one thread per section, a parsed-header table) was measured and dropped: 68 -> 73 us in one launch,
-        // 107 -> 134 us as four launches behind the copy.
-        uint64_t m[3];
-        uint32_t k[3];
-        int32_t r = parse_section_header(sec, P, s_present, s_woff, s_nw, m, k);
-        if (r == 0) {
-            uint64_t cursor = sl.slot_words;
-            for (uint32_t c = 0; c < 3; ++c) {
-                s_m[c] = m[c]; s_k[c] = k[c];
-                if (!((s_present >> c) & 1u)) continue;
-                s_dst[c] = cursor;
-                cursor += ((uint64_t)s_nw[c] + 15) / 16 * 16;
-            }
-            if (cursor - sl.slot_words > sl.slot_cap_words) r = -5;   // cannot happen for a slot sized from the section length
-        }
-        st = r;
+    // the section of the first item: the last one of the run whose first item is <= it0 (workgroup-uniform: scalar loads)
+    uint32_t slot = first, hi_s = first + n_sec;
+    while (hi_s - slot > 1) {
+        const uint32_t mid = (slot + hi_s) >> 1;
+        if (slots[mid].first_item <= it0) slot = mid; else hi_s = mid;
     }
-    if (tid == kDecodeThreads - 2) {
-        // this slice's distance to the payload's end: a table entry for sections of the default unit (the usual case), a
-        // square-and-multiply chain for the few sections large enough to take a wider one
-        s_last = j == 0 ? (1u << 31) : U == (uint32_t)BSG_DECODE_UNIT ? consts->upow[j] : crc_x2nmodp((uint64_t)U * j, 3, consts->x2n);
-    }
-    __syncthreads();
-    uint32_t raw = crc32c_payload(sec + lo, hi - lo, tab, consts, part, tid);      // valid in thread 0; ends with a barrier
-    // the words that start inside [lo, hi), byte-swapped into the slot (speculative: see above)
-    if (st == 0) {
-        for (uint32_t c = 0; c < 3; ++c) {
-            if (!((s_present >> c) & 1u)) continue;
-            const uint32_t w0 = s_woff[c];
-            const uint32_t a = lo > w0 ? (lo - w0 + 7) / 8 : 0u;
-            const uint32_t e = hi > w0 ? min(s_nw[c], (hi - w0 + 7) / 8) : 0u;
-            const uint8_t *src = sec + w0;
-            uint64_t *dst = arena + s_dst[c];
-            for (uint32_t w = a + tid; w < e; w += kDecodeThreads) dst[w] = __builtin_bswap64(load_u64_unaligned(src + 8ull * w));
-        }
-    }
-    if (tid == 0) {
-        uint32_t contrib = j ? crc_multmodp(s_last, raw) : raw ^ sl.init_image;     // slice 0 carries the initial value's image and the final xor
-        uint32_t *mine = scratch.part + (uint64_t)slot * kDecodeMaxSplits;
-        uint32_t arrived = n_split;
-        if (n_split > 1) {
-            __hip_atomic_store(mine + j, contrib, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // write-through
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            arrived = __hip_atomic_fetch_add(scratch.done + slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-        }
-        if (arrived == n_split) {                                   // the section's last workgroup: every contribution is published
-            uint32_t total = contrib;
-            if (n_split > 1) {
-                total = 0;
-                for (uint32_t i = 0; i < n_split; ++i) total ^= __hip_atomic_load(mine + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            int32_t r = total != rd_le32_dev(sec + P) ? -2 : st;
+    uint32_t parsed = 0xFFFFFFFFu;                                   // the section whose header H holds
+    for (uint32_t it = it0; it < it1;) {
+        const SectionSlot sl = slots[slot];
+        const uint32_t splits = decode_splits(sl.len);
+        const uint32_t j = it - sl.first_item;
+        if (j >= splits) { ++slot; continue; }
+        ++it;
+        const uint32_t b = sl.block;
+        if (sl.len < 5) { if (tid == 0) status[b] = -1; continue; }      // parseFilterSection: too small
+        const uint32_t P = sl.len - 4, U = decode_unit(P), n_split = splits;
+        const uint8_t *sec = region + sl.begin;
+        const uint32_t hi = P - j * U, lo = hi > U ? hi - U : 0u;       // this item's slice [lo, hi) of the payload
+        __syncthreads();                                                 // (everyone is done with H / part / s_last of the previous item)
+        if (parsed != slot && tid == kDecodeThreads - 1) {
+            // the header chain (untrusted until the checksum is known: every step is checked against the payload's length)
+            uint64_t m[3];
+            int32_t r = parse_section_header(sec, P, H.present, H.woff, H.nw, m, H.k);
             if (r == 0) {
+                uint64_t cursor = sl.slot_words;
                 for (uint32_t c = 0; c < 3; ++c) {
-                    if (!((s_present >> c) & 1u)) continue;
-                    uint64_t magic = s_m[c] <= 1 ? ~0ULL : ~0ULL / s_m[c];
-                    if (s_m[c] > 1 && (s_m[c] & (s_m[c] - 1)) == 0) magic += 1;
-                    desc[(uint64_t)b * 3 + c] = DevDesc{s_dst[c], s_m[c], magic, s_k[c], 0};
+                    H.m[c] = m[c];
+                    if (!((H.present >> c) & 1u)) continue;
+                    H.dst[c] = cursor;
+                    cursor += ((uint64_t)H.nw[c] + 15) / 16 * 16;
                 }
+                if (cursor - sl.slot_words > sl.slot_cap_words) r = -5;   // cannot happen for a slot sized from the section length
             }
-            status[b] = r;
+            H.st = r;
+        }
+        parsed = slot;
+        if (tid == kDecodeThreads - 2) {
+            // this slice's distance to the payload's end: a table entry for sections of the default unit (the usual case), a
+            // square-and-multiply chain for the few sections large enough to take a wider one
+            s_last = j == 0 ? (1u << 31) : U == (uint32_t)BSG_DECODE_UNIT ? consts->upow[j] : crc_x2nmodp((uint64_t)U * j, 3, consts->x2n);
+        }
+        __syncthreads();
+        const uint32_t raw = crc_and_swap_slice(sec, lo, hi, P, H, H.st == 0, arena, tab, consts, part, tid);      // valid in thread 0; ends with a barrier
+        if (tid == 0) {
+            const uint32_t contrib = j ? crc_multmodp(s_last, raw) : raw ^ sl.init_image;     // slice 0 carries the initial value's image and the final xor
+            uint32_t *mine = scratch.part + (uint64_t)slot * kDecodeMaxSplits;
+            uint32_t arrived = n_split;
+            if (n_split > 1) {
+                // publish, then count: the count's release orders the contribution before it, its acquire orders the last arrival's
+                // reads of the others' contributions after it (agent scope: L2 is the coherence point, nothing is written back)
+                __hip_atomic_store(mine + j, contrib, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                arrived = __hip_atomic_fetch_add(scratch.done + slot, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+            }
+            if (arrived == n_split) {                                   // the section's last arrival: every contribution is published
+                uint32_t total = contrib;
+                if (n_split > 1) {
+                    total = 0;
+                    for (uint32_t i = 0; i < n_split; ++i) total ^= __hip_atomic_load(mine + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                int32_t r = total != rd_le32_dev(sec + P) ? -2 : H.st;
+                if (r == 0) {
+                    for (uint32_t c = 0; c < 3; ++c) {
+                        if (!((H.present >> c) & 1u)) continue;
+                        uint64_t magic = H.m[c] <= 1 ? ~0ULL : ~0ULL / H.m[c];
+                        if (H.m[c] > 1 && (H.m[c] & (H.m[c] - 1)) == 0) magic += 1;
+                        desc[(uint64_t)b * 3 + c] = DevDesc{H.dst[c], H.m[c], magic, H.k[c], 0};
+                    }
+                }
+                status[b] = r;
+            }
         }
     }
 }
