@@ -47,7 +47,7 @@ __host__ __device__ inline uint32_t crc_init_image(uint64_t P, const uint32_t *x
     return crc_multmodp(crc_x2nmodp(P, 3, x2n), 0xFFFFFFFFu) ^ 0xFFFFFFFFu;
 }
 
-constexpr uint32_t kDecodeMaxSplits = 64;
+constexpr uint32_t kDecodeMaxSplits = 32;      // slices of one section: their arrivals are 32 flag bits beside the section's 32-bit checksum accumulator (k_decode_sections)
 #ifndef BSG_DECODE_UNIT
 #define BSG_DECODE_UNIT 16384
 #endif

@@ -1475,7 +1475,7 @@ __device__ __forceinline__ uint32_t crc32c_payload(const uint8_t *sec, uint32_t 
     uint32_t crc = 0;
     // granules are dealt from the END: thread t's last one is granule G - 1 - t, so its partial sits exactly
     // tail + 64 t bytes before the end of the payload — two table multiplies instead of a square-and-multiply chain
-    if (tid < G) {
+    if (tid < kDecodeThreads && tid < G) {
         const uint32_t g_last = G - 1 - tid;
         bool any = false;
         for (uint32_t g = g_last % kDecodeThreads; g <= g_last; g += kDecodeThreads) {
@@ -1501,7 +1501,38 @@ __device__ __forceinline__ uint32_t crc32c_payload(const uint8_t *sec, uint32_t 
         for (uint32_t i = P - tail; i < P; ++i) t = tab[0][(t ^ sec[i]) & 0xFF] ^ (t >> 8);
         crc ^= t;
     }
-    part[tid] = crc;
+    if (tid < kDecodeThreads) part[tid] = crc;      // (a launch may carry a wave beyond the checksumming threads: k_decode_sections' header wave)
+    __syncthreads();
+    for (uint32_t step = kDecodeThreads / 2; step > 0; step >>= 1) {
+        if (tid < step) part[tid] ^= part[tid + step];
+        __syncthreads();
+    }
+    return part[0];
+}
+
+// The same for a slice of at most one granule per thread (the usual 16 KB slice), with the thread's granule ALREADY in registers:
+// k_decode_sections requests it before it copies the tables into LDS, so the payload's trip from HBM and the tables' from L2 overlap.
+__device__ __forceinline__ uint32_t crc32c_payload_pre(const uint8_t *sec, uint32_t P, const uint64_t (&v)[kCrcGranule / 8], const uint32_t (*tab)[256],
+                                                      const CrcConsts *consts, uint32_t *part, uint32_t tid)
+{
+    const uint32_t G = P / kCrcGranule, tail = P % kCrcGranule;
+    uint32_t crc = 0;
+    if (tid < kDecodeThreads && tid < G) {
+#pragma unroll
+        for (int u = 0; u < (int)(kCrcGranule / 8); ++u) {
+            const uint32_t lo = (uint32_t)v[u] ^ crc, hi = (uint32_t)(v[u] >> 32);
+            crc = tab[7][lo & 0xFF] ^ tab[6][(lo >> 8) & 0xFF] ^ tab[5][(lo >> 16) & 0xFF] ^ tab[4][lo >> 24] ^
+                  tab[3][hi & 0xFF] ^ tab[2][(hi >> 8) & 0xFF] ^ tab[1][(hi >> 16) & 0xFF] ^ tab[0][hi >> 24];
+        }
+        if (tid) crc = crc_multmodp(consts->gpow[tid], crc);
+        if (tail) crc = crc_multmodp(consts->bpow[tail], crc);
+    }
+    if (tid == kDecodeThreads - 1 && tail) {                            // trailing bytes: already aligned to the end
+        uint32_t t = 0;
+        for (uint32_t i = P - tail; i < P; ++i) t = tab[0][(t ^ sec[i]) & 0xFF] ^ (t >> 8);
+        crc ^= t;
+    }
+    if (tid < kDecodeThreads) part[tid] = crc;
     __syncthreads();
     for (uint32_t step = kDecodeThreads / 2; step > 0; step >>= 1) {
         if (tid < step) part[tid] ^= part[tid + step];
@@ -1519,8 +1550,6 @@ struct SectionSlot {
     uint32_t len;            // section bytes incl. the 4-byte CRC trailer (0 => block without a section)
     uint32_t slot_cap_words; // words the slot holds (section bytes + room for the per-filter alignment)
     uint32_t block;          // local block index: where desc / status of this section live
-    uint32_t first_item;     // (section, slice) items of the sections before this one (the device's sections in file order): the persistent decode grid's numbering
-    uint32_t pad;
     uint32_t init_image;     // 0xFFFFFFFF shifted over the payload, xor the final 0xFFFFFFFF (crc_init_image(len - 4)): a function of the
                              // length alone, computed by the host — on the device it was ~17 serial 32-step multiplies per workgroup
 };
@@ -1532,22 +1561,36 @@ __device__ __forceinline__ uint32_t rd_le32_dev(const uint8_t *p) { uint32_t v; 
 
 // parseFilterSection's structural checks (file_format.go:392-448), after the CRC has passed.  Returns 0 or the status the
 // host-side parser would give (-3 unknown flags, -4 truncated, -5 bad filter, -6 trailing bytes); fills woff / nw / m / k.
+// One thread walks this chain while its workgroup waits, so the loads of a filter's header — length, m, k, bitset length: 28
+// bytes — are issued TOGETHER wherever the payload has 28 bytes left (round 5: a round trip per filter instead of two; with the
+// flags byte riding along with the first filter's, 3 dependent round trips for a section instead of 7).  Nothing is read outside
+// the payload, and the checks and their order are parseFilterSection's.
 __device__ inline int32_t parse_section_header(const uint8_t *sec, uint32_t plen, uint32_t &present, uint32_t woff[3], uint32_t nw[3],
                                                uint64_t m[3], uint32_t k[3])
 {
     present = 0;
+    // speculative first batch: the flags byte and the first header behind it
+    uint32_t flen_spec = 0; uint64_t mm_spec = 0, kk_spec = 0, bl_spec = 0;
+    const bool spec0 = plen >= 29;
+    if (spec0) { flen_spec = rd_le32_dev(sec + 1); mm_spec = rd_be64_dev(sec + 5); kk_spec = rd_be64_dev(sec + 13); bl_spec = rd_be64_dev(sec + 21); }
     const uint32_t flags = sec[0];
     if (flags & ~7u) return -3;
     uint64_t pos = 1;
+    bool first = true;
     for (uint32_t c = 0; c < 3; ++c) {
         woff[c] = nw[c] = 0; m[c] = 0; k[c] = 0;
         if (!((flags >> c) & 1u)) continue;
         if (plen - pos < 4) return -4;
-        const uint64_t flen = rd_le32_dev(sec + pos);
+        uint64_t flen, mm = 0, kk = 0, bl = 0;
+        const bool batch = plen - pos >= 28;
+        if (first && spec0) { flen = flen_spec; mm = mm_spec; kk = kk_spec; bl = bl_spec; }      // (pos == 1: exactly the speculative batch)
+        else if (batch) { const uint8_t *q = sec + pos; flen = rd_le32_dev(q); mm = rd_be64_dev(q + 4); kk = rd_be64_dev(q + 12); bl = rd_be64_dev(q + 20); }
+        else flen = rd_le32_dev(sec + pos);
+        first = false;
         pos += 4;
         if (flen > plen - pos) return -4;
         if (flen < 24) return -5;
-        const uint64_t mm = rd_be64_dev(sec + pos), kk = rd_be64_dev(sec + pos + 8), bl = rd_be64_dev(sec + pos + 16);
+        // (flen >= 24 and flen <= plen - pos: the 24 header bytes lie inside the payload, so they were part of the batch)
         if (bl > ~0ull - 63 || mm > ~0ull - 63 || mm == 0 || kk == 0 || kk > kMaxHashCountDev) return -5;   // (mm + 63 must not wrap: an m of 2^64 - 1 would pass as 0 words)
         const uint64_t words = (bl + 63) / 64;
         if (words > (flen - 24) / 8 || (mm + 63) / 64 > words) return -5;
@@ -1560,102 +1603,77 @@ __device__ inline int32_t parse_section_header(const uint8_t *sec, uint32_t plen
     return pos == plen ? 0 : -6;
 }
 
-// A section's decode is cut into SLICES (round 4): CRC-32C is linear over GF(2), so a section's payload is cut into slices counted
-// from its END — slice j = bytes [P - (j + 1) U, P - j U), U = decode_unit(P) —
-//   * the slice's checksum (zero initial value) times x^(8 U j) is its contribution to the payload's checksum; slice 0 also carries
-//     the 0xFFFFFFFF initial value shifted over the payload and the final xor;
-//   * contributions are published with write-through stores, an arrival counter tells the last arrival of the section, which XORs
-//     them, compares with the stored checksum and writes status + descriptors (a block whose checksum fails keeps nil descriptors
-//     (m = 0), so the words written for it are never looked at).
-// Round 5: the launch is a PERSISTENT grid — a few workgroups per CU, each walking a contiguous run of the launch's (section, slice)
-// items — instead of one workgroup per slice:
-//   * the 8 KB of CRC tables are copied into LDS once per workgroup, not once per 16 KB slice (that was half as many LDS bytes
-//     written as payload bytes read);
-//   * a run's slices mostly belong to one section: the header chain (flags, lengths, m, k: <= 3 dependent reads, bounds-checked
-//     because nothing is trusted before the checksum) is walked once per section and run, not once per slice;
-//   * the payload is read ONCE: the lane that checksums a 64-byte granule also byte-swaps the words that START inside it (the words
-//     are not aligned to the granules — a filter's first word sits 29 bytes into the section — so the lane takes 8 more bytes and
-//     funnel-shifts) and stores them into the section's slot: 64 contiguous bytes per lane, a wave 4 KB.  Round 4 re-read the
-//     slice for a separate byte-swap pass (13.6 of 68.5 us).
+// Several workgroups per section (round 4).  One workgroup per section left a 1 000-section launch at 4 workgroups per CU, each
+// walking ~70 KB behind one chain of dependent loads: 76 us = 0.23 of the HBM roofline, and a run of ~55 sections (one 4 MiB
+// chunk of the region cursor) did not fill a quarter of the chip.  CRC-32C is linear over GF(2), so a section's payload is cut
+// into SLICES counted from its END — slice j = bytes [P - (j + 1) U, P - j U), U = decode_unit(P) — one workgroup each:
+//   * the slice's checksum (crc32c_payload, zero initial value) times x^(8 U j) is its contribution to the payload's checksum;
+//     slice 0 also carries the 0xFFFFFFFF initial value shifted over the payload and the final xor;
+//   * every workgroup walks the header chain itself (flags, lengths, m, k: <= 3 dependent reads, bounds-checked against the
+//     payload because nothing is trusted before the checksum) and byte-swaps the words that START inside its slice into
+//     the section's slot — before the checksum is known: a block whose checksum fails keeps nil descriptors (m = 0), so
+//     its words are never looked at;
+//   * a contribution is published and counted by ONE atomic XOR into the section's word (checksum accumulator + one arrival flag per
+//     slice); the arrival that completes the flags compares with the stored checksum and writes status + descriptors.
+// grid = (most slices of any section of the run, sections [first, first + gridDim.y)).
 // (decode_unit / decode_splits / kDecodeMaxSplits and the GF(2) arithmetic live in crc_slices.h: tests/crc_slices_check.cpp walks the
 //  same slices on the host)
 struct DecodeScratch {
-    uint32_t *part;     // [slot][kDecodeMaxSplits] contributions to the section's checksum
-    uint32_t *done;     // [slot] arrivals (0 before the section's launch)
+    uint64_t *acc;      // [slot] low half: XOR of the slices' contributions so far; high half: one flag per slice that arrived (0 before the section's launch)
 };
 
-struct DecodeHeader {            // a section's parsed header, kept in LDS while the workgroup's items stay inside the section
-    uint32_t present, woff[3], nw[3], k[3];
-    int32_t st;
-    uint64_t dst[3], m[3];
-};
-
-// the words of the section's filters that start inside the 64-byte granule at byte `p` (of the section), byte-swapped into the slot.
-// v[0..7] = the granule, v[8] = the 8 bytes behind it.
-__device__ __forceinline__ void swap_granule_words(const DecodeHeader &H, uint64_t *arena, uint32_t p, const uint64_t (&v)[9])
+#ifndef BSG_DECODE_IMAGE
+#define BSG_DECODE_IMAGE 0        // lab: 1 = a slice of <= 16 KB is read once, coalesced, into an LDS image the checksum and the byte-swap work from (measured
+                                  // round 5: 77.8 vs 66.7 us per 1 000 sections — the image's bank conflicts and 28 KB of LDS per workgroup cost more than
+                                  // the 7 x fewer L1 accesses save); 0 = every lane loads its granule itself, the byte-swap re-reads the slice from L2
+#endif
+constexpr uint32_t kDecodeTrip = kDecodeThreads * kCrcGranule;                    // 16 KB: one granule per checksumming thread
+// the image in LDS: 8-byte words, ONE word of padding behind every 8 (a granule's words then lie 9 words from the next lane's: the
+// lanes of a wave reading "their" word hit different banks instead of all hitting two)
+constexpr uint32_t kImageBytes = kDecodeTrip + 16 + 8 + 16;                       // alignment slack in front, the 8 bytes behind, rounding
+constexpr uint32_t kImageWords = (kImageBytes / 8 + 7) / 8 * 9 + 9;
+__device__ __forceinline__ uint32_t image_word(uint32_t w) { return w + (w >> 3); }
+// the 8 bytes at byte offset o of the image
+__device__ __forceinline__ uint64_t image_u64(const uint64_t *img, uint32_t o)
 {
-#pragma unroll
-    for (uint32_t c = 0; c < 3; ++c) {
-        if (!((H.present >> c) & 1u)) continue;
-        const uint32_t w0 = H.woff[c], wend = w0 + 8u * H.nw[c];
-        if (p + 64u <= w0 || p >= wend) continue;                    // (most granules lie inside exactly one filter)
-        const uint32_t d = (w0 - p) & 7u;                            // where in every 8 bytes of the granule a word starts
-        uint64_t *dst = arena + H.dst[c];
-#pragma unroll
-        for (uint32_t k = 0; k < 8; ++k) {
-            const uint32_t at = p + d + 8u * k;                      // the word's first byte
-            if (at < w0 || at >= wend) continue;
-            const uint64_t x = d == 0 ? v[k] : (v[k] >> (8u * d)) | (v[k + 1] << (64u - 8u * d));
-            dst[(at - w0) >> 3] = __builtin_bswap64(x);
-        }
-    }
+    const uint32_t w = o >> 3, sh = (o & 7u) * 8u;
+    const uint64_t a = img[image_word(w)];
+    return sh ? (a >> sh) | (img[image_word(w + 1)] << (64u - sh)) : a;
 }
 
-// CRC32C (zero initial value) of the slice [lo, hi) of the section at `sec`, with the byte-swap of its words folded in.  The scheme
-// of crc32c_payload: 64-byte granules dealt to the threads from the slice's END, partials aligned to the end and XOR-ed.  Result
-// valid in thread 0; ends with a barrier.
-__device__ __forceinline__ uint32_t crc_and_swap_slice(const uint8_t *sec, uint32_t lo, uint32_t hi, uint32_t P, const DecodeHeader &H, bool do_swap,
-                                                       uint64_t *arena, const uint32_t (*tab)[256], const CrcConsts *consts, uint32_t *part, uint32_t tid)
+// crc32c_payload's checksum of the n (<= 16 KB) bytes that start `delta` bytes into the LDS image: granules dealt to the threads from
+// the END, partials aligned to the end and XOR-ed.  Result valid in thread 0; ends with a barrier.
+__device__ __forceinline__ uint32_t crc32c_image(const uint64_t *img, uint32_t delta, uint32_t n, const uint32_t (*tab)[256], const CrcConsts *consts,
+                                                uint32_t *part, uint32_t tid)
 {
-    const uint32_t n = hi - lo, G = n / kCrcGranule, tail = n % kCrcGranule;
-    const uint32_t skip = consts->skip;
+    const uint32_t G = n / kCrcGranule, tail = n % kCrcGranule;
     uint32_t crc = 0;
-    if (tid < G) {
-        const uint32_t g_last = G - 1 - tid;
-        bool any = false;
-        for (uint32_t g = g_last % kDecodeThreads; g <= g_last; g += kDecodeThreads) {
-            uint64_t v[9];
-            const uint32_t p = lo + g * kCrcGranule;
-            const uint8_t *src = sec + p;
+    if (tid < kDecodeThreads && tid < G) {
+        const uint32_t o = delta + (G - 1 - tid) * kCrcGranule;
+        const uint32_t w = o >> 3, sh = (o & 7u) * 8u;                // (sh is the same for every lane: delta & 7)
+        uint64_t x[9];
 #pragma unroll
-            for (int u = 0; u < 9; ++u) v[u] = load_u64_unaligned(src + 8 * u);      // (the region image is allocated 64 bytes longer than the file bytes it holds)
-            if (any) crc = crc_multmodp(skip, crc);
-            any = true;
+        for (int u = 0; u < 9; ++u) x[u] = img[image_word(w + u)];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const uint32_t l = (uint32_t)v[u] ^ crc, h = (uint32_t)(v[u] >> 32);
-                crc = tab[7][l & 0xFF] ^ tab[6][(l >> 8) & 0xFF] ^ tab[5][(l >> 16) & 0xFF] ^ tab[4][l >> 24] ^
-                      tab[3][h & 0xFF] ^ tab[2][(h >> 8) & 0xFF] ^ tab[1][(h >> 16) & 0xFF] ^ tab[0][h >> 24];
-            }
-            if (do_swap) swap_granule_words(H, arena, p, v);
+        for (int u = 0; u < 8; ++u) {
+            const uint64_t vv = sh ? (x[u] >> sh) | (x[u + 1] << (64u - sh)) : x[u];
+            const uint32_t lo = (uint32_t)vv ^ crc, hi = (uint32_t)(vv >> 32);
+            crc = tab[7][lo & 0xFF] ^ tab[6][(lo >> 8) & 0xFF] ^ tab[5][(lo >> 16) & 0xFF] ^ tab[4][lo >> 24] ^
+                  tab[3][hi & 0xFF] ^ tab[2][(hi >> 8) & 0xFF] ^ tab[1][(hi >> 16) & 0xFF] ^ tab[0][hi >> 24];
         }
         if (tid) crc = crc_multmodp(consts->gpow[tid], crc);
         if (tail) crc = crc_multmodp(consts->bpow[tail], crc);
     }
     if (tid == kDecodeThreads - 1 && tail) {                            // trailing bytes: already aligned to the end
         uint32_t t = 0;
-        for (uint32_t i = hi - tail; i < hi; ++i) t = tab[0][(t ^ sec[i]) & 0xFF] ^ (t >> 8);
+        for (uint32_t i = n - tail; i < n; ++i) {
+            const uint32_t o = delta + i;
+            const uint32_t byte = (uint32_t)(img[image_word(o >> 3)] >> ((o & 7u) * 8u)) & 0xFFu;
+            t = tab[0][(t ^ byte) & 0xFF] ^ (t >> 8);
+        }
         crc ^= t;
-        if (do_swap)                                                    // ... and the (<= 8) words that start among them
-            for (uint32_t c = 0; c < 3; ++c) {
-                if (!((H.present >> c) & 1u)) continue;
-                const uint32_t w0 = H.woff[c];
-                for (uint32_t w = hi - tail > w0 ? (hi - tail - w0 + 7) / 8 : 0u; w < H.nw[c] && w0 + 8u * w < hi; ++w)
-                    arena[H.dst[c] + w] = __builtin_bswap64(load_u64_unaligned(sec + w0 + 8ull * w));
-            }
     }
-    (void)P;
-    part[tid] = crc;
+    if (tid < kDecodeThreads) part[tid] = crc;
     __syncthreads();
     for (uint32_t step = kDecodeThreads / 2; step > 0; step >>= 1) {
         if (tid < step) part[tid] ^= part[tid + step];
@@ -1664,93 +1682,151 @@ __device__ __forceinline__ uint32_t crc_and_swap_slice(const uint8_t *sec, uint3
     return part[0];
 }
 
-// grid = (workgroups, 1): workgroup w walks the items [I0 + n w / W, I0 + n (w + 1) / W) of the run's sections [first, first + n_sec),
-// an item = (section, slice), numbered section by section (SectionSlot::first_item).
-__global__ __launch_bounds__(kDecodeThreads) void k_decode_sections(const uint8_t *region, const SectionSlot *slots, uint32_t first, uint32_t n_sec,
+#ifndef BSG_DECODE_HDR_WAVE
+#define BSG_DECODE_HDR_WAVE 0     // 1: a fifth wave walks the header chain while the four others checksum; 0: thread 255 walks it in front of its own granule (lab)
+#endif
+constexpr int kDecodeLaunchThreads = kDecodeThreads + (BSG_DECODE_HDR_WAVE ? kWave : 0);
+constexpr uint32_t kImagePieces = (kImageBytes / 16 + kDecodeLaunchThreads - 1) / kDecodeLaunchThreads;      // 16-byte pieces a thread carries from memory to the image
+__global__ __launch_bounds__(kDecodeLaunchThreads) void k_decode_sections(const uint8_t *region, const SectionSlot *slots, uint32_t first,
                                                                    const CrcConsts *consts, uint64_t *arena, DevDesc *desc,
                                                                    int32_t *status, const DecodeScratch scratch)
 {
     __shared__ uint32_t tab[8][256];
     __shared__ uint32_t part[kDecodeThreads];
-    __shared__ DecodeHeader H;
-    __shared__ uint32_t s_last;
+#if BSG_DECODE_IMAGE
+    __shared__ uint64_t img[kImageWords];
+#endif
+    __shared__ int32_t st;
+    __shared__ uint32_t s_present, s_woff[3], s_nw[3], s_k[3], s_last;
+    __shared__ uint64_t s_dst[3], s_m[3];
     const uint32_t tid = threadIdx.x;
-    const uint32_t I0 = slots[first].first_item;
-    const SectionSlot last_sl = slots[first + n_sec - 1];
-    const uint32_t n_items = last_sl.first_item + decode_splits(last_sl.len) - I0;
-    const uint32_t it0 = I0 + (uint32_t)((uint64_t)n_items * blockIdx.x / gridDim.x), it1 = I0 + (uint32_t)((uint64_t)n_items * (blockIdx.x + 1) / gridDim.x);
-    if (it0 >= it1) return;
-    for (uint32_t i = tid; i < 8 * 256; i += kDecodeThreads) (&tab[0][0])[i] = (&consts->table[0][0])[i];
-    // the section of the first item: the last one of the run whose first item is <= it0 (workgroup-uniform: scalar loads)
-    uint32_t slot = first, hi_s = first + n_sec;
-    while (hi_s - slot > 1) {
-        const uint32_t mid = (slot + hi_s) >> 1;
-        if (slots[mid].first_item <= it0) slot = mid; else hi_s = mid;
+    const uint32_t slot = first + blockIdx.y, j = blockIdx.x;
+    const SectionSlot sl = slots[slot];
+    const uint32_t b = sl.block;
+    if (sl.len == 0) return;                                       // block without a section: filters stay nil, status 0
+    if (sl.len < 5) { if (tid == 0 && j == 0) status[b] = -1; return; }      // parseFilterSection: too small
+    const uint32_t P = sl.len - 4, U = decode_unit(P), n_split = P == 0 ? 1u : (P + U - 1) / U;
+    if (j >= n_split) return;
+    const uint8_t *sec = region + sl.begin;
+    const uint32_t hi = P - j * U, lo = hi > U ? hi - U : 0u;       // this workgroup's slice [lo, hi) of the payload
+    // (lab, BSG_DECODE_IMAGE) The slice is read from memory ONCE, in 16-byte pieces dealt to the lanes in order (a wave's load covers 1 KiB of consecutive
+    // bytes: 8 cache lines), and parked in LDS; the checksum pass takes its 64-byte granules from there and the byte-swap its words.
+    // Round 4 had every lane load ITS granule straight from memory — 8-byte loads at a 64-byte lane stride: 32 cache lines per load
+    // instruction, 695 L1 accesses per wave for ~100 lines' worth of data (profiles/r05_decode_pmc.txt) — and re-read the slice for
+    // the byte-swap.  The pieces are requested FIRST: their trip from HBM overlaps the copy of the CRC tables into LDS.
+    const uint32_t n_slice = hi - lo;
+    const bool one_trip = n_slice <= kDecodeTrip;
+#if !BSG_DECODE_IMAGE
+    // the thread's granule is requested FIRST (round 5): its trip from HBM overlaps the copy of the CRC tables into LDS
+    uint64_t v[kCrcGranule / 8];
+    if (one_trip && tid < (uint32_t)kDecodeThreads && tid < n_slice / kCrcGranule) {
+        const uint8_t *p = sec + lo + (uint64_t)(n_slice / kCrcGranule - 1 - tid) * kCrcGranule;
+#pragma unroll
+        for (int u = 0; u < (int)(kCrcGranule / 8); ++u) v[u] = load_u64_unaligned(p + 8 * u);
+    } else {
+#pragma unroll
+        for (int u = 0; u < (int)(kCrcGranule / 8); ++u) v[u] = 0;
     }
-    uint32_t parsed = 0xFFFFFFFFu;                                   // the section whose header H holds
-    for (uint32_t it = it0; it < it1;) {
-        const SectionSlot sl = slots[slot];
-        const uint32_t splits = decode_splits(sl.len);
-        const uint32_t j = it - sl.first_item;
-        if (j >= splits) { ++slot; continue; }
-        ++it;
-        const uint32_t b = sl.block;
-        if (sl.len < 5) { if (tid == 0) status[b] = -1; continue; }      // parseFilterSection: too small
-        const uint32_t P = sl.len - 4, U = decode_unit(P), n_split = splits;
-        const uint8_t *sec = region + sl.begin;
-        const uint32_t hi = P - j * U, lo = hi > U ? hi - U : 0u;       // this item's slice [lo, hi) of the payload
-        __syncthreads();                                                 // (everyone is done with H / part / s_last of the previous item)
-        if (parsed != slot && tid == kDecodeThreads - 1) {
-            // the header chain (untrusted until the checksum is known: every step is checked against the payload's length)
-            uint64_t m[3];
-            int32_t r = parse_section_header(sec, P, H.present, H.woff, H.nw, m, H.k);
-            if (r == 0) {
-                uint64_t cursor = sl.slot_words;
-                for (uint32_t c = 0; c < 3; ++c) {
-                    H.m[c] = m[c];
-                    if (!((H.present >> c) & 1u)) continue;
-                    H.dst[c] = cursor;
-                    cursor += ((uint64_t)H.nw[c] + 15) / 16 * 16;
-                }
-                if (cursor - sl.slot_words > sl.slot_cap_words) r = -5;   // cannot happen for a slot sized from the section length
-            }
-            H.st = r;
+#else
+    const uintptr_t s0 = reinterpret_cast<uintptr_t>(sec + lo);
+    const uint32_t delta = (uint32_t)(s0 & 15u);                      // the slice starts `delta` bytes into the image
+    const uint4 *src16 = reinterpret_cast<const uint4 *>(s0 - delta);
+    const uint32_t n16 = (delta + n_slice + 8u + 15u) / 16u;          // (+ 8: a word may start in the slice's last bytes; the region image is allocated 64 bytes longer than the file bytes it holds)
+    uint4 piece[kImagePieces];
+    if (one_trip) {
+#pragma unroll
+        for (uint32_t r = 0; r < kImagePieces; ++r) {
+            const uint32_t i = tid + r * kDecodeLaunchThreads;
+            piece[r] = i < n16 ? src16[i] : uint4{0, 0, 0, 0};
         }
-        parsed = slot;
-        if (tid == kDecodeThreads - 2) {
-            // this slice's distance to the payload's end: a table entry for sections of the default unit (the usual case), a
-            // square-and-multiply chain for the few sections large enough to take a wider one
-            s_last = j == 0 ? (1u << 31) : U == (uint32_t)BSG_DECODE_UNIT ? consts->upow[j] : crc_x2nmodp((uint64_t)U * j, 3, consts->x2n);
+    }
+#endif
+    for (uint32_t i = tid; i < 8 * 256; i += kDecodeLaunchThreads) (&tab[0][0])[i] = (&consts->table[0][0])[i];
+    // the tables are in place; from here the header chain — 3 dependent round trips, one thread — runs BESIDE the checksum pass (round
+    // 5: it ran in front of it, every wave waiting): the pass does not need the header, only the byte-swap behind it does, and the
+    // pass ends with barriers
+    __syncthreads();
+    constexpr uint32_t kHdrThread = BSG_DECODE_HDR_WAVE ? kDecodeThreads : kDecodeThreads - 1;
+    if (tid == kHdrThread) {
+        // the header chain (untrusted until the checksum is known: every step is checked against the payload's length).  Every
+        // workgroup of the section walks it itself, while its other waves are already at their granules — a launch of its own
+        // for the headers (one thread per section, a parsed-header table) was measured and dropped: 68 -> 73 us in one launch,
+        // 107 -> 134 us as four launches behind the copy.
+        uint64_t m[3];
+        uint32_t k[3];
+        int32_t r = parse_section_header(sec, P, s_present, s_woff, s_nw, m, k);
+        if (r == 0) {
+            uint64_t cursor = sl.slot_words;
+            for (uint32_t c = 0; c < 3; ++c) {
+                s_m[c] = m[c]; s_k[c] = k[c];
+                if (!((s_present >> c) & 1u)) continue;
+                s_dst[c] = cursor;
+                cursor += ((uint64_t)s_nw[c] + 15) / 16 * 16;
+            }
+            if (cursor - sl.slot_words > sl.slot_cap_words) r = -5;   // cannot happen for a slot sized from the section length
+        }
+        st = r;
+    }
+    if (tid == (BSG_DECODE_HDR_WAVE ? kDecodeThreads + 1 : kDecodeThreads - 2)) {
+        // this slice's distance to the payload's end: a table entry for sections of the default unit (the usual case), a
+        // square-and-multiply chain for the few sections large enough to take a wider one
+        s_last = j == 0 ? (1u << 31) : U == (uint32_t)BSG_DECODE_UNIT ? consts->upow[j] : crc_x2nmodp((uint64_t)U * j, 3, consts->x2n);
+    }
+    uint32_t raw;
+#if !BSG_DECODE_IMAGE
+    raw = one_trip ? crc32c_payload_pre(sec + lo, n_slice, v, tab, consts, part, tid)
+                   : crc32c_payload(sec + lo, n_slice, tab, consts, part, tid);      // valid in thread 0; ends with barriers: the header is visible behind them
+#else
+    if (one_trip) {
+        // (the image is written behind the tables' barrier: nobody reads it before the barrier below)
+#pragma unroll
+        for (uint32_t r = 0; r < kImagePieces; ++r) {
+            const uint32_t i = tid + r * kDecodeLaunchThreads;
+            if (i < n16) { img[image_word(2 * i)] = (uint64_t)piece[r].x | ((uint64_t)piece[r].y << 32); img[image_word(2 * i + 1)] = (uint64_t)piece[r].z | ((uint64_t)piece[r].w << 32); }
         }
         __syncthreads();
-        const uint32_t raw = crc_and_swap_slice(sec, lo, hi, P, H, H.st == 0, arena, tab, consts, part, tid);      // valid in thread 0; ends with a barrier
-        if (tid == 0) {
-            const uint32_t contrib = j ? crc_multmodp(s_last, raw) : raw ^ sl.init_image;     // slice 0 carries the initial value's image and the final xor
-            uint32_t *mine = scratch.part + (uint64_t)slot * kDecodeMaxSplits;
-            uint32_t arrived = n_split;
-            if (n_split > 1) {
-                // publish, then count: the count's release orders the contribution before it, its acquire orders the last arrival's
-                // reads of the others' contributions after it (agent scope: L2 is the coherence point, nothing is written back)
-                __hip_atomic_store(mine + j, contrib, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                arrived = __hip_atomic_fetch_add(scratch.done + slot, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+        raw = crc32c_image(img, delta, n_slice, tab, consts, part, tid);      // valid in thread 0; ends with barriers: the header is visible behind them
+    } else raw = crc32c_payload(sec + lo, hi - lo, tab, consts, part, tid);
+#endif
+    // the words that start inside [lo, hi), byte-swapped into the slot (speculative: see above)
+    if (st == 0) {
+        for (uint32_t c = 0; c < 3; ++c) {
+            if (!((s_present >> c) & 1u)) continue;
+            const uint32_t w0 = s_woff[c];
+            const uint32_t a = lo > w0 ? (lo - w0 + 7) / 8 : 0u;
+            const uint32_t e = hi > w0 ? min(s_nw[c], (hi - w0 + 7) / 8) : 0u;
+            uint64_t *dst = arena + s_dst[c];
+            if (BSG_DECODE_IMAGE && one_trip) {
+#if BSG_DECODE_IMAGE
+                for (uint32_t w = a + tid; w < e; w += kDecodeLaunchThreads) dst[w] = __builtin_bswap64(image_u64(img, delta + (w0 + 8u * w - lo)));
+#endif
+            } else {
+                const uint8_t *src = sec + w0;
+                for (uint32_t w = a + tid; w < e; w += kDecodeLaunchThreads) dst[w] = __builtin_bswap64(load_u64_unaligned(src + 8ull * w));
             }
-            if (arrived == n_split) {                                   // the section's last arrival: every contribution is published
-                uint32_t total = contrib;
-                if (n_split > 1) {
-                    total = 0;
-                    for (uint32_t i = 0; i < n_split; ++i) total ^= __hip_atomic_load(mine + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (tid == 0) {
+        const uint32_t contrib = j ? crc_multmodp(s_last, raw) : raw ^ sl.init_image;     // slice 0 carries the initial value's image and the final xor
+        // ONE atomic publishes and counts (round 5; round 4: a write-through store, a wait, a counter, and the last arrival's reads):
+        // the section's word holds the XOR of the contributions in its low half and one arrival flag per slice in its high half
+        // (kDecodeMaxSplits = 32 slices at most).  Atomics on one address are totally ordered, so the arrival whose flags complete the
+        // set has every contribution in the value it computes from what the atomic returned — nothing else needs ordering (the
+        // byte-swapped words are consumed by later kernels), and nothing depends on this target's cache hierarchy.
+        uint64_t now = (uint64_t)contrib | (1ull << (32 + j));
+        if (n_split > 1) now ^= __hip_atomic_fetch_xor(scratch.acc + slot, now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((uint32_t)__popcll(now >> 32) == n_split) {             // the section's last arrival
+            const uint32_t total = (uint32_t)now;
+            int32_t r = total != rd_le32_dev(sec + P) ? -2 : st;
+            if (r == 0) {
+                for (uint32_t c = 0; c < 3; ++c) {
+                    if (!((s_present >> c) & 1u)) continue;
+                    uint64_t magic = s_m[c] <= 1 ? ~0ULL : ~0ULL / s_m[c];
+                    if (s_m[c] > 1 && (s_m[c] & (s_m[c] - 1)) == 0) magic += 1;
+                    desc[(uint64_t)b * 3 + c] = DevDesc{s_dst[c], s_m[c], magic, s_k[c], 0};
                 }
-                int32_t r = total != rd_le32_dev(sec + P) ? -2 : H.st;
-                if (r == 0) {
-                    for (uint32_t c = 0; c < 3; ++c) {
-                        if (!((H.present >> c) & 1u)) continue;
-                        uint64_t magic = H.m[c] <= 1 ? ~0ULL : ~0ULL / H.m[c];
-                        if (H.m[c] > 1 && (H.m[c] & (H.m[c] - 1)) == 0) magic += 1;
-                        desc[(uint64_t)b * 3 + c] = DevDesc{H.dst[c], H.m[c], magic, H.k[c], 0};
-                    }
-                }
-                status[b] = r;
             }
+            status[b] = r;
         }
     }
 }
