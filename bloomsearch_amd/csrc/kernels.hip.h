@@ -404,6 +404,11 @@ __device__ __forceinline__ void par_task_finish(const ParTask &p, BITS32 bits, l
 #endif
 constexpr uint32_t kGroup = BSG_KGROUP;          // chunks of 64 terms whose loads / reductions / LDS reads are in flight together (lab: -DBSG_KGROUP)
 constexpr uint32_t kTailBatch = BSG_TAIL_BATCH;
+#ifndef BSG_TAIL_SPLIT
+#define BSG_TAIL_SPLIT 0          // lab: 1 = the many-term tail in two parts with a compaction between.  Measured round 5 (needle batch, 4 054 terms, 64 arenas
+                                  // per launch): 1 191.6 vs 1 113.8 us — the second gather of the survivors' hashes and the extra ballots cost more than
+                                  // the lanes the second part saves (profiles/r05_probe_needle.txt).  The structural attempts on this kernel end here.
+#endif
 #ifndef BSG_COMPACT_ROUNDS
 #define BSG_COMPACT_ROUNDS 1
 #endif
@@ -528,6 +533,49 @@ __device__ __forceinline__ void probe_rounds(const ProbeArgs &a, const DevDesc &
     // ---- tail: remaining locations from registers, two chunks interleaved, wave-level early-out ----
     if (i < d.k && qn != 0) {
         const uint64_t *r1 = th + (uint64_t)a.Tp, *r2 = th + 2ull * a.Tp, *r3 = th + 3ull * a.Tp;
+#if BSG_TAIL_SPLIT
+        // (lab) The tail in TWO parts.  What reaches it is the present terms plus the false positives of the first locations
+        // (needle batch: ~150 of a wave's 512 terms, a quarter of them present); every further location halves the false positives,
+        // the present terms go through all of them.  So the first kTailBatch locations run over the whole queue, the survivors —
+        // now mostly present terms — are compacted in place, and only they pay for the remaining locations (their four hashes are
+        // gathered again: a quarter of the entries).  One wave-level pass of ballots buys the second half of the tail ~4 x fewer lanes.
+        if (i + kTailBatch < d.k && qn > 64) {
+            uint32_t out = 0;
+            for (uint32_t j = 0; j < qn; j += 128) {
+                const bool two = j + 64 < qn;                                         // scalar
+                bool aliveA = j + lane < qn, aliveB = two && (j + 64 + lane < qn);
+                const uint32_t liA = aliveA ? (uint32_t)q[j + lane] : 0u, liB = aliveB ? (uint32_t)q[j + 64 + lane] : 0u;
+                const uint64_t a0 = load_u64_at(th, liA * 8u), a1 = load_u64_at(r1, liA * 8u), a2 = load_u64_at(r2, liA * 8u), a3 = load_u64_at(r3, liA * 8u);
+                uint64_t b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+                if (two) { b0 = load_u64_at(th, liB * 8u); b1 = load_u64_at(r1, liB * 8u); b2 = load_u64_at(r2, liB * 8u); b3 = load_u64_at(r3, liB * 8u); }
+                uint32_t alla = 1u, allb = 1u;
+#pragma unroll
+                for (uint32_t v = 0; v < kTailBatch; ++v) {
+                    const uint32_t iv = i + v;                                        // uniform, < d.k
+                    const bool odd = iv & 1u, use3 = ((iv & 3u) == 1u) | ((iv & 3u) == 2u);
+                    const uint64_t xa = (odd ? a1 : a0) + (uint64_t)iv * (use3 ? a3 : a2);
+                    alla &= bit_at(bits, locate_c<M32>(d, xa));
+                    if (two) {
+                        const uint64_t xb = (odd ? b1 : b0) + (uint64_t)iv * (use3 ? b3 : b2);
+                        allb &= bit_at(bits, locate_c<M32>(d, xb));
+                    }
+                }
+                aliveA = aliveA & (alla != 0u);
+                aliveB = aliveB & (allb != 0u);
+                const uint64_t mA = __ballot(aliveA);                                 // (out <= j: in place is safe)
+                if (aliveA) q[out + lane_rank(mA)] = (uint16_t)liA;
+                out += (uint32_t)__builtin_popcountll(mA);
+                if (two) {
+                    const uint64_t mB = __ballot(aliveB);
+                    if (aliveB) q[out + lane_rank(mB)] = (uint16_t)liB;
+                    out += (uint32_t)__builtin_popcountll(mB);
+                }
+            }
+            qn = out;
+            i += kTailBatch;
+            if (qn == 0) return;
+        }
+#endif
         const uint32_t i0 = i;
         for (uint32_t j = 0; j < qn; j += 128) {
             const bool two = j + 64 < qn;                                         // scalar
