@@ -356,30 +356,65 @@ func (e *gpuEngine) arenaFor(s *bloomgpu.Context, file io.ReadSeeker, filePointe
 	}
 	e.arenaMu.Unlock()
 
-	begin := make([]uint64, 0, len(blocks)+len(haveOff))
-	end := make([]uint64, 0, len(blocks)+len(haveOff))
-	offsets := make([]int, 0, len(blocks)+len(haveOff))
 	for i := range blocks {
 		if i > 0 && blocks[i].RowDataOffset <= blocks[i-1].RowDataOffset {
 			return nil, false, errors.New("bloomgpu: candidate blocks are not in ascending RowDataOffset order")
 		}
 	}
-	for i, j := 0, 0; i < len(blocks) || j < len(haveOff); { // merge by RowDataOffset; a block both lists name is taken once
-		if j == len(haveOff) || (i < len(blocks) && blocks[i].RowDataOffset <= haveOff[j]) {
-			if j < len(haveOff) && blocks[i].RowDataOffset == haveOff[j] {
+	candBegin := make([]uint64, len(blocks))
+	candEnd := make([]uint64, len(blocks))
+	candOff := make([]int, len(blocks))
+	for i := range blocks {
+		candOff[i] = blocks[i].RowDataOffset
+		candBegin[i] = uint64(blocks[i].BloomFilterOffset)
+		candEnd[i] = uint64(blocks[i].BloomFilterOffset) + uint64(blocks[i].BloomFilterSize) // size 0: a block without a section (nil filters)
+	}
+	if len(haveOff) > 0 {
+		begin := make([]uint64, 0, len(blocks)+len(haveOff))
+		end := make([]uint64, 0, len(blocks)+len(haveOff))
+		offsets := make([]int, 0, len(blocks)+len(haveOff))
+		foreign := make([]bool, 0, len(blocks)+len(haveOff)) // a section only the cached arena asked for, not this query
+		for i, j := 0, 0; i < len(blocks) || j < len(haveOff); { // merge by RowDataOffset; a block both lists name is taken once
+			if j == len(haveOff) || (i < len(blocks) && candOff[i] <= haveOff[j]) {
+				if j < len(haveOff) && candOff[i] == haveOff[j] {
+					j++
+				}
+				offsets, begin, end, foreign = append(offsets, candOff[i]), append(begin, candBegin[i]), append(end, candEnd[i]), append(foreign, false)
+				i++
+			} else {
+				offsets, begin, end, foreign = append(offsets, haveOff[j]), append(begin, haveBegin[j]), append(end, haveEnd[j]), append(foreign, true)
 				j++
 			}
-			offsets = append(offsets, blocks[i].RowDataOffset)
-			begin = append(begin, uint64(blocks[i].BloomFilterOffset))
-			end = append(end, uint64(blocks[i].BloomFilterOffset)+uint64(blocks[i].BloomFilterSize)) // size 0: a block without a section (nil filters)
-			i++
-		} else {
-			offsets = append(offsets, haveOff[j])
-			begin = append(begin, haveBegin[j])
-			end = append(end, haveEnd[j])
-			j++
+		}
+		wide, wideReadFailed, wideErr := e.loadArena(s, file, begin, end, offsets)
+		// The widening reads sections this query never asked for.  The reference only ever reads the candidates' sections
+		// (query_exec.go:565-615): a failed read or a bad section among the FOREIGN ones must not fail this query's candidates, mark
+		// the handle unhealthy, or keep every later query re-reading the whole file — the candidates are then loaded by themselves.
+		foreignTrouble := wideErr != nil || wideReadFailed
+		if wide != nil {
+			for i := range wide.status {
+				if foreign[i] && wide.status[i] != 0 {
+					foreignTrouble = true
+				}
+			}
+		}
+		if !foreignTrouble {
+			return e.keepArena(key, wide), false, nil
+		}
+		if wide != nil {
+			e.g.ArenaFree(wide.arena)
 		}
 	}
+	only, readFailed, err := e.loadArena(s, file, candBegin, candEnd, candOff)
+	if err != nil || readFailed {
+		return nil, readFailed, err
+	}
+	return e.keepArena(key, only), false, nil
+}
+
+// loadArena reads the sections [begin[i], end[i]) — in runs of at most blockFilterChunkTarget bytes, skipping what lies between
+// them, as blockFilterCursor does — into an arena stream that decodes them on the device.
+func (e *gpuEngine) loadArena(s *bloomgpu.Context, file io.ReadSeeker, begin, end []uint64, offsets []int) (fa *gpuFileArena, readFailed bool, err error) {
 	stream, err := s.ArenaStreamBegin(begin, end)
 	if err != nil {
 		return nil, false, err
@@ -420,10 +455,19 @@ func (e *gpuEngine) arenaFor(s *bloomgpu.Context, file io.ReadSeeker, filePointe
 		return nil, false, err
 	}
 	fa = &gpuFileArena{arena: arena, offsets: offsets, begin: begin, end: end, status: status, users: 1}
-	clean := true
 	for i := range status {
 		fa.bytes += int64(end[i] - begin[i])
-		if status[i] != 0 {
+	}
+	return fa, false, nil
+}
+
+// keepArena makes a freshly loaded arena the file's resident one when it may be (clean, within the budget, not narrower than what a
+// concurrent query cached meanwhile); otherwise it serves this query only and is freed by done().
+func (e *gpuEngine) keepArena(key string, fa *gpuFileArena) *gpuFileArena {
+	offsets := fa.offsets
+	clean := true
+	for i := range fa.status {
+		if fa.status[i] != 0 {
 			clean = false
 		}
 	}
@@ -434,12 +478,12 @@ func (e *gpuEngine) arenaFor(s *bloomgpu.Context, file io.ReadSeeker, filePointe
 	// (query_exec.go:565-615) and recovers on the next one; a cached status would replay the failure until the file is merged.
 	if !clean || fa.bytes > e.arenaBudget {
 		fa.dead = true // serves this query, freed by done()
-		return fa, false, nil
+		return fa
 	}
 	if old := e.arenas[key]; old != nil {
 		if len(old.offsets) > len(offsets) {
 			fa.dead = true // a concurrent query cached a wider arena meanwhile: keep that one
-			return fa, false, nil
+			return fa
 		}
 		e.dropLocked(key, old)
 	}
@@ -448,7 +492,7 @@ func (e *gpuEngine) arenaFor(s *bloomgpu.Context, file io.ReadSeeker, filePointe
 	e.arenas[key] = fa
 	e.arenaBytes += fa.bytes
 	e.evictLocked(fa)
-	return fa, false, nil
+	return fa
 }
 
 // evaluateBlockFilters is the per-block loop of the reference's evaluateBlockFilters (query_exec.go:565-615) as one device

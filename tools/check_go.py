@@ -361,7 +361,7 @@ def check_patch(reference, problems, notes):
         # every hook the patch calls must exist, with that many arguments, in the real engine file AND in the stub
         real = hook_signatures(os.path.join(ROOT, "go", "overlay", "gpu_engine.go"))
         stub = hook_signatures(os.path.join(ROOT, "go", "overlay", "gpu_engine_stub.go"))
-        internal = {"gpuEngine.scope", "gpuEngine.release", "gpuEngine.done", "gpuEngine.arenaFor", "gpuEngine.dropLocked", "gpuEngine.evictLocked"}     # helpers the patch never calls
+        internal = {"gpuEngine.scope", "gpuEngine.release", "gpuEngine.done", "gpuEngine.arenaFor", "gpuEngine.loadArena", "gpuEngine.keepArena", "gpuEngine.dropLocked", "gpuEngine.evictLocked"}     # helpers the patch never calls
         if set(real) - internal != set(stub):
             problems.append("gpu_engine.go and gpu_engine_stub.go declare different hooks: %s" % sorted((set(real) - internal) ^ set(stub)))
         for name in set(real) & set(stub):
