@@ -1187,6 +1187,141 @@ def self_launch(args):
     os.execve(sys.executable, cmd, env)
 
 
+def traffic_from_profiles(dom, k, args, B):
+    """HBM bytes per launch from the PMC counters: collected in separate rocprofv3 --pmc passes of this same command (tools/profile.sh),
+    corrected as MI355X_MICROARCH.md prescribes (FETCH_SIZE x2 for wide coalesced reads on gfx950, + WRITE_SIZE), committed under
+    profiles/ — the builder's number from an earlier run of the same shape, labelled as such in traffic_source."""
+    try:
+        tname = next(n for n in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", n)))
+        rec = json.load(open(os.path.join(ROOT, "profiles", tname)))
+        per_arena = rec[dom]["hbm_bytes_corrected_per_arena"]
+        if args.workload == "c2" and B == 1000 and k:
+            return (per_arena * k["arenas_per_launch"],
+                    "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py; per 1 000-block arena x arenas per launch)" % tname)
+    except Exception:  # noqa: BLE001
+        pass
+    return None, None
+
+
+def valu_issue_from_profiles(kernel, k, B, n_kinds=1):
+    """The VALU-issue fraction of a kernel whose bound is not HBM (the many-term probe): VALU instructions per wave from the committed SQ
+    counter pass (tools/profile_pmc.sh -> profiles/rNN_needle_pmc.txt) x 4 cycles of a SIMD per wave64 instruction x the waves of one
+    launch (blocks x kinds x 8 waves x arenas), over the SIMD-cycles of this run's measured kernel time (1 024 SIMDs at 2.4 GHz)."""
+    if not k or not k.get("kernel_ms"):
+        return None
+    try:
+        tname = next(n for n in ("r05_needle_pmc.txt", "r04_needle_pmc.txt", "r03_needle_pmc.txt") if os.path.exists(os.path.join(ROOT, "profiles", n)))
+        per_wave = None
+        with open(os.path.join(ROOT, "profiles", tname)) as f:
+            inside = False
+            for ln in f:
+                if ln.startswith("=="):
+                    inside = ln.split()[1].rstrip(",") == kernel
+                elif inside and ln.split()[:1] == ["SQ_INSTS_VALU"] and "per wave" in ln:
+                    per_wave = float(ln.split()[-1])
+        if per_wave is None:
+            return None
+        waves = k["arenas_per_launch"] * B * n_kinds * 8
+        simd_cycles = k["kernel_ms"] * 1e-3 * 2.4e9 * 1024
+        return {"valu_issue_frac": per_wave * 4 * waves / simd_cycles, "valu_insts_per_wave": per_wave, "waves_per_launch": waves,
+                "source": "profiles/%s (SQ_INSTS_VALU per wave) x 4 SIMD cycles x waves, over this run's kernel time x 1 024 SIMDs x 2.4 GHz" % tname}
+    except Exception:  # noqa: BLE001
+        return None
+
+
+def scaled_leg(ctx, pr, args, plan, words, B, NQ, ft_bytes, n_terms, terms_per_query, log):
+    """C2' (SURVEY 8d): the same arena replicated x S inside ONE arena, one launch — steady-state streaming bandwidth next to the
+    launch-latency-bound 35 MB case (N = 1 only)."""
+    S = args.scaled
+    t0 = time.time()
+    big = ctx.arena_load(words, np.tile(plan.desc, S))       # S address-distinct copies of every filter
+    log("scaled arena: %d blocks (%.2f GB of FT bitsets per launch) loaded in %.1fs" % (B * S, ft_bytes * S / 1e9, time.time() - t0))
+    s_steps = max(4, min(args.steps, 20))
+    ctx.set_probe_group(1)
+    s_elapsed, s_tm = pr.measure(lambda i: [big], s_steps, 2, 1, nofuse=True)
+    ctx.set_probe_group(args.group)
+    s_bytes = s_tm.stream_bytes / max(s_tm.n_probes, 1) + 33 * n_terms
+    s_ms = s_tm.ms_terms_kernel / max(s_tm.n_probes, 1)
+    scaled = {"blocks": B * S, "steps": s_steps, "ms_per_step": s_elapsed / s_steps * 1e3,
+              "value": NQ * B * S * terms_per_query * s_steps / s_elapsed, "kernel_ms": s_ms,
+              "eval_kernel_ms": s_tm.ms_eval_kernel / max(s_tm.n_eval, 1),
+              "algorithmic_bytes_per_launch": s_bytes, "achieved": s_bytes / (s_ms * 1e-3) / 1e9,
+              "frac": s_bytes / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+    ctx.arena_free(big)
+    return scaled
+
+
+def decode_leg(ctx, plan, words, B, log):
+    """a8 (file_format.go:343-448) on the device, both directions: the same 1 000 blocks built and serialised as on-disk filter sections
+    (big-endian words + CRC32C) by bsg_build_sections, then uploaded as bytes and decoded by k_decode_sections — in one launch, as the
+    call runs by default (four launches behind the copy) and through the cursor-shaped API (a9).  A sample of sections is compared with
+    the host codec fed from the words of bsg_build."""
+    from bloomsearch_amd import host as Hst
+    t0 = time.time()
+    secs = ctx.build_sections(plan.blob, plan.off, plan.fstart, plan.desc, plan.n_words)
+    t_enc = time.time() - t0
+    enc_ms = ctx.last_encode_ms()
+    for b in (0, B // 2, B - 1):
+        fl = []
+        for c in range(3):
+            d = plan.desc[b * 3 + c]
+            nw = (int(d["m"]) + 63) // 64
+            fl.append((int(d["m"]), int(d["k"]), words[int(d["word_off"]): int(d["word_off"]) + nw]))
+        if Hst.section_encode(fl) != secs[b]:
+            sys.exit("device-encoded section %d differs from the host codec" % b)
+    sec_bytes = sum(len(x) for x in secs)
+    # the kernel by itself: one launch over all sections, after the whole copy (lab key 4 = 1) ...
+    ctx.set_lab(4, 1)
+    sid, st = ctx.arena_load_sections(secs)
+    dec_one_ms = ctx.last_kernel_ms()[2]
+    if st.any():
+        sys.exit("device section decode reported failures on clean sections")
+    ctx.arena_free(sid)
+    # ... and as the call runs by default: four launches, each behind its quarter of the copy
+    ctx.set_lab(4, 4)
+    t1 = time.time()
+    sid, st = ctx.arena_load_sections(secs)
+    t2 = time.time()
+    dec_ms = ctx.last_kernel_ms()[2]
+    if st.any():
+        sys.exit("device section decode reported failures on clean sections")
+    ctx.arena_free(sid)
+    # a9: the same region through the cursor-shaped API, 4 MiB at a time as blockFilterCursor reads it
+    # (file_format.go:618): the copy of chunk i + 1 overlaps the decode of chunk i
+    blob_secs = b"".join(secs)
+    offs = np.zeros(len(secs) + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum([len(x) for x in secs])
+    t3 = time.time()
+    stream = ctx.arena_stream_begin(offs[:-1], offs[1:])
+    for o in range(0, len(blob_secs), 4 << 20):
+        ctx.arena_stream_append(stream, o, blob_secs[o: o + (4 << 20)])
+    sid2, st2 = ctx.arena_stream_finish(stream, len(secs))
+    t4 = time.time()
+    stream_dec_ms = ctx.last_kernel_ms()[2]
+    if st2.any():
+        sys.exit("streamed section decode reported failures on clean sections")
+    ctx.arena_free(sid2)
+    decode = {"kernel": "k_decode_sections", "kernel_ms": dec_one_ms, "section_bytes": sec_bytes,
+              "algorithmic_bytes": 2 * sec_bytes, "achieved": 2 * sec_bytes / max(dec_one_ms, 1e-6) / 1e6, "unit": "GB/s",
+              "note": "CRC32C + BE->LE decode of %d filter sections on the device in one launch; bytes = sections read + words written" % B,
+              "pieces": {"launches": 4, "kernel_ms_sum": dec_ms, "end_to_end_s_incl_h2d": t2 - t1,
+                         "note": "bsg_arena_load_sections as it runs by default: the decode of each quarter starts behind its part of the copy "
+                                 "(round 4: a section is cut into 16 KB slices, one workgroup each, so a quarter's ~250 sections are ~1 100 workgroups)"},
+              "end_to_end_s_incl_h2d": t2 - t1,
+              "stream": {"api": "bsg_arena_stream_begin / append (4 MiB chunks) / finish", "chunks": (len(blob_secs) + (4 << 20) - 1) // (4 << 20),
+                         "end_to_end_s_incl_h2d": t4 - t3, "decode_kernels_ms_sum": stream_dec_ms,
+                         "note": "sections are parsed (flags, lengths, m, k), CRC-checked and decoded on the device as their last byte lands"},
+              "encode": {"kernels": "k_encode_payload + k_crc_sections", "kernel_ms": enc_ms,
+                         "achieved": 3 * sec_bytes / max(enc_ms, 1e-6) / 1e6, "unit": "GB/s",
+                         "note": "LE->BE + framing + CRC32C of the same sections on the device (bsg_build_sections); bytes = "
+                                 "words read + sections written + sections re-read by the checksum pass",
+                         "build_and_encode_end_to_end_s_incl_copies": t_enc}}
+    log("device section codec: %.1f MB of sections encoded in %.1f us (%.0f GB/s), decoded in %.1f us by one launch (%.0f GB/s; "
+        "%.1f us as four launches behind the copy), %.3fs incl. H2D"
+        % (sec_bytes / 1e6, enc_ms * 1e3, decode["encode"]["achieved"], dec_one_ms * 1e3, decode["achieved"], dec_ms * 1e3, t2 - t1))
+    return decode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -1292,74 +1427,7 @@ def main():
     log("built %d filters (%.1f MB of bitsets) on the GPU in %.2fs; k_build %.1f us = %.0f GB/s algorithmic"
         % (3 * B, plan.n_words * 8 / 1e6, time.time() - t0, build_ms * 1e3, build_bytes / max(build_ms, 1e-6) / 1e6))
 
-    # a8 (file_format.go:343-448) on the device, both directions: the same 1 000 blocks built and serialised as on-disk
-    # filter sections (big-endian words + CRC32C) by bsg_build_sections, then uploaded as bytes and decoded by
-    # k_decode_sections.  A sample of sections is compared with the host codec fed from the words of bsg_build.
-    decode = None
-    if rank == 0 and not args.no_decode:
-        from bloomsearch_amd import host as Hst
-        t0 = time.time()
-        secs = ctx.build_sections(plan.blob, plan.off, plan.fstart, plan.desc, plan.n_words)
-        t_enc = time.time() - t0
-        enc_ms = ctx.last_encode_ms()
-        for b in (0, B // 2, B - 1):
-            fl = []
-            for c in range(3):
-                d = plan.desc[b * 3 + c]
-                nw = (int(d["m"]) + 63) // 64
-                fl.append((int(d["m"]), int(d["k"]), words[int(d["word_off"]): int(d["word_off"]) + nw]))
-            if Hst.section_encode(fl) != secs[b]:
-                sys.exit("device-encoded section %d differs from the host codec" % b)
-        sec_bytes = sum(len(x) for x in secs)
-        # the kernel by itself: one launch over all sections, after the whole copy (lab key 4 = 1) ...
-        ctx.set_lab(4, 1)
-        sid, st = ctx.arena_load_sections(secs)
-        dec_one_ms = ctx.last_kernel_ms()[2]
-        if st.any():
-            sys.exit("device section decode reported failures on clean sections")
-        ctx.arena_free(sid)
-        # ... and as the call runs by default: four launches, each behind its quarter of the copy
-        ctx.set_lab(4, 4)
-        t1 = time.time()
-        sid, st = ctx.arena_load_sections(secs)
-        t2 = time.time()
-        dec_ms = ctx.last_kernel_ms()[2]
-        if st.any():
-            sys.exit("device section decode reported failures on clean sections")
-        ctx.arena_free(sid)
-        # a9: the same region through the cursor-shaped API, 4 MiB at a time as blockFilterCursor reads it
-        # (file_format.go:618): the copy of chunk i + 1 overlaps the decode of chunk i
-        blob_secs = b"".join(secs)
-        offs = np.zeros(len(secs) + 1, dtype=np.uint64)
-        offs[1:] = np.cumsum([len(x) for x in secs])
-        t3 = time.time()
-        stream = ctx.arena_stream_begin(offs[:-1], offs[1:])
-        for o in range(0, len(blob_secs), 4 << 20):
-            ctx.arena_stream_append(stream, o, blob_secs[o: o + (4 << 20)])
-        sid2, st2 = ctx.arena_stream_finish(stream, len(secs))
-        t4 = time.time()
-        stream_dec_ms = ctx.last_kernel_ms()[2]
-        if st2.any():
-            sys.exit("streamed section decode reported failures on clean sections")
-        ctx.arena_free(sid2)
-        decode = {"kernel": "k_decode_sections", "kernel_ms": dec_one_ms, "section_bytes": sec_bytes,
-                  "algorithmic_bytes": 2 * sec_bytes, "achieved": 2 * sec_bytes / max(dec_one_ms, 1e-6) / 1e6, "unit": "GB/s",
-                  "note": "CRC32C + BE->LE decode of %d filter sections on the device in one launch; bytes = sections read + words written" % B,
-                  "pieces": {"launches": 4, "kernel_ms_sum": dec_ms, "end_to_end_s_incl_h2d": t2 - t1,
-                             "note": "bsg_arena_load_sections as it runs by default: the decode of each quarter starts behind its part of the copy "
-                                     "(round 4: a section is cut into 16 KB slices, one workgroup each, so a quarter's ~250 sections are ~1 100 workgroups)"},
-                  "end_to_end_s_incl_h2d": t2 - t1,
-                  "stream": {"api": "bsg_arena_stream_begin / append (4 MiB chunks) / finish", "chunks": (len(blob_secs) + (4 << 20) - 1) // (4 << 20),
-                             "end_to_end_s_incl_h2d": t4 - t3, "decode_kernels_ms_sum": stream_dec_ms,
-                             "note": "sections are parsed (flags, lengths, m, k), CRC-checked and decoded on the device as their last byte lands"},
-                  "encode": {"kernels": "k_encode_payload + k_crc_sections", "kernel_ms": enc_ms,
-                             "achieved": 3 * sec_bytes / max(enc_ms, 1e-6) / 1e6, "unit": "GB/s",
-                             "note": "LE->BE + framing + CRC32C of the same sections on the device (bsg_build_sections); bytes = "
-                                     "words read + sections written + sections re-read by the checksum pass",
-                             "build_and_encode_end_to_end_s_incl_copies": t_enc}}
-        log("device section codec: %.1f MB of sections encoded in %.1f us (%.0f GB/s), decoded in %.1f us by one launch (%.0f GB/s; "
-            "%.1f us as four launches behind the copy), %.3fs incl. H2D"
-            % (sec_bytes / 1e6, enc_ms * 1e3, decode["encode"]["achieved"], dec_one_ms * 1e3, decode["achieved"], dec_ms * 1e3, t2 - t1))
+    decode = decode_leg(ctx, plan, words, B, log) if rank == 0 and not args.no_decode else None
 
     or_reduce, or_state = None, None
     if args.or_union > 0:
@@ -1484,29 +1552,12 @@ def main():
     if not args.no_concurrent and rank == 0 and world == 1:
         conc_q = concurrent_queries_leg(ctx, arenas, B, exprs, got, log)
 
-    # ---- C2' (SURVEY 8d): the same arena replicated x S inside ONE arena so steady-state streaming
-    # bandwidth is visible next to the launch-latency-bound 35 MB case (N=1 only) ----
     scaled = None
     if args.scaled > 1 and world == 1:
         for a in arenas[1:]:
             ctx.arena_free(a)
         arenas = arenas[:1]
-        S = args.scaled
-        t0 = time.time()
-        big = ctx.arena_load(words, np.tile(plan.desc, S))       # S address-distinct copies of every filter
-        log("scaled arena: %d blocks (%.2f GB of FT bitsets per launch) loaded in %.1fs" % (B * S, ft_bytes * S / 1e9, time.time() - t0))
-        s_steps = max(4, min(args.steps, 20))
-        ctx.set_probe_group(1)
-        s_elapsed, s_tm = pr.measure(lambda i: [big], s_steps, 2, 1, nofuse=True)
-        ctx.set_probe_group(args.group)
-        s_bytes = s_tm.stream_bytes / max(s_tm.n_probes, 1) + 33 * len(terms)
-        s_ms = s_tm.ms_terms_kernel / max(s_tm.n_probes, 1)
-        scaled = {"blocks": B * S, "steps": s_steps, "ms_per_step": s_elapsed / s_steps * 1e3,
-                  "value": NQ * B * S * terms_per_query * s_steps / s_elapsed, "kernel_ms": s_ms,
-                  "eval_kernel_ms": s_tm.ms_eval_kernel / max(s_tm.n_eval, 1),
-                  "algorithmic_bytes_per_launch": s_bytes, "achieved": s_bytes / (s_ms * 1e-3) / 1e9,
-                  "frac": s_bytes / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
-        ctx.arena_free(big)
+        scaled = scaled_leg(ctx, pr, args, plan, words, B, NQ, ft_bytes, len(terms), terms_per_query, log)
     for a in arenas:
         ctx.arena_free(a)
     arenas = []
@@ -1528,19 +1579,7 @@ def main():
         # start/stop timestamps, timed region and sampling passes together (same launch shape).
         dom = dominant_kernel(tm)
         k = allk.get(dom) or {}
-        # HBM bytes per launch from the PMC counters: collected in separate rocprofv3 --pmc passes of this same
-        # command (tools/profile.sh), corrected as MI355X_MICROARCH.md prescribes (FETCH_SIZE x2 for wide
-        # coalesced reads on gfx950, + WRITE_SIZE), committed under profiles/.
-        traffic = traffic_src = None
-        try:
-            tname = next(n for n in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", n)))
-            rec = json.load(open(os.path.join(ROOT, "profiles", tname)))
-            per_arena = rec[dom]["hbm_bytes_corrected_per_arena"]
-            if args.workload == "c2" and B == 1000 and k:
-                traffic = per_arena * k["arenas_per_launch"]
-                traffic_src = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py; per 1 000-block arena x arenas per launch)" % tname
-        except Exception:
-            pass
+        traffic, traffic_src = traffic_from_profiles(dom, k, args, B)
         copy_gbps = measured_copy_gbps(log)
         out = {
             "metric": "block-bloom probes/sec", "value": value, "unit": "probes/s", "n_gpus": world,
@@ -1572,6 +1611,7 @@ def main():
                          "copy_note": "copy_gbps = bytes read + written by a 1 GiB device-to-device copy on this box, measured in this run (SURVEY 8d: "
                                       "quote the fraction of the vendor peak and of the measured copy bandwidth)",
                          "timed_region": timed_region, "sampling_passes": samples, "all": allk},
+            "valu_issue": valu_issue_from_profiles(dom, k, B) if dom == "k_probe_terms_many" else None,
             "host_gather": {"ms_per_step": h_elapsed / args.steps * 1e3, "value": probes_per_step * args.steps / h_elapsed,
                             "survivor_bytes_per_step_per_gpu": wps * 8, "page_locked": page_locked,
                             "rows": None if r_elapsed is None else {
