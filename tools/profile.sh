@@ -10,7 +10,7 @@ OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-ARGS="--steps 64 --warmup 64 --group 64 --samples 16 --cpu-budget 0 --no-check --no-decode --ingest-blocks 0 --or-union 0 --scaled 0 --no-q1 --no-single --no-big-filters --c4-files 0 $*"
+ARGS="--steps 64 --warmup 64 --group 64 --samples 16 --cpu-budget 0 --no-check --no-decode --ingest-blocks 0 --or-union 0 --scaled 0 --no-q1 --no-single --no-big-filters --no-concurrent --c4-files 0 $*"
 # EXACT_ARGS="--steps 20 --warmup 5": profile exactly that bench command instead (the driver's), every leg included
 if [ -n "${EXACT_ARGS:-}" ]; then ARGS="$EXACT_ARGS"; fi
 timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/stats -o bench -- python $REPO/bench.py $ARGS > $OUT/stats.log 2>&1

@@ -8,7 +8,7 @@ OUT=$REPO/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-ARGS="--steps 64 --warmup 64 --group 64 --samples 4 --cpu-budget 0 --no-check --no-decode --ingest-blocks 0 --or-union 0 --scaled 0 --no-q1 --no-single --no-big-filters --c4-files 0 $*"
+ARGS="--steps 64 --warmup 64 --group 64 --samples 4 --cpu-budget 0 --no-check --no-decode --ingest-blocks 0 --or-union 0 --scaled 0 --no-q1 --no-single --no-big-filters --no-concurrent --c4-files 0 $*"
 i=0
 for SET in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_LDS"; do
   i=$((i+1))
