@@ -187,7 +187,13 @@ struct Device {
     std::mutex mu;                 // serialises enqueue + scratch reuse on this device
     DevBuf<uint64_t> V[2];         // verdict scratch (two slots: bsg_probe_many software-pipelines launches)
     DevBuf<uint64_t> out[2];       // survivors scratch
-    DevBuf<bsg::ArenaRef> ar_ext[2];            // arena records of a dispatch group beyond kMaxGroupArenas (per scratch slot; written by k_write_arena_table)
+    // arena records of dispatch groups beyond kMaxGroupArenas, in device memory (written by k_write_arena_table): the last few tables,
+    // found again by their records (probe_api.inc: group_table); ext_of_slot: the table the group in scratch slot i uses
+    struct TableEntry { uint64_t hash = 0; std::vector<bsg::ArenaRef> refs; DevBuf<bsg::ArenaRef> buf; uint64_t last_use = 0; };
+    static constexpr size_t kTableCache = 64;
+    std::vector<TableEntry> table_cache;
+    uint64_t table_tick = 0;
+    const bsg::ArenaRef *ext_of_slot[2] = {nullptr, nullptr};
     uint64_t fold_seq = 0;         // k_probe_eval: number of the last launch = the tag of its verdict entries
     DevBuf<uint8_t> stage_a;       // build/hash staging
     DevBuf<uint32_t> stage_off;
@@ -740,6 +746,7 @@ int32_t bsg_close(bsg_ctx *ctx)
         d.pool.trim(0);
         for (uint8_t *p : d.idle_staging) (void)hipHostFree(p);
         for (auto &p : d.direct_bufs) (void)hipHostFree(p.first);
+        for (auto &te : d.table_cache) te.buf.release();
         for (auto &cs : d.cmb_sets) {
             if (cs.d_block) (void)hipFree(cs.d_block);
             if (cs.stage.first) (void)hipHostFree(cs.stage.first);

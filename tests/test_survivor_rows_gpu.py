@@ -136,22 +136,3 @@ def test_rows_on_a_context_of_several_devices_merge_to_the_global_block_order():
             m.pinned_free(rows.view(np.uint8))
             m.pinned_free(hdr.view(np.uint8))
             m.batch_free(bid)
-
-
-def test_a_corrupt_list_header_is_rejected():
-    """bsg_survivor_row_list never reads past a row's slot: a LIST header that counts more ids than the slot holds, or ids that are
-    not ascending block numbers, is an error."""
-    from bloomsearch_amd import _lib
-    import ctypes as C
-    L = _lib.load()
-    n_blocks = 130                                            # G = 3: the slot holds 6 ids
-    row = np.zeros(3, dtype=np.uint64)
-    row.view(np.uint32)[:6] = [1, 5, 9, 64, 100, 129]
-    out = np.zeros(n_blocks, dtype=np.uint32)
-    n = C.c_uint32()
-    assert L.bsg_survivor_row_list((2 << 30) | 6, row.ctypes.data, n_blocks, out.ctypes.data, n_blocks, C.byref(n)) == 0 and n.value == 6
-    assert L.bsg_survivor_row_list((2 << 30) | 7, row.ctypes.data, n_blocks, out.ctypes.data, n_blocks, C.byref(n)) == _lib.BSG_E_INVALID
-    row.view(np.uint32)[2] = 5                                # not ascending
-    assert L.bsg_survivor_row_list((2 << 30) | 6, row.ctypes.data, n_blocks, out.ctypes.data, n_blocks, C.byref(n)) == _lib.BSG_E_INVALID
-    row.view(np.uint32)[:6] = [1, 5, 9, 64, 100, 130]         # an id past the arena
-    assert L.bsg_survivor_row_list((2 << 30) | 6, row.ctypes.data, n_blocks, out.ctypes.data, n_blocks, C.byref(n)) == _lib.BSG_E_INVALID
