@@ -1061,7 +1061,7 @@ def c4_leg(ctx, args, rank, world, workers, log, headline=False):
     c4_warm = max(0, args.warmup) if headline else max(2, min(args.warmup, 8))
     # untimed setup: one call of the timed region's shape sizes the library's verdict / survivor scratch (the warmup steps may be
     # fewer than one call covers, and a first call that grows the scratch calls hipMalloc inside the region: +8 us per step, measured)
-    pr.run(pr.plan([make(i) for i in range(min(per_call, steps))], per_call), 0)
+    pr.run(pr.plan([make(c4_warm + i) for i in range(min(per_call, steps))], per_call), 0)     # (the timed region's own first call: the steady state of a host that probes the same files again)
     ctx.sync()
     if args.events_in_headline:
         dt, tm = pr.measure(make, steps, c4_warm, per_call)

@@ -969,6 +969,9 @@ __device__ __forceinline__ void eval_role(const EvalArgs &a, const ArenaRef &ar,
 // LDS behind ONE barrier, then the programs of the gt groups run back to back.  eval_role pays a dependent global round trip,
 // two barriers and a serial transpose per group (round 4: 15.5 -> see profiles/r04 per 20 arenas of C2).
 // LDS: gt x max_cw transposed words + the per-lane stacks of tile-mask entries (eval_lds_bytes(max_cw * tile, depth * tile)).
+// TILE: masks a lane carries per op (the tile's groups): TILE, or 2 for arenas of <= 2 groups (a file's shard on one of 8
+// GPUs is 125 blocks: with 4 masks half of every op, stack entry and store was spent on groups that do not exist — round 5)
+template <uint32_t TILE>
 __device__ __forceinline__ void eval_role_all(const EvalArgs &a, const ArenaRef &ar, uint32_t g0, uint32_t gt, uint32_t c, uint32_t tid, uint64_t *lds)
 {
     const uint64_t *V = a.V + ar.v_off(a.Wt);
@@ -977,7 +980,7 @@ __device__ __forceinline__ void eval_role_all(const EvalArgs &a, const ArenaRef 
     constexpr uint32_t n_waves = kEvalThreads / kWave;
     const uint32_t ncw = a.max_cw;
     uint64_t *VT = lds;                                                          // VT[(t * ncw + s) * 64 + bit]
-    uint64_t *stk = lds + (uint64_t)kEvalGroupTile * ncw * 64 + tid;             // per-lane stack of kEvalGroupTile-mask entries, stride kEvalThreads
+    uint64_t *stk = lds + (uint64_t)TILE * ncw * 64 + tid;             // per-lane stack of TILE-mask entries, stride kEvalThreads
     constexpr uint32_t kPre = 8;
     uint32_t pre[kPre];
     const uint32_t *P = a.prog + (uint64_t)c * a.Lmax * kEvalThreads + tid;
@@ -1007,9 +1010,9 @@ __device__ __forceinline__ void eval_role_all(const EvalArgs &a, const ArenaRef 
     __syncthreads();
     const uint32_t q = c * kEvalThreads + tid;
     // every op is decoded ONCE and applied to the masks of all the tile's groups (the groups past gt hold zeros: harmless)
-    uint64_t res[kEvalGroupTile];
+    uint64_t res[TILE];
 #pragma unroll
-    for (uint32_t tt = 0; tt < kEvalGroupTile; ++tt) res[tt] = ~0ULL;            // empty program == nil query == true
+    for (uint32_t tt = 0; tt < TILE; ++tt) res[tt] = ~0ULL;            // empty program == nil query == true
     uint32_t sp = 0;
     const uint32_t gstride = ncw * 64;
     auto step = [&](uint32_t op) {
@@ -1017,27 +1020,27 @@ __device__ __forceinline__ void eval_role_all(const EvalArgs &a, const ArenaRef 
         if (opc == 7u) return;
         if (opc == 1u || opc == 2u) {
             --sp;
-            const uint64_t *u = stk + (uint64_t)(sp - 1) * kEvalGroupTile * kEvalThreads;
+            const uint64_t *u = stk + (uint64_t)(sp - 1) * TILE * kEvalThreads;
 #pragma unroll
-            for (uint32_t tt = 0; tt < kEvalGroupTile; ++tt) {
+            for (uint32_t tt = 0; tt < TILE; ++tt) {
                 const uint64_t under = u[(uint64_t)tt * kEvalThreads];
                 res[tt] = (opc == 1u) ? (under & res[tt]) : (under | res[tt]);
             }
         } else {
             if (sp > 0) {
-                uint64_t *u = stk + (uint64_t)(sp - 1) * kEvalGroupTile * kEvalThreads;
+                uint64_t *u = stk + (uint64_t)(sp - 1) * TILE * kEvalThreads;
 #pragma unroll
-                for (uint32_t tt = 0; tt < kEvalGroupTile; ++tt) u[(uint64_t)tt * kEvalThreads] = res[tt];
+                for (uint32_t tt = 0; tt < TILE; ++tt) u[(uint64_t)tt * kEvalThreads] = res[tt];
             }
             ++sp;
             if (opc == 0u) {
                 const uint64_t *vt = VT + (op & 0x0FFFFFFFu);
 #pragma unroll
-                for (uint32_t tt = 0; tt < kEvalGroupTile; ++tt) res[tt] = tt < gt ? vt[(uint64_t)tt * gstride] : 0ULL;
+                for (uint32_t tt = 0; tt < TILE; ++tt) res[tt] = tt < gt ? vt[(uint64_t)tt * gstride] : 0ULL;
             } else {
                 const uint64_t v = opc == 3u ? ~0ULL : 0ULL;
 #pragma unroll
-                for (uint32_t tt = 0; tt < kEvalGroupTile; ++tt) res[tt] = v;
+                for (uint32_t tt = 0; tt < TILE; ++tt) res[tt] = v;
             }
         }
     };
@@ -1045,7 +1048,7 @@ __device__ __forceinline__ void eval_role_all(const EvalArgs &a, const ArenaRef 
     for (uint32_t j = 0; j < kPre; ++j) if (j < len) step(pre[j]);
     for (uint32_t j = kPre; j < len; ++j) step(P[(uint64_t)j * kEvalThreads]);
 #pragma unroll
-    for (uint32_t tt = 0; tt < kEvalGroupTile; ++tt) {
+    for (uint32_t tt = 0; tt < TILE; ++tt) {
         if (tt < gt) {
             const uint32_t nvalid = ar.n_blocks - (g0 + tt) * 64u;
             res[tt] &= nvalid >= 64 ? ~0ULL : ((1ULL << nvalid) - 1);
@@ -1054,7 +1057,7 @@ __device__ __forceinline__ void eval_role_all(const EvalArgs &a, const ArenaRef 
     if (q < a.n_queries) {
         uint64_t *dst = a.out + ar.out_off(a.n_queries) + (uint64_t)q * ar.G() + g0;
 #pragma unroll
-        for (uint32_t tt = 0; tt < kEvalGroupTile; ++tt) if (tt < gt) dst[tt] = res[tt];
+        for (uint32_t tt = 0; tt < TILE; ++tt) if (tt < gt) dst[tt] = res[tt];
     }
 }
 
@@ -1080,7 +1083,10 @@ __device__ __forceinline__ void eval_block(const EvalArgs &a, const ArenaRef &ar
 {
     const uint32_t g0 = tx * tile;
     if (g0 >= ar.G()) return;
-    if (a.identity_cw & 2u) eval_role_all(a, ar, g0, min(tile, ar.G() - g0), c, threadIdx.x, lds64);
+    if (a.identity_cw & 2u) {
+        if (tile == 2u) eval_role_all<2>(a, ar, g0, min(tile, ar.G() - g0), c, threadIdx.x, lds64);
+        else eval_role_all<kEvalGroupTile>(a, ar, g0, min(tile, ar.G() - g0), c, threadIdx.x, lds64);
+    }
     else eval_role(a, ar, g0, min(tile, ar.G() - g0), c, threadIdx.x, lds64, true);
 }
 __global__ __launch_bounds__(kEvalThreads) void k_eval_programs(const EvalArgs a, const ArenaTable<kMaxGroupArenas> t, const uint32_t tile, const uint32_t nx,
