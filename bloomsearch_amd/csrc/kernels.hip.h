@@ -643,7 +643,12 @@ __device__ __forceinline__ void store_tagged(uint64_t *p, uint64_t v, uint64_t s
     asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(d) : "memory");
 #endif
 }
-// -> true when the entry at p belongs to launch `seq`; v = its word
+// -> true when the entry at p belongs to launch `seq`; v = its word.
+// gfx942 / gfx950 ONLY: this pair is inline assembly, not the memory model — an `sc1` (agent-scope, write-through)
+// 16-byte store on one side, an `sc1` load that bypasses the non-coherent caches on the other, and the assumption that a 16-byte
+// store is observed whole (the tag is keyed with the word, so a torn entry is rejected unless both halves agree).  No fence orders
+// anything else around it; nothing else needs ordering (an entry carries its own validity).  k_probe_eval, the only user, is a lab
+// path (bsg_set_lab key 11, off); on another architecture or compiler it must be re-derived, not recompiled.
 __device__ __forceinline__ bool load_tagged(const uint64_t *p, uint64_t seq, uint64_t &v)
 {
     u32x4 d;

@@ -526,6 +526,29 @@ func (g *Context) ProbeManyRows(arenas []Arena, b Batch, buf *RowsBuffer) ([]Sur
 	return out, nil
 }
 
+// QueryStats is bsg_query_stats: how the eligible Query calls were served since the last reset — concurrent calls share dispatches
+// inside the library (a hot arena streamed once for all its callers, the rest one job-list dispatch).
+type QueryStats struct {
+	Calls, SoloCalls, Cycles, CycleCalls, Dispatches, HotArenas, MaxCallsPerCycle uint64
+	PrepareNs, EnqueueNs, WaitNs, DealNs, WakeNs, ScatterNs, FreeNs, RetireNs       uint64
+}
+
+// QueryStats reads (and optionally resets) the combiner's counters.
+func (g *Context) QueryStats(reset bool) (QueryStats, error) {
+	var c C.bsg_query_stats
+	r := C.int32_t(0)
+	if reset {
+		r = 1
+	}
+	if err := g.err(C.bsg_query_stats_read(g.c, &c, r)); err != nil {
+		return QueryStats{}, err
+	}
+	return QueryStats{Calls: uint64(c.calls), SoloCalls: uint64(c.solo_calls), Cycles: uint64(c.cycles), CycleCalls: uint64(c.cycle_calls),
+		Dispatches: uint64(c.dispatches), HotArenas: uint64(c.hot_arenas), MaxCallsPerCycle: uint64(c.max_calls_per_cycle),
+		PrepareNs: uint64(c.ns_prepare), EnqueueNs: uint64(c.ns_enqueue), WaitNs: uint64(c.ns_wait), DealNs: uint64(c.ns_deal), WakeNs: uint64(c.ns_wake),
+		ScatterNs: uint64(c.ns_scatter), FreeNs: uint64(c.ns_free), RetireNs: uint64(c.ns_retire)}, nil
+}
+
 // RowsOnDevices is the result of ProbeManyRowsOnDevices: the rows every device of the context wrote for its shards (local block
 // numbers, a slice of the buffer per device).  List merges the shards' rows of one (arena, query) into GLOBAL block order.
 type RowsOnDevices struct {
