@@ -535,18 +535,18 @@ type QueryStats struct {
 
 // QueryStats reads (and optionally resets) the combiner's counters.
 func (g *Context) QueryStats(reset bool) (QueryStats, error) {
-	var c C.bsg_query_stats
+	var qstats C.bsg_query_stats
 	r := C.int32_t(0)
 	if reset {
 		r = 1
 	}
-	if err := g.err(C.bsg_query_stats_read(g.c, &c, r)); err != nil {
+	if err := g.err(C.bsg_query_stats_read(g.c, &qstats, r)); err != nil {
 		return QueryStats{}, err
 	}
-	return QueryStats{Calls: uint64(c.calls), SoloCalls: uint64(c.solo_calls), Cycles: uint64(c.cycles), CycleCalls: uint64(c.cycle_calls),
-		Dispatches: uint64(c.dispatches), HotArenas: uint64(c.hot_arenas), MaxCallsPerCycle: uint64(c.max_calls_per_cycle),
-		PrepareNs: uint64(c.ns_prepare), EnqueueNs: uint64(c.ns_enqueue), WaitNs: uint64(c.ns_wait), DealNs: uint64(c.ns_deal), WakeNs: uint64(c.ns_wake),
-		ScatterNs: uint64(c.ns_scatter), FreeNs: uint64(c.ns_free), RetireNs: uint64(c.ns_retire)}, nil
+	return QueryStats{Calls: uint64(qstats.calls), SoloCalls: uint64(qstats.solo_calls), Cycles: uint64(qstats.cycles), CycleCalls: uint64(qstats.cycle_calls),
+		Dispatches: uint64(qstats.dispatches), HotArenas: uint64(qstats.hot_arenas), MaxCallsPerCycle: uint64(qstats.max_calls_per_cycle),
+		PrepareNs: uint64(qstats.ns_prepare), EnqueueNs: uint64(qstats.ns_enqueue), WaitNs: uint64(qstats.ns_wait), DealNs: uint64(qstats.ns_deal),
+		WakeNs: uint64(qstats.ns_wake), ScatterNs: uint64(qstats.ns_scatter), FreeNs: uint64(qstats.ns_free), RetireNs: uint64(qstats.ns_retire)}, nil
 }
 
 // RowsOnDevices is the result of ProbeManyRowsOnDevices: the rows every device of the context wrote for its shards (local block

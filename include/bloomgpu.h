@@ -330,8 +330,14 @@ typedef struct bsg_query_stats {
     uint64_t max_calls_per_cycle;
     /* the combined cycles' phases on their collectors' clocks, summed (ns): merging + planning the batches; enqueueing (tables up,
      * dispatches); waiting for the device; dealing the rows out + releasing the callers (ns_wake: the releasing part of that) */
-    uint64_t ns_prepare, ns_enqueue, ns_wait, ns_deal, ns_wake;
-    uint64_t ns_scatter, ns_free, ns_retire;   /* parts of ns_deal: rows copied out; scratch given back (device lock); slot released + next collector appointed */
+    uint64_t ns_prepare;
+    uint64_t ns_enqueue;
+    uint64_t ns_wait;
+    uint64_t ns_deal;
+    uint64_t ns_wake;
+    uint64_t ns_scatter;           /* parts of ns_deal: rows copied out ...                                */
+    uint64_t ns_free;              /* ... scratch given back ...                                            */
+    uint64_t ns_retire;            /* ... slot released + next collector appointed                          */
 } bsg_query_stats;
 BSG_API int32_t bsg_query_stats_read(bsg_ctx *ctx, bsg_query_stats *out, int32_t reset);
 
