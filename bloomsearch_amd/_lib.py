@@ -63,7 +63,7 @@ EXPORTS = [
     "bsg_sync", "bsg_estimate_parameters", "bsg_probe_many_dev", "bsg_set_probe_group", "bsg_set_gather_cost", "bsg_set_fuse_limit", "bsg_set_spin_wait", "bsg_set_ingest_chunk", "bsg_set_lab",
     "bsg_hash_entries", "bsg_build", "bsg_build_hashed", "bsg_arena_load", "bsg_arena_load_sections", "bsg_arena_free",
     "bsg_arena_stream_begin", "bsg_arena_stream_append", "bsg_arena_stream_finish", "bsg_arena_stream_abort",
-    "bsg_batch_create", "bsg_batch_free", "bsg_probe_batch", "bsg_probe_many", "bsg_probe", "bsg_query", "bsg_query_stats_read", "bsg_survivor_list", "bsg_probe_many_rows", "bsg_survivor_row_list", "bsg_survivor_rows_size", "bsg_survivor_rows_list", "bsg_timing_read", "bsg_set_timed_stride", "bsg_last_kernel_ms",
+    "bsg_batch_create", "bsg_batch_free", "bsg_probe_batch", "bsg_probe_many", "bsg_probe", "bsg_query", "bsg_query_stats_read", "bsg_lab_query_cpu", "bsg_survivor_list", "bsg_probe_many_rows", "bsg_survivor_row_list", "bsg_survivor_rows_size", "bsg_survivor_rows_list", "bsg_timing_read", "bsg_set_timed_stride", "bsg_last_kernel_ms",
     "bsg_or_reduce", "bsg_or_words_dev", "bsg_or_reduce_dev", "bsg_last_or_ms",
     "bsg_comm_unique_id", "bsg_comm_init", "bsg_comm_destroy", "bsg_comm_info", "bsg_or_allreduce", "bsg_or_allreduce_dev",
     "bsg_ingest_rows", "bsg_ingest_fallback_rows", "bsg_ingest_add_entries", "bsg_ingest_finish", "bsg_ingest_build",
@@ -125,6 +125,7 @@ def load():
     L.bsg_survivor_rows_list.argtypes = [vp, vp, u32, u64, vp, vp, u32, u32, vp, u32, C.POINTER(u32)]
     L.bsg_survivor_list.argtypes = [vp, u32, vp, u32, C.POINTER(u32)]
     L.bsg_query.argtypes = [vp, vp, u32, vp, vp, vp, u32, vp, vp, u32, vp]
+    L.bsg_lab_query_cpu.argtypes = [vp, vp, i32]
     L.bsg_query_stats_read.argtypes = [vp, C.POINTER(QueryStats), i32]
     L.bsg_timing_read.argtypes = [vp, C.POINTER(Timing), i32]
     L.bsg_set_timed_stride.argtypes = [vp, u32]

@@ -193,6 +193,7 @@ static_assert(sizeof(QJob) == 64, "one job record per 64-byte line");
 struct JobsArgs {
     const QJob *jobs;            // device memory (the cycle's table; hashes and programs behind the records)
     const uint64_t *tab;         // the same table, as u64 / u32 words
+    const uint32_t *wg_job;      // the job of every workgroup (in the same table): one load instead of a search over the records
     uint64_t *out;               // page-locked host memory
     uint32_t n_jobs, n_wg;
     uint32_t *done_count; uint64_t *flag; uint64_t seq;
@@ -201,13 +202,9 @@ struct JobsArgs {
 __global__ __launch_bounds__(kEvalThreads) void k_query_jobs(const JobsArgs j)
 {
     extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
-    // the job of this workgroup: the last record whose first workgroup is <= blockIdx.x (wave-uniform: scalar loads)
-    uint32_t lo = 0, hi = j.n_jobs;
-    while (hi - lo > 1) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (j.jobs[mid].wg0 <= blockIdx.x) lo = mid; else hi = mid;
-    }
-    const QJob &J = j.jobs[lo];
+    // (a binary search over the records' first workgroups cost every workgroup ~7 dependent loads in front of its first useful one:
+    // 81 jobs 84 us; the table costs 4 bytes per workgroup)
+    const QJob &J = j.jobs[j.wg_job[blockIdx.x]];
     DirectArgs a{};
     a.out = j.out + J.out_off;
     a.Tp = J.th_stride; a.Wt = 1; a.n_queries = J.n_queries; a.Lmax = J.len; a.max_depth = J.max_depth; a.n_kinds = J.n_kinds;

@@ -340,6 +340,10 @@ typedef struct bsg_query_stats {
     uint64_t ns_retire;            /* ... slot released + next collector appointed                          */
 } bsg_query_stats;
 BSG_API int32_t bsg_query_stats_read(bsg_ctx *ctx, bsg_query_stats *out, int32_t reset);
+/* Lab (bsg_set_lab key 20 = 1 turns the accounting on): the CALLERS' own processor time, summed — out[0] profiled calls, out[1] ns
+ * inside bsg_query's combiner path, of which out[2] up to the end of the wait (push, polling, the futex), out[3] waking other
+ * callers, out[4] collecting (a collector's whole cycle).  tools/conc_lab.py prints them per call. */
+BSG_API int32_t bsg_lab_query_cpu(bsg_ctx *ctx, uint64_t *out, int32_t reset);
 
 /* The surviving blocks of ONE query as the reference's probe hands them on: blockScanCandidate{index} per survivor in the order
  * the blocks were consulted (ascending RowDataOffset, query_exec.go:321, 603) = the ascending bit positions of the query's row

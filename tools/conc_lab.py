@@ -44,8 +44,19 @@ def main():
                         if "SPIN" in os.environ:
                             ctx.set_lab(17, int(os.environ["SPIN"]))
                         ctx.query_stats(reset=True)
+                        prof = os.environ.get("PROF") == "1"
+                        cpu = np.zeros(5, dtype=np.uint64)
+                        if prof:
+                            ctx.set_lab(20, 1)
+                            ctx._check(ctx.L.bsg_lab_query_cpu(ctx.h, cpu.ctypes.data, 1))
                         r = conc.run(ctx, exprs, pool, B, expected, T, seconds, apc)
                         st = ctx.query_stats()
+                        if prof:
+                            ctx._check(ctx.L.bsg_lab_query_cpu(ctx.h, cpu.ctypes.data, 1))
+                            ctx.set_lab(20, 0)
+                            n = max(int(cpu[0]), 1)
+                            line += " [callers' cpu per call: %.2f us in the combiner path = wait %.2f + duty %.2f + collecting %.2f (amortised)]" % (
+                                cpu[1] / n / 1e3, cpu[2] / n / 1e3, cpu[3] / n / 1e3, cpu[4] / n / 1e3)
                         assert not (a["mismatches"] or a["errors"] or r["mismatches"] or r["errors"]), (a, r)
                         cyc = max(st["cycles"] - st["solo_calls"], 1)
                         line += " inflight %d hot>=%d: %.3g q/s (%.1fx) p50 %.0f p99 %.0f cpu %.1f us/call (%.1f busy), %.1f calls/cycle, %d solo; per combined cycle: prepare %.1f enqueue %.1f wait %.1f deal %.1f (scatter %.1f free %.1f retire %.1f wake %.1f) us, %.2f dispatches (%.2f hot) |" % (
