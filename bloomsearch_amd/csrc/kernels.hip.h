@@ -1780,8 +1780,14 @@ __global__ __launch_bounds__(kDecodeLaunchThreads) void k_decode_sections(const 
     uint64_t v[kCrcGranule / 8];
     if (one_trip && tid < (uint32_t)kDecodeThreads && tid < n_slice / kCrcGranule) {
         const uint8_t *p = sec + lo + (uint64_t)(n_slice / kCrcGranule - 1 - tid) * kCrcGranule;
+        // four 16-byte loads, not eight 8-byte ones (half the L1 accesses of this phase; measured: no change, 66.7 us — the L1's access
+        // rate is not what bounds the kernel either)
 #pragma unroll
-        for (int u = 0; u < (int)(kCrcGranule / 8); ++u) v[u] = load_u64_unaligned(p + 8 * u);
+        for (int u = 0; u < (int)(kCrcGranule / 16); ++u) {
+            struct U128 { uint64_t a, b; } w;
+            __builtin_memcpy(&w, p + 16 * u, 16);
+            v[2 * u] = w.a; v[2 * u + 1] = w.b;
+        }
     } else {
 #pragma unroll
         for (int u = 0; u < (int)(kCrcGranule / 8); ++u) v[u] = 0;
