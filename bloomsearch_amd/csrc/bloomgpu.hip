@@ -11,6 +11,7 @@
 #include "bin_build.hip.h"
 #include "direct.hip.h"
 #include "match.hip.h"
+#include "host/combiner_sync.hpp"
 #include "host/text.hpp"   // the host walker's Unicode tables: the device defers to the same data
 #include <hip/hip_ext.h>
 
@@ -269,23 +270,13 @@ struct Ingest;   // ingest_api.inc
 struct ArenaStream;   // stream_api.inc
 
 // concurrent bsg_query callers share dispatches (combine_api.inc).  No mutex on the way in: with hundreds of callers a contended
-// lock hands over at ~5-10 us a time (its waiters sleep), which by itself bounds the context at ~10^5 calls a second.
-struct QReq;
+// lock hands over at ~5-10 us a time (its waiters sleep), which by itself bounds the context at ~10^5 calls a second.  The
+// synchronisation — stacks of waiting calls, the collector role, the cycle slots, the wake-up tree — is host/combiner_sync.hpp.
 struct Combiner {
-    // calls waiting to be collected: lock-free stacks (callers push; only the collector takes), 8 of them on cache lines of their own
-    // — with 256 callers one stack head is a line every call rewrites (the callers' processor time up to the end of the wait: 9.1 us a
-    // call on one head, measured with bsg_set_lab key 20)
-    static constexpr uint32_t kStacks = 8;
-    struct alignas(64) Head { std::atomic<QReq *> p{nullptr}; };
-    Head head[kStacks];
-    std::atomic<uint32_t> gate{0};              // bit 31: a caller is collecting / preparing / enqueueing a cycle; low bits: cycles in flight
-    std::atomic<uint32_t> n_queued{0};          // (kept only while a collector lingers: bsg_set_lab key 15)
-    std::atomic<uint32_t> last_cycle_calls{0};  // running mean of the cycles' sizes, x 16: how busy the context is (callers poll only while it is small)
+    bsgsync::Gate sync;
     uint32_t mode = 1;            // 0: every call goes alone (bsg_set_lab key 12)
-    uint32_t max_inflight = 2;    // cycles in flight (bsg_set_lab key 13): prepared / enqueued / run side by side; the device takes them in enqueue order
     uint32_t linger_us = 0, linger_calls = 0;   // lab (bsg_set_lab key 15): a collector waits this long / for this many queued calls
     uint32_t hot_min_queries = 24;              // an arena asked at least this many queries in a cycle is streamed once for all of them (key 16; 0: never)
-    uint32_t spin_us = 60;                      // a queued caller polls this long before it sleeps in a futex (key 17)
     std::atomic<uint64_t> n_solo{0}, n_cycles{0}, n_cycle_calls{0}, n_dispatches{0}, n_hot{0}, max_cycle_calls{0};
     uint32_t profile = 0;                        // lab (key 20): callers account their own processor time (bsg_lab_query_cpu)
     std::atomic<uint64_t> n_cpu_calls{0}, ns_cpu_call{0}, ns_cpu_wait{0}, ns_cpu_duty{0}, ns_cpu_collect{0};
