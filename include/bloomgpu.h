@@ -313,7 +313,7 @@ BSG_API int32_t bsg_query(bsg_ctx *ctx, const uint64_t *arena_ids, uint32_t n_ar
  * goroutine of its own, query_exec.go:303-357, 427-431, and runs several Query() calls at once — mirrored call by call that is one
  * ~8 us dispatch per (query, file), serialised on the device's stream).  A call that finds the device idle goes alone, at once, as
  * described above.  Calls that arrive while another is collecting or in flight queue inside the library; the head of the queue
- * collects everything queued as (call, arena) pairs: an arena asked >= 24 queries in the cycle is STREAMED once for
+ * collects everything queued as (call, arena) pairs: an arena asked >= 8 queries in the cycle is STREAMED once for
  * all of them (their query sets merged into one batch, each distinct term probed once: k_probe_terms + k_eval_programs), every other
  * pair is a job of ONE k_query_jobs dispatch (gather regime: cost follows the pairs asked for — one query, one call per candidate
  * file is a list of such jobs).  The collector hands its role on (two cycles in flight) and deals every caller its rows.  Nobody

@@ -30,7 +30,7 @@ def main():
         terms["h"] = ctx.hash_strings(cb.term_strings)
         terms["kind"] = kinds
         expected = ctx.probe(arenas[0], B, terms, ops, poff)
-        hot = [int(x) for x in os.environ.get("HOT", "24").split(",")]
+        hot = [int(x) for x in os.environ.get("HOT", "8").split(",")]
         for apc, pool in ((1, arenas[:1]), (1, arenas), (10, arenas)):
             for T in (1, 16, 64, 256):
                 ctx.set_lab(12, 0)

@@ -17,7 +17,7 @@ python bench.py --workload needle --cpu-budget 0 --c4-files 0 --ingest-blocks 0 
 python bench.py --workload c4 --cpu-budget 6 --c4-files 0 --ingest-blocks 0 --no-decode --or-union 0 --no-concurrent > gpurun_out/${R}_bench_c4.json 2>/dev/null
 # round 5 labs: concurrent bsg_query callers (alone vs combined, collector phases), the step's tail split and the per-rank shard
 # sizes of the strong-scaling leg on one GPU (what N = 2 / 4 / 8 ranks each see), the section codec, the N > 1 host paths
-HOT=24 python tools/conc_lab.py 0.5 2 > gpurun_out/${R}_conc_lab.txt 2>&1
+HOT=8 python tools/conc_lab.py 0.5 2 > gpurun_out/${R}_conc_lab.txt 2>&1
 bash tools/r05_step.sh > gpurun_out/${R}_step.txt 2>&1
 grep "^tail split 0%" gpurun_out/${R}_step.txt | sed "s/^tail split 0%: //" > gpurun_out/${R}_c4_shard_sweep.txt
 python tools/decode_lab.py 2>&1 | tail -2 > gpurun_out/${R}_decode_lab_run.txt

@@ -116,7 +116,7 @@ def main():
                 for t in ths:
                     t.join()
                 ctx.set_lab(15, 0)
-                ctx.set_lab(16, 24)
+                ctx.set_lab(16, 8)
                 if errs:
                     sys.exit("seed %d: concurrent bsg_query differs (%d-entry context): %s" % (seed, nd, errs[:3]))
                 n_bits += 6 * 3 * 64
