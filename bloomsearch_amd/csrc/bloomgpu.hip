@@ -278,6 +278,7 @@ struct Combiner {
     uint32_t linger_us = 0, linger_calls = 0;   // lab (bsg_set_lab key 15): a collector waits this long / for this many queued calls
     uint32_t hot_min_queries = 8;               // an arena asked at least this many queries in a cycle is streamed once for all of them (key 16; 0: never).  Measured 4 / 8 / 12 / 24: a gather costs a 128-byte line, so streaming a 35 MB arena pays from ~9 three-term queries; 4 streams too much at 64 callers over 12 arenas (5.9 vs 8.8 x 10^5), 24 leaves 64 x 10 arenas at 1.9 vs 3.0 x 10^5
     std::atomic<uint64_t> n_solo{0}, n_cycles{0}, n_cycle_calls{0}, n_dispatches{0}, n_hot{0}, max_cycle_calls{0};
+    uint32_t inline_jobs = 1;                    // a job list whose table fits the kernel arguments travels in them (key 21; 0: always uploaded)
     uint32_t profile = 0;                        // lab (key 20): callers account their own processor time (bsg_lab_query_cpu)
     std::atomic<uint64_t> n_cpu_calls{0}, ns_cpu_call{0}, ns_cpu_wait{0}, ns_cpu_duty{0}, ns_cpu_collect{0};
     std::atomic<uint64_t> ns_scatter{0}, ns_free{0}, ns_retire{0};   // parts of ns_deal
@@ -302,6 +303,7 @@ struct bsg_ctx {
     uint32_t timed_stride = 1;   // with BSG_PROBE_TIMED, timestamp every timed_stride-th launch
     uint64_t timed_counter = 0;
     uint32_t group_limit = 1024;   // arenas one probe dispatch may cover (bsg_set_probe_group; beyond kMaxGroupArenas the records travel in device memory)
+    uint32_t solo_ring_wgs = 32;  // a lone bsg_query of more workgroups than this gets its doorbell from a dispatch behind the kernel (bsg_set_lab key 22)
     uint32_t gather_cost = 256;  // a filter is gathered instead of staged when terms * k * gather_cost < its bytes
     bsg::FpKey fp_key{};         // secret key of the entries' fingerprints (drawn at bsg_open; never leaves the process)
     std::vector<uint8_t> peer;   // [i * nd + j]: 1 = device i reaches device j's memory directly (xGMI peer access enabled, or the same device)

@@ -13,6 +13,10 @@
 
 namespace bsg {
 
+#ifndef BSG_DIRECT_TRIP
+#define BSG_DIRECT_TRIP 12
+#endif
+
 struct DirectArgs {
     const uint64_t *th;          // SoA term hashes: th[j * Tp + t]
     const uint32_t *prog;        // the batch's single 256-query chunk, lane-interleaved: prog[j * 256 + lane]
@@ -28,6 +32,22 @@ struct DirectArgs {
     uint64_t seq;
 };
 
+// The kinds a dispatch probes, as the body wants them: three (kind, first position, terms) triples packed into words — picked apart
+// with shifts, so that a body working from a job record keeps them in registers (three-element arrays indexed by a loop variable
+// put the whole argument struct into scratch memory: 128 bytes per lane in k_query_jobs).
+struct KindsPk {
+    uint32_t kind;               // kind of triple y in byte y
+    uint64_t begin, count;       // 16 bits per triple
+};
+__device__ __forceinline__ KindsPk pack_kinds(const uint32_t *kind, const uint32_t *begin, const uint32_t *count, uint32_t n_kinds)
+{
+    KindsPk k{0, 0, 0};
+#pragma unroll
+    for (uint32_t y = 0; y < 3; ++y)
+        if (y < n_kinds) { k.kind |= kind[y] << (8 * y); k.begin |= (uint64_t)begin[y] << (16 * y); k.count |= (uint64_t)count[y] << (16 * y); }
+    return k;
+}
+
 __host__ __device__ inline uint32_t direct_lds_bytes(uint32_t Wt, uint32_t max_depth)
 {
     return (Wt * 64u + max_depth * (uint32_t)kEvalThreads) * 8u;
@@ -36,7 +56,8 @@ __host__ __device__ inline uint32_t direct_lds_bytes(uint32_t Wt, uint32_t max_d
 // The shared body: th = SoA term hashes th[j * a.Tp + pos]; prog = the chunk's programs, op j of lane l at prog[j * prog_stride + l];
 // len = ops of the longest program.  A kind's terms sit at positions term_begin .. term_begin + term_count of th AND of VT.
 // g = the workgroup's 64-block group of the arena; n_wg = workgroups of the launch (the doorbell rings when all are done).
-__device__ __forceinline__ void direct_body(const DirectArgs &a, const uint64_t *th, const uint32_t *prog, uint32_t prog_stride, uint32_t len,
+template <uint32_t FIRST = 0, uint32_t TRIP = BSG_DIRECT_TRIP>
+__device__ __forceinline__ void direct_body(const DirectArgs &a, const KindsPk K, const uint64_t *th, const uint32_t *prog, uint32_t prog_stride, uint32_t len,
                                             const ArenaRef &ar, uint64_t *lds64, const uint32_t g, const uint32_t n_wg)
 {
     const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
@@ -56,12 +77,25 @@ __device__ __forceinline__ void direct_body(const DirectArgs &a, const uint64_t 
 
     const uint32_t b = g * 64 + lane;
     const bool valid = b < ar.n_blocks;
-    for (uint32_t y = 0; y < a.n_kinds; ++y) {
-        DevDesc d{0, 0, 0, 0, 0};
-        if (valid) d = ar.desc[(uint64_t)b * 3 + a.kind[y]];
-        const uint64_t *src = ar.words + d.word_off;
-        const uint32_t t0 = a.term_begin[y];
-        for (uint32_t t = wave; t < a.term_count[y]; t += n_waves) {       // wave-uniform term: its hashes are scalar loads
+    // the terms of all kinds dealt round-robin to the waves: a 3-term query with one term per kind runs its three
+    // descriptor -> words chains side by side on three waves instead of one after the other on the first
+    const uint32_t c0 = (uint32_t)K.count & 0xFFFFu, c1 = (uint32_t)(K.count >> 16) & 0xFFFFu, c2 = (uint32_t)(K.count >> 32) & 0xFFFFu;
+    const uint32_t total = c0 + c1 + c2;
+    uint32_t cur_y = ~0u;
+    DevDesc d{0, 0, 0, 0, 0};
+    const uint64_t *src = ar.words;
+    {
+        for (uint32_t q = wave; q < total; q += n_waves) {               // wave-uniform term: its hashes are scalar loads
+            uint32_t y = 0, t = q;
+            if (t >= c0) { t -= c0; y = 1; if (t >= c1) { t -= c1; y = 2; } }
+            if (y != cur_y) {
+                cur_y = y;
+                const uint32_t kind = (K.kind >> (8 * y)) & 0xFFu;
+                d = DevDesc{0, 0, 0, 0, 0};
+                if (valid) d = ar.desc[(uint64_t)b * 3 + kind];
+                src = ar.words + d.word_off;
+            }
+            const uint32_t t0 = (uint32_t)(K.begin >> (16 * y)) & 0xFFFFu;
             const uint64_t h0 = th[t0 + t], h1 = th[(uint64_t)a.Tp + t0 + t];
             const uint64_t h2 = th[2ull * a.Tp + t0 + t], h3 = th[3ull * a.Tp + t0 + t];
             // a nil filter cannot disqualify (query_exec.go:137-151); rows past the arena's end are masked at the end
@@ -69,14 +103,12 @@ __device__ __forceinline__ void direct_body(const DirectArgs &a, const uint64_t 
             uint32_t i = 0;
             const uint32_t k = d.m ? d.k : 0u;
             uint64_t s2 = 0, s3 = 0;                                      // i * h2, i * h3 as running sums
-#ifndef BSG_DIRECT_TRIP
-#define BSG_DIRECT_TRIP 12
-#endif
-            constexpr uint32_t kTrip = BSG_DIRECT_TRIP;                  // locations whose word reads are in flight together (lab: -DBSG_DIRECT_TRIP)
-            while (__ballot(pass && i < k) != 0ull) {
-                uint64_t w[kTrip]; uint32_t bit[kTrip]; bool live[kTrip];
+            constexpr uint32_t kTrip = TRIP;                             // locations whose word reads are in flight together (lab: -DBSG_DIRECT_TRIP)
+            auto trip = [&](auto n_c) {
+                constexpr uint32_t N = decltype(n_c)::value;
+                uint64_t w[N]; uint32_t bit[N]; bool live[N];
 #pragma unroll
-                for (uint32_t u = 0; u < kTrip; ++u) {
+                for (uint32_t u = 0; u < N; ++u) {
                     const uint32_t r = (i + u) & 3u;
                     const uint64_t x = (((i + u) & 1u) ? h1 : h0) + ((r == 1u || r == 2u) ? s3 : s2);
                     s2 += h2; s3 += h3;
@@ -86,10 +118,15 @@ __device__ __forceinline__ void direct_body(const DirectArgs &a, const uint64_t 
                     w[u] = live[u] ? src[loc >> 6] : 0;
                 }
 #pragma unroll
-                for (uint32_t u = 0; u < kTrip; ++u)
+                for (uint32_t u = 0; u < N; ++u)
                     if (live[u] && !((w[u] >> bit[u]) & 1ull)) pass = false;
-                i += kTrip;
-            }
+                i += N;
+            };
+            // FIRST > 0: a short first trip — an absent term fails within a few bits (half of a filter's bits are set) and only
+            // the lanes still passing read on: fewer line fetches for more dependent rounds.  A long job list is bound by the
+            // fetches themselves (below); a lone call (16 workgroups) by its rounds, and keeps the single trip.
+            if constexpr (FIRST > 0) trip(std::integral_constant<uint32_t, FIRST>{});
+            while (__ballot(pass && i < k) != 0ull) trip(std::integral_constant<uint32_t, kTrip>{});
             const uint64_t mask = __ballot(pass);
             if (lane == 0) VT[t0 + t] = mask;                            // (a batch's kind segments start on word boundaries: t0 is their slot * 64)
         }
@@ -137,7 +174,7 @@ __device__ __forceinline__ void direct_body(const DirectArgs &a, const uint64_t 
 __global__ __launch_bounds__(kEvalThreads) void k_probe_direct(const DirectArgs a, const ArenaTable<kMaxGroupArenas> t)
 {
     extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
-    direct_body(a, a.th, a.prog, kEvalThreads, a.chunk_len[0], t.ar[blockIdx.z], lds64, blockIdx.x, gridDim.x * gridDim.z);
+    direct_body(a, pack_kinds(a.kind, a.term_begin, a.term_count, a.n_kinds), a.th, a.prog, kEvalThreads, a.chunk_len[0], t.ar[blockIdx.z], lds64, blockIdx.x, gridDim.x * gridDim.z);
 }
 
 // ---- the same dispatch with NOTHING uploaded beforehand: bsg_query ----
@@ -167,7 +204,7 @@ __global__ __launch_bounds__(kEvalThreads) void k_query_direct(const QueryKernAr
     const uint64_t *th = reinterpret_cast<const uint64_t *>(ka + offsetof(QueryKernArgs, th));
     const uint32_t *prog = reinterpret_cast<const uint32_t *>(ka + offsetof(QueryKernArgs, prog));
     const ArenaRef *ar = reinterpret_cast<const ArenaRef *>(ka + offsetof(QueryKernArgs, t)) + blockIdx.z;
-    direct_body(q.a, th, prog, q.stride, q.len, *ar, lds64, blockIdx.x, gridDim.x * gridDim.z);
+    direct_body(q.a, pack_kinds(q.a.kind, q.a.term_begin, q.a.term_count, q.a.n_kinds), th, prog, q.stride, q.len, *ar, lds64, blockIdx.x, gridDim.x * gridDim.z);
 }
 
 // ---- MANY such calls in one dispatch: the job list of a combiner cycle (combine_api.inc) ----
@@ -195,25 +232,62 @@ struct JobsArgs {
     const uint64_t *tab;         // the same table, as u64 / u32 words
     const uint32_t *wg_job;      // the job of every workgroup (in the same table): one load instead of a search over the records
     uint64_t *out;               // page-locked host memory
-    uint32_t n_jobs, n_wg;
     uint32_t *done_count; uint64_t *flag; uint64_t seq;
+    uint32_t n_jobs, n_wg;
+    uint32_t wg_at, pad;         // k_query_jobs_inline: byte offset of wg_job in the table (the three pointers above are unused there)
 };
+
+// What bounds a long list (PMC, 7 000 workgroups per dispatch: tools/conc_pmc.sh): every bit test is an L2 miss (TCC_MISS 325 per wave
+// of 403 requests, no TLB misses), the waves wait all their life (SQ_WAIT_ANY / SQ_WAVE_CYCLES 1.05, instructions issue in 7 % of it),
+// and the misses arrive at ~50 x 10^9 per second — scattered 64-byte reads, each opening a DRAM row: the HBM's activation rate, not its
+// bandwidth (3 TB/s of sectors for 0.4 TB/s of useful words).  Hence bits are tested two at a time (FIRST = TRIP = 2: 2.7 fetches
+// per absent term instead of 10; measured against 4 + 6: +3 ... 8 % on lists of 850-10 000 workgroups where one term in three is present
+// in every block, level on short lists), 98 -> ~40 registers, and nothing in scratch memory (the kinds' triples packed into words above:
+// as arrays they cost 128 bytes per lane and a third of the kernel's time).
+#ifndef BSG_JOBS_FIRST
+#define BSG_JOBS_FIRST 2
+#endif
+#ifndef BSG_JOBS_TRIP
+#define BSG_JOBS_TRIP 2
+#endif
+__device__ __forceinline__ void jobs_body(const JobsArgs &j, const QJob *jobs, const uint64_t *tab, const uint32_t *wg_job, uint64_t *lds64)
+{
+    // (a binary search over the records' first workgroups cost every workgroup ~7 dependent loads in front of its first useful one:
+    // 81 jobs 84 us; the table costs 4 bytes per workgroup)
+    const QJob &J = jobs[wg_job[blockIdx.x]];
+    DirectArgs a{};
+    a.out = j.out + J.out_off;
+    a.Tp = J.th_stride; a.Wt = 1; a.n_queries = J.n_queries; a.Lmax = J.len; a.max_depth = J.max_depth; a.n_kinds = J.n_kinds;
+    KindsPk K{0, 0, 0};
+#pragma unroll
+    for (uint32_t y = 0; y < 3; ++y)
+        if (y < J.n_kinds) { K.kind |= (uint32_t)J.kind[y] << (8 * y); K.begin |= (uint64_t)J.term_begin[y] << (16 * y); K.count |= (uint64_t)J.term_count[y] << (16 * y); }
+    a.n_arenas = 1;
+    a.done_count = j.done_count; a.flag = j.flag; a.seq = j.seq;
+    const ArenaRef ar{J.words, J.desc, J.n_blocks, 0u};
+    direct_body<BSG_JOBS_FIRST, BSG_JOBS_TRIP>(a, K, tab + J.th_off, reinterpret_cast<const uint32_t *>(tab) + J.prog_off, J.n_queries, J.len, ar, lds64, blockIdx.x - J.wg0, j.n_wg);
+}
 
 __global__ __launch_bounds__(kEvalThreads) void k_query_jobs(const JobsArgs j)
 {
     extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
-    // (a binary search over the records' first workgroups cost every workgroup ~7 dependent loads in front of its first useful one:
-    // 81 jobs 84 us; the table costs 4 bytes per workgroup)
-    const QJob &J = j.jobs[j.wg_job[blockIdx.x]];
-    DirectArgs a{};
-    a.out = j.out + J.out_off;
-    a.Tp = J.th_stride; a.Wt = 1; a.n_queries = J.n_queries; a.Lmax = J.len; a.max_depth = J.max_depth; a.n_kinds = J.n_kinds;
-#pragma unroll
-    for (uint32_t y = 0; y < 3; ++y) { a.kind[y] = J.kind[y]; a.term_begin[y] = J.term_begin[y]; a.term_count[y] = J.term_count[y]; }
-    a.n_arenas = 1;
-    a.done_count = j.done_count; a.flag = j.flag; a.seq = j.seq;
-    const ArenaRef ar{J.words, J.desc, J.n_blocks, 0u};
-    direct_body(a, j.tab + J.th_off, reinterpret_cast<const uint32_t *>(j.tab) + J.prog_off, J.n_queries, J.len, ar, lds64, blockIdx.x - J.wg0, j.n_wg);
+    jobs_body(j, j.jobs, j.tab, j.wg_job, lds64);
+}
+
+// A SHORT job list (a cycle of a handful of callers: the table of ~16 three-term single-arena calls) rides in the kernel arguments
+// like k_query_direct's: no table upload in front of the dispatch — one enqueue less per cycle, and the copy's ~3 us on the stream.
+constexpr uint32_t kJobsInlineBytes = 4096 - (uint32_t)sizeof(JobsArgs);
+struct JobsInlineArgs {
+    JobsArgs a;
+    uint8_t table[kJobsInlineBytes];           // [jobs][per call: th | prog][job of every workgroup]
+};
+static_assert(sizeof(JobsInlineArgs) == 4096 && offsetof(JobsInlineArgs, table) % 8 == 0, "kernel arguments must stay within 4 KB");
+
+__global__ __launch_bounds__(kEvalThreads) void k_query_jobs_inline(const JobsInlineArgs q)
+{
+    extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
+    const char *tb = (const char *)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(JobsInlineArgs, table);
+    jobs_body(q.a, reinterpret_cast<const QJob *>(tb), reinterpret_cast<const uint64_t *>(tb), reinterpret_cast<const uint32_t *>(tb + q.a.wg_at), lds64);
 }
 
 // The completion doorbell of a combiner cycle: ONE system-scope store behind the cycle's last dispatch (same stream, in order) into

@@ -156,7 +156,7 @@ def _combiner_case(ctx, seed, n_threads, rounds):
     pool = [Q.And(Q.Token(vocab[i % 40]), Q.Or(Q.FieldToken("f%d" % (i % 9), vocab[(i * 7) % 40]), Q.Field("f%d" % (i % 45)))) for i in range(12)]
     pool += [H.random_expression(rng, vocab[:12], None) for _ in range(12)] + [None]
     want = [[O.survivors_tree(w, p.desc.view(O.DESC_DTYPE), [e])[0] for e in pool] for w, p in zip(words, plans)]
-    lists = [[0], [5], [2, 3], [5, 4], [1, 0, 5], [3]]
+    lists = [[0], [5], [2, 3], [5, 4], [1, 0, 5], [3], [2, 2, 1]]             # (an arena may be named twice by one call)
     errors = []
     gate = threading.Barrier(n_threads)
 
@@ -197,6 +197,18 @@ def test_concurrent_queries_equal_the_oracle_whatever_they_are_merged_with(ctx):
     # (a random expression beyond 16 terms / 128 program words goes alone without ever entering the combiner)
     assert 0.9 * 24 * ROUNDS * 10 <= st["calls"] <= 24 * ROUNDS * 10 and st["cycle_calls"] == st["calls"]
     assert st["max_calls_per_cycle"] >= 6 and st["dispatches"] > 0, "calls did not share cycles: %r" % (st,)
+
+
+def test_short_job_lists_in_the_kernel_arguments_and_uploaded(ctx):
+    # cycles of <= 4 calls: their job table fits the kernel arguments (k_query_jobs_inline); with key 21 = 0 the same lists are uploaded
+    for inline in (1, 0):
+        ctx.set_lab(21, inline)
+        ctx.set_lab(15, (1000 << 16) | 4)
+        try:
+            _combiner_case(ctx, 13 + inline, 8, ROUNDS * 4)
+        finally:
+            ctx.set_lab(15, 0)
+            ctx.set_lab(21, 1)
 
 
 def test_concurrent_queries_on_a_sharded_context():
