@@ -9,9 +9,9 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
 i=0
-for SET in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY" "SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_ACTIVE_INST_ANY SQ_WAIT_ANY" "GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCC_HIT_sum TCC_MISS_sum" "TCC_EA_RDREQ_sum TCC_EA_RDREQ_32B_sum TCC_EA_WRREQ_sum" "TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_REQUEST_sum"; do
+for SET in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY" "SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_ACTIVE_INST_ANY SQ_WAIT_ANY" "GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCC_HIT_sum TCC_MISS_sum" "FETCH_SIZE" "TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_REQUEST_sum"; do
   i=$((i+1))
-  timeout 200 rocprofv3 --kernel-trace --pmc $SET -d $OUT/p$i -o b -- python $REPO/tools/conc_lab.py 0.15 2 > $OUT/p$i.log 2>&1
+  timeout 60 rocprofv3 --kernel-trace --pmc $SET -d $OUT/p$i -o b -- python $REPO/tools/conc_lab.py 0.15 2 > $OUT/p$i.log 2>&1
 done
 cd $REPO
 python - "$OUT" > gpurun_out/conc_pmc_$TAG.txt 2>&1 <<'PY'
@@ -34,6 +34,6 @@ for k, c in sorted(vals.items()):
     for ctr, (v, _, n) in sorted(c.items()):
         print("   %-32s %16.0f%s" % (ctr, v, ("   per wave %10.1f" % (v / waves)) if waves and ctr != "SQ_WAVES" else ""))
 PY
-for f in $OUT/p*.log; do tail -2 $f | cut -c1-200; done >> gpurun_out/conc_pmc_$TAG.txt
+for f in $OUT/p*.log; do grep -i "error\|invalid\|not found" $f | head -2 | cut -c1-200; done >> gpurun_out/conc_pmc_$TAG.txt
 rm -rf $OUT
 cat gpurun_out/conc_pmc_$TAG.txt

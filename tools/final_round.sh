@@ -18,6 +18,10 @@ python bench.py --workload c4 --cpu-budget 6 --c4-files 0 --ingest-blocks 0 --no
 # round 5 labs: concurrent bsg_query callers (alone vs combined, collector phases), the step's tail split and the per-rank shard
 # sizes of the strong-scaling leg on one GPU (what N = 2 / 4 / 8 ranks each see), the section codec, the N > 1 host paths
 HOT=8 python tools/conc_lab.py 0.5 2 > gpurun_out/${R}_conc_lab.txt 2>&1
+# the job kernel of the combiner (k_query_jobs): durations by launch shape and the SQ / TCP / TCC counters of long lists (no hot arenas)
+CASES=2 TS=16,64 HOT=0 bash tools/conc_prof.sh jobs > /dev/null 2>&1
+CASES=2 TS=64 HOT=0 bash tools/conc_pmc.sh jobs > /dev/null 2>&1
+cp gpurun_out/conc_prof_jobs.txt gpurun_out/keep/${R}_jobs_rocprofv3.txt; cp gpurun_out/conc_pmc_jobs.txt gpurun_out/keep/${R}_jobs_pmc.txt
 bash tools/r05_step.sh > gpurun_out/${R}_step.txt 2>&1
 grep "^tail split 0%" gpurun_out/${R}_step.txt | sed "s/^tail split 0%: //" > gpurun_out/${R}_c4_shard_sweep.txt
 python tools/decode_lab.py 2>&1 | tail -2 > gpurun_out/${R}_decode_lab_run.txt
