@@ -278,6 +278,7 @@ struct Combiner {
     uint32_t linger_us = 0, linger_calls = 0;   // lab (bsg_set_lab key 15): a collector waits this long / for this many queued calls
     uint32_t hot_min_queries = 8;               // an arena asked at least this many queries in a cycle is streamed once for all of them (key 16; 0: never).  Measured 4 / 8 / 12 / 24: a gather costs a 128-byte line, so streaming a 35 MB arena pays from ~9 three-term queries; 4 streams too much at 64 callers over 12 arenas (5.9 vs 8.8 x 10^5), 24 leaves 64 x 10 arenas at 1.9 vs 3.0 x 10^5
     std::atomic<uint64_t> n_solo{0}, n_cycles{0}, n_cycle_calls{0}, n_dispatches{0}, n_hot{0}, max_cycle_calls{0};
+    uint64_t part_bytes = 64ull << 20;           // rows of one part of a cycle (page-locked scratch, kept): a cycle beyond it is served in parts (key 24)
     uint32_t inline_jobs = 1;                    // a job list whose table fits the kernel arguments travels in them (key 21; 0: always uploaded)
     uint32_t profile = 0;                        // lab (key 20): callers account their own processor time (bsg_lab_query_cpu)
     std::atomic<uint64_t> n_cpu_calls{0}, ns_cpu_call{0}, ns_cpu_wait{0}, ns_cpu_duty{0}, ns_cpu_collect{0};

@@ -247,11 +247,11 @@ BSG_API int32_t bsg_set_probe_group(bsg_ctx *ctx, uint32_t max_arenas_per_launch
  * which a construct or match call on a context over several devices is cut into one part per device; key 9: 1 = file-level unions
  * through global hash tables instead of LDS partitions, key 10: start that partitioning 2^value x too coarse; key 11: evaluators per
  * tile of k_probe_eval — probe and program evaluation of few-term batches in ONE dispatch —, 0 = two dispatches, the default;
- * keys 12-17, 20-22: the combiner of concurrent bsg_query calls — 12: 0 = every call alone, 1 = combine (default), 2 = lab, the caller's
+ * keys 12-17, 20-22, 24: the combiner of concurrent bsg_query calls — 12: 0 = every call alone, 1 = combine (default), 2 = lab, the caller's
  * preparation only, nothing probed; 13: cycles in flight (2; one more while cycles average > 32 calls); 15: (microseconds << 16) |
  * calls a collector waits for company (tests); 16: queries asked of one arena in a cycle from which it is streamed once for all of
  * them (8); 17: microseconds a queued caller polls while the context is quiet (60); 20: account the callers' processor time
- * (bsg_lab_query_cpu); 21: 0 = a cycle's job table is always uploaded (default 1: a table of <= ~4 KB rides in the kernel arguments); 22: workgroups of a lone call's dispatch beyond which its doorbell is a dispatch behind it (32); key 19: percent of a single-group device-resident run whose evaluation moves to a second stream (0 = off));
+ * (bsg_lab_query_cpu); 21: 0 = a cycle's job table is always uploaded (default 1: a table of <= ~4 KB rides in the kernel arguments); 22: workgroups of a lone call's dispatch beyond which its doorbell is a dispatch behind it (32); 24: bytes of survivor rows beyond which a cycle is served in parts (64 MB); key 19: percent of a single-group device-resident run whose evaluation moves to a second stream (0 = off));
  * not part of the seam. */
 BSG_API int32_t bsg_set_lab(bsg_ctx *ctx, uint32_t key, uint64_t value);
 /* Synchronous probes poll their stream for up to this long before they block (default 0: block at once).  A single

@@ -211,6 +211,18 @@ def test_short_job_lists_in_the_kernel_arguments_and_uploaded(ctx):
             ctx.set_lab(21, 1)
 
 
+def test_a_cycle_beyond_its_scratch_budget_is_served_in_parts(ctx):
+    # key 24: a part holds at most 512 bytes of survivor rows, so cycles of 8 calls split into several parts (one call alone in a part
+    # when it exceeds the budget by itself)
+    ctx.set_lab(24, 512)
+    ctx.set_lab(15, (2000 << 16) | 8)
+    try:
+        _combiner_case(ctx, 21, 16, ROUNDS * 4)
+    finally:
+        ctx.set_lab(15, 0)
+        ctx.set_lab(24, 64 << 20)
+
+
 def test_concurrent_queries_on_a_sharded_context():
     from bloomsearch_amd.gpu import Context
     with Context((0, 0, 0)) as m:
