@@ -276,7 +276,7 @@ struct Combiner {
     bsgsync::Gate sync;
     uint32_t mode = 1;            // 0: every call goes alone (bsg_set_lab key 12)
     uint32_t linger_us = 0, linger_calls = 0;   // lab (bsg_set_lab key 15): a collector waits this long / for this many queued calls
-    uint32_t hot_min_queries = 8;               // an arena asked at least this many queries in a cycle is streamed once for all of them (key 16; 0: never).  Measured 4 / 8 / 12 / 24: a gather costs a 128-byte line, so streaming a 35 MB arena pays from ~9 three-term queries; 4 streams too much at 64 callers over 12 arenas (5.9 vs 8.8 x 10^5), 24 leaves 64 x 10 arenas at 1.9 vs 3.0 x 10^5
+    uint32_t hot_min_queries = 8;               // an arena is streamed once for all its callers of a cycle from this many 3-term queries per 35 KB of filters per block (key 16; 0: never; scaled by the arena's bytes per block and the calls' terms: combine_api.inc).  Measured 4 / 8 / 12 / 24 on C2's arena: 4 streams too much at 64 callers over 12 arenas (5.9 vs 8.8 x 10^5), 24 leaves 64 x 10 arenas at 1.9 vs 3.0 x 10^5
     std::atomic<uint64_t> n_solo{0}, n_cycles{0}, n_cycle_calls{0}, n_dispatches{0}, n_hot{0}, max_cycle_calls{0};
     uint64_t part_bytes = 64ull << 20;           // rows of one part of a cycle (page-locked scratch, kept): a cycle beyond it is served in parts (key 24)
     uint32_t inline_jobs = 1;                    // a job list whose table fits the kernel arguments travels in them (key 21; 0: always uploaded)

@@ -249,8 +249,8 @@ BSG_API int32_t bsg_set_probe_group(bsg_ctx *ctx, uint32_t max_arenas_per_launch
  * tile of k_probe_eval — probe and program evaluation of few-term batches in ONE dispatch —, 0 = two dispatches, the default;
  * keys 12-17, 20-22, 24: the combiner of concurrent bsg_query calls — 12: 0 = every call alone, 1 = combine (default), 2 = lab, the caller's
  * preparation only, nothing probed; 13: cycles in flight (2; one more while cycles average > 32 calls); 15: (microseconds << 16) |
- * calls a collector waits for company (tests); 16: queries asked of one arena in a cycle from which it is streamed once for all of
- * them (8); 17: microseconds a queued caller polls while the context is quiet (60); 20: account the callers' processor time
+ * calls a collector waits for company (tests); 16: 3-term queries asked of one arena in a cycle from which it is streamed once for all of
+ * them (8, for 35 KB of filters per block: scaled by the arena's bytes per block and the calls' distinct terms); 17: microseconds a queued caller polls while the context is quiet (60); 20: account the callers' processor time
  * (bsg_lab_query_cpu); 21: 0 = a cycle's job table is always uploaded (default 1: a table of <= ~4 KB rides in the kernel arguments); 22: workgroups of a lone call's dispatch beyond which its doorbell is a dispatch behind it (32); 24: bytes of survivor rows beyond which a cycle is served in parts (64 MB); key 19: percent of a single-group device-resident run whose evaluation moves to a second stream (0 = off));
  * not part of the seam. */
 BSG_API int32_t bsg_set_lab(bsg_ctx *ctx, uint32_t key, uint64_t value);
@@ -318,7 +318,7 @@ BSG_API int32_t bsg_query(bsg_ctx *ctx, const uint64_t *arena_ids, uint32_t n_ar
  * goroutine of its own, query_exec.go:303-357, 427-431, and runs several Query() calls at once — mirrored call by call that is one
  * ~8 us dispatch per (query, file), serialised on the device's stream).  A call that finds the device idle goes alone, at once, as
  * described above.  Calls that arrive while another is collecting or in flight queue inside the library; the head of the queue
- * collects everything queued as (call, arena) pairs: an arena asked >= 8 queries in the cycle is STREAMED once for
+ * collects everything queued as (call, arena) pairs: an arena asked enough in the cycle (8 three-term queries per 35 KB of filters per block) is STREAMED once for
  * all of them (their query sets merged into one batch, each distinct term probed once: k_probe_terms + k_eval_programs), every other
  * pair is a job of ONE k_query_jobs dispatch (gather regime: cost follows the pairs asked for — one query, one call per candidate
  * file is a list of such jobs).  The collector hands its role on (two cycles in flight) and deals every caller its rows.  Nobody
