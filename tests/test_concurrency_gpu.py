@@ -259,3 +259,31 @@ def test_native_callers_share_dispatches_bit_exactly(ctx):
         assert st["max_calls_per_cycle"] > 4 and st["cycles"] < st["calls"], st
     for a in aids:
         ctx.arena_free(a)
+
+
+def test_a_freed_arena_id_is_forgotten_by_the_callers_caches(ctx):
+    """bsg_query looks arena ids up in a per-thread cache (the shared table is a cache line 256 callers would write): freeing an id must
+    reach every thread's cache — the next call fails with NOTFOUND instead of probing freed memory — and a new arena is found."""
+    from bloomsearch_amd._lib import BloomGpuError
+    rng = np.random.default_rng(5)
+    plans = [H.make_random_arena(rng, nb, absent_frac=0.03, max_tokens=60, vocab_size=20) for nb in (70, 130)]
+    vocab = plans[0][2]
+    exprs = [Q.Token(vocab[3]), Q.Or(Q.Token(vocab[5]), Q.Field("f1")), None]
+    cb = Q.compile_queries(exprs)
+    words = [ctx.build(p.blob, p.off, p.fstart, p.desc, p.n_words) for p, _, _ in plans]
+    want = [O.survivors_tree(w, p.desc.view(O.DESC_DTYPE), exprs) for w, (p, _, _) in zip(words, plans)]
+    a0 = ctx.arena_load(words[0], plans[0][0].desc)
+    seen = []
+
+    def other_thread():                                    # a second thread caches the id too
+        seen.append(np.array_equal(np.stack(ctx.query([a0], [70], cb)[0]), want[0]))
+
+    t = threading.Thread(target=other_thread); t.start(); t.join()
+    assert seen == [True]
+    assert np.array_equal(np.stack(ctx.query([a0], [70], cb)[0]), want[0])
+    ctx.arena_free(a0)
+    with pytest.raises(BloomGpuError):
+        ctx.query([a0], [70], cb)
+    a1 = ctx.arena_load(words[1], plans[1][0].desc)
+    assert np.array_equal(np.stack(ctx.query([a1], [130], cb)[0]), want[1])
+    ctx.arena_free(a1)
