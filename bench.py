@@ -1322,7 +1322,132 @@ def decode_leg(ctx, plan, words, B, log):
     return decode
 
 
-def main():
+def c2_line(value, world, probes_per_step, args, h_elapsed, r_elapsed, elapsed, elapsed_ev, clock, rows, B, NQ, R, G0, terms, dom, k, traffic, traffic_src, copy_gbps, timed_region, samples, allk, wps, page_locked, rows_tags):
+    """The JSON line of the weak-scaling C2 run (the headline at N = 1)."""
+    return {
+        "metric": "block-bloom probes/sec", "value": value, "unit": "probes/s", "n_gpus": world,
+        # `value` leaves the survivor bitsets on the device (inputs and outputs resident, nothing crosses PCIe in the timed
+        # region); the north star's "host-side gather of surviving block IDs" costs what the next field says — the same steps
+        # with every rank's survivors DMA-ed into host memory (details under host_gather)
+        "value_survivors_delivered_to_host": probes_per_step * args.steps / min(h_elapsed, r_elapsed or h_elapsed),
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "ms_per_step_with_dispatch_timestamps": elapsed_ev / args.steps * 1e3, "clock": dict(clock, note=CLOCK_NOTE),
+        "timing_note": "value / ms_per_step: exactly K steps between barrier + synchronize, launches bare; the same K steps were then repeated "
+                       "with HIP timestamps on every dispatch (hipExtLaunchKernelGGL start/stop events on the library's stream): "
+                       "ms_per_step_with_dispatch_timestamps, and roofline.timed_region holds those dispatches' durations"
+                       if not args.events_in_headline else "HIP timestamps on every dispatch of the headline region",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {"workload": "%s probe: %d rows/block x %d blocks per GPU, Q=%d %s [%s], "
+                               "fpr %g, %d address-distinct arena replicas rotated per step, %d arenas (steps) per dispatch"
+                               % ("C4" if args.workload == "c4" else "C2", rows, B, NQ,
+                                  "8-term Or(FieldToken)" if args.workload == "c4" else "3-term And(FieldToken)",
+                                  args.workload, args.fpr, R, G0),
+                   "blocks_per_gpu": B, "queries": NQ, "distinct_terms": int(len(terms)),
+                   "probes_per_step": probes_per_step, "sharding": "round-robin blocks, no collective",
+                   "survivors": "left on the device (host_gather: the same steps with every rank's survivors delivered to host memory)"},
+        "roofline": {"bound": "hbm", "kernel": dom, "achieved": k.get("achieved"), "peak": HBM_PEAK_GBPS,
+                     "unit": "GB/s", "frac": k.get("frac"), "traffic": traffic, "traffic_source": traffic_src,
+                     "algorithmic_bytes_per_launch": k.get("algorithmic_bytes_per_launch"), "kernel_ms": k.get("kernel_ms"),
+                     "samples": k.get("samples"), "arenas_per_launch": k.get("arenas_per_launch"),
+                     "copy_gbps": copy_gbps,
+                     "frac_of_copy": (k.get("achieved") / copy_gbps) if (copy_gbps and k.get("achieved")) else None,
+                     "copy_note": "copy_gbps = bytes read + written by a 1 GiB device-to-device copy on this box, measured in this run (SURVEY 8d: "
+                                  "quote the fraction of the vendor peak and of the measured copy bandwidth)",
+                     "timed_region": timed_region, "sampling_passes": samples, "all": allk},
+        "valu_issue": valu_issue_from_profiles(dom, k, B) if dom == "k_probe_terms_many" else None,
+        "host_gather": {"ms_per_step": h_elapsed / args.steps * 1e3, "value": probes_per_step * args.steps / h_elapsed,
+                        "survivor_bytes_per_step_per_gpu": wps * 8, "page_locked": page_locked,
+                        "rows": None if r_elapsed is None else {
+                            "api": "bsg_probe_many_rows", "ms_per_step": r_elapsed / args.steps * 1e3, "value": probes_per_step * args.steps / r_elapsed,
+                            "rows_by_tag_none_all_list_dense": rows_tags,
+                            "note": "per query a 4-byte header (tag, count) + block ids / words only where the row needs them, written by the device "
+                                    "straight into the page-locked segment: what crosses PCIe depends on what survives"},
+                        "note": "same steps, every rank's survivors DMA-ed (copy stream, overlapped with the next dispatch) into one shared "
+                                "page-locked host segment that rank 0 reads: PCIe-inclusive, never `value`"},
+    }
+
+
+def closing_legs(out, json_out, ctx, args, rank, world, local_rank, plan, words, block_ids, rows, terms, ops, poff, got, or_reduce, or_state, log):
+    """The legs that may not come back (one context over every GPU of the job; the RCCL exchange), each under a watchdog that still
+    prints the line; then the line itself — exactly once."""
+    import torch.distributed as dist
+    import threading
+    emitted = threading.Lock()
+
+    def emit():
+        if rank == 0 and emitted.acquire(blocking=False):
+            print(json.dumps(out), file=json_out, flush=True)
+
+    # ---- one process, one context over every GPU of the job (rank 0, after every timed leg; the other ranks wait at the
+    # barrier below).  BSG_BENCH_MULTI_CTX=n (lab): a context of n entries that all name this rank's GPU. ----
+    if rank == 0:
+        import torch
+        n_lab = int(os.environ.get("BSG_BENCH_MULTI_CTX", "0"))
+        ids = [local_rank] * n_lab if n_lab > 1 else (
+            list(range(world)) if world > 1 and COLL_DEVICE() == "cuda" and torch.cuda.device_count() >= world else None)
+        if ids:
+            finished = threading.Event()
+
+            mdc = out["multi_device_context"] = {"devices": ids}      # filled in place, stage by stage
+
+            def giving_up():
+                if not finished.wait(float(os.environ.get("BSG_BENCH_MULTI_CTX_TIMEOUT", "240"))):
+                    mdc["error"] = "stage %r gave no answer within the watchdog's time; the leg was abandoned (stages_done lists what did finish)" % mdc.get("stage_running")
+                    emit()
+                    os._exit(0)
+            threading.Thread(target=giving_up, daemon=True).start()
+            try:
+                multi_device_context_leg(ctx, ids, plan, words, block_ids, rows, 0xB100F5EA4C4, args.fpr, terms, ops, poff, got, log, res=mdc)
+            except Exception as exc:  # noqa: BLE001 - reported in the line
+                mdc["error"] = "stage %r: %r" % (mdc.get("stage_running"), exc)
+                log("multi-device context leg failed: %r" % (exc,))
+            finished.set()
+        elif world > 1:
+            out["multi_device_context"] = {"skipped": "%d device(s) visible to rank 0" % torch.cuda.device_count()}
+    if world > 1:
+        dist.barrier()
+    if or_state is not None:
+        # the RCCL leg last, under a watchdog: if a collective never returns, rank 0 still prints the line (with the error
+        # noted) and every rank leaves — a hung collective cannot be cancelled from Python
+        done = threading.Event()
+
+        def watchdog():
+            if not done.wait(float(os.environ.get("BSG_BENCH_RCCL_TIMEOUT", "120"))):
+                if rank == 0:
+                    out["or_reduce"]["allreduce_error"] = "no answer within the watchdog's time; the leg was abandoned"
+                    emit()
+                os._exit(0)
+        threading.Thread(target=watchdog, daemon=True).start()
+        or_exchange_leg(ctx, or_reduce, or_state, world, log)
+        done.set()
+    emit()
+
+
+def strong_scaling_headline(out, c4, args, NQ, copy_gbps):
+    # N > 1: the line's headline is BASELINE configs[3] — C4, STRONG scaling (10 000 blocks in total, block b on rank
+    # b % N, the 8-term Or batch, exactly --steps timed steps) — and the weak-scaling C2 run above moves to `c2_weak`.
+    # The C4 curve over N reads: this line's `value` at N > 1, and the `c4.value` of the N = 1 line.
+    ck = (c4.get("kernels") or {}).get(c4.get("dominant_kernel")) or {}
+    c2 = {key: out[key] for key in ("value", "value_survivors_delivered_to_host", "steps", "warmup", "ms_per_step", "clock", "scaling", "config",
+                                    "roofline", "host_gather")}
+    out["c2_weak"] = c2
+    out.update({
+        "value": c4["value"], "value_survivors_delivered_to_host": (c4["host_gather"].get("rows") or c4["host_gather"])["value"], "steps": c4["steps"],
+        "warmup": c4["warmup"], "ms_per_step": c4["ms_per_step"], "clock": c4["clock"], "scaling": "strong",
+        "config": {"workload": c4["workload"], "blocks_total": args.c4_files * args.c4_blocks_per_file, "queries": NQ,
+                   "probes_per_step": c4["probes_per_step"], "sharding": "block b -> rank b % N, no collective; survivors left on the "
+                   "device (host_gather: delivered to one shared page-locked host segment)",
+                   "curve": "strong scaling of BASELINE configs[3]: compare with `c4.value` of the N = 1 line (same 10 000 blocks on one GPU)"},
+        "roofline": {"bound": "hbm", "kernel": c4.get("dominant_kernel"), "achieved": ck.get("achieved"), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": ck.get("frac"), "traffic": None, "algorithmic_bytes_per_launch": ck.get("algorithmic_bytes_per_launch"),
+                     "kernel_ms": ck.get("kernel_ms"), "samples": ck.get("samples"), "arenas_per_launch": ck.get("arenas_per_launch"),
+                     "copy_gbps": copy_gbps,
+                     "note": "rank 0's dispatches of the timed region; every rank's own kernel time is under c4.per_rank"},
+        "host_gather": c4["host_gather"],
+    })
+
+
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -1359,7 +1484,11 @@ def main():
     ap.add_argument("--no-concurrent", action="store_true", help="skip the concurrent_queries leg (T host threads x bsg_query)")
     ap.add_argument("--no-big-filters", action="store_true", help="skip the leg with block filters beyond the LDS budget (~1 MB each)")
     ap.add_argument("--no-single", action="store_true", help="skip the one-arena-per-launch sampling pass")
-    args = ap.parse_args()
+    return ap.parse_args()
+
+
+def main():
+    args = parse_args()
     self_launch(args)
 
     # stdout carries exactly one JSON line: libraries that print banners through C stdio (librccl writes its version block
@@ -1581,69 +1710,9 @@ def main():
         k = allk.get(dom) or {}
         traffic, traffic_src = traffic_from_profiles(dom, k, args, B)
         copy_gbps = measured_copy_gbps(log)
-        out = {
-            "metric": "block-bloom probes/sec", "value": value, "unit": "probes/s", "n_gpus": world,
-            # `value` leaves the survivor bitsets on the device (inputs and outputs resident, nothing crosses PCIe in the timed
-            # region); the north star's "host-side gather of surviving block IDs" costs what the next field says — the same steps
-            # with every rank's survivors DMA-ed into host memory (details under host_gather)
-            "value_survivors_delivered_to_host": probes_per_step * args.steps / min(h_elapsed, r_elapsed or h_elapsed),
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "ms_per_step_with_dispatch_timestamps": elapsed_ev / args.steps * 1e3, "clock": dict(clock, note=CLOCK_NOTE),
-            "timing_note": "value / ms_per_step: exactly K steps between barrier + synchronize, launches bare; the same K steps were then repeated "
-                           "with HIP timestamps on every dispatch (hipExtLaunchKernelGGL start/stop events on the library's stream): "
-                           "ms_per_step_with_dispatch_timestamps, and roofline.timed_region holds those dispatches' durations"
-                           if not args.events_in_headline else "HIP timestamps on every dispatch of the headline region",
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "%s probe: %d rows/block x %d blocks per GPU, Q=%d %s [%s], "
-                                   "fpr %g, %d address-distinct arena replicas rotated per step, %d arenas (steps) per dispatch"
-                                   % ("C4" if args.workload == "c4" else "C2", rows, B, NQ,
-                                      "8-term Or(FieldToken)" if args.workload == "c4" else "3-term And(FieldToken)",
-                                      args.workload, args.fpr, R, G0),
-                       "blocks_per_gpu": B, "queries": NQ, "distinct_terms": int(len(terms)),
-                       "probes_per_step": probes_per_step, "sharding": "round-robin blocks, no collective",
-                       "survivors": "left on the device (host_gather: the same steps with every rank's survivors delivered to host memory)"},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": k.get("achieved"), "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": k.get("frac"), "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": k.get("algorithmic_bytes_per_launch"), "kernel_ms": k.get("kernel_ms"),
-                         "samples": k.get("samples"), "arenas_per_launch": k.get("arenas_per_launch"),
-                         "copy_gbps": copy_gbps,
-                         "frac_of_copy": (k.get("achieved") / copy_gbps) if (copy_gbps and k.get("achieved")) else None,
-                         "copy_note": "copy_gbps = bytes read + written by a 1 GiB device-to-device copy on this box, measured in this run (SURVEY 8d: "
-                                      "quote the fraction of the vendor peak and of the measured copy bandwidth)",
-                         "timed_region": timed_region, "sampling_passes": samples, "all": allk},
-            "valu_issue": valu_issue_from_profiles(dom, k, B) if dom == "k_probe_terms_many" else None,
-            "host_gather": {"ms_per_step": h_elapsed / args.steps * 1e3, "value": probes_per_step * args.steps / h_elapsed,
-                            "survivor_bytes_per_step_per_gpu": wps * 8, "page_locked": page_locked,
-                            "rows": None if r_elapsed is None else {
-                                "api": "bsg_probe_many_rows", "ms_per_step": r_elapsed / args.steps * 1e3, "value": probes_per_step * args.steps / r_elapsed,
-                                "rows_by_tag_none_all_list_dense": rows_tags,
-                                "note": "per query a 4-byte header (tag, count) + block ids / words only where the row needs them, written by the device "
-                                        "straight into the page-locked segment: what crosses PCIe depends on what survives"},
-                            "note": "same steps, every rank's survivors DMA-ed (copy stream, overlapped with the next dispatch) into one shared "
-                                    "page-locked host segment that rank 0 reads: PCIe-inclusive, never `value`"},
-        }
+        out = c2_line(value, world, probes_per_step, args, h_elapsed, r_elapsed, elapsed, elapsed_ev, clock, rows, B, NQ, R, G0, terms, dom, k, traffic, traffic_src, copy_gbps, timed_region, samples, allk, wps, page_locked, rows_tags)
         if world > 1 and c4:
-            # N > 1: the line's headline is BASELINE configs[3] — C4, STRONG scaling (10 000 blocks in total, block b on rank
-            # b % N, the 8-term Or batch, exactly --steps timed steps) — and the weak-scaling C2 run above moves to `c2_weak`.
-            # The C4 curve over N reads: this line's `value` at N > 1, and the `c4.value` of the N = 1 line.
-            ck = (c4.get("kernels") or {}).get(c4.get("dominant_kernel")) or {}
-            c2 = {key: out[key] for key in ("value", "value_survivors_delivered_to_host", "steps", "warmup", "ms_per_step", "clock", "scaling", "config",
-                                            "roofline", "host_gather")}
-            out["c2_weak"] = c2
-            out.update({
-                "value": c4["value"], "value_survivors_delivered_to_host": (c4["host_gather"].get("rows") or c4["host_gather"])["value"], "steps": c4["steps"],
-                "warmup": c4["warmup"], "ms_per_step": c4["ms_per_step"], "clock": c4["clock"], "scaling": "strong",
-                "config": {"workload": c4["workload"], "blocks_total": args.c4_files * args.c4_blocks_per_file, "queries": NQ,
-                           "probes_per_step": c4["probes_per_step"], "sharding": "block b -> rank b % N, no collective; survivors left on the "
-                           "device (host_gather: delivered to one shared page-locked host segment)",
-                           "curve": "strong scaling of BASELINE configs[3]: compare with `c4.value` of the N = 1 line (same 10 000 blocks on one GPU)"},
-                "roofline": {"bound": "hbm", "kernel": c4.get("dominant_kernel"), "achieved": ck.get("achieved"), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                             "frac": ck.get("frac"), "traffic": None, "algorithmic_bytes_per_launch": ck.get("algorithmic_bytes_per_launch"),
-                             "kernel_ms": ck.get("kernel_ms"), "samples": ck.get("samples"), "arenas_per_launch": ck.get("arenas_per_launch"),
-                             "copy_gbps": copy_gbps,
-                             "note": "rank 0's dispatches of the timed region; every rank's own kernel time is under c4.per_rank"},
-                "host_gather": c4["host_gather"],
-            })
+            strong_scaling_headline(out, c4, args, NQ, copy_gbps)
         if single:
             s1 = single.get(PROBE_KERNEL, {})
             out["roofline_single_launch"] = dict(s1, bound="hbm", kernel=PROBE_KERNEL, peak=HBM_PEAK_GBPS, unit="GB/s",
@@ -1680,56 +1749,7 @@ def main():
                 out["cpu_baseline_port"] = base
     else:
         out = None
-    import threading
-    emitted = threading.Lock()
-
-    def emit():
-        if rank == 0 and emitted.acquire(blocking=False):
-            print(json.dumps(out), file=json_out, flush=True)
-
-    # ---- one process, one context over every GPU of the job (rank 0, after every timed leg; the other ranks wait at the
-    # barrier below).  BSG_BENCH_MULTI_CTX=n (lab): a context of n entries that all name this rank's GPU. ----
-    if rank == 0:
-        import torch
-        n_lab = int(os.environ.get("BSG_BENCH_MULTI_CTX", "0"))
-        ids = [local_rank] * n_lab if n_lab > 1 else (
-            list(range(world)) if world > 1 and COLL_DEVICE() == "cuda" and torch.cuda.device_count() >= world else None)
-        if ids:
-            finished = threading.Event()
-
-            mdc = out["multi_device_context"] = {"devices": ids}      # filled in place, stage by stage
-
-            def giving_up():
-                if not finished.wait(float(os.environ.get("BSG_BENCH_MULTI_CTX_TIMEOUT", "240"))):
-                    mdc["error"] = "stage %r gave no answer within the watchdog's time; the leg was abandoned (stages_done lists what did finish)" % mdc.get("stage_running")
-                    emit()
-                    os._exit(0)
-            threading.Thread(target=giving_up, daemon=True).start()
-            try:
-                multi_device_context_leg(ctx, ids, plan, words, block_ids, rows, 0xB100F5EA4C4, args.fpr, terms, ops, poff, got, log, res=mdc)
-            except Exception as exc:  # noqa: BLE001 - reported in the line
-                mdc["error"] = "stage %r: %r" % (mdc.get("stage_running"), exc)
-                log("multi-device context leg failed: %r" % (exc,))
-            finished.set()
-        elif world > 1:
-            out["multi_device_context"] = {"skipped": "%d device(s) visible to rank 0" % torch.cuda.device_count()}
-    if world > 1:
-        dist.barrier()
-    if or_state is not None:
-        # the RCCL leg last, under a watchdog: if a collective never returns, rank 0 still prints the line (with the error
-        # noted) and every rank leaves — a hung collective cannot be cancelled from Python
-        done = threading.Event()
-
-        def watchdog():
-            if not done.wait(float(os.environ.get("BSG_BENCH_RCCL_TIMEOUT", "120"))):
-                if rank == 0:
-                    out["or_reduce"]["allreduce_error"] = "no answer within the watchdog's time; the leg was abandoned"
-                    emit()
-                os._exit(0)
-        threading.Thread(target=watchdog, daemon=True).start()
-        or_exchange_leg(ctx, or_reduce, or_state, world, log)
-        done.set()
-    emit()
+    closing_legs(out, json_out, ctx, args, rank, world, local_rank, plan, words, block_ids, rows, terms, ops, poff, got, or_reduce, or_state, log)
     stop_pool()
     ctx.batch_free(bid)
     ctx.close()
