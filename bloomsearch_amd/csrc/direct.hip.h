@@ -237,13 +237,14 @@ struct JobsArgs {
     uint32_t wg_at, pad;         // k_query_jobs_inline: byte offset of wg_job in the table (the three pointers above are unused there)
 };
 
-// What bounds a long list (PMC, 7 000 workgroups per dispatch: tools/conc_pmc.sh): every bit test is an L2 miss (TCC_MISS 325 per wave
-// of 403 requests, no TLB misses), the waves wait all their life (SQ_WAIT_ANY / SQ_WAVE_CYCLES 1.05, instructions issue in 7 % of it),
-// and the misses arrive at ~50 x 10^9 per second — scattered 64-byte reads, each opening a DRAM row: the HBM's activation rate, not its
-// bandwidth (3 TB/s of sectors for 0.4 TB/s of useful words).  Hence bits are tested two at a time (FIRST = TRIP = 2: 2.7 fetches
-// per absent term instead of 10; measured against 4 + 6: +3 ... 8 % on lists of 850-10 000 workgroups where one term in three is present
-// in every block, level on short lists), 98 -> ~40 registers, and nothing in scratch memory (the kinds' triples packed into words above:
-// as arrays they cost 128 bytes per lane and a third of the kernel's time).
+// What bounds a long list (PMC, 5 000-7 000 workgroups per dispatch: tools/conc_pmc.sh): every bit test is an L2 miss (TCC_MISS 1 223 per
+// workgroup against 375 hits, 64 bytes each by FETCH_SIZE, no TLB misses), the waves wait all their life (SQ_WAIT_ANY / SQ_WAVE_CYCLES
+// 0.7-1.0, instructions issue in 3-7 % of it), and a workgroup costs 23.5 ns whatever the occupancy or the number of dependent rounds:
+// 52 x 10^9 scattered sector reads per second — the HBM's rate for scattered accesses (each opens a DRAM row), 3.3 TB/s of sectors for
+// 0.42 TB/s of useful words.  Hence bits are tested two at a time (FIRST = TRIP = 2: 2.7 fetches per absent term instead of 10; measured
+// against 4 + 6: +3 ... 8 % on lists of 850-10 000 workgroups where one term in three is present in every block, level on short lists),
+// 98 -> ~40 registers, and nothing in scratch memory (the kinds' triples packed into words above: as arrays they cost 128 bytes per
+// lane and 15 % of the kernel's time).
 #ifndef BSG_JOBS_FIRST
 #define BSG_JOBS_FIRST 2
 #endif

@@ -15,24 +15,24 @@ for SET in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY" "SQ_INSTS_V
 done
 cd $REPO
 python - "$OUT" > gpurun_out/conc_pmc_$TAG.txt 2>&1 <<'PY'
+# every counter set is a run of its own with cycles of its own sizes: a counter is normalised by the workgroups of the dispatches IT
+# was collected on (sum of values / sum of workgroups), never by another pass's wave count
 import glob, os, sqlite3, sys
 root = sys.argv[1]
 vals = {}
 for db in sorted(glob.glob(os.path.join(root, "p*", "**", "*.db"), recursive=True)):
     d = sqlite3.connect(db)
     try:
-        rows = list(d.execute("select kernel_name, counter_name, avg(value), avg(grid_size_x), count(*) from counters_collection "
+        rows = list(d.execute("select kernel_name, counter_name, sum(value), sum((grid_size_x / workgroup_size_x) * (grid_size_y / workgroup_size_y) * (grid_size_z / workgroup_size_z)), count(*) from counters_collection "
                               "where kernel_name like 'bsg::k_query%' group by kernel_name, counter_name"))
     except Exception as exc:
         print("db %s: %r" % (db, exc)); continue
-    for name, ctr, v, gx, n in rows:
-        vals.setdefault(name.split("(")[0].replace("bsg::", ""), {})[ctr] = (v, gx, n)
+    for name, ctr, v, wgs, n in rows:
+        vals.setdefault(name.split("(")[0].replace("bsg::", ""), {})[ctr] = (v, wgs, n)
 for k, c in sorted(vals.items()):
-    gx = max(g for _, g, _ in c.values())
-    print("== %s: mean grid %.0f workgroups (%d dispatches)" % (k, gx / 256, max(n for _, _, n in c.values())))
-    waves = c.get("SQ_WAVES", (0, 0, 0))[0]
-    for ctr, (v, _, n) in sorted(c.items()):
-        print("   %-32s %16.0f%s" % (ctr, v, ("   per wave %10.1f" % (v / waves)) if waves and ctr != "SQ_WAVES" else ""))
+    print("== %s (a workgroup = 4 waves = 64 blocks of one (call, arena) pair)" % k)
+    for ctr, (v, wgs, n) in sorted(c.items()):
+        print("   %-32s %12.1f per workgroup   (%d dispatches, %.0f workgroups each on average)" % (ctr, v / max(wgs, 1), n, wgs / max(n, 1)))
 PY
 for f in $OUT/p*.log; do grep -i "error\|invalid\|not found" $f | head -2 | cut -c1-200; done >> gpurun_out/conc_pmc_$TAG.txt
 rm -rf $OUT
