@@ -109,3 +109,48 @@ def test_two_rank_gather_and_or_reduce_gloo(n_blocks):
     for p in procs:
         p.join(60)
     assert sorted(results) == [(0, True), (1, True)]
+
+
+def _barrier_worker(rank, world, port, q):
+    import time
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from benchlib.common import HostBarrier
+        hb = HostBarrier(rank, world)
+        ok = True
+        for i in range(50):
+            # the late rank alternates: nobody may leave round i before the late rank has entered it
+            late = i % world
+            if rank == late:
+                time.sleep(0.002)
+            t_in = time.monotonic()
+            hb.wait()
+            t_out = time.monotonic()
+            ins = [None] * world
+            dist.all_gather_object(ins, (t_in, t_out))
+            ok = ok and min(o for _, o in ins) >= max(i_ for i_, _ in ins)       # CLOCK_MONOTONIC is one clock for all processes of a node
+        hb.close()
+        q.put((rank, bool(ok) and (rank != 0 or not os.path.exists(hb.path))))       # rank 0 removes the segment after everybody closed it
+    except Exception as exc:
+        q.put((rank, repr(exc)))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def test_host_barrier_two_ranks_gloo():
+    """bench.py's closing barrier at N > 1 (benchlib.common.HostBarrier: epoch flags in a shared-memory segment)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_barrier_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert sorted(results) == [(0, True), (1, True)]

@@ -1,7 +1,7 @@
 import sys, os, time
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, os.getcwd())
 import numpy as np
-import bench
+from benchlib import common as bench
 from bloomsearch_amd.arena import plan_blocks
 from bloomsearch_amd.gpu import Context
 ctx = Context((0,))

@@ -10,7 +10,7 @@ import numpy as np
 from bloomsearch_amd import _lib, query as Q, synth
 from bloomsearch_amd.arena import plan_blocks
 from bloomsearch_amd.gpu import Context
-import bench
+from benchlib import common as bench
 
 
 def main():

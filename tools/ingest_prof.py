@@ -6,7 +6,7 @@ import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 
-import bench
+from benchlib import common as bench
 if os.environ.get('BSG_LAB_LIB'):
     from bloomsearch_amd import _lib
     _lib.LIB_PATH = os.environ['BSG_LAB_LIB']

@@ -4,7 +4,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bloomsearch_amd import synth, query as Q
 from bloomsearch_amd.gpu import Context
-import bench
+from benchlib import common as bench
 nb=300
 parts=[bench._gen_rows((b,10000,1)) for b in range(nb)]
 blob=np.frombuffer(b"".join(p[0] for p in parts),dtype=np.uint8)

@@ -6,7 +6,7 @@ python - <<'PY'
 import sys, time, os
 sys.path.insert(0, os.getcwd())
 import numpy as np
-import bench
+from benchlib import common as bench
 from bloomsearch_amd import ingest as I
 from bloomsearch_amd.gpu import Context
 n_blocks, rows = int(os.environ.get("NB", "300")), 10000
