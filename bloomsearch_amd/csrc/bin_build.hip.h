@@ -61,13 +61,7 @@ __device__ __forceinline__ uint32_t bin_tile_list(const BinArgs &a, uint32_t *li
 template <typename F>
 __device__ __forceinline__ void bin_locations(const DevDesc &d, const uint64_t h[4], F f)
 {
-    uint64_t s2 = 0, s3 = 0;
-    for (uint32_t i = 0; i < d.k; ++i) {
-        const uint32_t r = i & 3u;
-        const uint64_t x = ((i & 1u) ? h[1] : h[0]) + ((r == 1u || r == 2u) ? s3 : s2);
-        s2 += h[2]; s3 += h[3];
-        f((uint32_t)locate<true>(d, x));
-    }
+    for_each_location_x(d.k, h[0], h[1], h[2], h[3], [&](uint64_t x) { f((uint32_t)locate<true>(d, x)); });
 }
 
 // DENSE: the source is an array of base hashes, 4 words per entry (bsg_build / bsg_build_hashed), not a table

@@ -1299,14 +1299,8 @@ __device__ __forceinline__ void build_from_slots(const IngestTable t, const SetB
                 const ulonglong2 *q = reinterpret_cast<const ulonglong2 *>(t.slots + (base + list[e2]) * 4);
                 x1 = q[0]; y1 = q[1];
             }
-            {
-                const uint64_t h[4] = {x0.x, x0.y, y0.x, y0.y};
-                set_entry_bits<M32>(bits, d, h);
-            }
-            if (e2 < n) {
-                const uint64_t h[4] = {x1.x, x1.y, y1.x, y1.y};
-                set_entry_bits<M32>(bits, d, h);
-            }
+            set_entry_bits<M32>(bits, d, x0.x, x0.y, y0.x, y0.y);
+            if (e2 < n) set_entry_bits<M32>(bits, d, x1.x, x1.y, y1.x, y1.y);
         }
         __syncthreads();
     }

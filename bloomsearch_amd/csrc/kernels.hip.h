@@ -1423,23 +1423,38 @@ struct BuildArgs {
     uint64_t *out;
 };
 
-// Sets the k bits of one entry.  Locations use running sums i*h2, i*h3 (64-bit adds) instead of a
-// 64-bit multiply per location.
-template <bool M32, typename BITS32>
-__device__ __forceinline__ void set_entry_bits(BITS32 bits, const DevDesc &d, const uint64_t h[4])
+// location(h, i), i = 0 .. k - 1, of bloom/v3 (h[i % 2] + i * h[2 + (((i + i % 2) % 4) / 2)], wrapping u64; oracle/bloom_oracle.c):
+//     i % 4 == 0: h0 + i h2      1: h1 + i h3      2: h0 + i h3      3: h1 + i h2
+// four per trip from running multiples of h2 and h3, every hash word in a register of its own.  Until round 6 the loop took one
+// location per trip and picked h[i & 1] out of the array: the compiler answered the dynamic index by keeping h[] in SCRATCH memory
+// (48 bytes per lane) — a scratch_load + s_waitcnt vmcnt(0) in front of every location, which is what profiles/r04_build_pmc.txt's
+// "78 % of a wave's life waiting" was (found reading the ISA; k is wave-uniform, the three guards are scalar branches).
+template <typename F>
+__device__ __forceinline__ void for_each_location_x(uint32_t k, uint64_t h0, uint64_t h1, uint64_t h2, uint64_t h3, F f)
 {
-    uint64_t s2 = 0, s3 = 0;
-    for (uint32_t i = 0; i < d.k; ++i) {
-        const uint32_t r = i & 3u;
-        const uint64_t x = ((i & 1u) ? h[1] : h[0]) + ((r == 1u || r == 2u) ? s3 : s2);
-        s2 += h[2]; s3 += h[3];
+    const uint64_t h3x2 = h3 + h3, h2x3 = h2 + h2 + h2, h2x4 = h2x3 + h2, h3x4 = h3x2 + h3x2;
+    uint64_t s2 = 0, s3 = 0;                          // i h2, i h3 at the trip's first i
+    for (uint32_t i = 0; i < k; i += 4) {
+        f(h0 + s2);
+        if (i + 1 < k) f(h1 + s3 + h3);
+        if (i + 2 < k) f(h0 + s3 + h3x2);
+        if (i + 3 < k) f(h1 + s2 + h2x3);
+        s2 += h2x4; s3 += h3x4;
+    }
+}
+
+// Sets the k bits of one entry.
+template <bool M32, typename BITS32>
+__device__ __forceinline__ void set_entry_bits(BITS32 bits, const DevDesc &d, uint64_t h0, uint64_t h1, uint64_t h2, uint64_t h3)
+{
+    for_each_location_x(d.k, h0, h1, h2, h3, [&](uint64_t x) {
         const uint64_t loc = locate<M32>(d, x);
 #ifdef BSG_LAB_NO_ATOMICS      // lab only: keep the location live without touching the bitset
         asm volatile("" ::"v"((uint32_t)loc));
 #else
         __hip_atomic_fetch_or(&bits[loc >> 5], 1u << ((uint32_t)loc & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
-    }
+    });
 }
 
 template <bool M32, typename BITS32>
@@ -1449,19 +1464,17 @@ __device__ __forceinline__ void build_entries(const BuildArgs &a, const BuildIte
         for (uint32_t e = it.e_begin + tid; e < it.e_end; e += kBuildThreads) {
             const ulonglong2 *hp = reinterpret_cast<const ulonglong2 *>(a.h + (uint64_t)e * 4);
             const ulonglong2 x = hp[0], y = hp[1];
-            const uint64_t h[4] = {x.x, x.y, y.x, y.y};
-            set_entry_bits<M32>(bits, d, h);
+            set_entry_bits<M32>(bits, d, x.x, x.y, y.x, y.y);
         }
         return;
     }
-    // One entry per lane per trip.  Measured on gfx950 (tools/build_lab.hip): preloading 32 bytes of 2-4
-    // entries per lane is slower on real (10-23 byte) entries — the extra unaligned 8-byte loads cost more
-    // than the overlap buys; k_build is bound by 64-bit integer multiplies (murmur + Barrett), not by loads.
+    // One entry per lane per trip (preloading 32 bytes of 2-4 entries per lane measured slower on real 10-23 byte entries:
+    // tools/build_lab.hip, round 3).
     for (uint32_t e = it.e_begin + tid; e < it.e_end; e += kBuildThreads) {
         const uint32_t o0 = a.off[e], o1 = a.off[e + 1];
         uint64_t h[4];
         base_hashes_words(a.bytes + o0, o1 - o0, h);
-        set_entry_bits<M32>(bits, d, h);
+        set_entry_bits<M32>(bits, d, h[0], h[1], h[2], h[3]);
     }
 }
 
