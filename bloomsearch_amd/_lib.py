@@ -41,6 +41,11 @@ class QueryStats(C.Structure):
                 ("ns_scatter", C.c_uint64), ("ns_free", C.c_uint64), ("ns_retire", C.c_uint64)]
 
 
+class ArenaCacheStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("budget_bytes", "resident_bytes", "resident_files", "leases", "leased_dead_bytes", "hits", "misses", "published",
+                                          "widenings", "evictions", "forgotten", "rejected_dirty", "rejected_over_budget", "rejected_narrower")]
+
+
 class IngestStats(C.Structure):
     _fields_ = [("n_rows", C.c_uint32), ("n_fallback_rows", C.c_uint32), ("table_grows", C.c_uint32), ("reserved", C.c_uint32),
                 ("row_bytes", C.c_uint64), ("table_bytes", C.c_uint64), ("ms_walk", C.c_float), ("ms_union", C.c_float),
@@ -57,13 +62,18 @@ def op(opcode: int, arg: int = 0) -> int:
     return (opcode << 28) | (arg & 0x0FFFFFFF)
 
 
+# every symbol include/bloomgpu_lab.h declares: lab switches, not part of the drop-in contract
+LAB_EXPORTS = ["bsg_set_lab", "bsg_set_spin_wait", "bsg_set_fuse_limit", "bsg_set_gather_cost", "bsg_lab_query_cpu", "bsg_set_timed_stride"]
+
 # every symbol include/bloomgpu.h declares (tests assert the .so exports all of them)
 EXPORTS = [
     "bsg_device_count", "bsg_peer_access", "bsg_device_calls", "bsg_open", "bsg_open_err", "bsg_close", "bsg_last_error", "bsg_last_error_copy", "bsg_scope_open",
-    "bsg_sync", "bsg_estimate_parameters", "bsg_probe_many_dev", "bsg_set_probe_group", "bsg_set_gather_cost", "bsg_set_fuse_limit", "bsg_set_spin_wait", "bsg_set_ingest_chunk", "bsg_set_lab",
+    "bsg_sync", "bsg_estimate_parameters", "bsg_probe_many_dev", "bsg_set_probe_group", "bsg_set_ingest_chunk",
     "bsg_hash_entries", "bsg_build", "bsg_build_hashed", "bsg_arena_load", "bsg_arena_load_sections", "bsg_arena_free",
     "bsg_arena_stream_begin", "bsg_arena_stream_append", "bsg_arena_stream_finish", "bsg_arena_stream_abort",
-    "bsg_batch_create", "bsg_batch_free", "bsg_probe_batch", "bsg_probe_many", "bsg_probe", "bsg_query", "bsg_query_stats_read", "bsg_lab_query_cpu", "bsg_survivor_list", "bsg_probe_many_rows", "bsg_survivor_row_list", "bsg_survivor_rows_size", "bsg_survivor_rows_list", "bsg_timing_read", "bsg_set_timed_stride", "bsg_last_kernel_ms",
+    "bsg_set_arena_budget", "bsg_file_arena_acquire", "bsg_file_arena_have", "bsg_file_arena_publish", "bsg_file_arena_release",
+    "bsg_file_arena_forget", "bsg_arena_cache_stats_read",
+    "bsg_batch_create", "bsg_batch_free", "bsg_probe_batch", "bsg_probe_many", "bsg_probe", "bsg_query", "bsg_query_stats_read", "bsg_survivor_list", "bsg_probe_many_rows", "bsg_survivor_row_list", "bsg_survivor_rows_size", "bsg_survivor_rows_list", "bsg_timing_read", "bsg_last_kernel_ms",
     "bsg_or_reduce", "bsg_or_words_dev", "bsg_or_reduce_dev", "bsg_last_or_ms",
     "bsg_comm_unique_id", "bsg_comm_init", "bsg_comm_destroy", "bsg_comm_info", "bsg_or_allreduce", "bsg_or_allreduce_dev",
     "bsg_ingest_rows", "bsg_ingest_fallback_rows", "bsg_ingest_add_entries", "bsg_ingest_finish", "bsg_ingest_build",
@@ -114,6 +124,13 @@ def load():
     L.bsg_arena_stream_append.argtypes = [vp, u64, u64, vp, u64]
     L.bsg_arena_stream_finish.argtypes = [vp, u64, vp, C.POINTER(u64)]
     L.bsg_arena_stream_abort.argtypes = [vp, u64]
+    L.bsg_set_arena_budget.argtypes = [vp, u64]
+    L.bsg_file_arena_acquire.argtypes = [vp, vp, u32, vp, u32, C.POINTER(u64), C.POINTER(u64), vp]
+    L.bsg_file_arena_have.argtypes = [vp, vp, u32, vp, vp, vp, u32, C.POINTER(u32)]
+    L.bsg_file_arena_publish.argtypes = [vp, vp, u32, u64, vp, vp, vp, vp, u32, C.POINTER(u64), C.POINTER(i32)]
+    L.bsg_file_arena_release.argtypes = [vp, u64]
+    L.bsg_file_arena_forget.argtypes = [vp, vp, u32]
+    L.bsg_arena_cache_stats_read.argtypes = [vp, C.POINTER(ArenaCacheStats), i32]
     L.bsg_batch_create.argtypes = [vp, vp, u32, vp, vp, u32, C.POINTER(u64)]
     L.bsg_batch_free.argtypes = [vp, u64]
     L.bsg_probe_batch.argtypes = [vp, u64, u64, u32, vp]
@@ -157,7 +174,7 @@ def load():
     L.bsg_pinned_free.argtypes = [vp, vp]
     L.bsg_host_register.argtypes = [vp, vp, u64]
     L.bsg_host_unregister.argtypes = [vp, vp]
-    for name in EXPORTS:
+    for name in EXPORTS + LAB_EXPORTS:
         if name != "bsg_last_error":
             getattr(L, name).restype = i32
     _lib = L

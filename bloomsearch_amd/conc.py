@@ -29,6 +29,15 @@ class ConcResult(C.Structure):
     _fields_ = [("calls", C.c_uint64), ("mismatches", C.c_uint64), ("errors", C.c_uint64), ("seconds", C.c_double), ("n_lat", C.c_uint64), ("cpu_seconds", C.c_double)]
 
 
+class CacheFile(C.Structure):
+    _fields_ = [("region", C.c_void_p), ("sec_off", C.c_void_p), ("n_blocks", C.c_uint32)]
+
+
+class CacheResult(C.Structure):
+    _fields_ = [("calls", C.c_uint64), ("mismatches", C.c_uint64), ("errors", C.c_uint64), ("hits", C.c_uint64), ("misses", C.c_uint64),
+                ("forgets", C.c_uint64), ("seconds", C.c_double)]
+
+
 def build(force: bool = False) -> str:
     if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= os.path.getmtime(SRC):
         return LIB
@@ -53,7 +62,49 @@ def load():
         _drv.conc_run.argtypes = [C.c_void_p, C.c_uint32, C.c_double, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
                                   C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(ConcResult)]
         _drv.conc_run.restype = C.c_int32
+        _drv.cache_run.argtypes = [C.c_void_p, C.c_uint32, C.c_double, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint64,
+                                   C.POINTER(CacheResult)]
+        _drv.cache_run.restype = C.c_int32
     return _drv
+
+
+def _marshal_queries(exprs):
+    from . import query as Q
+    keep, qs = [], (ConcQuery * len(exprs))()
+    for i, e in enumerate(exprs):
+        cb = Q.compile_queries([e])
+        tb, to = pack_entries(cb.term_strings)
+        ops, poff, kinds = cb.arrays()
+        ops = np.ascontiguousarray(ops, dtype=np.uint32)
+        kinds = np.ascontiguousarray(kinds, dtype=np.uint32)
+        tb = np.ascontiguousarray(np.frombuffer(tb, dtype=np.uint8) if isinstance(tb, (bytes, bytearray)) else tb)
+        to = np.ascontiguousarray(to, dtype=np.uint32)
+        keep.append((tb, to, kinds, ops))
+        qs[i] = ConcQuery(tb.ctypes.data if tb.size else None, to.ctypes.data, kinds.ctypes.data if kinds.size else None, len(kinds),
+                          ops.ctypes.data if ops.size else None, len(ops))
+    return keep, qs
+
+
+def cache_run(ctx, exprs, files, expected, n_threads, seconds, forget_every=0, seed=1):
+    """T native threads over the resident file-arena cache (tools/native/conc_driver.cpp::cache_run).  files: list of lists of section
+    bytes (one list per file, one section per block); expected[f]: [len(exprs), ceil(blocks_f / 64)] survivors of the file's full block set."""
+    keep, qs = _marshal_queries(exprs)
+    cf, hold = (CacheFile * len(files))(), []
+    for i, secs in enumerate(files):
+        region = np.frombuffer(b"".join(secs), dtype=np.uint8)
+        off = np.zeros(len(secs) + 1, dtype=np.uint64)
+        off[1:] = np.cumsum([len(x) for x in secs], dtype=np.uint64)
+        hold.append((region, off))
+        cf[i] = CacheFile(region.ctypes.data, off.ctypes.data, len(secs))
+    exp = [np.ascontiguousarray(e, dtype=np.uint64) for e in expected]
+    for e, secs in zip(exp, files):
+        assert e.shape == (len(exprs), (len(secs) + 63) // 64), e.shape
+    ptrs = (C.c_void_p * len(exp))(*[e.ctypes.data for e in exp])
+    res = CacheResult()
+    rc = load().cache_run(ctx.h, n_threads, float(seconds), C.cast(qs, C.c_void_p), len(exprs), C.cast(cf, C.c_void_p), len(files),
+                          C.cast(ptrs, C.c_void_p), forget_every, seed, C.byref(res))
+    assert rc == 0
+    return {f: getattr(res, f) for f, _ in res._fields_}
 
 
 def run(ctx, exprs, arena_ids, n_blocks, expected, n_threads, seconds, arenas_per_call=1, lat_cap=1 << 18):

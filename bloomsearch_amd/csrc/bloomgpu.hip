@@ -6,6 +6,7 @@
 // There is no CPU fallback anywhere in this file: without a GPU every compute
 // entry point fails with BSG_E_NODEVICE / BSG_E_HIP.
 #include "bloomgpu.h"
+#include "bloomgpu_lab.h"
 #include "kernels.hip.h"
 #include "ingest.hip.h"
 #include "bin_build.hip.h"
@@ -30,6 +31,8 @@
 #include <random>
 #include <string>
 #include <thread>
+#include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 namespace {
@@ -288,7 +291,10 @@ struct Combiner {
 
 }  // namespace
 
+struct bsg_arena_cache;   // cache_api.inc
+
 struct bsg_ctx {
+    std::shared_ptr<bsg_arena_cache> cache;   // resident file arenas across queries (cache_api.inc); the root context's
     bsg_ctx *parent = nullptr;   // non-null: this object is an error scope aliasing `parent` (bsg_scope_open)
     std::mutex err_mu;
     std::string err;             // last failure recorded on this scope / context
@@ -350,6 +356,8 @@ bsg_ctx *root_of(bsg_ctx *c) { return c->parent ? c->parent : c; }
 void free_all_ingests(bsg_ctx *ctx);   // ingest_api.inc
 void destroy_comms(bsg_ctx *ctx);      // comm_api.inc
 void free_all_streams(bsg_ctx *ctx);   // stream_api.inc
+std::shared_ptr<bsg_arena_cache> arena_cache_create(); // cache_api.inc
+void arena_cache_destroy(bsg_ctx *ctx);
 int32_t ensure_lower_table(Device &d);   // ingest_api.inc: the unicode.ToLower table the walkers fold with
 
 struct SectionsOut { uint8_t *region; uint64_t cap; uint64_t *sec_off; };   // encode_api.inc
@@ -654,6 +662,7 @@ int32_t bsg_open(const int32_t *device_ids, int32_t n_devices, bsg_ctx **out_ctx
     if (hipGetDeviceCount(&count) != hipSuccess || count == 0)
         return fail(BSG_E_NODEVICE, "no HIP device visible (libbloomgpu has no CPU fallback)");
     auto ctx = std::make_unique<bsg_ctx>();
+    ctx->cache = arena_cache_create();
     ctx->arena_epoch.store(g_arena_epoch.fetch_add(1, std::memory_order_relaxed), std::memory_order_relaxed);
     {
         std::random_device rd;
@@ -765,6 +774,7 @@ int32_t bsg_close(bsg_ctx *ctx)
         d.stage_fstart.release(); d.stage_desc.release(); d.stage_items.release(); d.stage_words.release(); d.stage_region.release();
         if (d.stream) (void)hipStreamDestroy(d.stream);
     }
+    arena_cache_destroy(ctx);
     delete ctx;
     return BSG_OK;
 }
@@ -1239,10 +1249,13 @@ inline uint32_t rd_le32(const uint8_t *p) { uint32_t v; memcpy(&v, p, 4); return
 
 extern "C" {
 
-int32_t bsg_arena_free(bsg_ctx *ctx, uint64_t arena_id)
+}  // extern "C"
+
+namespace {
+bool cache_owns(bsg_ctx *ctx, uint64_t arena_id);   // cache_api.inc
+
+int32_t arena_free_by_id(bsg_ctx *ctx, uint64_t arena_id)
 {
-    BSG_ENTER(ctx);
-    if (!ctx) return fail(BSG_E_INVALID, "ctx is null");
     std::shared_ptr<Arena> a;
     {
         std::lock_guard<std::shared_mutex> lk(ctx->mu);
@@ -1259,6 +1272,17 @@ int32_t bsg_arena_free(bsg_ctx *ctx, uint64_t arena_id)
     }
     free_arena(ctx, *a);
     return BSG_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int32_t bsg_arena_free(bsg_ctx *ctx, uint64_t arena_id)
+{
+    BSG_ENTER(ctx);
+    if (cache_owns(ctx, arena_id))
+        return fail(BSG_E_INVALID, "arena %llu belongs to the file-arena cache (bsg_file_arena_publish): end its leases with bsg_file_arena_release", (unsigned long long)arena_id);
+    return arena_free_by_id(ctx, arena_id);
 }
 
 }  // extern "C"
@@ -1499,3 +1523,4 @@ int32_t bsg_or_reduce(bsg_ctx *ctx, uint64_t arena_id, uint32_t kind, uint64_t *
 #include "match_api.inc"
 #include "comm_api.inc"
 #include "stream_api.inc"
+#include "cache_api.inc"

@@ -70,11 +70,9 @@ struct DataFile {
     std::vector<DataBlock> blocks;
     BloomEntryCounts counts;
     std::vector<uint8_t> filter_section; // file-level filters
-    // the file's block filters as a resident probe arena: left on the device by the flush / merge that built them
-    // (DeviceIngest), or decoded from the stored sections on first use; kept until the file goes away
-    uint64_t arena = 0;
-    bool arena_valid = false;
-    std::vector<int32_t> block_status;   // parseFilterSection outcome per block (0 ok); all 0 for a flush-resident arena
+    // The file's block filters as a resident probe arena live in the LIBRARY's file-arena cache (bsg_file_arena_*, keyed by
+    // file_id): published by the flush / merge that built them on the device, or decoded from the stored sections by the first
+    // query that misses; least recently used files leave when the byte budget is exceeded, a merged-away file is forgotten.
 };
 
 struct BlockStats {                      // query_exec.go:63-72
@@ -122,7 +120,7 @@ public:
         }
         if (byte_index >= sec->size()) return false;
         (*sec)[byte_index] ^= 0x5A;
-        if (block_index >= 0) drop_file_arena(files_[file_index]);   // re-read (and re-checked) from the stored bytes on next use
+        if (block_index >= 0) forget_file_arena(files_[file_index]);   // re-read (and re-checked) from the stored bytes on next use
         else drop_files_arena();
         return true;
     }
@@ -249,7 +247,7 @@ public:
             off += out.blocks[b].row_bytes;
         }
         out.filter_section = std::move(sections.back());
-        for (auto &f : files_) drop_file_arena(f);
+        for (auto &f : files_) forget_file_arena(f);    // tombstoned sources (merge.go:178-185)
         files_.clear();
         files_.push_back(std::move(out));
         drop_files_arena();
@@ -283,15 +281,19 @@ public:
             if (int32_t rc = ensure_files_arena()) return rc;
             std::vector<uint64_t> fs((files_.size() + 63) / 64);
             if (bsg_probe_batch(ctx_, files_arena_, batch, 0, fs.data())) return fail(kErrGpu, bsg_last_error(ctx_));
-            // block stage: only the files that passed, each through its own resident arena, one pipelined call
+            // block stage: only the files that passed, each through its arena — resident in the library's cache, or decoded now
+            // and published there — all in one pipelined call; the leases end when the survivors are on the host
             std::vector<uint64_t> ids;
             std::vector<size_t> which;
+            std::vector<FileLease> leases;
+            struct ReleaseAll { bsg_ctx *c; std::vector<FileLease> &v; ~ReleaseAll() { for (auto &l : v) bsg_file_arena_release(c, l.lease); } } release{ctx_, leases};
             size_t words = 0;
             for (size_t f = 0; f < files_.size(); ++f) {
                 file_ok[f] = (fs[f >> 6] >> (f & 63)) & 1;   // a corrupt file-level section decodes to nil filters: cannot disqualify
                 if (!file_ok[f] || files_[f].blocks.empty()) continue;
-                if (int32_t rc = ensure_file_arena(files_[f])) return rc;
-                ids.push_back(files_[f].arena);
+                leases.emplace_back();
+                if (int32_t rc = lease_file_arena(files_[f], leases.back())) { leases.pop_back(); return rc; }
+                ids.push_back(leases.back().arena);
                 which.push_back(f);
                 words += (files_[f].blocks.size() + 63) / 64;
             }
@@ -299,10 +301,12 @@ public:
             if (!ids.empty() && bsg_probe_many(ctx_, ids.data(), (uint32_t)ids.size(), batch, 0, bs.data()))
                 return fail(kErrGpu, bsg_last_error(ctx_));
             size_t o = 0;
-            for (size_t f : which) {
+            for (size_t i = 0; i < which.size(); ++i) {
+                const size_t f = which[i];
                 for (size_t b = 0; b < files_[f].blocks.size(); ++b) {
-                    block_ok[f][b] = (bs[o + (b >> 6)] >> (b & 63)) & 1;
-                    if (files_[f].block_status[b] != 0) block_ok[f][b] = 2;   // unreadable filters: neither pruned nor scanned (query_exec.go:580-590)
+                    const uint32_t r = leases[i].rows[b];                      // block b's row in the arena
+                    block_ok[f][b] = (bs[o + (r >> 6)] >> (r & 63)) & 1;
+                    if (leases[i].status[b] != 0) block_ok[f][b] = 2;   // unreadable filters: neither pruned nor scanned (query_exec.go:580-590)
                 }
                 o += (files_[f].blocks.size() + 63) / 64;
             }
@@ -404,15 +408,68 @@ private:
         if (files_arena_valid_) bsg_arena_free(ctx_, files_arena_);
         files_arena_valid_ = false;
     }
-    void drop_file_arena(DataFile &f)
+    // ---- the file's block filters through the library's resident-arena cache (cache_api.inc) ----
+    struct FileLease {
+        uint64_t lease = 0, arena = 0;
+        std::vector<uint32_t> rows;        // block b's row in the arena
+        std::vector<int32_t> status;       // parseFilterSection outcome per block (0 ok); all 0 for a resident arena (only clean decodes stay)
+    };
+    static void file_key(const DataFile &f, uint8_t key[8]) { for (int i = 0; i < 8; ++i) key[i] = (uint8_t)(f.file_id >> (8 * i)); }
+    // block keys (RowDataOffset) and the sections' extents in the (virtual) file's filter region
+    static void block_extents(const DataFile &f, std::vector<uint64_t> &keys, std::vector<uint64_t> &begin, std::vector<uint64_t> &end)
     {
-        if (f.arena_valid) bsg_arena_free(ctx_, f.arena);
-        f.arena_valid = false;
+        uint64_t at = 0;
+        for (auto &b : f.blocks) {
+            keys.push_back(b.block_offset);
+            begin.push_back(at);
+            at += b.filter_section.size();
+            end.push_back(at);
+        }
+    }
+    void forget_file_arena(const DataFile &f)
+    {
+        uint8_t key[8];
+        file_key(f, key);
+        bsg_file_arena_forget(ctx_, key, 8);
     }
     void drop_arenas()
     {
         drop_files_arena();
-        for (auto &f : files_) drop_file_arena(f);
+        for (auto &f : files_) forget_file_arena(f);
+    }
+    // a freshly built / decoded arena of ALL the file's blocks becomes the cache's (and this lease's)
+    int32_t publish_file_arena(const DataFile &f, uint64_t arena, const int32_t *status, FileLease &out)
+    {
+        uint8_t key[8];
+        file_key(f, key);
+        std::vector<uint64_t> keys, begin, end;
+        block_extents(f, keys, begin, end);
+        if (bsg_file_arena_publish(ctx_, key, 8, arena, keys.data(), begin.data(), end.data(), status, (uint32_t)keys.size(), &out.lease, nullptr)) {
+            bsg_arena_free(ctx_, arena);
+            return fail(kErrGpu, bsg_last_error(ctx_));
+        }
+        out.arena = arena;
+        out.rows.resize(keys.size());
+        for (size_t b = 0; b < keys.size(); ++b) out.rows[b] = (uint32_t)b;
+        if (status) out.status.assign(status, status + keys.size()); else out.status.assign(keys.size(), 0);
+        return kEngineOk;
+    }
+    int32_t lease_file_arena(const DataFile &f, FileLease &out)
+    {
+        uint8_t key[8];
+        file_key(f, key);
+        std::vector<uint64_t> keys;
+        for (auto &b : f.blocks) keys.push_back(b.block_offset);
+        out.rows.assign(keys.size(), 0);
+        if (bsg_file_arena_acquire(ctx_, key, 8, keys.data(), (uint32_t)keys.size(), &out.lease, &out.arena, out.rows.data()))
+            return fail(kErrGpu, bsg_last_error(ctx_));
+        if (out.lease) { out.status.assign(keys.size(), 0); return kEngineOk; }
+        std::vector<const std::vector<uint8_t> *> bsec;
+        for (auto &b : f.blocks) bsec.push_back(&b.filter_section);
+        uint64_t arena = 0;
+        std::vector<int32_t> status;
+        if (int32_t rc = load_arena(bsec, arena, status)) return rc;
+        return publish_file_arena(f, arena, status.data(), out);
     }
 
     // buildFilters for many entry-set triples at once: sizes via EstimateParameters(max(n,1), fpr),
@@ -517,12 +574,22 @@ private:
         std::vector<uint8_t> region(total);
         std::vector<uint64_t> sec_off(nb + 2);
         // the block filters stay on the device as this file's probe arena: a query right after the flush uploads nothing
-        drop_file_arena(file);
-        if (bsg_ingest_build_sections(ctx_, ing, desc.data(), region.data(), region.size(), sec_off.data(), &file.arena, nullptr))
+        forget_file_arena(file);
+        uint64_t built_arena = 0;
+        if (bsg_ingest_build_sections(ctx_, ing, desc.data(), region.data(), region.size(), sec_off.data(), &built_arena, nullptr))
             return fail(kErrGpu, bsg_last_error(ctx_));
-        file.arena_valid = file.arena != 0;      // 0: the context does not keep single-device arenas; decoded from the sections on first use
-        file.block_status.assign(nb, 0);
         split_sections(region, sec_off, sections);
+        uint64_t blk_off = 0;
+        for (size_t s = 0; s < nb; ++s) {        // what the cache records: the blocks' keys (RowDataOffset, as the callers assign it) and section extents
+            file.blocks[s].filter_section = sections[s];
+            file.blocks[s].block_offset = blk_off;
+            blk_off += file.blocks[s].row_bytes;
+        }
+        if (built_arena) {                       // 0: the context does not keep this arena; decoded from the sections on first use
+            FileLease l;
+            if (int32_t rc = publish_file_arena(file, built_arena, nullptr, l)) return rc;
+            bsg_file_arena_release(ctx_, l.lease);
+        }
         for (size_t s = 0; s <= nb; ++s) {
             BloomEntryCounts &bc = s < nb ? file.blocks[s].counts : file.counts;
             bc = BloomEntryCounts{counts[s * 3], counts[s * 3 + 1], counts[s * 3 + 2]};
@@ -599,16 +666,6 @@ private:
         for (auto &f : files_) fsec.push_back(&f.filter_section);
         if (int32_t rc = load_arena(fsec, files_arena_, file_status_)) return rc;
         files_arena_valid_ = true;
-        return kEngineOk;
-    }
-
-    int32_t ensure_file_arena(DataFile &f)
-    {
-        if (f.arena_valid) return kEngineOk;
-        std::vector<const std::vector<uint8_t> *> bsec;
-        for (auto &b : f.blocks) bsec.push_back(&b.filter_section);
-        if (int32_t rc = load_arena(bsec, f.arena, f.block_status)) return rc;
-        f.arena_valid = true;
         return kEngineOk;
     }
 

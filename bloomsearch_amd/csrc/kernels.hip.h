@@ -1423,7 +1423,7 @@ struct BuildArgs {
     uint64_t *out;
 };
 
-// location(h, i), i = 0 .. k - 1, of bloom/v3 (h[i % 2] + i * h[2 + (((i + i % 2) % 4) / 2)], wrapping u64; oracle/bloom_oracle.c):
+// location(h, i), i = 0 .. k - 1, of bloom/v3 (h[i % 2] + i * h[2 + (((i + i % 2) % 4) / 2)], wrapping u64):
 //     i % 4 == 0: h0 + i h2      1: h1 + i h3      2: h0 + i h3      3: h1 + i h2
 // four per trip from running multiples of h2 and h3, every hash word in a register of its own.  Until round 6 the loop took one
 // location per trip and picked h[i & 1] out of the array: the compiler answered the dynamic index by keeping h[] in SCRATCH memory

@@ -182,6 +182,56 @@ class Context:
     def arena_free(self, arena_id: int):
         self._check(self.L.bsg_arena_free(self.h, arena_id))
 
+    # ---- resident file arenas across queries (cache_api.inc) ----
+    def set_arena_budget(self, n_bytes: int):
+        self._check(self.L.bsg_set_arena_budget(self.h, int(n_bytes)))
+
+    def file_arena_acquire(self, key: bytes, block_keys):
+        """-> (lease, arena_id, rows) when the file's resident arena covers every block key, else (0, 0, None)."""
+        bk = np.ascontiguousarray(block_keys, dtype=np.uint64)
+        kb = np.frombuffer(key, dtype=np.uint8)
+        rows = np.zeros(max(len(bk), 1), dtype=np.uint32)
+        lease, aid = C.c_uint64(), C.c_uint64()
+        self._check(self.L.bsg_file_arena_acquire(self.h, _lib._ptr(kb), len(kb), _lib._ptr(bk), len(bk), C.byref(lease), C.byref(aid), _lib._ptr(rows)))
+        return (int(lease.value), int(aid.value), rows[: len(bk)]) if lease.value else (0, 0, None)
+
+    def file_arena_have(self, key: bytes):
+        """Block keys and section extents (file offsets) of the file's resident arena: three u64 arrays (empty when there is none)."""
+        kb = np.frombuffer(key, dtype=np.uint8)
+        n = C.c_uint32()
+        self._check(self.L.bsg_file_arena_have(self.h, _lib._ptr(kb), len(kb), None, None, None, 0, C.byref(n)))
+        while True:
+            cap = int(n.value)
+            keys, sb, se = (np.zeros(max(cap, 1), dtype=np.uint64) for _ in range(3))
+            rc = self.L.bsg_file_arena_have(self.h, _lib._ptr(kb), len(kb), _lib._ptr(keys), _lib._ptr(sb), _lib._ptr(se), max(cap, 1), C.byref(n))
+            if rc == 0 and int(n.value) <= max(cap, 1):
+                m = int(n.value)
+                return keys[:m], sb[:m], se[:m]
+            if int(n.value) <= cap:             # a real failure, not a wider arena published in between
+                self._check(rc)
+
+    def file_arena_publish(self, key: bytes, arena_id: int, block_keys, sec_begin, sec_end, status=None):
+        """-> (lease, resident): the cache owns the arena from here on."""
+        kb = np.frombuffer(key, dtype=np.uint8)
+        bk, sb, se = (np.ascontiguousarray(a, dtype=np.uint64) for a in (block_keys, sec_begin, sec_end))
+        st = None if status is None else np.ascontiguousarray(status, dtype=np.int32)
+        lease, res = C.c_uint64(), C.c_int32()
+        self._check(self.L.bsg_file_arena_publish(self.h, _lib._ptr(kb), len(kb), arena_id, _lib._ptr(bk), _lib._ptr(sb), _lib._ptr(se), _lib._ptr(st), len(bk),
+                                                  C.byref(lease), C.byref(res)))
+        return int(lease.value), bool(res.value)
+
+    def file_arena_release(self, lease: int):
+        self._check(self.L.bsg_file_arena_release(self.h, lease))
+
+    def file_arena_forget(self, key: bytes):
+        kb = np.frombuffer(key, dtype=np.uint8)
+        self._check(self.L.bsg_file_arena_forget(self.h, _lib._ptr(kb), len(kb)))
+
+    def arena_cache_stats(self, reset: bool = False) -> dict:
+        st = _lib.ArenaCacheStats()
+        self._check(self.L.bsg_arena_cache_stats_read(self.h, C.byref(st), 1 if reset else 0))
+        return {f: int(getattr(st, f)) for f, _ in st._fields_}
+
     def batch_create(self, terms: np.ndarray, prog_ops, prog_off) -> int:
         assert terms.dtype == TERM_DTYPE
         ops = np.ascontiguousarray(prog_ops, dtype=np.uint32)

@@ -203,6 +203,41 @@ BSG_API int32_t bsg_arena_stream_finish(bsg_ctx *ctx, uint64_t stream_id, int32_
 BSG_API int32_t bsg_arena_stream_abort(bsg_ctx *ctx, uint64_t stream_id);
 BSG_API int32_t bsg_arena_free(bsg_ctx *ctx, uint64_t arena_id);
 
+/* ---- resident file arenas across queries ----
+ * The reference re-reads and re-parses a file's block-filter sections on every query (blockFilterCursor, file_format.go:511-662;
+ * evaluateBlockFilters, query_exec.go:546-615).  Here a file's decoded filters stay on the device between queries, under one
+ * policy inside the library: least recently used by BYTES against a budget, an arena somebody holds a lease on is never evicted,
+ * only clean decodes become resident, a miss widens the resident arena to the union of the block sets, a tombstoned file
+ * (merge.go:178-185) is forgotten at once and freed by its last user.
+ *   key            the file's identity (MaybeFile.Pointer bytes)
+ *   block_keys     strictly ascending u64 per candidate block (DataBlockMetadata.RowDataOffset, the order evaluateBlockFilters
+ *                  walks them in); row i of a published arena holds block_keys[i]
+ *   acquire        covered: *out_lease != 0, *out_arena_id, out_rows[i] = candidate i's row (block index) in that arena;
+ *                  not covered: *out_lease == 0 — load (have + own candidates), publish
+ *   have           cap == 0: *out_n only; else the resident arena's block keys and section extents (file offsets)
+ *   publish        arena_id from bsg_arena_stream_finish / bsg_arena_load_sections of exactly these blocks, status = its out_status
+ *                  (NULL: all clean).  The cache OWNS the arena from here on (bsg_arena_free on it is BSG_E_INVALID); the returned
+ *                  lease keeps it alive for this query whether or not it became resident (*out_resident).
+ *   release        ends a lease (unknown / already released: BSG_E_NOTFOUND)
+ * Thread-safe; device memory is freed outside the cache's lock. */
+typedef struct bsg_arena_cache_stats {
+    uint64_t budget_bytes, resident_bytes, resident_files, leases;
+    uint64_t leased_dead_bytes;      /* arenas alive only through leases (evicted-from-table, dirty, narrower, forgotten while in use) */
+    uint64_t hits, misses, published, widenings, evictions, forgotten;
+    uint64_t rejected_dirty, rejected_over_budget, rejected_narrower;
+} bsg_arena_cache_stats;
+BSG_API int32_t bsg_set_arena_budget(bsg_ctx *ctx, uint64_t bytes);
+BSG_API int32_t bsg_file_arena_acquire(bsg_ctx *ctx, const uint8_t *key, uint32_t key_len, const uint64_t *block_keys, uint32_t n_blocks,
+                                       uint64_t *out_lease, uint64_t *out_arena_id, uint32_t *out_rows);
+BSG_API int32_t bsg_file_arena_have(bsg_ctx *ctx, const uint8_t *key, uint32_t key_len, uint64_t *out_block_keys, uint64_t *out_sec_begin,
+                                    uint64_t *out_sec_end, uint32_t cap, uint32_t *out_n);
+BSG_API int32_t bsg_file_arena_publish(bsg_ctx *ctx, const uint8_t *key, uint32_t key_len, uint64_t arena_id, const uint64_t *block_keys,
+                                       const uint64_t *sec_begin, const uint64_t *sec_end, const int32_t *status, uint32_t n_blocks,
+                                       uint64_t *out_lease, int32_t *out_resident);
+BSG_API int32_t bsg_file_arena_release(bsg_ctx *ctx, uint64_t lease);
+BSG_API int32_t bsg_file_arena_forget(bsg_ctx *ctx, const uint8_t *key, uint32_t key_len);
+BSG_API int32_t bsg_arena_cache_stats_read(bsg_ctx *ctx, bsg_arena_cache_stats *out, int32_t reset);
+
 /* Compile + upload a batch of queries: n_terms distinct terms and, per query q,
  * the postfix program prog_ops[prog_off[q] .. prog_off[q+1]).  No limit on the batch: one launch holds ~22 000 distinct terms
  * of a kind and ~100 verdict words per 256-query chunk, and a batch beyond that is cut — inside the library — into runs of
@@ -239,30 +274,6 @@ BSG_API int32_t bsg_probe_many_dev(bsg_ctx *ctx, const uint64_t *arena_ids, uint
 /* Arenas one probe dispatch may cover (1..4096; 0 = the default, 1 024).  Up to 128 arena records ride in the dispatch's kernel
  * arguments; a larger group uploads its records into device memory in front of the dispatch (same stream). */
 BSG_API int32_t bsg_set_probe_group(bsg_ctx *ctx, uint32_t max_arenas_per_launch);
-/* Lab knobs for tools/, bench sweeps and tests (key 1: compaction rounds of the many-term probe mode; key 2: HBM bytes a
- * binned build of a bitset beyond LDS may park its locations in, 0 = build it with global atomics; key 3: most distinct terms
- * of a synchronous batch of <= 256 queries that is answered by one dispatch, 0 = never; key 4: launches the decode of
- * bsg_arena_load_sections is split into, 1 = one launch after the whole copy; key 6: fewest locations (entries x k) from
- * which a bitset beyond LDS is built from binned locations instead of global atomics; keys 7 / 8: fewest entries / row bytes from
- * which a construct or match call on a context over several devices is cut into one part per device; key 9: 1 = file-level unions
- * through global hash tables instead of LDS partitions, key 10: start that partitioning 2^value x too coarse; key 11: evaluators per
- * tile of k_probe_eval — probe and program evaluation of few-term batches in ONE dispatch —, 0 = two dispatches, the default;
- * keys 12-17, 20-22, 24: the combiner of concurrent bsg_query calls — 12: 0 = every call alone, 1 = combine (default), 2 = lab, the caller's
- * preparation only, nothing probed; 13: cycles in flight (2; one more while cycles average > 32 calls); 15: (microseconds << 16) |
- * calls a collector waits for company (tests); 16: 3-term queries asked of one arena in a cycle from which it is streamed once for all of
- * them (8, for 35 KB of filters per block: scaled by the arena's bytes per block and the calls' distinct terms); 17: microseconds a queued caller polls while the context is quiet (60); 20: account the callers' processor time
- * (bsg_lab_query_cpu); 21: 0 = a cycle's job table is always uploaded (default 1: a table of <= ~4 KB rides in the kernel arguments); 22: workgroups of a lone call's dispatch beyond which its doorbell is a dispatch behind it (32); 24: bytes of survivor rows beyond which a cycle is served in parts (64 MB); key 19: percent of a single-group device-resident run whose evaluation moves to a second stream (0 = off));
- * not part of the seam. */
-BSG_API int32_t bsg_set_lab(bsg_ctx *ctx, uint32_t key, uint64_t value);
-/* Synchronous probes poll their stream for up to this long before they block (default 0: block at once).  A single
- * query's kernels finish in ~10 us; being woken from a blocking wait costs more than that. */
-BSG_API int32_t bsg_set_spin_wait(bsg_ctx *ctx, uint32_t microseconds);
-/* Groups of up to this many arenas ride fused (k_probe_fused: the probe of group i and the program evaluation of group
- * i-1 in one dispatch; default 4, 0 = never).  Larger groups run as k_probe_terms + k_eval_programs. */
-BSG_API int32_t bsg_set_fuse_limit(bsg_ctx *ctx, uint32_t max_arenas);
-/* Gather regime: a filter is read by <= terms * k sector gathers instead of being streamed into LDS when
- * terms * k * bytes_per_probe < its size (default 256; 0 = always stream). */
-BSG_API int32_t bsg_set_gather_cost(bsg_ctx *ctx, uint32_t bytes_per_probe);
 
 /* ---- survivor ROWS: surviving block ids for the host, not Q x B / 8 bytes whatever they hold ----
  * bsg_probe_many with the host-side gather of the north star in mind (query_exec.go:321,603: the consumer walks the surviving
@@ -323,8 +334,7 @@ BSG_API int32_t bsg_query(bsg_ctx *ctx, const uint64_t *arena_ids, uint32_t n_ar
  * pair is a job of ONE k_query_jobs dispatch (gather regime: cost follows the pairs asked for — one query, one call per candidate
  * file is a list of such jobs).  The collector hands its role on (two cycles in flight) and deals every caller its rows.  Nobody
  * waits for a window to fill; results equal the solo path's bit for bit.  Calls beyond 16 terms / 128 program words / 64 queries /
- * 32 arenas always go alone.  bsg_set_lab key 12 = 0 turns combining off (13: cycles in flight, 16: the
- * hot-arena threshold, 17: microseconds a queued caller polls before it sleeps).  bsg_query_stats_read: how calls were served. */
+ * 32 arenas always go alone (the combiner's lab switches: bloomgpu_lab.h).  bsg_query_stats_read: how calls were served. */
 typedef struct bsg_query_stats {
     uint64_t calls;                /* bsg_query calls that were eligible for combining                      */
     uint64_t solo_calls;           /* ... served by a dispatch of their own                                */
@@ -345,10 +355,6 @@ typedef struct bsg_query_stats {
     uint64_t ns_retire;            /* ... slot released + next collector appointed                          */
 } bsg_query_stats;
 BSG_API int32_t bsg_query_stats_read(bsg_ctx *ctx, bsg_query_stats *out, int32_t reset);
-/* Lab (bsg_set_lab key 20 = 1 turns the accounting on): the CALLERS' own processor time, summed — out[0] profiled calls, out[1] ns
- * inside bsg_query's combiner path, of which out[2] up to the end of the wait (push, polling, the futex), out[3] waking other
- * callers, out[4] collecting (a collector's whole cycle).  tools/conc_lab.py prints them per call. */
-BSG_API int32_t bsg_lab_query_cpu(bsg_ctx *ctx, uint64_t *out, int32_t reset);
 
 /* The surviving blocks of ONE query as the reference's probe hands them on: blockScanCandidate{index} per survivor in the order
  * the blocks were consulted (ascending RowDataOffset, query_exec.go:321, 603) = the ascending bit positions of the query's row
@@ -357,8 +363,6 @@ BSG_API int32_t bsg_lab_query_cpu(bsg_ctx *ctx, uint64_t *out, int32_t reset);
 BSG_API int32_t bsg_survivor_list(const uint64_t *survivor_row, uint32_t n_blocks, uint32_t *out_blocks, uint32_t cap, uint32_t *out_n);
 
 BSG_API int32_t bsg_timing_read(bsg_ctx *ctx, bsg_timing *out, int32_t reset);
-/* With BSG_PROBE_TIMED, only every stride-th dispatch group is timestamped (default 1 = all). */
-BSG_API int32_t bsg_set_timed_stride(bsg_ctx *ctx, uint32_t stride);
 /* Device time (the dispatch's own start/stop timestamps) of the most recent k_build / k_hash_entries /
  * k_decode_sections launch made through bsg_build* / bsg_hash_entries / bsg_arena_load_sections (the slowest device
  * of the call, when it was cut over several; any pointer may be NULL). */

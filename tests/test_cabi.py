@@ -24,6 +24,13 @@ def test_header_symbols_all_exported(lib):
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
+    # the lab switches live in a header of their own: a binder of the contract never sees them
+    lab = open(os.path.join(ROOT, "include", "bloomgpu_lab.h")).read()
+    lab_declared = set(re.findall(r"BSG_API\s+[\w\s\*]+?\b(bsg_\w+)\s*\(", lab))
+    assert lab_declared == set(_lib.LAB_EXPORTS) and not (lab_declared & declared)
+    for name in lab_declared:
+        assert hasattr(lib, name), name
+    assert not re.search(r"bsg_set_lab|bsg_lab_|bsg_set_fuse_limit|bsg_set_timed_stride|bsg_set_spin_wait|bsg_set_gather_cost", hdr)
 
 
 def test_struct_layouts_match_header():

@@ -151,6 +151,8 @@ def check_cgo(files, header, problems):
     for path in files:
         src = strip_go(open(path).read())
         rel = os.path.relpath(path, ROOT)
+        if "bloomgpu_lab.h" in open(path).read():      # the lab switches are not the contract: a host binding includes bloomgpu.h only
+            problems.append("%s: includes bloomgpu_lab.h (lab switches are not part of the drop-in contract)" % rel)
         for m in re.finditer(r"\bC\.(bsg_\w+)\s*\(", src):
             name = m.group(1)
             line = src.count("\n", 0, m.start()) + 1
