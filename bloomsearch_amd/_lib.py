@@ -125,7 +125,7 @@ def load():
     L.bsg_arena_stream_finish.argtypes = [vp, u64, vp, C.POINTER(u64)]
     L.bsg_arena_stream_abort.argtypes = [vp, u64]
     L.bsg_set_arena_budget.argtypes = [vp, u64]
-    L.bsg_file_arena_acquire.argtypes = [vp, vp, u32, vp, u32, C.POINTER(u64), C.POINTER(u64), vp]
+    L.bsg_file_arena_acquire.argtypes = [vp, vp, u32, vp, u32, C.POINTER(u64), C.POINTER(u64), C.POINTER(u32), vp]
     L.bsg_file_arena_have.argtypes = [vp, vp, u32, vp, vp, vp, u32, C.POINTER(u32)]
     L.bsg_file_arena_publish.argtypes = [vp, vp, u32, u64, vp, vp, vp, vp, u32, C.POINTER(u64), C.POINTER(i32)]
     L.bsg_file_arena_release.argtypes = [vp, u64]

@@ -175,7 +175,7 @@ struct DevPool {
 };
 
 // scratch of one combined query dispatch (combine_api.inc): the table's device block, its page-locked stage, the page-locked result
-struct CmbSet { void *d_block = nullptr; size_t d_cap = 0; std::pair<uint64_t *, size_t> stage{nullptr, 0}, result{nullptr, 0}; };
+struct CmbSet { void *d_block = nullptr; size_t d_cap = 0; std::pair<uint64_t *, size_t> stage{nullptr, 0}, result{nullptr, 0}; hipEvent_t drained = nullptr; /* blocking-sync event of a wait that outlived its spin (finish_dispatches) */ };
 
 struct Device {
     int id = 0;
@@ -282,6 +282,7 @@ struct Combiner {
     uint32_t hot_min_queries = 8;               // an arena is streamed once for all its callers of a cycle from this many 3-term queries per 35 KB of filters per block (key 16; 0: never; scaled by the arena's bytes per block and the calls' terms: combine_api.inc).  Measured 4 / 8 / 12 / 24 on C2's arena: 4 streams too much at 64 callers over 12 arenas (5.9 vs 8.8 x 10^5), 24 leaves 64 x 10 arenas at 1.9 vs 3.0 x 10^5
     std::atomic<uint64_t> n_solo{0}, n_cycles{0}, n_cycle_calls{0}, n_dispatches{0}, n_hot{0}, max_cycle_calls{0};
     uint64_t part_bytes = 64ull << 20;           // rows of one part of a cycle (page-locked scratch, kept): a cycle beyond it is served in parts (key 24)
+    uint32_t wait_spin_us = 50;                  // a collector polls its dispatch's doorbell this long, then sleeps on an event behind it (key 25)
     uint32_t inline_jobs = 1;                    // a job list whose table fits the kernel arguments travels in them (key 21; 0: always uploaded)
     uint32_t profile = 0;                        // lab (key 20): callers account their own processor time (bsg_lab_query_cpu)
     std::atomic<uint64_t> n_cpu_calls{0}, ns_cpu_call{0}, ns_cpu_wait{0}, ns_cpu_duty{0}, ns_cpu_collect{0};
@@ -602,6 +603,9 @@ struct ArenaCache {
     std::map<uint64_t, std::shared_ptr<Arena>> arenas;
     std::shared_ptr<int> owner = std::make_shared<int>(0);
 };
+// The returned pointer is a NON-OWNING alias of the entry in this thread's cache: valid for the duration of the calling bsg_query
+// only (QReq::arenas must not outlive the call).  The cache holds host objects, never device memory (bsg_arena_free frees that at
+// once); a thread keeps at most 4 096 of them and drops them all when any arena id of its context stops naming its arena (epoch).
 int32_t get_arena_cached(bsg_ctx *ctx, uint64_t id, std::shared_ptr<Arena> &out)
 {
     thread_local ArenaCache cache;
@@ -761,6 +765,7 @@ int32_t bsg_close(bsg_ctx *ctx)
             if (cs.d_block) (void)hipFree(cs.d_block);
             if (cs.stage.first) (void)hipHostFree(cs.stage.first);
             if (cs.result.first) (void)hipHostFree(cs.result.first);
+            if (cs.drained) (void)hipEventDestroy(cs.drained);
         }
         if (d.d_direct_count) (void)hipFree(d.d_direct_count);
         if (d.d_crc) (void)hipFree(d.d_crc);

@@ -56,6 +56,13 @@ inline void set_state(Waiter &w, uint32_t v)
     if (addr->exchange(v, std::memory_order_seq_cst) == 3u) futex_wake(addr);
 }
 
+inline void cpu_relax()
+{
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
+}
+
 // Poll briefly (a cycle on an idle device is tens of microseconds: the answer often arrives while polling), then sleep in a futex:
 // with as many callers as processors, callers that keep polling take the processor from the collector and the runtime's threads.
 inline void wait_while_queued(Waiter &w, uint32_t spin_us)
@@ -64,9 +71,7 @@ inline void wait_while_queued(Waiter &w, uint32_t spin_us)
         const auto t0 = std::chrono::steady_clock::now();
         for (uint32_t i = 0;; ++i) {
             if (w.state.load(std::memory_order_acquire) != 0) return;
-#if defined(__x86_64__)
-            __builtin_ia32_pause();
-#endif
+            cpu_relax();
             if ((i & 31) == 31 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(spin_us)) break;
         }
     }
@@ -127,7 +132,7 @@ inline void kick(Gate &g)
         Waiter *t = k < kStacks ? g.head[k].p.load(std::memory_order_acquire) : nullptr;
         while (t && !g.head[k].p.compare_exchange_weak(t, t->next, std::memory_order_acq_rel)) {}
         if (t) { set_state(*t, 1); return; }
-        g.gate.fetch_and(~kGateCollecting, std::memory_order_seq_cst);     // (cannot happen: nobody else pops) give both back and look again
+        g.gate.fetch_and(~kGateCollecting, std::memory_order_seq_cst);     // the stacks were emptied between waiting_stack and here (a collector's drain took them): give both back and look again
         g.gate.fetch_sub(1u, std::memory_order_seq_cst);
     }
 }

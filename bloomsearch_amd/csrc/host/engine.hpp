@@ -461,7 +461,7 @@ private:
         std::vector<uint64_t> keys;
         for (auto &b : f.blocks) keys.push_back(b.block_offset);
         out.rows.assign(keys.size(), 0);
-        if (bsg_file_arena_acquire(ctx_, key, 8, keys.data(), (uint32_t)keys.size(), &out.lease, &out.arena, out.rows.data()))
+        if (bsg_file_arena_acquire(ctx_, key, 8, keys.data(), (uint32_t)keys.size(), &out.lease, &out.arena, nullptr, out.rows.data()))
             return fail(kErrGpu, bsg_last_error(ctx_));
         if (out.lease) { out.status.assign(keys.size(), 0); return kEngineOk; }
         std::vector<const std::vector<uint8_t> *> bsec;

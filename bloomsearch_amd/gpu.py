@@ -192,7 +192,7 @@ class Context:
         kb = np.frombuffer(key, dtype=np.uint8)
         rows = np.zeros(max(len(bk), 1), dtype=np.uint32)
         lease, aid = C.c_uint64(), C.c_uint64()
-        self._check(self.L.bsg_file_arena_acquire(self.h, _lib._ptr(kb), len(kb), _lib._ptr(bk), len(bk), C.byref(lease), C.byref(aid), _lib._ptr(rows)))
+        self._check(self.L.bsg_file_arena_acquire(self.h, _lib._ptr(kb), len(kb), _lib._ptr(bk), len(bk), C.byref(lease), C.byref(aid), None, _lib._ptr(rows)))
         return (int(lease.value), int(aid.value), rows[: len(bk)]) if lease.value else (0, 0, None)
 
     def file_arena_have(self, key: bytes):

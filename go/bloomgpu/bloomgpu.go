@@ -328,6 +328,87 @@ func (s *ArenaStream) Abort() error { return s.g.err(C.bsg_arena_stream_abort(s.
 // ArenaFree is bsg_arena_free.
 func (g *Context) ArenaFree(a Arena) error { return g.err(C.bsg_arena_free(g.c, C.uint64_t(a.ID))) }
 
+// ---- resident file arenas across queries (the library's cache: bsg_file_arena_*) ----
+
+// FileLease is a query's hold on a file's arena: Rows[i] is candidate i's row (block index) in Arena.
+type FileLease struct {
+	ID    uint64
+	Arena Arena
+	Rows  []uint32
+}
+
+// SetArenaBudget bounds the device memory the resident arenas may hold (bsg_set_arena_budget).
+func (g *Context) SetArenaBudget(bytes uint64) error {
+	return g.err(C.bsg_set_arena_budget(g.c, C.uint64_t(bytes)))
+}
+
+// FileArenaAcquire leases the file's resident arena when it covers every candidate block (blockKeys strictly ascending:
+// RowDataOffset); nil when it does not.
+func (g *Context) FileArenaAcquire(key []byte, blockKeys []uint64) (*FileLease, error) {
+	rows := make([]uint32, len(blockKeys))
+	var rp *C.uint32_t
+	if len(rows) > 0 {
+		rp = (*C.uint32_t)(unsafe.Pointer(&rows[0]))
+	}
+	var lease, arena C.uint64_t
+	var arenaBlocks C.uint32_t
+	rc := C.bsg_file_arena_acquire(g.c, u8p(key), C.uint32_t(len(key)), u64p(blockKeys), C.uint32_t(len(blockKeys)), &lease, &arena, &arenaBlocks, rp)
+	if err := g.err(rc); err != nil || lease == 0 {
+		return nil, err
+	}
+	return &FileLease{ID: uint64(lease), Arena: Arena{ID: uint64(arena), Blocks: uint32(arenaBlocks)}, Rows: rows}, nil
+}
+
+// FileArenaHave returns what the file's resident arena holds: block keys and the sections' extents in the file.
+func (g *Context) FileArenaHave(key []byte) (blockKeys, secBegin, secEnd []uint64, err error) {
+	var n C.uint32_t
+	if err = g.err(C.bsg_file_arena_have(g.c, u8p(key), C.uint32_t(len(key)), nil, nil, nil, 0, &n)); err != nil || n == 0 {
+		return nil, nil, nil, err
+	}
+	for {
+		c := int(n)
+		blockKeys, secBegin, secEnd = make([]uint64, c), make([]uint64, c), make([]uint64, c)
+		rc := C.bsg_file_arena_have(g.c, u8p(key), C.uint32_t(len(key)), u64p(blockKeys), u64p(secBegin), u64p(secEnd), C.uint32_t(c), &n)
+		if rc == 0 && int(n) <= c {
+			return blockKeys[:n], secBegin[:n], secEnd[:n], nil
+		}
+		if int(n) <= c { // a failure, not a wider arena published in between
+			return nil, nil, nil, g.err(rc)
+		}
+	}
+}
+
+// FileArenaPublish hands a freshly decoded arena of exactly these blocks to the cache, which owns it from here on; the lease
+// keeps it alive for this query whether or not it became the file's resident arena.
+func (g *Context) FileArenaPublish(key []byte, a Arena, blockKeys, secBegin, secEnd []uint64, status []int32) (*FileLease, bool, error) {
+	var sp *C.int32_t
+	if len(status) > 0 {
+		sp = (*C.int32_t)(unsafe.Pointer(&status[0]))
+	}
+	var lease C.uint64_t
+	var resident C.int32_t
+	rc := C.bsg_file_arena_publish(g.c, u8p(key), C.uint32_t(len(key)), C.uint64_t(a.ID), u64p(blockKeys), u64p(secBegin), u64p(secEnd), sp,
+		C.uint32_t(len(blockKeys)), &lease, &resident)
+	if err := g.err(rc); err != nil {
+		return nil, false, err
+	}
+	rows := make([]uint32, len(blockKeys))
+	for i := range rows {
+		rows[i] = uint32(i)
+	}
+	return &FileLease{ID: uint64(lease), Arena: a, Rows: rows}, resident != 0, nil
+}
+
+// FileArenaRelease ends a lease (bsg_file_arena_release).
+func (g *Context) FileArenaRelease(l *FileLease) error {
+	return g.err(C.bsg_file_arena_release(g.c, C.uint64_t(l.ID)))
+}
+
+// FileArenaForget drops a tombstoned file's arena (bsg_file_arena_forget); its last user frees it.
+func (g *Context) FileArenaForget(key []byte) error {
+	return g.err(C.bsg_file_arena_forget(g.c, u8p(key), C.uint32_t(len(key))))
+}
+
 // BatchCreate compiles and uploads a query batch: distinct terms + per query the postfix program
 // progOps[progOff[q]:progOff[q+1]] (bsg_batch_create).
 func (g *Context) BatchCreate(terms []Term, progOps, progOff []uint32) (Batch, error) {

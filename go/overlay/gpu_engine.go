@@ -39,34 +39,25 @@ type gpuEngine struct {
 	scopeMu   sync.Mutex
 	idle, all []*bloomgpu.Context // error scopes: one per goroutine-confined caller at a time (bsg_scope_open)
 
-	arenaMu     sync.Mutex
-	arenas      map[string]*gpuFileArena // resident block filters by file pointer
-	arenaBytes  int64                    // Σ bytes of the cached arenas
-	arenaBudget int64                    // eviction starts above this (least recently used first, never one in use)
-	arenaTick   uint64
 }
 
-// gpuFileArena is one file's block filters decoded on the device.  Blocks are in ascending RowDataOffset order, the order
-// evaluateBlockFilters consults them in (blocksByAscendingRowDataOffset, query_exec.go:321).
+// gpuFileArena is a query's lease on one file's block filters decoded on the device.  Blocks are in ascending RowDataOffset
+// order, the order evaluateBlockFilters consults them in (blocksByAscendingRowDataOffset, query_exec.go:321).  Which arenas stay
+// resident between queries — least recently used by bytes against a budget, never one in use, clean decodes only, widened to the
+// union of the block sets, forgotten with the file — is decided inside libbloomgpu (bsg_file_arena_*, csrc/cache_api.inc,
+// tests/test_arena_cache_gpu.py): this file only reads the bytes the library asks for.
 type gpuFileArena struct {
-	arena   bloomgpu.Arena
-	offsets []int    // RowDataOffset of arena block i
-	begin   []uint64 // its filter section's byte range in the file (what a later, wider load of the same file reads again)
-	end     []uint64
-	status  []int32 // parseFilterSection's verdict for block i (0 ok)
-	bytes   int64   // section bytes behind the arena (≈ the HBM it holds)
-	lastUse uint64  // tick of the most recent query that used it (LRU)
-	users   int
-	dead    bool // tombstoned, evicted or never cached while in use: freed by the last user
+	lease  *bloomgpu.FileLease
+	status []int32 // parseFilterSection's verdict per candidate block (0 ok); nil for a resident arena (only clean decodes stay)
 }
 
 // defaultArenaBudget bounds the decoded block filters kept resident across queries (BLOOMSEARCH_GPU_ARENA_BYTES overrides it):
 // without a bound every file ever queried would hold HBM until it is merged away, and the build / ingest calls of the flush
 // worker would start failing with BSG_E_NOMEM on a large store.
-const defaultArenaBudget = int64(32) << 30
+const defaultArenaBudget = uint64(32) << 30
 
-func arenaBudgetFromEnv() int64 {
-	if v, err := strconv.ParseInt(strings.TrimSpace(os.Getenv("BLOOMSEARCH_GPU_ARENA_BYTES")), 10, 64); err == nil && v >= 0 {
+func arenaBudgetFromEnv() uint64 {
+	if v, err := strconv.ParseUint(strings.TrimSpace(os.Getenv("BLOOMSEARCH_GPU_ARENA_BYTES")), 10, 64); err == nil {
 		return v
 	}
 	return defaultArenaBudget
@@ -100,20 +91,17 @@ func openGPUEngine(config BloomSearchEngineConfig, logger *slog.Logger) (*gpuEng
 		logger.Warn("GPUIngest needs the default tokenizer; rows stay on the host walker")
 		ingest = false
 	}
-	return &gpuEngine{g: g, ingest: ingest, logger: logger, arenas: map[string]*gpuFileArena{}, arenaBudget: arenaBudgetFromEnv()}, nil
+	if err := g.SetArenaBudget(arenaBudgetFromEnv()); err != nil {
+		g.Close()
+		return nil, err
+	}
+	return &gpuEngine{g: g, ingest: ingest, logger: logger}, nil
 }
 
 func (e *gpuEngine) close() {
 	if e == nil {
 		return
 	}
-	e.arenaMu.Lock()
-	for k, fa := range e.arenas {
-		e.g.ArenaFree(fa.arena)
-		delete(e.arenas, k)
-	}
-	e.arenaBytes = 0
-	e.arenaMu.Unlock()
 	e.scopeMu.Lock()
 	for _, s := range e.all {
 		s.Close()
@@ -259,54 +247,10 @@ func (e *gpuEngine) forget(filePointer []byte) {
 	if e == nil {
 		return
 	}
-	e.arenaMu.Lock()
-	defer e.arenaMu.Unlock()
-	if fa := e.arenas[string(filePointer)]; fa != nil {
-		e.dropLocked(string(filePointer), fa)
-	}
+	e.g.FileArenaForget(filePointer) // out of the table now; freed by its last user (merge.go:178-185)
 }
 
-// dropLocked takes a cached arena out of the table (arenaMu held): freed now, or by its last user.
-func (e *gpuEngine) dropLocked(key string, fa *gpuFileArena) {
-	delete(e.arenas, key)
-	e.arenaBytes -= fa.bytes
-	if fa.users == 0 {
-		e.g.ArenaFree(fa.arena)
-	} else {
-		fa.dead = true
-	}
-}
-
-// evictLocked frees least-recently-used arenas nobody is using until the cache fits its budget again (arenaMu held).  `keep`
-// is never evicted (the arena the caller is about to use).
-func (e *gpuEngine) evictLocked(keep *gpuFileArena) {
-	for e.arenaBytes > e.arenaBudget {
-		var victimKey string
-		var victim *gpuFileArena
-		for k, fa := range e.arenas {
-			if fa == keep || fa.users > 0 {
-				continue
-			}
-			if victim == nil || fa.lastUse < victim.lastUse {
-				victimKey, victim = k, fa
-			}
-		}
-		if victim == nil {
-			return // everything left is in use: the budget is exceeded until those queries finish
-		}
-		e.dropLocked(victimKey, victim)
-	}
-}
-
-func (e *gpuEngine) done(fa *gpuFileArena) {
-	e.arenaMu.Lock()
-	fa.users--
-	free := fa.dead && fa.users == 0
-	e.arenaMu.Unlock()
-	if free {
-		e.g.ArenaFree(fa.arena)
-	}
-}
+func (e *gpuEngine) done(s *bloomgpu.Context, fa *gpuFileArena) { s.FileArenaRelease(fa.lease) }
 
 // sectionError is parseFilterSection's failure for a status of bsg_arena_stream_finish.
 func sectionError(status int32) error {
@@ -324,103 +268,97 @@ func sectionError(status int32) error {
 	}
 }
 
-// arenaFor returns the file's resident arena if it covers every candidate block, else reads the candidates' filter
-// sections — in runs of at most blockFilterChunkTarget bytes, skipping what lies between them, as blockFilterCursor does —
-// into an arena stream that decodes them on the device, and keeps the result for the next query.
+// arenaFor leases the file's resident arena if it covers every candidate block (bsg_file_arena_acquire); else it reads the
+// candidates' filter sections — together with what the resident arena already holds (bsg_file_arena_have), so that two queries
+// alternating over different blocks of one file stop replacing each other's arena — into an arena stream that decodes them on
+// the device, and publishes the result (bsg_file_arena_publish).
 func (e *gpuEngine) arenaFor(s *bloomgpu.Context, file io.ReadSeeker, filePointer []byte, blocks []DataBlockMetadata) (fa *gpuFileArena, readFailed bool, err error) {
-	key := string(filePointer)
-	e.arenaMu.Lock()
-	if fa = e.arenas[key]; fa != nil {
-		covered := true
-		for i := range blocks {
-			j := sort.SearchInts(fa.offsets, blocks[i].RowDataOffset)
-			if j == len(fa.offsets) || fa.offsets[j] != blocks[i].RowDataOffset {
-				covered = false
-				break
-			}
-		}
-		if covered {
-			fa.users++
-			e.arenaTick++
-			fa.lastUse = e.arenaTick
-			e.arenaMu.Unlock()
-			return fa, false, nil
-		}
-	}
-	// what the cached arena of this file already holds is loaded again together with the new candidates: the result covers
-	// both candidate sets, so two queries that alternate over different blocks of one file stop replacing each other's arena
-	var haveOff []int
-	var haveBegin, haveEnd []uint64
-	if fa != nil {
-		haveOff, haveBegin, haveEnd = fa.offsets, fa.begin, fa.end
-	}
-	e.arenaMu.Unlock()
-
+	cand := make([]uint64, len(blocks))
+	candBegin := make([]uint64, len(blocks))
+	candEnd := make([]uint64, len(blocks))
 	for i := range blocks {
 		if i > 0 && blocks[i].RowDataOffset <= blocks[i-1].RowDataOffset {
 			return nil, false, errors.New("bloomgpu: candidate blocks are not in ascending RowDataOffset order")
 		}
-	}
-	candBegin := make([]uint64, len(blocks))
-	candEnd := make([]uint64, len(blocks))
-	candOff := make([]int, len(blocks))
-	for i := range blocks {
-		candOff[i] = blocks[i].RowDataOffset
+		cand[i] = uint64(blocks[i].RowDataOffset)
 		candBegin[i] = uint64(blocks[i].BloomFilterOffset)
 		candEnd[i] = uint64(blocks[i].BloomFilterOffset) + uint64(blocks[i].BloomFilterSize) // size 0: a block without a section (nil filters)
 	}
-	if len(haveOff) > 0 {
-		begin := make([]uint64, 0, len(blocks)+len(haveOff))
-		end := make([]uint64, 0, len(blocks)+len(haveOff))
-		offsets := make([]int, 0, len(blocks)+len(haveOff))
-		foreign := make([]bool, 0, len(blocks)+len(haveOff)) // a section only the cached arena asked for, not this query
-		for i, j := 0, 0; i < len(blocks) || j < len(haveOff); { // merge by RowDataOffset; a block both lists name is taken once
-			if j == len(haveOff) || (i < len(blocks) && candOff[i] <= haveOff[j]) {
-				if j < len(haveOff) && candOff[i] == haveOff[j] {
+	lease, err := s.FileArenaAcquire(filePointer, cand)
+	if err != nil {
+		return nil, false, err
+	}
+	if lease != nil {
+		return &gpuFileArena{lease: lease}, false, nil
+	}
+	if haveKeys, haveBegin, haveEnd, herr := s.FileArenaHave(filePointer); herr == nil && len(haveKeys) > 0 {
+		keys := make([]uint64, 0, len(cand)+len(haveKeys))
+		begin := make([]uint64, 0, cap(keys))
+		end := make([]uint64, 0, cap(keys))
+		foreign := make([]bool, 0, cap(keys)) // a section only the resident arena asked for, not this query
+		for i, j := 0, 0; i < len(cand) || j < len(haveKeys); { // merge by RowDataOffset; a block both lists name is taken once
+			if j == len(haveKeys) || (i < len(cand) && cand[i] <= haveKeys[j]) {
+				if j < len(haveKeys) && cand[i] == haveKeys[j] {
 					j++
 				}
-				offsets, begin, end, foreign = append(offsets, candOff[i]), append(begin, candBegin[i]), append(end, candEnd[i]), append(foreign, false)
+				keys, begin, end, foreign = append(keys, cand[i]), append(begin, candBegin[i]), append(end, candEnd[i]), append(foreign, false)
 				i++
 			} else {
-				offsets, begin, end, foreign = append(offsets, haveOff[j]), append(begin, haveBegin[j]), append(end, haveEnd[j]), append(foreign, true)
+				keys, begin, end, foreign = append(keys, haveKeys[j]), append(begin, haveBegin[j]), append(end, haveEnd[j]), append(foreign, true)
 				j++
 			}
 		}
-		wide, wideReadFailed, wideErr := e.loadArena(s, file, begin, end, offsets)
+		arena, status, wideReadFailed, wideErr := e.loadArena(s, file, begin, end)
 		// The widening reads sections this query never asked for.  The reference only ever reads the candidates' sections
 		// (query_exec.go:565-615): a failed read or a bad section among the FOREIGN ones must not fail this query's candidates, mark
 		// the handle unhealthy, or keep every later query re-reading the whole file — the candidates are then loaded by themselves.
 		foreignTrouble := wideErr != nil || wideReadFailed
-		if wide != nil {
-			for i := range wide.status {
-				if foreign[i] && wide.status[i] != 0 {
-					foreignTrouble = true
-				}
+		for i := range status {
+			if foreign[i] && status[i] != 0 {
+				foreignTrouble = true
 			}
 		}
 		if !foreignTrouble {
-			return e.keepArena(key, wide), false, nil
+			wide, _, perr := s.FileArenaPublish(filePointer, arena, keys, begin, end, status)
+			if perr != nil {
+				s.ArenaFree(arena)
+				return nil, false, perr
+			}
+			// this query's view: its candidates' rows and statuses inside the wide arena
+			rows := make([]uint32, len(cand))
+			st := make([]int32, len(cand))
+			for i := range cand {
+				j := sort.Search(len(keys), func(k int) bool { return keys[k] >= cand[i] })
+				rows[i], st[i] = uint32(j), status[j]
+			}
+			wide.Rows = rows
+			return &gpuFileArena{lease: wide, status: st}, false, nil
 		}
-		if wide != nil {
-			e.g.ArenaFree(wide.arena)
+		if wideErr == nil && !wideReadFailed {
+			s.ArenaFree(arena)
 		}
 	}
-	only, readFailed, err := e.loadArena(s, file, candBegin, candEnd, candOff)
+	arena, status, readFailed, err := e.loadArena(s, file, candBegin, candEnd)
 	if err != nil || readFailed {
 		return nil, readFailed, err
 	}
-	return e.keepArena(key, only), false, nil
+	only, _, err := s.FileArenaPublish(filePointer, arena, cand, candBegin, candEnd, status)
+	if err != nil {
+		s.ArenaFree(arena)
+		return nil, false, err
+	}
+	return &gpuFileArena{lease: only, status: status}, false, nil
 }
 
 // loadArena reads the sections [begin[i], end[i]) — in runs of at most blockFilterChunkTarget bytes, skipping what lies between
 // them, as blockFilterCursor does — into an arena stream that decodes them on the device.
-func (e *gpuEngine) loadArena(s *bloomgpu.Context, file io.ReadSeeker, begin, end []uint64, offsets []int) (fa *gpuFileArena, readFailed bool, err error) {
+func (e *gpuEngine) loadArena(s *bloomgpu.Context, file io.ReadSeeker, begin, end []uint64) (arena bloomgpu.Arena, status []int32, readFailed bool, err error) {
 	stream, err := s.ArenaStreamBegin(begin, end)
 	if err != nil {
-		return nil, false, err
+		return arena, nil, false, err
 	}
-	order := make([]int, 0, len(offsets)) // sections in file order
-	for i := range offsets {
+	order := make([]int, 0, len(begin)) // sections in file order
+	for i := range begin {
 		if end[i] > begin[i] {
 			order = append(order, i)
 		}
@@ -442,57 +380,16 @@ func (e *gpuEngine) loadArena(s *bloomgpu.Context, file io.ReadSeeker, begin, en
 			buf = buf[:n]
 			if err := readFullAt(file, buf, int64(at)); err != nil {
 				stream.Abort()
-				return nil, true, err
+				return arena, nil, true, err
 			}
 			if err := stream.Append(at, buf); err != nil {
 				stream.Abort()
-				return nil, false, err
+				return arena, nil, false, err
 			}
 		}
 	}
-	arena, status, err := stream.Finish()
-	if err != nil {
-		return nil, false, err
-	}
-	fa = &gpuFileArena{arena: arena, offsets: offsets, begin: begin, end: end, status: status, users: 1}
-	for i := range status {
-		fa.bytes += int64(end[i] - begin[i])
-	}
-	return fa, false, nil
-}
-
-// keepArena makes a freshly loaded arena the file's resident one when it may be (clean, within the budget, not narrower than what a
-// concurrent query cached meanwhile); otherwise it serves this query only and is freed by done().
-func (e *gpuEngine) keepArena(key string, fa *gpuFileArena) *gpuFileArena {
-	offsets := fa.offsets
-	clean := true
-	for i := range fa.status {
-		if fa.status[i] != 0 {
-			clean = false
-		}
-	}
-	e.arenaMu.Lock()
-	defer e.arenaMu.Unlock()
-	// Only a clean decode becomes resident.  A section that failed its CRC or its structural checks may be a transient bad read
-	// (short or garbled bytes without an I/O error): the reference re-reads the sections on every query
-	// (query_exec.go:565-615) and recovers on the next one; a cached status would replay the failure until the file is merged.
-	if !clean || fa.bytes > e.arenaBudget {
-		fa.dead = true // serves this query, freed by done()
-		return fa
-	}
-	if old := e.arenas[key]; old != nil {
-		if len(old.offsets) > len(offsets) {
-			fa.dead = true // a concurrent query cached a wider arena meanwhile: keep that one
-			return fa
-		}
-		e.dropLocked(key, old)
-	}
-	e.arenaTick++
-	fa.lastUse = e.arenaTick
-	e.arenas[key] = fa
-	e.arenaBytes += fa.bytes
-	e.evictLocked(fa)
-	return fa
+	arena, status, err = stream.Finish()
+	return arena, status, false, err
 }
 
 // evaluateBlockFilters is the per-block loop of the reference's evaluateBlockFilters (query_exec.go:565-615) as one device
@@ -523,12 +420,12 @@ func (e *gpuEngine) evaluateBlockFilters(r *Results, file io.ReadSeeker, job fil
 		e.logger.Warn("bloomgpu: block filters could not be loaded; evaluating on the host", "error", err)
 		return dst, false, true
 	}
-	defer e.done(fa)
+	defer e.done(s, fa)
 	var l loweredQuery
 	if q != nil && q.Expression != nil {
 		l.emit(q.Expression)
 	}
-	survivors, err := s.Query([]bloomgpu.Arena{fa.arena}, l.keys, l.kinds, l.ops, []uint32{0, uint32(len(l.ops))})
+	survivors, err := s.Query([]bloomgpu.Arena{fa.lease.Arena}, l.keys, l.kinds, l.ops, []uint32{0, uint32(len(l.ops))})
 	if err != nil {
 		e.logger.Warn("bloomgpu: probe failed; evaluating on the host", "error", err)
 		return dst, false, true
@@ -539,8 +436,9 @@ func (e *gpuEngine) evaluateBlockFilters(r *Results, file io.ReadSeeker, job fil
 		if r.ctx.Err() != nil {
 			return dst, true, true
 		}
-		j := sort.SearchInts(fa.offsets, blocks[i].RowDataOffset)
-		if st := fa.status[j]; st != 0 {
+		j := fa.lease.Rows[i]
+		if fa.status != nil && fa.status[i] != 0 {
+			st := fa.status[i]
 			fail(fmt.Errorf("failed to read data block bloom filters: %w", sectionError(st)))
 			recordUnreadBlocks(r, job.filePointer, blocks[i:i+1], share)
 			continue

@@ -212,7 +212,8 @@ BSG_API int32_t bsg_arena_free(bsg_ctx *ctx, uint64_t arena_id);
  *   key            the file's identity (MaybeFile.Pointer bytes)
  *   block_keys     strictly ascending u64 per candidate block (DataBlockMetadata.RowDataOffset, the order evaluateBlockFilters
  *                  walks them in); row i of a published arena holds block_keys[i]
- *   acquire        covered: *out_lease != 0, *out_arena_id, out_rows[i] = candidate i's row (block index) in that arena;
+ *   acquire        covered: *out_lease != 0, *out_arena_id, *out_arena_blocks (may be NULL) = blocks the arena holds (its survivor
+ *                  rows have ceil(that / 64) words), out_rows[i] = candidate i's row (block index) in that arena;
  *                  not covered: *out_lease == 0 — load (have + own candidates), publish
  *   have           cap == 0: *out_n only; else the resident arena's block keys and section extents (file offsets)
  *   publish        arena_id from bsg_arena_stream_finish / bsg_arena_load_sections of exactly these blocks, status = its out_status
@@ -228,7 +229,7 @@ typedef struct bsg_arena_cache_stats {
 } bsg_arena_cache_stats;
 BSG_API int32_t bsg_set_arena_budget(bsg_ctx *ctx, uint64_t bytes);
 BSG_API int32_t bsg_file_arena_acquire(bsg_ctx *ctx, const uint8_t *key, uint32_t key_len, const uint64_t *block_keys, uint32_t n_blocks,
-                                       uint64_t *out_lease, uint64_t *out_arena_id, uint32_t *out_rows);
+                                       uint64_t *out_lease, uint64_t *out_arena_id, uint32_t *out_arena_blocks, uint32_t *out_rows);
 BSG_API int32_t bsg_file_arena_have(bsg_ctx *ctx, const uint8_t *key, uint32_t key_len, uint64_t *out_block_keys, uint64_t *out_sec_begin,
                                     uint64_t *out_sec_end, uint32_t cap, uint32_t *out_n);
 BSG_API int32_t bsg_file_arena_publish(bsg_ctx *ctx, const uint8_t *key, uint32_t key_len, uint64_t arena_id, const uint64_t *block_keys,

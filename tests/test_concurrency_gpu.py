@@ -287,3 +287,63 @@ def test_a_freed_arena_id_is_forgotten_by_the_callers_caches(ctx):
     a1 = ctx.arena_load(words[1], plans[1][0].desc)
     assert np.array_equal(np.stack(ctx.query([a1], [130], cb)[0]), want[1])
     ctx.arena_free(a1)
+
+
+def test_combined_queries_beside_a_long_ingest_sleep_instead_of_spinning(ctx):
+    """a collector whose dispatch sits behind somebody else's long work on the device (the flush worker's
+    bsg_ingest_rows: tens of milliseconds of k_ingest_rows per call at 10 M rows) used to busy-wait 20 ms on its doorbell before it
+    fell back to hipStreamSynchronize under the device lock.  Now it polls <= 50 us (bsg_set_lab key 25), then sleeps on a
+    blocking-sync event recorded behind its dispatch.  64 native callers for 1.5 s next to a thread that ingests ~1 GB of rows over
+    and over: every result bit-exact, and the whole process (callers + collector + the ingesting thread + the runtime) stays far
+    below a processor per caller — the 20 ms spins cost milliseconds of processor time per call."""
+    from bloomsearch_amd import conc
+    from bloomsearch_amd.arena import plan_blocks
+    blocks = [synth.block_entry_sets(b * 400, 400) for b in range(200)]
+    plan = plan_blocks(blocks, 0.001)
+    words = ctx.build(plan.blob, plan.off, plan.fstart, plan.desc, plan.n_words)
+    aids = [ctx.arena_load(words, plan.desc) for _ in range(6)]
+    exprs = synth.make_queries(48, "c2", seed=78)
+    ctx.set_lab(12, 0)
+    expected = np.stack([ctx.query([aids[0]], [200], Q.compile_queries([e]))[0][0] for e in exprs])
+    assert np.array_equal(expected, O.survivors_tree(words, plan.desc.view(O.DESC_DTYPE), exprs))
+    ctx.set_lab(12, 1)
+    # ~1 GB of JSON rows (4 000 distinct rows, tiled): k_ingest_rows runs ~10 ms per call, back to back
+    base = synth.rows_json(0, 4000)
+    reps = 1000
+    one = np.frombuffer(b"".join(base), dtype=np.uint8)
+    blob = np.tile(one, reps)
+    lens = np.tile(np.asarray([len(r) for r in base], dtype=np.uint64), reps)
+    off = np.zeros(len(lens) + 1, dtype=np.uint64)
+    np.cumsum(lens, out=off[1:])
+    n_rows = len(lens)
+    first = np.asarray([0, n_rows], dtype=np.uint32)
+    stop, ingests, failures = threading.Event(), [], []
+
+    def flush_worker():
+        try:
+            while not stop.is_set():
+                ing = ctx.ingest_rows((blob, off), first, np.zeros(1, dtype=np.uint32), 1, flags=1)
+                ingests.append(ctx.ingest_stats(ing).ms_walk)
+                ctx.ingest_free(ing)
+        except Exception as exc:  # noqa: BLE001 - reported by the assertion below
+            failures.append(repr(exc))
+
+    quiet = conc.run(ctx, exprs, aids, 200, expected, n_threads=64, seconds=0.5)
+    t = threading.Thread(target=flush_worker)
+    t.start()
+    try:
+        while not ingests and not failures and t.is_alive():
+            threading.Event().wait(0.05)                 # the first call has uploaded its rows: the device is busy from here on
+        busy = conc.run(ctx, exprs, aids, 200, expected, n_threads=64, seconds=1.5)
+    finally:
+        stop.set()
+        t.join()
+    assert not failures, failures
+    assert len(ingests) >= 2 and max(ingests) > 5.0, ingests          # milliseconds of k_ingest_rows per call: the device WAS busy
+    assert quiet["mismatches"] == 0 and quiet["errors"] == 0
+    assert busy["mismatches"] == 0 and busy["errors"] == 0 and busy["calls"] > 200
+    # processor time of the whole process per wall second: 64 callers that spin would hold ~their quota; sleeping ones a few CPUs
+    assert busy["cpus_busy"] < 8.0, busy
+    assert busy["p99_us"] < 200_000, busy
+    for a in aids:
+        ctx.arena_free(a)

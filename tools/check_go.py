@@ -37,7 +37,7 @@ GO_PREDECLARED = set("bool byte complex64 complex128 error float32 float64 int i
 STD_NAMES = set("""
     Error Errorf Sprintf Printf Println Fprintf New Is As Join Unwrap Lock Unlock RLock RUnlock Add Done Wait Warn Debug Info Since Now Sub
     Duration Nanosecond Microsecond Millisecond Second Seconds Nanoseconds Milliseconds Search SearchInts Slice Ints IntsAreSorted Strings Split TrimSpace
-    Atoi Itoa ParseInt Getenv Setenv ReadFile WriteFile Open Create Close Read Write Seek ReadFull SeekStart ReadSeeker ReadSeekCloser Reader Writer Mutex RWMutex
+    Atoi Itoa ParseInt ParseUint Getenv Setenv ReadFile WriteFile Open Create Close Read Write Seek ReadFull SeekStart ReadSeeker ReadSeekCloser Reader Writer Mutex RWMutex
     WaitGroup Pool Get Put Logger Handler DiscardHandler Context Background WithCancel WithTimeout Err TODO Fatal Fatalf Skip Skipf Helper Run Logf Log
     Errorf Name Cleanup TempDir Setenv B N T TB ResetTimer StopTimer StartTimer ReportMetric ReportAllocs Loop Pointer Sizeof Slice SliceData String StringData
     BloomFilter EstimateParameters FromWithM NewWithEstimates AddString TestString Cap K BitSet Bytes Equal WriteTo ReadFrom NumCPU GOMAXPROCS

@@ -160,7 +160,7 @@ int32_t cache_run(bsg_ctx *ctx, uint32_t n_threads, double seconds, const conc_q
             for (size_t i = 0; i < cand.size(); ++i) keys[i] = key_of(cand[i]);
             rows.assign(cand.size(), 0);
             uint64_t lease = 0, arena = 0;
-            bool ok = bsg_file_arena_acquire(scope, fkey, 4, keys.data(), (uint32_t)keys.size(), &lease, &arena, rows.data()) == BSG_OK;
+            bool ok = bsg_file_arena_acquire(scope, fkey, 4, keys.data(), (uint32_t)keys.size(), &lease, &arena, nullptr, rows.data()) == BSG_OK;
             if (ok && lease) {
                 hits++;
             } else if (ok) {
