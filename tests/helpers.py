@@ -10,6 +10,17 @@ from bloomsearch_amd.arena import entry_sets_from_strings, plan_blocks
 from oracle import oracle as O
 
 
+def device_ids(n: int):
+    """Device ids for a context of n entries: REAL devices 0 .. n-1 where the box has them (peer copies, bsg_peer_access, per-device
+    PCIe slices then run between distinct GPUs), else n aliases of device 0 — all a 1-GPU box can offer ("multi-device
+    contexts are only ever (0,)*N aliases").  BSG_TEST_ALIAS_DEVICES=1 forces the aliases."""
+    import os
+    import torch
+    if os.environ.get("BSG_TEST_ALIAS_DEVICES") != "1" and torch.cuda.is_available() and torch.cuda.device_count() >= n:
+        return tuple(range(n))
+    return (0,) * n
+
+
 def random_block_strings(rng, n_fields, n_tokens, vocab):
     fields = ["f%d" % i for i in rng.choice(40, size=min(n_fields, 40), replace=False)]
     toks = sorted({vocab[i] for i in rng.integers(0, len(vocab), size=n_tokens)})

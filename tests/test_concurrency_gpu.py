@@ -13,6 +13,7 @@ from bloomsearch_amd import ingest as I, query as Q, synth
 from oracle import oracle as O
 from oracle import walker_oracle as W
 from tests import helpers as H
+from tests.helpers import device_ids
 
 pytestmark = pytest.mark.gpu
 
@@ -120,7 +121,7 @@ def test_many_threads_one_sharded_context():
     every result still equals the oracle's."""
     from bloomsearch_amd.gpu import Context
     errors = []
-    with Context((0, 0, 0)) as m:
+    with Context(device_ids(3)) as m:
         m.set_lab(7, 1)
         m.set_lab(8, 1)
         barrier = threading.Barrier(9)
@@ -225,7 +226,7 @@ def test_a_cycle_beyond_its_scratch_budget_is_served_in_parts(ctx):
 
 def test_concurrent_queries_on_a_sharded_context():
     from bloomsearch_amd.gpu import Context
-    with Context((0, 0, 0)) as m:
+    with Context(device_ids(3)) as m:
         m.set_lab(15, (2000 << 16) | 6)
         _combiner_case(m, 12, 12, ROUNDS * 8)
         st = m.query_stats()

@@ -14,6 +14,7 @@ from bloomsearch_amd.arena import plan_blocks
 from bloomsearch_amd.gpu import Context, pack_entries
 from oracle import oracle as O
 from tests import helpers as H
+from tests.helpers import device_ids
 
 pytestmark = pytest.mark.gpu
 
@@ -83,7 +84,7 @@ def test_c4_10000_blocks_on_an_8_entry_multi_device_context():
     shards, block b on entry b % 8) as 10 files of 1 000 blocks probed by one bsg_probe_many; the host-interleaved
     survivors must equal the oracle's over every file, and a single-device context's."""
     n_files, per_file, nq = 10, 1000, 48
-    with Context((0,) * 8) as mctx, Context((0,)) as sctx:
+    with Context(device_ids(8)) as mctx, Context((0,)) as sctx:
         cb, terms, ops, poff = c4_batch(sctx, nq, seed=7)
         mb = mctx.batch_create(terms, ops, poff)
         sb = sctx.batch_create(terms, ops, poff)
@@ -109,7 +110,7 @@ def test_sharded_context_interleaves_any_block_count(n_entries):
     extract + parallel deposit per output word) for block counts around the word and shard boundaries, dense and sparse
     survivors, against the oracle."""
     rng = np.random.default_rng(1000 + n_entries)
-    with Context((0,) * n_entries) as mctx:
+    with Context(device_ids(n_entries)) as mctx:
         for n_blocks in (1, n_entries - 1, n_entries, n_entries + 1, 63, 64, 65, 64 * n_entries - 1, 64 * n_entries + 1, 321):
             plan, _, vocab = H.make_random_arena(rng, n_blocks, absent_frac=0.05, max_tokens=200, vocab_size=30)
             words = mctx.build(plan.blob, plan.off, plan.fstart, plan.desc, plan.n_words)
@@ -164,7 +165,7 @@ def test_c5_or_reduce_of_1250_fixed_geometry_blocks_equals_oracle_build_of_the_u
         want.add(t)
     assert np.array_equal(got, want.words)
     # and on a context that shards the same arena over 8 entries (partials combined inside the library)
-    with Context((0,) * 8) as mctx:
+    with Context(device_ids(8)) as mctx:
         aid = mctx.arena_load(words, desc)
         assert np.array_equal(mctx.or_reduce(aid, 1, nw), want.words)
 
@@ -491,7 +492,7 @@ def test_region_cursor_streams_chunks_like_blockFilterCursor():
     unread sections report -7 and behave as nil filters; a corrupt one is isolated."""
     rng = np.random.default_rng(123)
     n_blocks = 61
-    with Context((0,)) as c1, Context((0,) * 3) as c3:
+    with Context((0,)) as c1, Context(device_ids(3)) as c3:
         plan, words, vocab, sections = _sections_of(c1, rng, n_blocks)
         cb = Q.compile_queries([None] + [H.random_expression(rng, vocab, None) for _ in range(300)])
         ops, poff, _ = cb.arrays()
@@ -599,7 +600,7 @@ def test_shards_that_disagree_on_the_one_dispatch_path():
     copy) and device 1 holds one (k_probe_direct + doorbell): the doorbell of device 1 must not excuse device 0 from its
     stream wait (round-2 advice: survivors were read before their copy had landed)."""
     rng = np.random.default_rng(5)
-    with Context((0, 0)) as mctx:
+    with Context(device_ids(2)) as mctx:
         plans = []
         for i in range(65):
             n_blocks = 2 if i == 40 else 1                     # only arena 40 has a block for device 1
@@ -642,7 +643,7 @@ def test_bsg_query_one_call_strings_in_survivors_out(ctx):
         "many queries (batch path)": [Q.Token(vocab[i % 12]) for i in range(300)],
     }
     for n_dev in (1, 3):
-        with Context((0,) * n_dev) as c:
+        with Context(device_ids(n_dev)) as c:
             ids = [c.arena_load(w, p.desc) for p, w in plans]
             empty = c.arena_load(np.zeros(2, dtype=np.uint64), np.zeros(0, dtype=DESC_DTYPE))
             nbs = [p.n_blocks for p, _ in plans]

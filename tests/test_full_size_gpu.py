@@ -16,6 +16,7 @@ from bloomsearch_amd import query as Q, synth
 from bloomsearch_amd._lib import TERM_DTYPE
 from bloomsearch_amd.arena import plan_blocks
 from oracle import oracle as O
+from tests.helpers import device_ids
 
 pytestmark = pytest.mark.gpu
 
@@ -228,7 +229,7 @@ def test_full_size_c4_eight_term_or_batch_single_and_eight_entry_context(ctx, c2
     ctx.batch_free(bid)
     ctx.arena_free(aid)
     # the same file and batch on a context of 8 entries
-    with Context((0,) * 8) as m8:
+    with Context(device_ids(8)) as m8:
         a8 = m8.arena_load(words, plan.desc)
         b8 = m8.batch_create(terms, ops, poff)
         g8 = m8.probe_batch(a8, b8, NQ, B)

@@ -12,6 +12,7 @@ from bloomsearch_amd.arena import entry_sets_from_strings, plan_blocks
 from bloomsearch_amd.gpu import pack_entries
 from oracle import oracle as O
 from tests import helpers as H
+from tests.helpers import device_ids
 
 pytestmark = pytest.mark.gpu
 
@@ -359,7 +360,7 @@ def test_multi_device_context_shards_round_robin_and_gathers():
     host-side interleave are exactly the N-GPU code path."""
     from bloomsearch_amd.gpu import Context
     rng = np.random.default_rng(55)
-    for devs, n_blocks in (((0, 0), 131), ((0, 0, 0), 64), ((0, 0), 1)):
+    for devs, n_blocks in ((device_ids(2), 131), (device_ids(3), 64), (device_ids(2), 1)):
         plan, blocks_str, vocab = H.make_random_arena(rng, n_blocks, absent_frac=0.03)
         with Context(devs) as mctx:
             words = mctx.build(plan.blob, plan.off, plan.fstart, plan.desc, plan.n_words)

@@ -15,6 +15,7 @@ from bloomsearch_amd import host as Hst, ingest as I, query as Q, synth
 from oracle import oracle as O
 from oracle import walker_oracle as W
 from tests.test_host_tables import JSON_MATCHING, KEYS, _random_value, go_marshal
+from tests.helpers import device_ids
 
 pytestmark = pytest.mark.gpu
 
@@ -357,7 +358,7 @@ def test_resident_arenas_on_a_sharded_context(n_entries):
     from bloomsearch_amd import query as Q
     from bloomsearch_amd.gpu import Context
     from tests import helpers as H
-    with Context((0,) * n_entries) as mctx:
+    with Context(device_ids(n_entries)) as mctx:
         row_sets = [synth.rows_json(b * 150, 150) for b in range(11)] + [[]]
         first = np.zeros(len(row_sets) + 1, dtype=np.uint32)
         first[1:] = np.cumsum([len(r) for r in row_sets])

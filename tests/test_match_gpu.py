@@ -13,6 +13,7 @@ from bloomsearch_amd import host as Hst, query as Q, synth
 from oracle import walker_oracle as W
 from tests import helpers as H
 from tests.test_host_tables import JSON_MATCHING, KEYS, WORDS, _expr, _random_value, go_marshal
+from tests.helpers import device_ids
 
 pytestmark = pytest.mark.gpu
 
@@ -188,7 +189,7 @@ def test_chunked_upload_overlapping_the_match(ctx):
             assert ctx.last_match_ms() > 0
     finally:
         ctx.set_ingest_chunk(0)
-    with Context((0, 0, 0)) as m:
+    with Context(device_ids(3)) as m:
         m.set_lab(8, 1)                                     # shard whatever the size
         m.set_ingest_chunk(1 << 16)
         got, fb = m.match_rows(rows, Q.CompiledMatcher(e))

@@ -23,6 +23,7 @@ from bloomsearch_amd.gpu import Context
 from oracle import oracle as O
 from oracle import walker_oracle as W
 from tests import helpers as H
+from tests.helpers import device_ids
 
 pytestmark = pytest.mark.gpu
 
@@ -30,7 +31,7 @@ FPR = 0.001
 
 
 def sharded(n):
-    c = Context((0,) * n)
+    c = Context(device_ids(n))
     c.set_lab(7, 1)        # every construct call is cut over the devices, however small
     c.set_lab(8, 1)
     return c
@@ -207,7 +208,7 @@ def test_independent_callers_spread_over_the_devices(ctx):
     single-device context's."""
     row_sets = [synth.rows_json(b * 400, 400) for b in range(3)]
     want = I.device_ingest(ctx, row_sets, FPR, parent_of_set=[0, 0, 0], n_parents=1)
-    with Context((0, 0)) as m:
+    with Context(device_ids(2)) as m:
         results, errors = {}, []
 
         def worker(k):

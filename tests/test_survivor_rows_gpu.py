@@ -9,6 +9,7 @@ from bloomsearch_amd import _lib, query as Q
 from bloomsearch_amd.gpu import BloomGpuError, rows_to_dense, survivor_list, survivor_row_list
 from oracle import oracle as O
 from tests import helpers as H
+from tests.helpers import device_ids
 
 pytestmark = pytest.mark.gpu
 
@@ -100,7 +101,7 @@ def test_rows_on_a_context_of_several_devices_merge_to_the_global_block_order():
     from bloomsearch_amd.gpu import Context
     rng = np.random.default_rng(77)
     for nd in (8, 3):
-        with Context((0,) * nd) as m:
+        with Context(device_ids(nd)) as m:
             plans, words, aids = [], [], []
             for nb in (1000, 5, 64 * nd + 1, 1, 130):
                 plan, _, vocab = H.make_random_arena(rng, nb, absent_frac=0.02, max_tokens=60, vocab_size=30)
