@@ -152,3 +152,21 @@ def test_64bit_modulo_ingest_build_from_table_slots(ctx):
         nw = O.words_for(int(desc[c]["m"]))
         want = O.build_many(b, o, np.asarray([0, len(ents)], dtype=np.uint32), d1, nw)
         assert np.array_equal(words[int(desc[c]["word_off"]): int(desc[c]["word_off"]) + nw], want), c
+
+
+@pytest.mark.parametrize("m", [(1 << 30) + 77, (1 << 31) - 1], ids=["m=2^30+77", "m=2^31-1"])
+def test_build_modulo_at_the_top_of_the_32_bit_range(ctx, m):
+    """The 32-bit modulo of the build kernels (x - q m taken modulo 2^32, remainder candidate in [0, 2m)) at the top of its range —
+    2m just below 2^32 — through the entries route (global atomics), the hashed route and the binned route (bsg_set_lab key 6 = 0:
+    every bitset beyond LDS is binned), against the oracle's bitsets."""
+    n_blocks = 1
+    blob, off, fstart, desc, n_words, per_filter = big_plan(m, n_blocks)
+    want = O.build_many(blob, off, fstart, desc.view(O.DESC_DTYPE), n_words, n_threads=4)
+    assert np.array_equal(ctx.build(blob, off, fstart, desc, n_words), want), "bsg_build (global atomics) at m = %d" % m
+    h = ctx.hash_entries(blob, off)
+    assert np.array_equal(ctx.build_hashed(h, fstart, desc, n_words), want), "bsg_build_hashed at m = %d" % m
+    try:
+        ctx.set_lab(6, 0)
+        assert np.array_equal(ctx.build(blob, off, fstart, desc, n_words), want), "binned bsg_build at m = %d" % m
+    finally:
+        ctx.set_lab(6, 4 << 20)
