@@ -208,6 +208,10 @@ struct Device {
     DevBuf<uint64_t> stage_words;
     DevBuf<uint8_t> stage_region;  // encoded filter sections
     std::vector<uint8_t *> idle_staging;   // pinned 4 MiB chunk buffers of finished arena streams
+    // copy stream + events of finished arena streams (stream_api.inc): hipStreamCreate + hipStreamDestroy alone were ~3 ms of EVERY
+    // bsg_arena_load_sections / arena stream, whatever its size — the miss path of the file-arena cache (tools/miss_lab.py, round 6)
+    struct StreamKit { hipStream_t copy = nullptr; hipEvent_t copied = nullptr; hipEvent_t staged_free[2] = {nullptr, nullptr}; };
+    std::vector<StreamKit> idle_kits;
     std::vector<std::pair<uint64_t *, size_t>> direct_bufs;   // idle page-locked result buffers of k_probe_direct (pointer, bytes)
     std::mutex cmb_mu;                        // guards cmb_sets only
     std::vector<CmbSet> cmb_sets;             // idle scratch sets of combined query dispatches
@@ -759,6 +763,10 @@ int32_t bsg_close(bsg_ctx *ctx)
         if (d.aux_stream) { (void)hipEventDestroy(d.ev_aux[0]); (void)hipEventDestroy(d.ev_aux[1]); (void)hipStreamDestroy(d.aux_stream); }
         d.pool.trim(0);
         for (uint8_t *p : d.idle_staging) (void)hipHostFree(p);
+        for (auto &k : d.idle_kits) {
+            (void)hipStreamDestroy(k.copy); (void)hipEventDestroy(k.copied);
+            (void)hipEventDestroy(k.staged_free[0]); (void)hipEventDestroy(k.staged_free[1]);
+        }
         for (auto &p : d.direct_bufs) (void)hipHostFree(p.first);
         for (auto &te : d.table_cache) te.buf.release();
         for (auto &cs : d.cmb_sets) {

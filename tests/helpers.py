@@ -13,12 +13,24 @@ from oracle import oracle as O
 def device_ids(n: int):
     """Device ids for a context of n entries: REAL devices 0 .. n-1 where the box has them (peer copies, bsg_peer_access, per-device
     PCIe slices then run between distinct GPUs), else n aliases of device 0 — all a 1-GPU box can offer ("multi-device
-    contexts are only ever (0,)*N aliases").  BSG_TEST_ALIAS_DEVICES=1 forces the aliases."""
+    contexts are only ever (0,)*N aliases").  BSG_TEST_ALIAS_DEVICES=1 forces the aliases.  Asks the library, not torch: torch brings
+    its own copy of the HIP / HSA runtime into the process, after which /opt/rocm's librccl — which the library binds for
+    bsg_comm_init — finds an HSA runtime nobody initialised ("no ROCm-capable device is detected")."""
     import os
-    import torch
-    if os.environ.get("BSG_TEST_ALIAS_DEVICES") != "1" and torch.cuda.is_available() and torch.cuda.device_count() >= n:
+    from bloomsearch_amd import _lib
+    if os.environ.get("BSG_TEST_ALIAS_DEVICES") != "1" and _lib.load().bsg_device_count() >= n:
         return tuple(range(n))
     return (0,) * n
+
+
+def device_free_bytes() -> int:
+    """hipMemGetInfo's free bytes of the current device, through the HIP runtime the library itself is linked against (not torch's)."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    free, total = ctypes.c_size_t(), ctypes.c_size_t()
+    rc = hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total))
+    assert rc == 0, rc
+    return int(free.value)
 
 
 def random_block_strings(rng, n_fields, n_tokens, vocab):

@@ -12,7 +12,7 @@ import pytest
 from bloomsearch_amd import _lib, query as Q
 from bloomsearch_amd.gpu import Context
 from oracle import oracle as O
-from tests.helpers import make_random_arena, oracle_words, random_expression
+from tests.helpers import device_free_bytes, make_random_arena, oracle_words, random_expression
 
 pytestmark = pytest.mark.gpu
 
@@ -65,7 +65,6 @@ def want_bits(want, blocks):
 
 
 def test_policy_hit_widen_narrower_dirty_lru_forget_and_no_leak():
-    import torch
     rng = np.random.default_rng(606)
     nb = 40
     files = {k: make_file(rng, nb) for k in (b"f1", b"f2", b"f3", b"f4")}
@@ -75,7 +74,7 @@ def test_policy_hit_widen_narrower_dirty_lru_forget_and_no_leak():
     with Context((0,)) as ctx:
         ctx.arena_free(ctx.arena_load_sections(secs1)[0])            # (warms the library's scratch pool: what it keeps is not a leak)
         ctx.sync()
-        free0 = torch.cuda.mem_get_info()[0]
+        free0 = device_free_bytes()
         ctx.set_arena_budget(1 << 40)
         # miss -> load a run of blocks -> publish -> resident
         run = list(range(5, 20))
@@ -165,7 +164,7 @@ def test_policy_hit_widen_narrower_dirty_lru_forget_and_no_leak():
         with pytest.raises(_lib.BloomGpuError):
             ctx.query([a3], [len(union)], Q.compile_queries(exprs[:1]))
         ctx.sync()
-        assert abs(torch.cuda.mem_get_info()[0] - free0) <= (8 << 20), "device memory did not come back"
+        assert abs(device_free_bytes() - free0) <= (8 << 20), "device memory did not come back"
 
 
 def test_bad_arguments_fail_before_anything_changes():
@@ -196,7 +195,6 @@ def test_64_native_threads_over_a_budget_that_holds_a_quarter_of_the_files(threa
     """64 native threads (tools/native/conc_driver.cpp::cache_run) x random files x random candidate subsets; the budget holds about
     a quarter of the files, so arenas are evicted, re-read, widened and (second run) forgotten while leased, all at once.  Every
     candidate's verdict of every call is compared with the tree oracle's inside the driver."""
-    import torch
     from bloomsearch_amd import conc
     rng = np.random.default_rng(2026)
     n_files, nb = 16, 48
@@ -212,7 +210,7 @@ def test_64_native_threads_over_a_budget_that_holds_a_quarter_of_the_files(threa
     with Context((0,)) as ctx:
         ctx.arena_free(ctx.arena_load_sections(files[0])[0])         # (warms the library's scratch pool: what it keeps is not a leak)
         ctx.sync()
-        free0 = torch.cuda.mem_get_info()[0]
+        free0 = device_free_bytes()
         # size of one whole-file arena -> a budget of a quarter of the files
         lease, _, _ = load_and_publish(ctx, b"probe", files[0], range(nb))
         one = ctx.arena_cache_stats()["resident_bytes"]
@@ -236,4 +234,4 @@ def test_64_native_threads_over_a_budget_that_holds_a_quarter_of_the_files(threa
         st = ctx.arena_cache_stats()
         assert st["resident_bytes"] == 0 and st["resident_files"] == 0
         ctx.sync()
-        assert abs(torch.cuda.mem_get_info()[0] - free0) <= (16 << 20), "device memory did not come back"
+        assert abs(device_free_bytes() - free0) <= (16 << 20), "device memory did not come back"

@@ -237,3 +237,13 @@ def test_a_corrupt_list_header_is_rejected():
     assert L.bsg_survivor_row_list((2 << 30) | 6, row.ctypes.data, n_blocks, out.ctypes.data, n_blocks, C.byref(n)) == _lib.BSG_E_INVALID
     row.view(np.uint32)[:6] = [1, 5, 9, 64, 100, 130]         # an id past the arena
     assert L.bsg_survivor_row_list((2 << 30) | 6, row.ctypes.data, n_blocks, out.ctypes.data, n_blocks, C.byref(n)) == _lib.BSG_E_INVALID
+
+
+def test_gpu_test_modules_do_not_import_torch():
+    """torch ships its own HIP / HSA runtime: once it is in the pytest process, /opt/rocm's librccl (bound by bsg_comm_init) finds an
+    uninitialised HSA runtime and the real-RCCL test fails with "no ROCm-capable device is detected" (round 6).  The GPU tests talk
+    to the device through libbloomgpu only; bench.py (torch first, the library bound to torch's librccl) runs in its own process."""
+    import glob
+    for path in glob.glob(os.path.join(ROOT, "tests", "test_*_gpu.py")) + [os.path.join(ROOT, "tests", "helpers.py"), os.path.join(ROOT, "tests", "conftest.py")]:
+        src = open(path).read()
+        assert not re.search(r"^\s*(import torch|from torch)", src, re.M), path
