@@ -208,15 +208,20 @@ def test_64_native_threads_over_a_budget_that_holds_a_quarter_of_the_files(threa
         expected.append(expected_survivors(words, desc, exprs))
     assert any(e.any() for e in expected) and not all(bool((e == e[0]).all()) for e in expected)
     with Context((0,)) as ctx:
-        ctx.arena_free(ctx.arena_load_sections(files[0])[0])         # (warms the library's scratch pool: what it keeps is not a leak)
-        ctx.sync()
-        free0 = device_free_bytes()
         # size of one whole-file arena -> a budget of a quarter of the files
         lease, _, _ = load_and_publish(ctx, b"probe", files[0], range(nb))
         one = ctx.arena_cache_stats()["resident_bytes"]
         ctx.file_arena_release(lease)
         ctx.file_arena_forget(b"probe")
         ctx.set_arena_budget(one * n_files // 4)
+        # a first, short run brings the library's scratch pool (regions, slot tables, staging: what `threads` concurrent loads hold at
+        # once, kept for reuse) to its steady state; the leak check is that the long run after it leaves no more device memory behind
+        warm = conc.cache_run(ctx, exprs, files, expected, n_threads=threads, seconds=0.7, forget_every=forget_every, seed=5)
+        assert warm["errors"] == 0 and warm["mismatches"] == 0
+        for f in range(n_files):
+            ctx.file_arena_forget(bytes([f, 0, 0, 0]))
+        ctx.sync()
+        free0 = device_free_bytes()
         ctx.arena_cache_stats(reset=True)
         r = conc.cache_run(ctx, exprs, files, expected, n_threads=threads, seconds=3.0, forget_every=forget_every, seed=11)
         st = ctx.arena_cache_stats()
@@ -234,4 +239,6 @@ def test_64_native_threads_over_a_budget_that_holds_a_quarter_of_the_files(threa
         st = ctx.arena_cache_stats()
         assert st["resident_bytes"] == 0 and st["resident_files"] == 0
         ctx.sync()
-        assert abs(device_free_bytes() - free0) <= (16 << 20), "device memory did not come back"
+        delta = free0 - device_free_bytes()
+        assert delta <= (16 << 20), "device memory did not come back: %.1f MB more held than before the run (%d calls, %d arenas published)" % (
+            delta / 1e6, r["calls"], st["published"])
