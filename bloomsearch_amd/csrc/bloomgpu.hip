@@ -286,7 +286,9 @@ struct Combiner {
     uint32_t hot_min_queries = 8;               // an arena is streamed once for all its callers of a cycle from this many 3-term queries per 35 KB of filters per block (key 16; 0: never; scaled by the arena's bytes per block and the calls' terms: combine_api.inc).  Measured 4 / 8 / 12 / 24 on C2's arena: 4 streams too much at 64 callers over 12 arenas (5.9 vs 8.8 x 10^5), 24 leaves 64 x 10 arenas at 1.9 vs 3.0 x 10^5
     std::atomic<uint64_t> n_solo{0}, n_cycles{0}, n_cycle_calls{0}, n_dispatches{0}, n_hot{0}, max_cycle_calls{0};
     uint64_t part_bytes = 64ull << 20;           // rows of one part of a cycle (page-locked scratch, kept): a cycle beyond it is served in parts (key 24)
-    uint32_t wait_spin_us = 50;                  // a collector polls its dispatch's doorbell this long, then sleeps on an event behind it (key 25)
+    uint32_t wait_spin_us = 0;                   // a collector polls its dispatch's doorbell this long, then sleeps on an event behind it (key 25); 0 = adaptive:
+                                                 // 4 x the running mean of the waits that ended while polling, within [50 us, 1 ms]
+    std::atomic<uint32_t> wait_ema_ns{20000};    // that mean (a cycle of 256 callers x 10 arenas runs ~150 us on an idle device, 16 callers ~15 us)
     uint32_t inline_jobs = 1;                    // a job list whose table fits the kernel arguments travels in them (key 21; 0: always uploaded)
     uint32_t profile = 0;                        // lab (key 20): callers account their own processor time (bsg_lab_query_cpu)
     std::atomic<uint64_t> n_cpu_calls{0}, ns_cpu_call{0}, ns_cpu_wait{0}, ns_cpu_duty{0}, ns_cpu_collect{0};

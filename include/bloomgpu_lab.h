@@ -24,7 +24,7 @@ extern "C" {
  * preparation only, nothing probed; 13: cycles in flight (2; one more while cycles average > 32 calls); 15: (microseconds << 16) |
  * calls a collector waits for company (tests); 16: 3-term queries asked of one arena in a cycle from which it is streamed once for all of
  * them (8, for 35 KB of filters per block: scaled by the arena's bytes per block and the calls' distinct terms); 17: microseconds a queued caller polls while the context is quiet (60); 20: account the callers' processor time
- * (bsg_lab_query_cpu); 21: 0 = a cycle's job table is always uploaded (default 1: a table of <= ~4 KB rides in the kernel arguments); 22: workgroups of a lone call's dispatch beyond which its doorbell is a dispatch behind it (32); 24: bytes of survivor rows beyond which a cycle is served in parts (64 MB); 25: microseconds a collector polls its dispatch's doorbell before it sleeps on an event behind the dispatch (50); key 19: percent of a single-group device-resident run whose evaluation moves to a second stream (0 = off))) */
+ * (bsg_lab_query_cpu); 21: 0 = a cycle's job table is always uploaded (default 1: a table of <= ~4 KB rides in the kernel arguments); 22: workgroups of a lone call's dispatch beyond which its doorbell is a dispatch behind it (32); 24: bytes of survivor rows beyond which a cycle is served in parts (64 MB); 25: microseconds a collector polls its dispatch's doorbell before it sleeps on an event behind the dispatch (0 = adaptive, the default: 4 x the running mean of the polled waits within [50 us, 1 ms]); key 19: percent of a single-group device-resident run whose evaluation moves to a second stream (0 = off))) */
 BSG_API int32_t bsg_set_lab(bsg_ctx *ctx, uint32_t key, uint64_t value);
 /* Synchronous probes poll their stream for up to this long before they block (default 0: block at once).  A single
  * query's kernels finish in ~10 us; being woken from a blocking wait costs more than that. */

@@ -293,7 +293,7 @@ def test_a_freed_arena_id_is_forgotten_by_the_callers_caches(ctx):
 def test_combined_queries_beside_a_long_ingest_sleep_instead_of_spinning(ctx):
     """a collector whose dispatch sits behind somebody else's long work on the device (the flush worker's
     bsg_ingest_rows: tens of milliseconds of k_ingest_rows per call at 10 M rows) used to busy-wait 20 ms on its doorbell before it
-    fell back to hipStreamSynchronize under the device lock.  Now it polls <= 50 us (bsg_set_lab key 25), then sleeps on a
+    fell back to hipStreamSynchronize under the device lock.  Now it polls a few times its usual wait (<= 1 ms; bsg_set_lab key 25), then sleeps on a
     blocking-sync event recorded behind its dispatch.  64 native callers for 1.5 s next to a thread that ingests ~1 GB of rows over
     and over: every result bit-exact, and the whole process (callers + collector + the ingesting thread + the runtime) stays far
     below a processor per caller — the 20 ms spins cost milliseconds of processor time per call."""

@@ -27,7 +27,7 @@ with Context((0,)) as ctx:
     off = np.zeros(len(lens) + 1, dtype=np.uint64)
     np.cumsum(lens, out=off[1:])
     first = np.asarray([0, len(lens)], dtype=np.uint32)
-    for spin_us, name in ((50, "poll 50 us, then sleep on an event (default)"), (20000, "poll 20 ms (round 5)")):
+    for spin_us, name in ((0, "adaptive poll (4 x the mean polled wait, 50 us .. 1 ms), then sleep on an event (default)"), (50, "poll 50 us, then sleep"), (20000, "poll 20 ms (round 5)")):
         ctx.set_lab(25, spin_us)
         quiet = conc.run(ctx, exprs, aids, 200, expected, n_threads=64, seconds=0.5)
         stop, walks = threading.Event(), []
