@@ -28,6 +28,7 @@ bash tools/shard_sweep.sh > $K/${R}_c4_shard_sweep.txt 2>&1
 HOT=8 python tools/conc_lab.py 0.5 2 > $K/${R}_conc_lab.txt 2>&1
 python tools/conc_busy.py > $K/${R}_conc_busy.txt 2>&1
 python tools/cache_lab.py > $K/${R}_cache_lab.txt 2>&1
+python tools/miss_lab.py > $K/${R}_miss_lab.txt 2>&1
 # 6. the N > 1 host paths on one GPU (both ranks on device 0, gloo), and one context over 8 entries
 BSG_BENCH_SHARE_GPU=1 python bench.py --gpus 2 --steps 20 --warmup 5 --ingest-blocks 0 --no-decode --cpu-budget 0 --no-q1 --no-single --scaled 0 --no-big-filters --no-concurrent > $K/${R}_bench_gpus2_shared_gpu.json 2> gpurun_out/${R}_bench_gpus2_shared_gpu.err
 cp bench_legs.json $K/${R}_bench_gpus2_shared_gpu_legs.json
@@ -40,6 +41,6 @@ python -c "import json; print(json.dumps(json.load(open('bench_legs.json'))['mul
  echo "== tools/fuzz_build.py 1200 100"; timeout 100 python tools/fuzz_build.py 1200 100 2>&1 | tail -1
  echo "== tools/fuzz_walker.py 1200 30"; timeout 120 python tools/fuzz_walker.py 1200 30 2>&1 | tail -1) > $K/${R}_fuzz.txt 2>&1
 # 8. the GPU suite and smoke at this commit
-(python -m pytest tests -q -m gpu 2>&1 | tail -3; python __graft_entry__.py --smoke 2>&1 | tail -1) > $K/${R}_gpu_suite.txt 2>&1
+(python -m pytest tests -q -m gpu 2>&1 | grep -E "passed|failed|FAILED|ERROR"; python __graft_entry__.py --smoke 2>&1 | grep -E "smoke|Error|error" | tail -2) > $K/${R}_gpu_suite.txt 2>&1
 rm -rf gpurun_out/prof_${R}_* gpurun_out/pmc_${R}
 ls -la $K

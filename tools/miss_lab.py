@@ -1,6 +1,8 @@
+"""What a miss of the file-arena cache pays: bsg_arena_load_sections + bsg_arena_free of 1 / 8 / 64 small sections, one caller.
+Round 6: 3.2 ms whatever the size (a hipStreamCreate / Destroy pair per load) -> 0.10 ms with the copy stream and events reused."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bloomsearch_amd.gpu import Context
 from tests.test_arena_cache_gpu import make_file
 rng = np.random.default_rng(1)
