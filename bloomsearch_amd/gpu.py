@@ -6,6 +6,7 @@ arithmetic of the hot path is done in Python.
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 
 import numpy as np
 
@@ -87,6 +88,7 @@ class Context:
             raise BloomGpuError(rc, self.L.bsg_last_error(None).decode())
         self.h = h
         self.n_devices = len(device_ids)
+        self._dependents = weakref.WeakSet()     # objects that hold this handle (host.Engine): closed before the context is
 
     def _check(self, rc):
         if rc:
@@ -94,6 +96,8 @@ class Context:
 
     def close(self):
         if self.h:
+            for dep in list(self._dependents):
+                dep.close()
             self.L.bsg_close(self.h)
             self.h = None
 

@@ -248,6 +248,7 @@ class Engine:
         if rc:
             raise HostError(rc, "ErrInvalidConfig" if rc == -101 else "")
         self.h = h
+        ctx._dependents.add(self)            # an engine that outlives its context (a traceback keeps it) must not call into freed memory
 
     def close(self):
         if getattr(self, "h", None):

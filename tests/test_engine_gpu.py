@@ -6,6 +6,8 @@ Scenarios after: query_cursor_test.go:442-524 (TestBlockStatsAccuracy), file_for
 (TestMeasuredFilterSizing), :940-1055 (TestMergeRebuildsFilters), no_false_negatives_test.go:103-321 and
 :467-611 (TestPropertyNoFalseNegatives), bloom_tree_engine_test.go:1867-1901 (file-level prune).
 """
+import json
+
 import numpy as np
 import pytest
 
@@ -391,3 +393,56 @@ def test_device_ingest_writes_the_same_bytes_as_host_ingest(ctx):
             by_partition.setdefault("p%d" % (i % 4), []).append(r)
     for e in engines:
         assert_file_equals_oracle(e, 0, by_partition, 0.001)
+
+
+def test_queries_are_the_same_whatever_the_arena_budget_keeps_resident(ctx):
+    """The engine mirror leases its files' block filters from the library's resident-arena cache (csrc/cache_api.inc).  Five files,
+    the same queries under a budget that holds everything, one that holds about two files (arenas are evicted between and inside
+    queries and decoded again from the stored sections) and one that holds nothing (every arena serves its query and is freed):
+    identical rows and BlockStats; a corrupted section is re-read on every query and recovers when the bytes do (only clean decodes
+    become resident); merged-away files are forgotten."""
+    e = new_engine(ctx, PartitionField="partition", MaxBufferedRows=100000)
+    for f in range(5):
+        ingest_and_flush(e, [{"id": f * 1000 + i, "partition": "p%d" % (i % 6), "msg": "w%d f%d shared" % (i % 17, f), "k%d" % (i % 4): i} for i in range(240)])
+    queries = [Q.Token("w3"), Q.And(Q.Field("k2"), Q.Token("f4")), Q.Or(Q.FieldToken("msg", "w16"), Q.Token("f0")), Q.Token("zzz"), Q.Token("shared")]
+
+    def answers():
+        out = []
+        for q in queries:
+            r = e.query(q)
+            out.append((sorted(json.dumps(x, sort_keys=True) for x in r["rows"]), [(b["FileID"], b["BlockOffset"], b["BloomFilterSkipped"], b["RowsProcessed"]) for b in r["stats"]["BlockStats"]], r["stats"]["Errors"]))
+        return out
+    try:
+        ctx.set_arena_budget(1 << 40)
+        ctx.arena_cache_stats(reset=True)
+        want = answers()
+        st = ctx.arena_cache_stats()
+        assert st["resident_files"] == 5 and st["leases"] == 0 and (DEVICE_INGEST or st["misses"] == 5) and st["hits"] >= 10     # (file-level filters prune "zzz" everywhere and "f4" in four files: those never lease)
+        one = st["resident_bytes"] // 5
+        ctx.set_arena_budget(2 * one + one // 2)
+        assert ctx.arena_cache_stats()["resident_files"] == 2
+        ctx.arena_cache_stats(reset=True)
+        assert answers() == want
+        st = ctx.arena_cache_stats()
+        assert st["evictions"] > 0 and st["resident_bytes"] <= st["budget_bytes"] and st["leases"] == 0
+        ctx.set_arena_budget(0)
+        ctx.arena_cache_stats(reset=True)
+        assert answers() == want
+        st = ctx.arena_cache_stats()
+        assert st["resident_files"] == 0 and st["rejected_over_budget"] > 0 and st["hits"] == 0 and st["leases"] == 0 and st["leased_dead_bytes"] == 0
+        # a corrupt section: the block is unread in every query while the bytes are bad (never cached), the other files' arenas stay resident
+        ctx.set_arena_budget(1 << 40)
+        answers()
+        e.corrupt_section_byte(2, 1, 40)
+        bad1, bad2 = e.query(Q.Token("shared")), e.query(Q.Token("shared"))
+        assert len(bad1["stats"]["Errors"]) == 1 and bad1["stats"]["Errors"] == bad2["stats"]["Errors"]
+        assert ctx.arena_cache_stats()["resident_files"] == 4 and ctx.arena_cache_stats()["rejected_dirty"] >= 2
+        e.corrupt_section_byte(2, 1, 40)           # the same flip again: the bytes are good again, the next query recovers
+        assert e.query(Q.Token("shared"))["stats"]["Errors"] == [] and ctx.arena_cache_stats()["resident_files"] == 5
+        e.merge()                                   # five sources tombstoned, one merged file
+        st = ctx.arena_cache_stats()
+        assert st["resident_files"] <= 1 and st["forgotten"] >= 5
+        merged = e.query(Q.Token("w3"))
+        assert sorted(json.dumps(x, sort_keys=True) for x in merged["rows"]) == want[0][0]
+    finally:
+        ctx.set_arena_budget(32 << 30)
