@@ -1265,10 +1265,12 @@ constexpr uint32_t kBuildSetsThreads = 1024;   // one workgroup per table: 16 wa
 constexpr uint32_t kSetTile = 4 * kBuildSetsThreads;            // slots scanned per trip
 constexpr uint32_t kSetListBytes = kSetTile * 4 + 16;            // static LDS of k_build_sets beside the staged bitset
 
-template <bool M32, typename BITS32>
+template <int MODE, typename BITS32>
 __device__ __forceinline__ void build_from_slots(const IngestTable t, const SetBuildItem &it, const DevDesc &d, BITS32 bits, uint32_t tid,
                                                  uint32_t *list, uint32_t *n_list)
 {
+    ModF64 fm{};
+    if (MODE == kModFp64) fm = make_modf64(d.m, d.magic);
     for (uint64_t base = it.slot_begin; base < it.slot_end; base += kSetTile) {
         if (tid == 0) *n_list = 0;
         __syncthreads();
@@ -1299,8 +1301,8 @@ __device__ __forceinline__ void build_from_slots(const IngestTable t, const SetB
                 const ulonglong2 *q = reinterpret_cast<const ulonglong2 *>(t.slots + (base + list[e2]) * 4);
                 x1 = q[0]; y1 = q[1];
             }
-            set_entry_bits<M32>(bits, d, x0.x, x0.y, y0.x, y0.y);
-            if (e2 < n) set_entry_bits<M32>(bits, d, x1.x, x1.y, y1.x, y1.y);
+            set_entry_bits<MODE>(bits, d, fm, x0.x, x0.y, y0.x, y0.y);
+            if (e2 < n) set_entry_bits<MODE>(bits, d, fm, x1.x, x1.y, y1.x, y1.y);
         }
         __syncthreads();
     }
@@ -1317,18 +1319,19 @@ __global__ __launch_bounds__(kBuildSetsThreads) void k_build_sets(const SetBuild
     const uint32_t tid = threadIdx.x;
     if (d.m == 0) return;
     const uint64_t nw = (d.m + 63) >> 6;
-    const bool m32 = d.m < (1ull << 31);
+    const int mode = mod_mode(d.m);
     if (it.staged) {
         for (uint32_t i = tid; i < nw; i += kBuildSetsThreads) lds64[i] = 0;
         lds_u32 *bits = (lds_u32 *)lds64;                        // (build_from_slots starts with a barrier)
-        if (m32) build_from_slots<true>(t, it, d, bits, tid, list, &n_list);
-        else     build_from_slots<false>(t, it, d, bits, tid, list, &n_list);
+        if (mode == kModFp64)           build_from_slots<kModFp64>(t, it, d, bits, tid, list, &n_list);
+        else if (mode == kModBarrett32) build_from_slots<kModBarrett32>(t, it, d, bits, tid, list, &n_list);
+        else                            build_from_slots<kModBarrett64>(t, it, d, bits, tid, list, &n_list);
         uint64_t *dst = a.out + d.word_off;
         for (uint32_t i = tid; i < nw; i += kBuildSetsThreads) dst[i] = lds64[i];
     } else {
         uint32_t *bits = reinterpret_cast<uint32_t *>(a.out + d.word_off);
-        if (m32) build_from_slots<true>(t, it, d, bits, tid, list, &n_list);
-        else     build_from_slots<false>(t, it, d, bits, tid, list, &n_list);
+        if (mode == kModBarrett64) build_from_slots<kModBarrett64>(t, it, d, bits, tid, list, &n_list);
+        else                       build_from_slots<kModBarrett32>(t, it, d, bits, tid, list, &n_list);
     }
 }
 

@@ -141,33 +141,41 @@ __device__ __forceinline__ uint64_t load_u64_unaligned(const uint8_t *p)
     return v;
 }
 
+// The tail's shape by table instead of by branch (round 6): kTail[t] = {mask of the low t bytes (two words), the 0x01 of d || 0x01 at
+// byte t (two words)}.  The lanes of a wave disagree on t, so every branch on it ran both ways for the whole wave (ISA of k_build);
+// 512 bytes that live in the L1, two 16-byte loads issued beside the tail's own.
+#define BSG_TAIL_ROW(t) { (t) >= 8 ? ~0ULL : ((1ULL << (8 * ((t) & 7))) - 1), (t) > 8 ? ((1ULL << (8 * ((t) & 7))) - 1) : 0ULL, \
+                          (t) < 8 ? 1ULL << (8 * ((t) & 7)) : 0ULL, (t) >= 8 ? 1ULL << (8 * ((t) & 7)) : 0ULL }
+__device__ __constant__ static const uint64_t kTail[16][4] = {
+    BSG_TAIL_ROW(0), BSG_TAIL_ROW(1), BSG_TAIL_ROW(2), BSG_TAIL_ROW(3), BSG_TAIL_ROW(4), BSG_TAIL_ROW(5), BSG_TAIL_ROW(6), BSG_TAIL_ROW(7),
+    BSG_TAIL_ROW(8), BSG_TAIL_ROW(9), BSG_TAIL_ROW(10), BSG_TAIL_ROW(11), BSG_TAIL_ROW(12), BSG_TAIL_ROW(13), BSG_TAIL_ROW(14), BSG_TAIL_ROW(15)};
+#undef BSG_TAIL_ROW
+
+// k * c1, rotl 31, * c2 (what mix_k1 XORs into h1) and its twin; zero for k == 0, so an absent tail word needs no branch
+__device__ __forceinline__ uint64_t mixed_k1(uint64_t k1) { k1 *= kC1; k1 = rotl64(k1, 31); return k1 * kC2; }
+__device__ __forceinline__ uint64_t mixed_k2(uint64_t k2) { k2 *= kC2; k2 = rotl64(k2, 33); return k2 * kC1; }
+
 __device__ __forceinline__ void base_hashes_words(const uint8_t *p, uint32_t len, uint64_t h[4])
 {
     uint64_t h1 = 0, h2 = 0;
     const uint32_t nb = len >> 4;
-    for (uint32_t i = 0; i < nb; ++i) bmix(h1, h2, load_u64_unaligned(p + 16 * i), load_u64_unaligned(p + 16 * i + 8));
     const uint32_t t = len & 15u;
+    const ulonglong2 *row = reinterpret_cast<const ulonglong2 *>(kTail[t]);
+    const ulonglong2 mask = row[0], one = row[1];
     uint64_t k1 = load_u64_unaligned(p + 16 * nb), k2 = load_u64_unaligned(p + 16 * nb + 8);
-    if (t < 8) { k1 = t ? (k1 & (~0ULL >> (64 - 8 * t))) : 0; k2 = 0; }
-    else       { k2 = t > 8 ? (k2 & (~0ULL >> (64 - 8 * (t - 8)))) : 0; }
-    {
-        uint64_t a1 = h1, a2 = h2;
-        if (t > 8) mix_k2(a2, k2);
-        if (t > 0) mix_k1(a1, k1);
-        murmur_finalize(a1, a2, len, h[0], h[1]);
+    for (uint32_t i = 0; i < nb; ++i) bmix(h1, h2, load_u64_unaligned(p + 16 * i), load_u64_unaligned(p + 16 * i + 8));
+    k1 &= mask.x; k2 &= mask.y;
+    murmur_finalize(h1 ^ mixed_k1(k1), h2 ^ mixed_k2(k2), len, h[0], h[1]);
+    // d || 0x01: the extra byte lands at tail position t; at t == 15 the padded tail is a whole block (bmix) and the tail is empty
+    uint64_t b1 = h1 ^ mixed_k1(k1 | one.x), b2 = h2;
+    const uint64_t x2 = mixed_k2(k2 | one.y);
+    if (t == 15) {
+        b1 = (rotl64(b1, 27) + b2) * 5 + 0x52dce729ULL;
+        b2 = (rotl64(b2 ^ x2, 31) + b1) * 5 + 0x38495ab5ULL;
+    } else {
+        b2 ^= x2;
     }
-    {
-        if (t < 8) k1 |= 1ULL << (8 * t);
-        else       k2 |= 1ULL << (8 * (t - 8));
-        uint64_t b1 = h1, b2 = h2;
-        if (t == 15) {
-            bmix(b1, b2, k1, k2);
-        } else {
-            if (t + 1 > 8) mix_k2(b2, k2);
-            mix_k1(b1, k1);
-        }
-        murmur_finalize(b1, b2, (uint64_t)len + 1, h[2], h[3]);
-    }
+    murmur_finalize(b1, b2, (uint64_t)len + 1, h[2], h[3]);
 }
 
 // Same as base_hashes_words with the entry's first 32 bytes already in registers (w[0..3], loaded
@@ -307,6 +315,43 @@ __device__ __forceinline__ uint32_t mod_m32(uint64_t x, uint32_t m, uint64_t mag
     uint32_t r = (uint32_t)x - (uint32_t)q * m;
     if (r >= m) r -= m;
     return r;
+}
+
+// x mod m for 64 <= m <= 2^19 through the fp64 pipe (round 6; v_fma_f64 issues at full rate on gfx950, tools/ubench_valu.hip):
+//   y = xh * T + xl,  T = 2^32 mod m            == x (mod m) and < 2^51: ONE v_mad_u64_u32
+//   Y = as_double(0x433 << 52 | y)              = 2^52 + y exactly: one v_or_b32 on the high word
+//   t = fma(Y, inv, C)                          inv = K 2^-53 with K = floor(2^53 / m) - 1 (so inv < 1/m, and 2^52 inv is a multiple of
+//                                               1/2), C = 2^52 - 1/2 - 2^52 inv — both exact doubles, so the exact value of the fma is
+//                                               2^52 + y inv - 1/2, in [2^52 - 1/2, 2^53): it is rounded ONCE, to an integer, and the low
+//                                               word of its mantissa is q = F or F - 1 (F = floor(y / m)): y inv < y/m and frac(y/m) <=
+//                                               1 - 1/m give q <= F; y inv > y/m - y 2^-52 > y/m - 1/2 gives q >= F - 1 (q = -1 included)
+//   r = lo32(y) - q m  in [0, 2m)               one v_mad_u64_u32 (by 2^32 - m), one unsigned-min fix-up
+// 6 VALU instructions against the 13 the compiler makes of the 64x64 Barrett quotient (ISA of k_build, round 6).  Exact: nothing
+// approximate survives into r.  Both constants come out of the descriptor's magic = floor(2^64 / m) without a division.
+struct ModF64 {
+    uint32_t T;        // 2^32 mod m
+    uint32_t negm;     // 2^32 - m
+    double inv;        // (floor(2^53 / m) - 1) 2^-53
+    double C;          // 2^52 - 1/2 - 2^52 inv
+};
+constexpr uint64_t kModF64MaxM = 1ull << 19;
+__host__ __device__ __forceinline__ bool modf64_ok(uint64_t m) { return m >= 64 && m <= kModF64MaxM; }
+__host__ __device__ __forceinline__ ModF64 make_modf64(uint64_t m, uint64_t magic)
+{
+    ModF64 f;
+    f.negm = 0u - (uint32_t)m;
+    f.T = (uint32_t)(magic >> 32) * f.negm;                      // 2^32 - floor(2^32 / m) m   (mod 2^32; < m)
+    const uint64_t K = (magic >> 11) - 1;                        // floor(floor(2^64 / m) / 2^11) = floor(2^53 / m);  K < 2^47
+    f.inv = (double)K * 0x1p-53;
+    f.C = 0x1p52 - (double)(K + 1) * 0.5;
+    return f;
+}
+__device__ __forceinline__ uint32_t mod_f64(uint64_t x, const ModF64 &f)
+{
+    const uint64_t Y = ((uint64_t)(uint32_t)(x >> 32) * f.T + (uint32_t)x) | 0x4330000000000000ull;
+    const uint32_t q = (uint32_t)__double_as_longlong(__builtin_fma(__longlong_as_double((long long)Y), f.inv, f.C));
+    const uint32_t r = (uint32_t)((uint64_t)q * f.negm + Y);
+    return min(r, r - (0u - f.negm));
 }
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -1432,41 +1477,54 @@ struct BuildArgs {
 template <typename F>
 __device__ __forceinline__ void for_each_location_x(uint32_t k, uint64_t h0, uint64_t h1, uint64_t h2, uint64_t h3, F f)
 {
-    const uint64_t h3x2 = h3 + h3, h2x3 = h2 + h2 + h2, h2x4 = h2x3 + h2, h3x4 = h3x2 + h3x2;
-    uint64_t s2 = 0, s3 = 0;                          // i h2, i h3 at the trip's first i
+    // four running sums, one per residue of i mod 4, each advanced by 4 h2 or 4 h3 per trip: one 64-bit add per location
+    uint64_t x0 = h0, x1 = h1 + h3, x2 = h0 + h3 + h3, x3 = h1 + h2 + h2 + h2;
+    const uint64_t d2 = h2 << 2, d3 = h3 << 2;
     for (uint32_t i = 0; i < k; i += 4) {
-        f(h0 + s2);
-        if (i + 1 < k) f(h1 + s3 + h3);
-        if (i + 2 < k) f(h0 + s3 + h3x2);
-        if (i + 3 < k) f(h1 + s2 + h2x3);
-        s2 += h2x4; s3 += h3x4;
+        f(x0);
+        if (i + 1 < k) f(x1);
+        if (i + 2 < k) f(x2);
+        if (i + 3 < k) f(x3);
+        x0 += d2; x1 += d3; x2 += d3; x3 += d2;
     }
 }
 
 // Sets the k bits of one entry.  (Measured and dropped, round 6: an approximate-quotient modulo for m < 2^30 — lo32(xh mh) + hi32(xh ml) +
 // hi32(xl mh), remainder candidate in [0, 4m), two unsigned-min fix-ups: 10 instructions on paper against 12-13 — is 7 % SLOWER,
 // 239 -> 256 us per 1 000 x 19 600 entries: v_mul_hi_u32 issues slower than the v_mad_u64_u32 the exact quotient is made of.)
-template <bool M32, typename BITS32>
-__device__ __forceinline__ void set_entry_bits(BITS32 bits, const DevDesc &d, uint64_t h0, uint64_t h1, uint64_t h2, uint64_t h3)
+// MODE: how a location index becomes a bit position
+constexpr int kModBarrett64 = 0, kModBarrett32 = 1, kModFp64 = 2;
+__device__ __forceinline__ int mod_mode(uint64_t m) { return modf64_ok(m) ? kModFp64 : m < (1ull << 31) ? kModBarrett32 : kModBarrett64; }
+
+template <int MODE, typename BITS32>
+__device__ __forceinline__ void set_entry_bits(BITS32 bits, const DevDesc &d, const ModF64 &fm, uint64_t h0, uint64_t h1, uint64_t h2, uint64_t h3)
 {
     for_each_location_x(d.k, h0, h1, h2, h3, [&](uint64_t x) {
-        const uint64_t loc = locate<M32>(d, x);
+        const uint64_t loc = MODE == kModFp64 ? (uint64_t)mod_f64(x, fm) : locate<MODE == kModBarrett32>(d, x);
 #ifdef BSG_LAB_NO_ATOMICS      // lab only: keep the location live without touching the bitset
         asm volatile("" ::"v"((uint32_t)loc));
 #else
-        __hip_atomic_fetch_or(&bits[loc >> 5], 1u << ((uint32_t)loc & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint64_t w = loc >> 5;
+        if (MODE != kModBarrett64) {             // (kept opaque: otherwise the word's byte address becomes (loc >> 3) & ~3, + base: three instructions for two)
+            uint32_t w32 = (uint32_t)w;
+            asm volatile("" : "+v"(w32));
+            w = w32;
+        }
+        __hip_atomic_fetch_or(&bits[w], 1u << ((uint32_t)loc & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
     });
 }
 
-template <bool M32, typename BITS32>
+template <int MODE, typename BITS32>
 __device__ __forceinline__ void build_entries(const BuildArgs &a, const BuildItem &it, const DevDesc &d, BITS32 bits, uint32_t tid)
 {
+    ModF64 fm{};
+    if (MODE == kModFp64) fm = make_modf64(d.m, d.magic);
     if (a.h) {
         for (uint32_t e = it.e_begin + tid; e < it.e_end; e += kBuildThreads) {
             const ulonglong2 *hp = reinterpret_cast<const ulonglong2 *>(a.h + (uint64_t)e * 4);
             const ulonglong2 x = hp[0], y = hp[1];
-            set_entry_bits<M32>(bits, d, x.x, x.y, y.x, y.y);
+            set_entry_bits<MODE>(bits, d, fm, x.x, x.y, y.x, y.y);
         }
         return;
     }
@@ -1476,7 +1534,7 @@ __device__ __forceinline__ void build_entries(const BuildArgs &a, const BuildIte
         const uint32_t o0 = a.off[e], o1 = a.off[e + 1];
         uint64_t h[4];
         base_hashes_words(a.bytes + o0, o1 - o0, h);
-        set_entry_bits<M32>(bits, d, h[0], h[1], h[2], h[3]);
+        set_entry_bits<MODE>(bits, d, fm, h[0], h[1], h[2], h[3]);
     }
 }
 
@@ -1488,20 +1546,21 @@ __global__ __launch_bounds__(kBuildThreads) void k_build(const BuildArgs a)
     const uint32_t tid = threadIdx.x;
     if (d.m == 0) return;
     const uint64_t nw = (d.m + 63) >> 6;
-    const bool m32 = d.m < (1ull << 31);
+    const int mode = mod_mode(d.m);
     if (it.staged) {
         for (uint32_t i = tid; i < nw; i += kBuildThreads) lds64[i] = 0;
         __syncthreads();
         lds_u32 *bits = (lds_u32 *)lds64;
-        if (m32) build_entries<true>(a, it, d, bits, tid);
-        else     build_entries<false>(a, it, d, bits, tid);
+        if (mode == kModFp64)           build_entries<kModFp64>(a, it, d, bits, tid);
+        else if (mode == kModBarrett32) build_entries<kModBarrett32>(a, it, d, bits, tid);
+        else                            build_entries<kModBarrett64>(a, it, d, bits, tid);
         __syncthreads();
         uint64_t *dst = a.out + d.word_off;
         for (uint32_t i = tid; i < nw; i += kBuildThreads) dst[i] = lds64[i];
     } else {
         uint32_t *bits = reinterpret_cast<uint32_t *>(a.out + d.word_off);
-        if (m32) build_entries<true>(a, it, d, bits, tid);
-        else     build_entries<false>(a, it, d, bits, tid);
+        if (mode == kModBarrett64) build_entries<kModBarrett64>(a, it, d, bits, tid);
+        else                       build_entries<kModBarrett32>(a, it, d, bits, tid);
     }
 }
 

@@ -1,4 +1,6 @@
-// build_lab: time k_build variants on synthetic entries.  ./build_lab N_FILTERS ENTRIES_PER_FILTER ENTRY_LEN
+// build_lab: time k_build variants on synthetic entries.  ./build_lab N_FILTERS ENTRIES_PER_FILTER ENTRY_LEN [K [ENTRY_LEN_MAX]]
+// (with ENTRY_LEN_MAX the lengths are uniform in [ENTRY_LEN, ENTRY_LEN_MAX]: the lanes of a wave then disagree on the tail's shape,
+// as real tokens do)
 #include "../bloomsearch_amd/csrc/kernels.hip.h"
 #include <hip/hip_ext.h>
 #include <cstdio>
@@ -9,13 +11,14 @@
 using namespace bsg;
 int main(int argc, char **argv)
 {
-    const uint32_t F = argc > 1 ? atoi(argv[1]) : 600, E = argc > 2 ? atoi(argv[2]) : 19600, L = argc > 3 ? atoi(argv[3]) : 13, K = argc > 4 ? atoi(argv[4]) : 10;
+    const uint32_t F = argc > 1 ? atoi(argv[1]) : 600, E = argc > 2 ? atoi(argv[2]) : 19600, L = argc > 3 ? atoi(argv[3]) : 13, K = argc > 4 ? atoi(argv[4]) : 10, Lmax = argc > 5 ? atoi(argv[5]) : L;
     const uint64_t n = (uint64_t)F * E;
     std::mt19937_64 rng(1);
-    std::vector<uint8_t> bytes(n * L + 64);
-    for (auto &b : bytes) b = (uint8_t)rng();
     std::vector<uint32_t> off(n + 1);
-    for (uint64_t i = 0; i <= n; ++i) off[i] = (uint32_t)(i * L);
+    off[0] = 0;
+    for (uint64_t i = 0; i < n; ++i) off[i + 1] = off[i] + L + (Lmax > L ? (uint32_t)(rng() % (Lmax - L + 1)) : 0);
+    std::vector<uint8_t> bytes((size_t)off[n] + 64);
+    for (auto &b : bytes) b = (uint8_t)rng();
     const uint64_t m = 281629, nw = (m + 63) / 64, stride = (nw + 15) / 16 * 16;
     std::vector<DevDesc> desc(F);
     std::vector<BuildItem> items(F);
@@ -36,6 +39,6 @@ int main(int argc, char **argv)
         if (it) { tot += ms; best = ms < best ? ms : best; }
     }
     printf("F=%u E=%u L=%u K=%u threads=%d: avg %.1f us  best %.1f us  (%.2f ns/entry, %.0f GB/s entry bytes+offsets)\n", F, E, L, K, kBuildThreads,
-           tot / 5 * 1e3, best * 1e3, tot / 5 * 1e6 / n, (double)n * (L + 4) / (tot / 5 * 1e-3) / 1e9);
+           tot / 5 * 1e3, best * 1e3, tot / 5 * 1e6 / n, ((double)off[n] + 4.0 * n) / (tot / 5 * 1e-3) / 1e9);
     return 0;
 }

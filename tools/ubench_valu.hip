@@ -26,6 +26,13 @@ __global__ __launch_bounds__(256) void k(uint64_t *out, uint32_t a0, uint32_t b0
             if (OP == 8) a[j] = (uint32_t)((double)a[j] * 0.999) + 3;            // cvt u32->f64, mul, cvt f64->u32
             if (OP == 9) a[j] = (uint32_t)((float)a[j] * 0.999f) + 3;            // cvt u32->f32, mul, cvt
             if (OP == 10) w[j] = w[j] * (0x9E3779B97F4A7C15ull ^ b) + 1;         // 64x64 mul lo
+            if (OP == 11) w[j] = ((w[j] << 31) | (w[j] >> 33)) + 1;              // rotl64 (2 x v_alignbit) + add
+            if (OP == 12) w[j] = (w[j] ^ (w[j] >> 33)) + 1;                      // xorshift 33 + add
+            if (OP == 13) d[j] = __builtin_floor(d[j] * 1.0000001) + 0.5;        // v_mul_f64, v_floor_f64, v_add_f64
+            if (OP == 14) d[j] = (double)(uint32_t)a[j] + d[j], a[j] += b;       // v_cvt_f64_u32 + v_add_f64 + v_add_u32
+            if (OP == 15) w[j] = w[j] * 0xff51afd7ed558ccdULL + 1;               // 64x64 mul lo by a CONSTANT
+            if (OP == 16) a[j] = a[j] >= b ? a[j] - b : a[j] + 7u;               // compare + select style fix-up
+            if (OP == 17) a[j] = min(a[j] + 12345u, a[j] + 12345u - b);          // the unsigned-min fix-up
         }
     }
     uint64_t acc = 0;
@@ -52,5 +59,7 @@ int main()
     run<4>("v_add_u32", d); run<0>("v_mul_lo_u32+add", d); run<1>("v_mul_hi_u32+add", d); run<2>("v_mad_u64_u32", d);
     run<3>("mul_u24+add", d); run<5>("add_u64", d); run<6>("v_fma_f64", d); run<7>("umul64hi+add", d);
     run<10>("mul64lo+add", d); run<8>("cvt/mul/cvt f64", d); run<9>("cvt/mul/cvt f32", d);
+    run<11>("rotl64+add", d); run<12>("xorshift33+add", d); run<13>("mul/floor/add f64", d); run<14>("cvt_f64_u32+add_f64+add", d);
+    run<15>("mul64lo const+add", d); run<16>("cmp/select fixup", d); run<17>("min fixup", d);
     return 0;
 }
