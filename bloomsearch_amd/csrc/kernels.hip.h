@@ -71,12 +71,23 @@ __host__ __device__ __forceinline__ void mix_k2(uint64_t &h2, uint64_t k2)
 {
     k2 *= kC2; k2 = rotl64(k2, 33); k2 *= kC1; h2 ^= k2;
 }
+// 5 h + c as two 64-bit shift-adds (v_lshl_add_u64); spelled as a multiply the compiler makes two v_mad_u64_u32 and two moves of it
+__host__ __device__ __forceinline__ uint64_t times5_plus(uint64_t h, uint64_t c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint64_t h5;
+    asm("v_lshl_add_u64 %0, %1, 2, %1" : "=v"(h5) : "v"(h));
+    return h5 + c;
+#else
+    return h * 5 + c;
+#endif
+}
 __host__ __device__ __forceinline__ void bmix(uint64_t &h1, uint64_t &h2, uint64_t k1, uint64_t k2)
 {
     mix_k1(h1, k1);
-    h1 = rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729ULL;
+    h1 = rotl64(h1, 27); h1 += h2; h1 = times5_plus(h1, 0x52dce729ULL);
     mix_k2(h2, k2);
-    h2 = rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5ULL;
+    h2 = rotl64(h2, 31); h2 += h1; h2 = times5_plus(h2, 0x38495ab5ULL);
 }
 __host__ __device__ __forceinline__ void murmur_finalize(uint64_t h1, uint64_t h2, uint64_t len, uint64_t &o1, uint64_t &o2)
 {
@@ -165,15 +176,22 @@ __device__ __forceinline__ void base_hashes_words(const uint8_t *p, uint32_t len
     uint64_t k1 = load_u64_unaligned(p + 16 * nb), k2 = load_u64_unaligned(p + 16 * nb + 8);
     for (uint32_t i = 0; i < nb; ++i) bmix(h1, h2, load_u64_unaligned(p + 16 * i), load_u64_unaligned(p + 16 * i + 8));
     k1 &= mask.x; k2 &= mask.y;
-    murmur_finalize(h1 ^ mixed_k1(k1), h2 ^ mixed_k2(k2), len, h[0], h[1]);
+    // Below 8 tail bytes neither hash has a second tail word; from 8 on the appended byte leaves the first word alone.  Entries
+    // arrive sorted, so a wave usually agrees on the side: the two wave-uniform branches skip 2 of the 4 tail mixes (a mixed wave
+    // takes both; a lane on the other side gets the same value again, or mixes zero into zero).
+    const bool any_short = __ballot(t < 8) != 0, any_long = __ballot(t >= 8) != 0;
+    const uint64_t xa1 = mixed_k1(k1);
+    uint64_t xb1 = xa1, xa2 = 0, xb2 = 0;
+    if (any_short) xb1 = mixed_k1(k1 | one.x);
+    if (any_long) { xa2 = mixed_k2(k2); xb2 = mixed_k2(k2 | one.y); }
+    murmur_finalize(h1 ^ xa1, h2 ^ xa2, len, h[0], h[1]);
     // d || 0x01: the extra byte lands at tail position t; at t == 15 the padded tail is a whole block (bmix) and the tail is empty
-    uint64_t b1 = h1 ^ mixed_k1(k1 | one.x), b2 = h2;
-    const uint64_t x2 = mixed_k2(k2 | one.y);
+    uint64_t b1 = h1 ^ xb1, b2 = h2;
     if (t == 15) {
-        b1 = (rotl64(b1, 27) + b2) * 5 + 0x52dce729ULL;
-        b2 = (rotl64(b2 ^ x2, 31) + b1) * 5 + 0x38495ab5ULL;
+        b1 = times5_plus(rotl64(b1, 27) + b2, 0x52dce729ULL);
+        b2 = times5_plus(rotl64(b2 ^ xb2, 31) + b1, 0x38495ab5ULL);
     } else {
-        b2 ^= x2;
+        b2 ^= xb2;
     }
     murmur_finalize(b1, b2, (uint64_t)len + 1, h[2], h[3]);
 }
