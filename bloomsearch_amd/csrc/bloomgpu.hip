@@ -976,6 +976,10 @@ static int32_t build_on_device(bsg_ctx *ctx, Device &d, BuildPart &P, const uint
                 items.push_back({f, e, std::min(fstart[f + 1], e + kBuildSliceEntries), 0u});
         }
     }
+    // Longest first: workgroups are handed out in item order, so the few-entry items (a block's field filter: nine entries) fill the
+    // tail of the launch instead of taking slots between the long ones.
+    if (items.size() > 1)
+        std::stable_sort(items.begin(), items.end(), [](const bsg::BuildItem &x, const bsg::BuildItem &y) { return x.e_end - x.e_begin > y.e_end - y.e_begin; });
     d.calls.fetch_add(1, std::memory_order_relaxed);
     std::lock_guard<std::mutex> lk(d.mu);
     if (int32_t rc = use_device(d)) return rc;

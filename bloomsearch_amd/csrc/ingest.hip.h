@@ -981,7 +981,7 @@ __global__ __launch_bounds__(256) void k_ingest_add(const uint8_t *bytes, const 
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n) return;
     uint64_t h[4];
-    base_hashes_words(bytes + off[e], off[e + 1] - off[e], h);
+    base_hashes_at(bytes, off[e], off[e + 1] - off[e], h);
     const uint64_t f = entry_fp(bytes + off[e], off[e + 1] - off[e], key);
     const uint32_t t = table_of_entry[e];
     set_insert(tables[t], h, f, counts + t, status + t);
@@ -994,7 +994,7 @@ __global__ __launch_bounds__(256) void k_hash_fp_entries(const uint8_t *bytes, c
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n) return;
     uint64_t h[4];
-    base_hashes_words(bytes + off[e], off[e + 1] - off[e], h);
+    base_hashes_at(bytes, off[e], off[e + 1] - off[e], h);
     for (int j = 0; j < 4; ++j) out_h[(uint64_t)e * 4 + j] = h[j];
     out_fp[e] = entry_fp(bytes + off[e], off[e + 1] - off[e], key);
 }
