@@ -327,6 +327,7 @@ class Context:
         self._check(self.L.bsg_scope_open(self.h, C.byref(h)))
         sc = Context.__new__(Context)
         sc.L, sc.h, sc.n_devices = self.L, h, self.n_devices
+        sc._dependents = weakref.WeakSet()
         return sc
 
     def probe(self, arena_id: int, n_blocks: int, terms: np.ndarray, prog_ops, prog_off) -> np.ndarray:
