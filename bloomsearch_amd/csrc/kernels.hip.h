@@ -363,11 +363,28 @@ typedef __attribute__((address_space(3))) uint32_t lds_u32;
 typedef __attribute__((address_space(3))) uint64_t lds_u64;
 typedef __attribute__((address_space(3))) uint16_t lds_u16;
 
+// MODE: how a location index becomes a bit position (0 / 1 are also what the older `bool M32` instantiations convert to)
+constexpr int kModBarrett64 = 0, kModBarrett32 = 1, kModFp64 = 2;
+__device__ __forceinline__ int mod_mode(uint64_t m) { return modf64_ok(m) ? kModFp64 : m < (1ull << 31) ? kModBarrett32 : kModBarrett64; }
+
+// A probe workgroup's filter: the descriptor plus the fp64 route's constants (filled when mod_mode(d.m) == kModFp64)
+struct ProbeDesc : DevDesc {
+    ModF64 f;
+};
+
 // location index -> bit position in the filter
-template <bool M32>
+template <int MODE>
 __device__ __forceinline__ uint64_t locate(const DevDesc &d, uint64_t x)
 {
-    if (M32) return mod_m32(x, (uint32_t)d.m, d.magic);
+    static_assert(MODE != kModFp64, "the fp64 route needs a ProbeDesc");
+    if (MODE == kModBarrett32) return mod_m32(x, (uint32_t)d.m, d.magic);
+    return mod_m(x, d.m, d.magic);
+}
+template <int MODE>
+__device__ __forceinline__ uint64_t locate(const ProbeDesc &d, uint64_t x)
+{
+    if (MODE == kModFp64) return mod_f64(x, d.f);
+    if (MODE == kModBarrett32) return mod_m32(x, (uint32_t)d.m, d.magic);
     return mod_m(x, d.m, d.magic);
 }
 template <typename BITS32>
@@ -402,8 +419,8 @@ constexpr uint32_t kParallelKMaxWords = 2;  // term words (x64 terms) up to whic
 // waits for the bitset DMA; only the LDS bit test sits behind the barrier.
 struct ParTask { uint64_t loc; uint32_t w; bool real; };
 
-template <bool M32>
-__device__ __forceinline__ ParTask par_task_prepare(const ProbeArgs &a, const DevDesc &d, uint32_t t0, uint32_t n_real,
+template <int M32>
+__device__ __forceinline__ ParTask par_task_prepare(const ProbeArgs &a, const ProbeDesc &d, uint32_t t0, uint32_t n_real,
                                                     uint32_t n_tw, uint32_t task, uint32_t lane)
 {
     const uint32_t i = task / n_tw, w = task - i * n_tw;
@@ -471,10 +488,11 @@ __device__ __forceinline__ uint32_t mod_m32_parts(uint32_t xl, uint32_t xh, uint
     const uint32_t r = xl - qlo * m;
     return min(r, r - m);   // r in [0, 2m): r - m wraps far above r exactly when r < m
 }
-template <bool M32>
-__device__ __forceinline__ uint64_t locate_c(const DevDesc &d, uint64_t x)
+template <int M32>
+__device__ __forceinline__ uint64_t locate_c(const ProbeDesc &d, uint64_t x)
 {
-    if (M32) return mod_m32_parts((uint32_t)x, (uint32_t)(x >> 32), (uint32_t)d.m, (uint32_t)d.magic, (uint32_t)(d.magic >> 32));
+    if (M32 == kModFp64) return mod_f64(x, d.f);
+    if (M32 == kModBarrett32) return mod_m32_parts((uint32_t)x, (uint32_t)(x >> 32), (uint32_t)d.m, (uint32_t)d.magic, (uint32_t)(d.magic >> 32));
     return mod_m(x, d.m, d.magic);
 }
 // One bit of the filter as 0 / 1.  The staged image sits at LDS offset 0, so its words are addressed by plain integers
@@ -498,8 +516,8 @@ __device__ __forceinline__ uint32_t lane_rank(uint64_t mask)
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
-template <bool M32, uint32_t NW, typename BITS32>
-__device__ __forceinline__ void probe_rounds(const ProbeArgs &a, const DevDesc &d, BITS32 bits, uint32_t t0,
+template <int M32, uint32_t NW, typename BITS32>
+__device__ __forceinline__ void probe_rounds(const ProbeArgs &a, const ProbeDesc &d, BITS32 bits, uint32_t t0,
                                              uint32_t n_tw, lds_u16 *queues, lds_u32 *vbits,
                                              uint32_t wave, uint32_t lane, const uint64_t (&loc_first)[kGroup])
 {
@@ -712,8 +730,8 @@ __device__ __forceinline__ void store_verdict(uint64_t *vout, uint32_t w, uint64
     else vout[(uint64_t)w * 64] = v;
 }
 
-template <bool M32, bool STAGED, uint32_t NT, bool ONLY_PAR, bool VSC1 = false>
-__device__ __forceinline__ void probe_block(const ProbeArgs &a, const DevDesc &d, const uint64_t *src, char *image,
+template <int M32, bool STAGED, uint32_t NT, bool ONLY_PAR, bool VSC1 = false>
+__device__ __forceinline__ void probe_block(const ProbeArgs &a, const ProbeDesc &d, const uint64_t *src, char *image,
                                             uint32_t t0, uint32_t n_real, uint32_t n_tw, lds_u64 *vw, lds_u16 *queues,
                                             uint64_t *vout, uint32_t tid)
 {
@@ -794,7 +812,8 @@ __device__ __forceinline__ void probe_role(const ProbeArgs &a, const ArenaRef &a
     const uint32_t wave = tid / kWave;
 
     if (b >= ar.n_blocks) return;   // arenas of a group may differ in size
-    const DevDesc d = load_desc_uniform(ar.desc + ((uint64_t)b * 3 + a.kind[y]));
+    ProbeDesc d;
+    static_cast<DevDesc &>(d) = load_desc_uniform(ar.desc + ((uint64_t)b * 3 + a.kind[y]));
     const uint32_t t0 = a.term_begin[y];
     const uint32_t n_real = a.term_count[y];
     const uint32_t n_tw = (n_real + 63) >> 6;
@@ -811,7 +830,17 @@ __device__ __forceinline__ void probe_role(const ProbeArgs &a, const ArenaRef &a
 
     const uint64_t nw = (d.m + 63) >> 6;
     const uint64_t *src = ar.words + d.word_off;
-    const bool m32 = d.m < (1ull << 31);
+    // The fp64 route only where the probe is bound by instruction issue — the many-term kernels (ONLY_PAR == false).  Measured on one
+    // box, round 6 (tools/ab_probe_mod.sh, Barrett vs fp64 in every probe kernel): needle batch (4 054 terms, k_probe_terms_many)
+    // 373-377 -> 362-364 us per 20 arenas; C2 103.6-103.8 -> 102.5-103.0; C4 (77 terms, two tasks per wave behind the barrier)
+    // 1 112-1 122 -> 1 128-1 153 us: the few-term kernels stream, and there the route's set-up per workgroup costs what it saves.
+#ifdef BSG_LAB_PROBE_FP64          // lab only: the fp64 route in the few-term kernels too
+    const int mode = mod_mode(d.m);
+#else
+    const int mode = ONLY_PAR ? (d.m < (1ull << 31) ? kModBarrett32 : kModBarrett64) : mod_mode(d.m);
+#endif
+    d.f = ModF64{};
+    if (mode == kModFp64) d.f = make_modf64(d.m, d.magic);
     // Few probes against a large bitset (a single query, Q = 1): touching <= terms * k sectors straight from L2 / HBM
     // beats streaming the whole bitset into LDS (the "gather regime" of SURVEY 8d).
     const bool gather = (uint64_t)n_real * d.k * a.gather_cost < nw * 8;
@@ -825,11 +854,13 @@ __device__ __forceinline__ void probe_role(const ProbeArgs &a, const ArenaRef &a
             if (boff < nbytes)
                 __builtin_amdgcn_global_load_lds((glb_void *)(g + boff), (lds_void *)(image + c), 16, 0, BSG_DMA_AUX);
         }
-        if (m32) probe_block<true, true, NT, ONLY_PAR, VSC1>(a, d, src, image, t0, n_real, n_tw, vw, queues, vout, tid);
-        else     probe_block<false, true, NT, ONLY_PAR, VSC1>(a, d, src, image, t0, n_real, n_tw, vw, queues, vout, tid);
+        if (mode == kModFp64)           probe_block<kModFp64, true, NT, ONLY_PAR, VSC1>(a, d, src, image, t0, n_real, n_tw, vw, queues, vout, tid);
+        else if (mode == kModBarrett32) probe_block<kModBarrett32, true, NT, ONLY_PAR, VSC1>(a, d, src, image, t0, n_real, n_tw, vw, queues, vout, tid);
+        else                            probe_block<kModBarrett64, true, NT, ONLY_PAR, VSC1>(a, d, src, image, t0, n_real, n_tw, vw, queues, vout, tid);
     } else {
-        if (m32) probe_block<true, false, NT, ONLY_PAR, VSC1>(a, d, src, image, t0, n_real, n_tw, vw, queues, vout, tid);
-        else     probe_block<false, false, NT, ONLY_PAR, VSC1>(a, d, src, image, t0, n_real, n_tw, vw, queues, vout, tid);
+        // (gathered and beyond-LDS filters: the fp64 route's range ends far below them; small gathered ones take Barrett)
+        if (mode != kModBarrett64) probe_block<kModBarrett32, false, NT, ONLY_PAR, VSC1>(a, d, src, image, t0, n_real, n_tw, vw, queues, vout, tid);
+        else                       probe_block<kModBarrett64, false, NT, ONLY_PAR, VSC1>(a, d, src, image, t0, n_real, n_tw, vw, queues, vout, tid);
     }
 }
 
@@ -1495,10 +1526,6 @@ __device__ __forceinline__ void for_each_location_x(uint32_t k, uint64_t h0, uin
 // Sets the k bits of one entry.  (Measured and dropped, round 6: an approximate-quotient modulo for m < 2^30 — lo32(xh mh) + hi32(xh ml) +
 // hi32(xl mh), remainder candidate in [0, 4m), two unsigned-min fix-ups: 10 instructions on paper against 12-13 — is 7 % SLOWER,
 // 239 -> 256 us per 1 000 x 19 600 entries: v_mul_hi_u32 issues slower than the v_mad_u64_u32 the exact quotient is made of.)
-// MODE: how a location index becomes a bit position
-constexpr int kModBarrett64 = 0, kModBarrett32 = 1, kModFp64 = 2;
-__device__ __forceinline__ int mod_mode(uint64_t m) { return modf64_ok(m) ? kModFp64 : m < (1ull << 31) ? kModBarrett32 : kModBarrett64; }
-
 template <int MODE, typename BITS32>
 __device__ __forceinline__ void set_entry_bits(BITS32 bits, const DevDesc &d, const ModF64 &fm, uint64_t h0, uint64_t h1, uint64_t h2, uint64_t h3)
 {
