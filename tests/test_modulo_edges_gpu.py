@@ -96,3 +96,43 @@ def test_full_recurrence_with_wrapping_sums(ctx, m, k):
                 bit = O.location(hh, i) % m
                 want[bit >> 6] |= np.uint64(1 << (bit & 63))
         assert np.array_equal(got[f * stride: f * stride + nw], want)
+
+
+@pytest.mark.parametrize("n_terms", [40, 300])        # 40: the few-term kernel (Barrett); 300: the many-term kernel (fp64 route below 2^19 bits)
+@pytest.mark.parametrize("m,k", [(64, 11), (65, 7), (4096, 10), (281629, 10), ((1 << 19) - 1, 10), (1 << 19, 10), ((1 << 19) + 1, 10), (1 << 20, 4)])
+def test_probe_with_chosen_term_hashes(ctx, m, k, n_terms):
+    """The probe's side of the same routes: term hashes are an input of bsg_probe, so the location indices can be chosen here too.
+    Bitsets are random words (half the bits set): a verdict is right only if every one of the k tested positions is."""
+    from bloomsearch_amd import query as Q
+    from bloomsearch_amd._lib import TERM_DTYPE
+    rng = np.random.default_rng(m * 7 + k + n_terms)
+    n_blocks = 3
+    nw = (m + 63) // 64
+    stride = (nw + 15) // 16 * 16
+    desc = np.zeros(n_blocks * 3, dtype=DESC_DTYPE)
+    words = rng.integers(0, U64, size=stride * n_blocks * 3, dtype=np.uint64, endpoint=True)
+    for f in range(n_blocks * 3):
+        desc[f] = (f * stride, m, k, 0)
+    if m % 64:
+        for f in range(n_blocks * 3):
+            words[f * stride + nw - 1] &= np.uint64((1 << (m % 64)) - 1)
+    xs = crafted_indices(m, rng)
+    picks = [xs[int(i) % len(xs)] for i in rng.permutation(max(len(xs), 2 * n_terms))[: 2 * n_terms]]
+    cb = Q.compile_queries([Q.Token("t%d" % i) for i in range(n_terms)])
+    ops, poff, kinds = cb.arrays()
+    terms = np.zeros(len(cb.term_strings), dtype=TERM_DTYPE)
+    assert len(terms) == n_terms
+    terms["kind"] = kinds
+    h = np.zeros((n_terms, 4), dtype=np.uint64)
+    h[:, 0] = np.array(picks[0::2], dtype=np.uint64)
+    h[:, 1] = np.array(picks[1::2], dtype=np.uint64)
+    h[n_terms // 2:, 2:] = rng.integers(0, U64, size=(n_terms - n_terms // 2, 2), dtype=np.uint64, endpoint=True)   # half with the full recurrence
+    terms["h"] = h
+    aid = ctx.arena_load(words, desc)
+    try:
+        got = ctx.probe(aid, n_blocks, terms, ops, poff)
+    finally:
+        ctx.arena_free(aid)
+    want = O.probe_batch(words, desc.view(O.DESC_DTYPE), terms.view(O.TERM_DTYPE), ops, poff)
+    assert np.array_equal(got, want)
+    assert want.any() or k > 4                           # (with k = 10 random bits, few verdicts pass: the comparison above is the test)
