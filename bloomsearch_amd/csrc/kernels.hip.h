@@ -331,6 +331,12 @@ __device__ __forceinline__ uint32_t mod_m32(uint64_t x, uint32_t m, uint64_t mag
 //   r = lo32(y) - q m  in [0, 2m)               one v_mad_u64_u32 (by 2^32 - m), one unsigned-min fix-up
 // 6 VALU instructions against the 13 the compiler makes of the 64x64 Barrett quotient (ISA of k_build, round 6).  Exact: nothing
 // approximate survives into r.  Both constants come out of the descriptor's magic = floor(2^64 / m) without a division.
+// (Measured and dropped, round 6: the fix-up traded for an exact quotient — yd = Y - (2^52 - m), the smallest double above 1/m as
+// the reciprocal, the low mantissa word is floor(y/m) + 1 always — with the result (x mod m) - m addressing the staged bitset from
+// its top and a funnel shift in the copy-out: 9 instructions per location instead of 10, bit-exact in the whole suite, and on one
+// box C3 builds in 355.4-356.9 us against 355.9-356.7: the v_add_f64 it needs costs what the subtract and the minimum did.
+// A first version of it, positions in [1, m] with one spare bit, was wrong for x mod m < m/2 with x < m — the sum falls below 2^52,
+// where doubles step by 1/2 — and tests/test_modulo_edges_gpu.py said so at once.)
 struct ModF64 {
     uint32_t T;        // 2^32 mod m
     uint32_t negm;     // 2^32 - m
