@@ -11,7 +11,7 @@
 using namespace bsg;
 int main(int argc, char **argv)
 {
-    const uint32_t F = argc > 1 ? atoi(argv[1]) : 600, E = argc > 2 ? atoi(argv[2]) : 19600, L = argc > 3 ? atoi(argv[3]) : 13, K = argc > 4 ? atoi(argv[4]) : 10, Lmax = argc > 5 ? atoi(argv[5]) : L;
+    const uint32_t F = argc > 1 ? atoi(argv[1]) : 600, E = argc > 2 ? atoi(argv[2]) : 19600, L = argc > 3 ? atoi(argv[3]) : 13, K = argc > 4 ? atoi(argv[4]) : 10, Lmax = argc > 5 ? atoi(argv[5]) : L, lds_pad = argc > 6 ? atoi(argv[6]) : 0;   // lds_pad: extra LDS bytes per workgroup (fewer workgroups per CU)
     const uint64_t n = (uint64_t)F * E;
     std::mt19937_64 rng(1);
     std::vector<uint32_t> off(n + 1);
@@ -33,12 +33,12 @@ int main(int argc, char **argv)
     BuildArgs a{db, doff, nullptr, di, dd, dout};
     float best = 1e9, tot = 0;
     for (int it = 0; it < 6; ++it) {
-        hipExtLaunchKernelGGL(k_build, dim3(F), dim3(kBuildThreads), (uint32_t)(nw * 8), 0, e0, e1, 0, a);
+        hipExtLaunchKernelGGL(k_build, dim3(F), dim3(kBuildThreads), (uint32_t)(nw * 8) + lds_pad, 0, e0, e1, 0, a);
         CHECK(hipEventSynchronize(e1));
         float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
         if (it) { tot += ms; best = ms < best ? ms : best; }
     }
-    printf("F=%u E=%u L=%u K=%u threads=%d: avg %.1f us  best %.1f us  (%.2f ns/entry, %.0f GB/s entry bytes+offsets)\n", F, E, L, K, kBuildThreads,
+    printf("F=%u E=%u L=%u K=%u lds+%u threads=%d: avg %.1f us  best %.1f us  (%.2f ns/entry, %.0f GB/s entry bytes+offsets)\n", F, E, L, K, lds_pad, kBuildThreads,
            tot / 5 * 1e3, best * 1e3, tot / 5 * 1e6 / n, ((double)off[n] + 4.0 * n) / (tot / 5 * 1e-3) / 1e9);
     return 0;
 }
