@@ -752,7 +752,8 @@ __device__ __forceinline__ void probe_block(const ProbeArgs &a, const ProbeDesc 
         vw[w] = par ? (rem >= 64 ? ~0ULL : ((1ULL << rem) - 1)) : 0ULL;   // A: AND failures in; C: OR hits in
     }
     // mode A: the first kParPre tasks of every wave (hash loads + reductions) are done while the bitset is still on its way
-    // (measured per 20 arenas, C2 / the C4 batch: 1 task 103.1 / 115.7 us, 2 tasks 101.7 / 114.0, 3 tasks 103.8 / 115.6)
+    // (measured per 20 arenas, C2 / the C4 batch: 1 task 103.1 / 115.7 us, 2 tasks 101.7 / 114.0, 3 tasks 103.8 / 115.6; round 6: the
+    // third task's hash LOADS alone ahead of the barrier, C4 per 200 arenas on one box: 1 109-1 114 vs 1 100-1 112 us without)
 #ifndef BSG_PAR_PRE
 #define BSG_PAR_PRE 2
 #endif
