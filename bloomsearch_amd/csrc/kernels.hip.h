@@ -355,12 +355,14 @@ __host__ __device__ __forceinline__ ModF64 make_modf64(uint64_t m, uint64_t magi
     f.C = 0x1p52 - (double)(K + 1) * 0.5;
     return f;
 }
-__device__ __forceinline__ uint32_t mod_f64(uint64_t x, const ModF64 &f)
+// (__host__ too: tests/modf64_check.hip sweeps it on the CPU against % — the arithmetic is IEEE fma on both sides)
+__host__ __device__ __forceinline__ uint32_t mod_f64(uint64_t x, const ModF64 &f)
 {
     const uint64_t Y = ((uint64_t)(uint32_t)(x >> 32) * f.T + (uint32_t)x) | 0x4330000000000000ull;
-    const uint32_t q = (uint32_t)__double_as_longlong(__builtin_fma(__longlong_as_double((long long)Y), f.inv, f.C));
+    const uint32_t q = (uint32_t)__builtin_bit_cast(uint64_t, __builtin_fma(__builtin_bit_cast(double, Y), f.inv, f.C));
     const uint32_t r = (uint32_t)((uint64_t)q * f.negm + Y);
-    return min(r, r - (0u - f.negm));
+    const uint32_t r2 = r - (0u - f.negm);
+    return r2 < r ? r2 : r;                      // unsigned minimum: r - m wraps far above r exactly when r < m
 }
 
 typedef __attribute__((address_space(3))) void lds_void;
