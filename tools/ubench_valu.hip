@@ -19,8 +19,8 @@ __global__ __launch_bounds__(256) void k(uint64_t *out, uint32_t a0, uint32_t b0
             if (OP == 1) a[j] = __umulhi(a[j], b) + a[j];                        // v_mul_hi_u32 (+add)
             if (OP == 2) w[j] = (uint64_t)(uint32_t)w[j] * b + w[j];             // v_mad_u64_u32
             if (OP == 3) a[j] = __umul24(a[j], b) + 1;                           // v_mul_u32_u24 / mad_u32_u24
-            if (OP == 4) a[j] = a[j] + b;                                        // v_add_u32
-            if (OP == 5) w[j] = w[j] + ((uint64_t)b << 32 | a0);                 // 64-bit add
+            if (OP == 4) a[j] = a[j] + a[(j + 1) & 7];                            // v_add_u32 (operands the compiler cannot fold)
+            if (OP == 5) w[j] = w[j] + w[(j + 1) & 7];                            // 64-bit add (v_lshl_add_u64)
             if (OP == 6) d[j] = __builtin_fma(d[j], 1.0000001, 0.5);             // v_fma_f64
             if (OP == 7) w[j] = __umul64hi(w[j], 0x9E3779B97F4A7C15ull ^ b) + 1; // 64x64 mulhi
             if (OP == 8) a[j] = (uint32_t)((double)a[j] * 0.999) + 3;            // cvt u32->f64, mul, cvt f64->u32
@@ -33,6 +33,8 @@ __global__ __launch_bounds__(256) void k(uint64_t *out, uint32_t a0, uint32_t b0
             if (OP == 15) w[j] = w[j] * 0xff51afd7ed558ccdULL + 1;               // 64x64 mul lo by a CONSTANT
             if (OP == 16) a[j] = a[j] >= b ? a[j] - b : a[j] + 7u;               // compare + select style fix-up
             if (OP == 17) a[j] = min(a[j] + 12345u, a[j] + 12345u - b);          // the unsigned-min fix-up
+            if (OP == 18) d[j] = d[j] + d[(j + 1) & 7];                           // v_add_f64
+            if (OP == 19) d[j] = d[j] * d[(j + 1) & 7];                           // v_mul_f64
         }
     }
     uint64_t acc = 0;
@@ -60,6 +62,6 @@ int main()
     run<3>("mul_u24+add", d); run<5>("add_u64", d); run<6>("v_fma_f64", d); run<7>("umul64hi+add", d);
     run<10>("mul64lo+add", d); run<8>("cvt/mul/cvt f64", d); run<9>("cvt/mul/cvt f32", d);
     run<11>("rotl64+add", d); run<12>("xorshift33+add", d); run<13>("mul/floor/add f64", d); run<14>("cvt_f64_u32+add_f64+add", d);
-    run<15>("mul64lo const+add", d); run<16>("cmp/select fixup", d); run<17>("min fixup", d);
+    run<15>("mul64lo const+add", d); run<16>("cmp/select fixup", d); run<17>("min fixup", d); run<18>("v_add_f64", d); run<19>("v_mul_f64", d);
     return 0;
 }
