@@ -1462,8 +1462,19 @@ __global__ __launch_bounds__(256) void k_survivor_rows(const RowsArgs a, const A
         const uint64_t *src = base + (uint64_t)q0 * G;
         const uint32_t dr = 256u / G, dc = 256u % G;         // (one division per lane, not one per word)
         uint32_t r = threadIdx.x / G, c = threadIdx.x % G;
-        for (uint32_t i = threadIdx.x; i < rows * G; i += 256u) {
-            tile[r * Gp + c] = src[i];
+        // all of a lane's words are requested before the first one is used: as a loop with one load per trip (until round 6) the
+        // compiler waited for every load in turn — up to 16 round trips, with 1.25 workgroups per CU nothing else to run meanwhile
+        // (20 arenas x 4 096 rows: 21 us, most of it this).  rows * G <= 256 * kRowsStageG: kRowsStageG trips cover the tile.
+        const uint32_t n = rows * G;
+        uint64_t v[kRowsStageG];
+#pragma unroll
+        for (uint32_t u = 0; u < kRowsStageG; ++u) {
+            const uint32_t i = threadIdx.x + u * 256u;
+            v[u] = i < n ? src[i] : 0;
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < kRowsStageG; ++u) {
+            if (threadIdx.x + u * 256u < n) tile[r * Gp + c] = v[u];
             r += dr; c += dc;
             if (c >= G) { c -= G; ++r; }
         }
