@@ -1044,7 +1044,15 @@ __device__ __forceinline__ void eval_role(const EvalArgs &a, const ArenaRef &ar,
                 };
 #pragma unroll
                 for (uint32_t j = 0; j < kPre; ++j) if (j < len) step(pre[j]);
-                for (uint32_t j = kPre; j < len; ++j) step(P[(uint64_t)j * kEvalThreads]);
+                // longer programs: the next kPre op words requested together (one load per trip, each waited for, was a round trip
+                // to L2 per op: the C4 batch's 8-term Or is 15 ops)
+                for (uint32_t j0 = kPre; j0 < len; j0 += kPre) {
+                    uint32_t more[kPre];
+#pragma unroll
+                    for (uint32_t u = 0; u < kPre; ++u) more[u] = j0 + u < len ? P[(uint64_t)(j0 + u) * kEvalThreads] : (7u << 28);
+#pragma unroll
+                    for (uint32_t u = 0; u < kPre; ++u) if (j0 + u < len) step(more[u]);
+                }
             }
             const uint32_t nvalid = ar.n_blocks - g * 64;
             res[t] = top & (nvalid >= 64 ? ~0ULL : ((1ULL << nvalid) - 1));
@@ -1139,7 +1147,13 @@ __device__ __forceinline__ void eval_role_all(const EvalArgs &a, const ArenaRef 
     };
 #pragma unroll
     for (uint32_t j = 0; j < kPre; ++j) if (j < len) step(pre[j]);
-    for (uint32_t j = kPre; j < len; ++j) step(P[(uint64_t)j * kEvalThreads]);
+    for (uint32_t j0 = kPre; j0 < len; j0 += kPre) {        // (the next kPre op words together: see eval_role)
+        uint32_t more[kPre];
+#pragma unroll
+        for (uint32_t u = 0; u < kPre; ++u) more[u] = j0 + u < len ? P[(uint64_t)(j0 + u) * kEvalThreads] : (7u << 28);
+#pragma unroll
+        for (uint32_t u = 0; u < kPre; ++u) if (j0 + u < len) step(more[u]);
+    }
 #pragma unroll
     for (uint32_t tt = 0; tt < TILE; ++tt) {
         if (tt < gt) {
