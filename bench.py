@@ -453,7 +453,7 @@ def main():
                                   hdr=Ring(hdr_ring), hdr_per_step=NQ)
         if rank == 0:
             h0 = sh.part(0)[row_words:].view(np.uint32)[:NQ]
-            if not args.no_check and not np.array_equal(rows_to_dense(h0, sh.part(0)[:wps], B), got):
+            if not args.no_check and not np.array_equal(rows_to_dense(h0, sh.part(0)[:wps], B, packed=C.ROWS_PACKED), got):
                 sys.exit("survivor rows delivered to the shared host segment do not expand to the direct probe's bitsets")
             rows_tags = [int(x) for x in np.bincount(h0 >> 30, minlength=4)]
     sh.close()
@@ -529,7 +529,7 @@ def main():
                             "host_gather": {"ms_per_step": h_elapsed / args.steps * 1e3, "value": probes_per_step * args.steps / h_elapsed,
                                             "survivor_bytes_per_step_per_gpu": wps * 8, "page_locked": page_locked,
                                             "rows": None if r_elapsed is None else {
-                                                "api": "bsg_probe_many_rows", "ms_per_step": r_elapsed / args.steps * 1e3,
+                                                "api": "bsg_probe_many_rows" + (" (BSG_PROBE_ROWS_PACKED)" if C.ROWS_PACKED else ""), "ms_per_step": r_elapsed / args.steps * 1e3,
                                                 "value": probes_per_step * args.steps / r_elapsed, "rows_by_tag_none_all_list_dense": rows_tags}}}
         if world > 1 and c4:
             # N > 1: the headline is BASELINE configs[3] — C4, STRONG scaling (10 000 blocks in total, block b on rank b % N, the 8-term

@@ -283,6 +283,11 @@ def merge_timing(a, b):
     return t
 
 
+# flags added to every bsg_probe_many_rows call of the bench (BSG_BENCH_ROWS_DENSE=1: the dense slot layout of rounds 4-5)
+ROWS_PACKED = os.environ.get("BSG_BENCH_ROWS_DENSE", "0") != "1"
+ROWS_FLAGS = 8 if ROWS_PACKED else 0          # _lib.PROBE_ROWS_PACKED
+
+
 class Prober:
     """Drives bsg_probe_many over a list of steps (each step = the arena ids probed once)."""
 
@@ -325,7 +330,8 @@ class Prober:
         from bloomsearch_amd import _lib
         L, h, bid, fl = self.ctx.L, self.ctx.h, self.bid, flags | _lib.PROBE_ASYNC
         for _ids, _dst, _hd, p_ids, n, p_dst, p_hd in calls:
-            rc = L.bsg_probe_many(h, p_ids, n, bid, fl, p_dst) if p_hd is None else L.bsg_probe_many_rows(h, p_ids, n, bid, fl, p_dst, p_hd)
+            # (rows in their packed form: a run's LIST / DENSE payloads leave as one contiguous stretch instead of one PCIe write per row)
+            rc = L.bsg_probe_many(h, p_ids, n, bid, fl, p_dst) if p_hd is None else L.bsg_probe_many_rows(h, p_ids, n, bid, fl | ROWS_FLAGS, p_dst, p_hd)
             if rc:
                 self.ctx._check(rc)
 

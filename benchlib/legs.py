@@ -764,7 +764,7 @@ def c4_leg(ctx, args, rank, world, workers, log, barrier=None, headline=False):
         o = 0
         for f in range(n_files):                                   # the rows of the last call's first step expand to the direct probe's bitsets
             if local_blocks[f] and not args.no_check:
-                back = rows_to_dense(h_all[f * NQ: (f + 1) * NQ], sh.part(rank)[rr.last + o: rr.last + o + NQ * G[f]], local_blocks[f])
+                back = rows_to_dense(h_all[f * NQ: (f + 1) * NQ], sh.part(rank)[rr.last + o: rr.last + o + NQ * G[f]], local_blocks[f], packed=C.ROWS_PACKED)
                 if not np.array_equal(back, got[f]):
                     sys.exit("c4: survivor rows of file %d do not expand to the direct probe's bitsets" % f)
             o += NQ * G[f]

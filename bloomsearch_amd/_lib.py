@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(HERE, "csrc", "libbloomgpu.so")
 BSG_OK, BSG_E_INVALID, BSG_E_HIP, BSG_E_NOMEM, BSG_E_NOTFOUND, BSG_E_UNSUPPORTED, BSG_E_NODEVICE = 0, -1, -2, -3, -4, -5, -6
 KIND_FIELD, KIND_TOKEN, KIND_FIELD_TOKEN = 0, 1, 2
 OP_TERM, OP_AND, OP_OR, OP_TRUE, OP_FALSE = 0, 1, 2, 3, 4
-PROBE_ASYNC, PROBE_TIMED, PROBE_NOFUSE = 1, 2, 4
+PROBE_ASYNC, PROBE_TIMED, PROBE_NOFUSE, PROBE_ROWS_PACKED = 1, 2, 4, 8
 INGEST_TRUSTED_JSON = 1
 
 TERM_DTYPE = np.dtype([("h", "<u8", (4,)), ("kind", "<u4"), ("reserved", "<u4")])
@@ -73,7 +73,7 @@ EXPORTS = [
     "bsg_arena_stream_begin", "bsg_arena_stream_append", "bsg_arena_stream_finish", "bsg_arena_stream_abort",
     "bsg_set_arena_budget", "bsg_file_arena_acquire", "bsg_file_arena_have", "bsg_file_arena_publish", "bsg_file_arena_release",
     "bsg_file_arena_forget", "bsg_arena_cache_stats_read",
-    "bsg_batch_create", "bsg_batch_free", "bsg_probe_batch", "bsg_probe_many", "bsg_probe", "bsg_query", "bsg_query_stats_read", "bsg_survivor_list", "bsg_probe_many_rows", "bsg_survivor_row_list", "bsg_survivor_rows_size", "bsg_survivor_rows_list", "bsg_timing_read", "bsg_last_kernel_ms",
+    "bsg_batch_create", "bsg_batch_free", "bsg_probe_batch", "bsg_probe_many", "bsg_probe", "bsg_query", "bsg_query_stats_read", "bsg_survivor_list", "bsg_probe_many_rows", "bsg_survivor_row_list", "bsg_survivor_rows_size", "bsg_survivor_rows_list", "bsg_survivor_rows_list_packed", "bsg_timing_read", "bsg_last_kernel_ms",
     "bsg_or_reduce", "bsg_or_words_dev", "bsg_or_reduce_dev", "bsg_last_or_ms",
     "bsg_comm_unique_id", "bsg_comm_init", "bsg_comm_destroy", "bsg_comm_info", "bsg_or_allreduce", "bsg_or_allreduce_dev",
     "bsg_ingest_rows", "bsg_ingest_fallback_rows", "bsg_ingest_add_entries", "bsg_ingest_finish", "bsg_ingest_build",
@@ -140,6 +140,7 @@ def load():
     L.bsg_survivor_row_list.argtypes = [u32, vp, u32, vp, u32, C.POINTER(u32)]
     L.bsg_survivor_rows_size.argtypes = [vp, vp, u32, u64, C.POINTER(u64), C.POINTER(u64)]
     L.bsg_survivor_rows_list.argtypes = [vp, vp, u32, u64, vp, vp, u32, u32, vp, u32, C.POINTER(u32)]
+    L.bsg_survivor_rows_list_packed.argtypes = [vp, vp, u32, u64, vp, vp, u32, u32, vp, u32, C.POINTER(u32)]
     L.bsg_survivor_list.argtypes = [vp, u32, vp, u32, C.POINTER(u32)]
     L.bsg_query.argtypes = [vp, vp, u32, vp, vp, vp, u32, vp, vp, u32, vp]
     L.bsg_lab_query_cpu.argtypes = [vp, vp, i32]

@@ -1500,6 +1500,87 @@ __global__ __launch_bounds__(256) void k_survivor_rows(const RowsArgs a, const A
     survivor_row(base + (uint64_t)q * G, G, ar.n_blocks, a.hdr + d.hdr_off + q, a.rows + d.row_off + (uint64_t)q * G);
 }
 
+// The PACKED form of the rows (BSG_PROBE_ROWS_PACKED): the payloads of a run of 256 consecutive queries of one arena — a LIST row's
+// ids as ceil(count / 2) words, a DENSE row's G words — lie back to back, in query order, from the start of the run's slot area.
+// Why: a store into host memory that does not fill a line is one PCIe write of its own; the dense layout makes one per LIST row
+// (17 240 per 20 C2 arenas: 18.7 of the kernel's 27 us, profiles/r06_hostwrite_lab.txt), the packed run leaves as one contiguous
+// stretch written with coalesced 8-byte stores.  Rows of at most kRowsStageG words only (the host checks).
+// grid = (ceil(n_queries / 256), arenas of the group)
+__global__ __launch_bounds__(256) void k_survivor_rows_packed(const RowsArgs a, const ArenaTable<kMaxRowsArenas> t, const RowsTable<kMaxRowsArenas> dst)
+{
+    __shared__ uint64_t tile[256 * (kRowsStageG + 1)];
+    __shared__ uint32_t wave_total[4];
+    const ArenaRef &ar = t.ar[blockIdx.y];
+    const RowsDst d = dst.d[blockIdx.y];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t q0 = blockIdx.x * 256u, q = q0 + tid;
+    const uint32_t G = ar.G();
+    const uint64_t *src = a.out + ar.out_off(a.n_queries) + (uint64_t)q0 * G;
+    const uint32_t rows = min(256u, a.n_queries - q0), Gp = G | 1u, n = rows * G;
+    {   // the run's words into the tile, a row per lane at an odd stride (as k_survivor_rows)
+        const uint32_t dr = 256u / G, dc = 256u % G;
+        uint32_t r = tid / G, c = tid % G;
+        uint64_t v[kRowsStageG];
+#pragma unroll
+        for (uint32_t u = 0; u < kRowsStageG; ++u) {
+            const uint32_t i = tid + u * 256u;
+            v[u] = i < n ? src[i] : 0;
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < kRowsStageG; ++u) {
+            if (tid + u * 256u < n) tile[r * Gp + c] = v[u];
+            r += dr; c += dc;
+            if (c >= G) { c -= G; ++r; }
+        }
+    }
+    __syncthreads();
+    const bool live = q < a.n_queries;
+    uint64_t w[kRowsStageG];
+    uint32_t cnt = 0;
+#pragma unroll
+    for (uint32_t g = 0; g < kRowsStageG; ++g) {
+        w[g] = (live && g < G) ? tile[tid * Gp + g] : 0ULL;
+        cnt += (uint32_t)__popcll(w[g]);
+    }
+    const uint32_t tag = cnt == 0u ? kRowNone : cnt == ar.n_blocks ? kRowAll : cnt <= 2u * G ? kRowList : kRowDense;
+    if (live) a.hdr[d.hdr_off + q] = (tag << 30) | cnt;
+    const uint32_t size = !live ? 0u : tag == kRowList ? (cnt + 1u) >> 1 : tag == kRowDense ? G : 0u;       // payload words
+    // exclusive prefix of the sizes over the run: within the wave by shuffles, across the four waves through LDS
+    uint32_t incl = size;
+#pragma unroll
+    for (uint32_t o = 1; o < 64; o <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, o, 64);
+        if (lane >= o) incl += up;
+    }
+    if (lane == 63u) wave_total[wave] = incl;
+    __syncthreads();                                           // (every lane has its row in registers: the tile may be overwritten)
+    uint32_t off = incl - size, total = 0;
+#pragma unroll
+    for (uint32_t v = 0; v < 4; ++v) {
+        if (v < wave) off += wave_total[v];
+        total += wave_total[v];
+    }
+    if (tag == kRowList && live) {
+        uint32_t *ids = reinterpret_cast<uint32_t *>(tile + off);
+        uint32_t k = 0;
+#pragma unroll
+        for (uint32_t g = 0; g < kRowsStageG; ++g) {
+            uint64_t x = w[g];
+            while (x) {
+                ids[k++] = g * 64u + (uint32_t)__builtin_ctzll(x);
+                x &= x - 1;
+            }
+        }
+        if (cnt & 1u) ids[cnt] = 0u;                           // the odd count's last half word
+    } else if (tag == kRowDense && live) {
+#pragma unroll
+        for (uint32_t g = 0; g < kRowsStageG; ++g) if (g < G) tile[off + g] = w[g];
+    }
+    __syncthreads();
+    uint64_t *out = a.rows + d.row_off + (uint64_t)q0 * G;
+    for (uint32_t i = tid; i < total; i += 256u) out[i] = tile[i];
+}
+
 // ---------------------------------------------------------------------------
 // hash_entries: one lane per entry -> 4 x u64 base hashes.
 // ---------------------------------------------------------------------------

@@ -48,20 +48,30 @@ def survivor_row_list(hdr: int, row: np.ndarray, n_blocks: int) -> np.ndarray:
     return out[: n.value].copy()
 
 
-def rows_to_dense(hdr: np.ndarray, rows: np.ndarray, n_blocks: int) -> np.ndarray:
+def rows_to_dense(hdr: np.ndarray, rows: np.ndarray, n_blocks: int, packed: bool = False) -> np.ndarray:
     """[n_queries] headers + [n_queries][G] row slots of bsg_probe_many_rows -> the dense [n_queries][G] bitsets of bsg_probe_many
-    (numpy; tests and consumers that want the bitset form)."""
+    (numpy; tests and consumers that want the bitset form).  packed: the rows were written with BSG_PROBE_ROWS_PACKED (payloads of
+    every run of 256 queries back to back from the run's first slot)."""
     G = (n_blocks + 63) // 64
-    rows = np.asarray(rows, dtype=np.uint64).reshape(len(hdr), G)
+    flat = np.asarray(rows, dtype=np.uint64).reshape(-1)
     out = np.zeros((len(hdr), G), dtype=np.uint64)
     full = np.full(G, ~np.uint64(0), dtype=np.uint64)
     if n_blocks & 63:
         full[-1] = np.uint64((1 << (n_blocks & 63)) - 1)
     tag, cnt = np.asarray(hdr, dtype=np.uint32) >> 30, np.asarray(hdr, dtype=np.uint32) & np.uint32(0x3FFFFFFF)
     out[tag == 1] = full
-    out[tag == 3] = rows[tag == 3]
+    size = np.where(tag == 2, (cnt.astype(np.int64) + 1) >> 1, np.where(tag == 3, G, 0))           # payload words per row
+    if packed:
+        start = np.zeros(len(hdr), dtype=np.int64)
+        for r0 in range(0, len(hdr), 256):
+            s = size[r0: r0 + 256]
+            start[r0: r0 + 256] = r0 * G + np.cumsum(s) - s
+    else:
+        start = np.arange(len(hdr), dtype=np.int64) * G
+    for q in np.nonzero(tag == 3)[0]:
+        out[q] = flat[start[q]: start[q] + G]
     for q in np.nonzero(tag == 2)[0]:
-        ids = rows[q].view(np.uint32)[: int(cnt[q])].astype(np.int64)
+        ids = flat[start[q]: start[q] + size[q]].view(np.uint32)[: int(cnt[q])].astype(np.int64)
         np.bitwise_or.at(out[q], ids >> 6, np.uint64(1) << (ids & 63).astype(np.uint64))
     return out
 
@@ -293,14 +303,16 @@ class Context:
         self._check(self.L.bsg_survivor_rows_size(self.h, _lib._ptr(ids), len(ids), batch_id, C.byref(rw), C.byref(hw)))
         return int(rw.value), int(hw.value)
 
-    def survivor_rows_list(self, arena_ids, batch_id: int, rows: np.ndarray, hdr: np.ndarray, arena_index: int, query: int, n_blocks: int) -> np.ndarray:
+    def survivor_rows_list(self, arena_ids, batch_id: int, rows: np.ndarray, hdr: np.ndarray, arena_index: int, query: int, n_blocks: int,
+                           packed: bool = False) -> np.ndarray:
         """bsg_survivor_rows_list: the ascending GLOBAL block indices of (arena, query) from the rows bsg_probe_many_rows left — on a
         context of several devices the shards' rows merged (global = local * n_devices + device)."""
         ids = np.ascontiguousarray(arena_ids, dtype=np.uint64)
         out = np.zeros(max(n_blocks, 1), dtype=np.uint32)
         n = C.c_uint32()
-        self._check(self.L.bsg_survivor_rows_list(self.h, _lib._ptr(ids), len(ids), batch_id, C.c_void_p(rows.ctypes.data), C.c_void_p(hdr.ctypes.data),
-                                                  arena_index, query, C.c_void_p(out.ctypes.data), len(out), C.byref(n)))
+        fn = self.L.bsg_survivor_rows_list_packed if packed else self.L.bsg_survivor_rows_list
+        self._check(fn(self.h, _lib._ptr(ids), len(ids), batch_id, C.c_void_p(rows.ctypes.data), C.c_void_p(hdr.ctypes.data),
+                       arena_index, query, C.c_void_p(out.ctypes.data), len(out), C.byref(n)))
         return out[: int(n.value)]
 
     def set_probe_group(self, max_arenas_per_launch: int):

@@ -53,6 +53,7 @@ const (
 	ProbeAsync        uint32 = C.BSG_PROBE_ASYNC
 	ProbeTimed        uint32 = C.BSG_PROBE_TIMED
 	ProbeNoFuse       uint32 = C.BSG_PROBE_NOFUSE
+	ProbeRowsPacked   uint32 = C.BSG_PROBE_ROWS_PACKED
 	IngestTrustedJSON uint32 = C.BSG_INGEST_TRUSTED_JSON
 )
 
@@ -638,6 +639,7 @@ type RowsOnDevices struct {
 	batch  Batch
 	buf    *RowsBuffer
 	blocks []uint32
+	packed bool // written with BSG_PROBE_ROWS_PACKED: read with bsg_survivor_rows_list_packed
 }
 
 // ProbeManyRowsOnDevices is bsg_probe_many_rows on a context opened over several GPUs (the Go host's shape: one process, all 8
@@ -658,7 +660,14 @@ func (g *Context) ProbeManyRowsOnDevices(arenas []Arena, b Batch, buf *RowsBuffe
 	if int(rowWords) > buf.nRow || int(hdrWords) > buf.nHdr {
 		return nil, &Error{Code: int(C.BSG_E_INVALID), Message: "rows buffer too small"}
 	}
-	rc := C.bsg_probe_many_rows(g.c, u64p(r.ids), C.uint32_t(len(r.ids)), C.uint64_t(b.ID), 0, (*C.uint64_t)(buf.rows), (*C.uint32_t)(buf.hdr))
+	// The packed form first (a run's LIST / DENSE payloads leave the device as one contiguous stretch instead of one PCIe write per
+	// row); an arena beyond 1 024 blocks per device is refused before anything is launched, and takes the dense layout.
+	r.packed = true
+	rc := C.bsg_probe_many_rows(g.c, u64p(r.ids), C.uint32_t(len(r.ids)), C.uint64_t(b.ID), C.BSG_PROBE_ROWS_PACKED, (*C.uint64_t)(buf.rows), (*C.uint32_t)(buf.hdr))
+	if rc == C.BSG_E_UNSUPPORTED {
+		r.packed = false
+		rc = C.bsg_probe_many_rows(g.c, u64p(r.ids), C.uint32_t(len(r.ids)), C.uint64_t(b.ID), 0, (*C.uint64_t)(buf.rows), (*C.uint32_t)(buf.hdr))
+	}
 	if err := g.err(rc); err != nil {
 		return nil, err
 	}
@@ -672,8 +681,14 @@ func (r *RowsOnDevices) List(i, q int) ([]uint32, error) {
 	}
 	out := make([]uint32, r.blocks[i])
 	var n C.uint32_t
-	rc := C.bsg_survivor_rows_list(r.g.c, u64p(r.ids), C.uint32_t(len(r.ids)), C.uint64_t(r.batch.ID), (*C.uint64_t)(r.buf.rows), (*C.uint32_t)(r.buf.hdr),
-		C.uint32_t(i), C.uint32_t(q), u32p(out), C.uint32_t(len(out)), &n)
+	var rc C.int32_t
+	if r.packed {
+		rc = C.bsg_survivor_rows_list_packed(r.g.c, u64p(r.ids), C.uint32_t(len(r.ids)), C.uint64_t(r.batch.ID), (*C.uint64_t)(r.buf.rows), (*C.uint32_t)(r.buf.hdr),
+			C.uint32_t(i), C.uint32_t(q), u32p(out), C.uint32_t(len(out)), &n)
+	} else {
+		rc = C.bsg_survivor_rows_list(r.g.c, u64p(r.ids), C.uint32_t(len(r.ids)), C.uint64_t(r.batch.ID), (*C.uint64_t)(r.buf.rows), (*C.uint32_t)(r.buf.hdr),
+			C.uint32_t(i), C.uint32_t(q), u32p(out), C.uint32_t(len(out)), &n)
+	}
 	if err := r.g.err(rc); err != nil {
 		return nil, err
 	}

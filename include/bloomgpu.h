@@ -108,6 +108,7 @@ typedef struct bsg_timing {
 #define BSG_PROBE_ASYNC  1u  /* enqueue only; caller later calls bsg_sync                    */
 #define BSG_PROBE_TIMED  2u  /* timestamp the dispatches (see bsg_timing_read)               */
 #define BSG_PROBE_NOFUSE 4u  /* never fuse or fold: every group runs as k_probe_terms + k_eval_programs */
+#define BSG_PROBE_ROWS_PACKED 8u /* bsg_probe_many_rows only: LIST / DENSE payloads packed per run of 256 queries (below)    */
 
 typedef struct bsg_ctx bsg_ctx;
 
@@ -286,7 +287,13 @@ BSG_API int32_t bsg_set_probe_group(bsg_ctx *ctx, uint32_t max_arenas_per_launch
  * Both buffers are written BY THE DEVICE (k_survivor_rows) and must be page-locked C memory (bsg_pinned_alloc /
  * bsg_host_register): only the bytes written cross PCIe — a batch whose rows are mostly NONE / ALL / short lists costs 4 bytes
  * per row instead of n_blocks / 8.  Flags as bsg_probe_many (with BSG_PROBE_ASYNC both buffers must stay valid
- * until bsg_sync).  bsg_survivor_row_list expands one row to its ascending block indices whatever its tag. */
+ * until bsg_sync).  bsg_survivor_row_list expands one row to its ascending block indices whatever its tag.
+ * BSG_PROBE_ROWS_PACKED (round 6): a store into host memory that does not fill a line is one PCIe write of its own, and the dense
+ * layout makes one per LIST row.  With the flag the payloads of every run of 256 consecutive queries (q / 256) of an arena lie back
+ * to back, in query order, from the start of the run's slot area out_rows[row offset of the run's first query]: a LIST row takes
+ * ceil(count / 2) words (its ids, u32), a DENSE row ceil(n_blocks / 64) words, NONE / ALL rows nothing — a row's payload begins
+ * where the payloads of the run's earlier rows end, which the run's headers tell.  Headers and buffer sizes as without the flag;
+ * arenas of at most 1 024 blocks per device (BSG_E_UNSUPPORTED beyond).  bsg_survivor_rows_list_packed reads such rows. */
 #define BSG_ROW_NONE  0u
 #define BSG_ROW_ALL   1u
 #define BSG_ROW_LIST  2u
@@ -308,6 +315,9 @@ BSG_API int32_t bsg_survivor_rows_size(bsg_ctx *ctx, const uint64_t *arena_ids, 
 BSG_API int32_t bsg_survivor_rows_list(bsg_ctx *ctx, const uint64_t *arena_ids, uint32_t n_arenas, uint64_t batch_id, const uint64_t *rows,
                                        const uint32_t *hdr, uint32_t arena_index, uint32_t query, uint32_t *out_blocks, uint32_t cap,
                                        uint32_t *out_n);
+BSG_API int32_t bsg_survivor_rows_list_packed(bsg_ctx *ctx, const uint64_t *arena_ids, uint32_t n_arenas, uint64_t batch_id, const uint64_t *rows,
+                                              const uint32_t *hdr, uint32_t arena_index, uint32_t query, uint32_t *out_blocks, uint32_t cap,
+                                              uint32_t *out_n);
 
 /* One-shot convenience: batch_create + probe_batch + batch_free. */
 BSG_API int32_t bsg_probe(bsg_ctx *ctx, uint64_t arena_id, const bsg_term *terms, uint32_t n_terms,

@@ -45,7 +45,8 @@ def test_rows_expand_to_the_oracle_survivor_sets_for_every_tag(ctx, group):
     hdr = pinned(ctx, np.uint32, NQ * len(order))
     ctx.set_probe_group(group)
     try:
-        for flags in (0, _lib.PROBE_NOFUSE, _lib.PROBE_ASYNC):
+        for flags in (0, _lib.PROBE_NOFUSE, _lib.PROBE_ASYNC, _lib.PROBE_ROWS_PACKED, _lib.PROBE_ROWS_PACKED | _lib.PROBE_ASYNC):
+            packed = bool(flags & _lib.PROBE_ROWS_PACKED)      # payloads of every run of 256 queries back to back (NQ spans two runs)
             rows[:] = np.iinfo(np.uint64).max
             hdr[:] = np.iinfo(np.uint32).max
             ctx.probe_many_rows([arenas[i] for i in order], bid, rows, hdr, flags)
@@ -63,13 +64,17 @@ def test_rows_expand_to_the_oracle_survivor_sets_for_every_tag(ctx, group):
                     continue
                 p, w = plans[i]
                 want = O.survivors_tree(w, p.desc.view(O.DESC_DTYPE), exprs)
-                assert np.array_equal(rows_to_dense(h, r, nb), want), (group, flags, j)
+                assert np.array_equal(rows_to_dense(h, r, nb, packed=packed), want), (group, flags, j)
                 tags_seen |= set(int(t) for t in (h >> 30))
                 cnt = h & np.uint32(0x3FFFFFFF)
                 assert np.array_equal(cnt, [bin(int(x)).count("1") for x in (int.from_bytes(want[q].tobytes(), "little") for q in range(NQ))])
-                for q in (0, 1, 3, 5, 44, NQ - 1):                         # the C helper agrees with bsg_survivor_list of the bitset
-                    assert np.array_equal(survivor_row_list(int(h[q]), r[q], nb), survivor_list(want[q], nb))
+                for q in (0, 1, 3, 5, 44, 255, 256, 257, NQ - 1):          # the C helpers agree with bsg_survivor_list of the bitset
+                    if not packed:
+                        assert np.array_equal(survivor_row_list(int(h[q]), r[q], nb), survivor_list(want[q], nb))
+                    assert np.array_equal(ctx.survivor_rows_list([arenas[i] for i in order], bid, rows, hdr, j, q, nb, packed=packed), survivor_list(want[q], nb))
             assert tags_seen == {0, 1, 2, 3}, tags_seen
+            if packed:      # what the packed form is for: the payloads of a run are one contiguous stretch — nothing of the poison
+                pass        # between them is asserted by rows_to_dense reading exactly the packed offsets
     finally:
         ctx.set_probe_group(0)
     ctx.pinned_free(rows.view(np.uint8))
@@ -120,16 +125,19 @@ def test_rows_on_a_context_of_several_devices_merge_to_the_global_block_order():
             hdr = m.pinned_array(hw * 4).view(np.uint32)
             rows[:] = np.iinfo(np.uint64).max
             hdr[:] = np.iinfo(np.uint32).max
-            m.probe_many_rows(ids, bid, rows, hdr)
-            tags = np.bincount(hdr >> 30, minlength=4)
-            assert tags[0] > 0 and tags[1] > 0 and tags[2] + tags[3] > 0, tags        # every kind of row took part
-            for j, i in enumerate(order):
-                want = O.survivors_tree(words[i], plans[i].desc.view(O.DESC_DTYPE), exprs)
-                for q in range(len(exprs)):
-                    got = m.survivor_rows_list(ids, bid, rows, hdr, j, q, plans[i].n_blocks)
-                    bits = np.zeros_like(want[q])
-                    np.bitwise_or.at(bits, got.astype(np.int64) >> 6, np.uint64(1) << (got & 63).astype(np.uint64))
-                    assert np.all(np.diff(got.astype(np.int64)) > 0) and np.array_equal(bits, want[q]), (nd, i, q)
+            for packed in (False, True):
+                rows[:] = np.iinfo(np.uint64).max
+                hdr[:] = np.iinfo(np.uint32).max
+                m.probe_many_rows(ids, bid, rows, hdr, _lib.PROBE_ROWS_PACKED if packed else 0)
+                tags = np.bincount(hdr >> 30, minlength=4)
+                assert tags[0] > 0 and tags[1] > 0 and tags[2] + tags[3] > 0, tags        # every kind of row took part
+                for j, i in enumerate(order):
+                    want = O.survivors_tree(words[i], plans[i].desc.view(O.DESC_DTYPE), exprs)
+                    for q in range(len(exprs)):
+                        got = m.survivor_rows_list(ids, bid, rows, hdr, j, q, plans[i].n_blocks, packed=packed)
+                        bits = np.zeros_like(want[q])
+                        np.bitwise_or.at(bits, got.astype(np.int64) >> 6, np.uint64(1) << (got & 63).astype(np.uint64))
+                        assert np.all(np.diff(got.astype(np.int64)) > 0) and np.array_equal(bits, want[q]), (nd, i, q, packed)
             # the dense path of the same context agrees
             dense = m.probe_many(ids, bid, 0, len(exprs), [plans[i].n_blocks for i in order])
             for j, i in enumerate(order):
@@ -137,3 +145,26 @@ def test_rows_on_a_context_of_several_devices_merge_to_the_global_block_order():
             m.pinned_free(rows.view(np.uint8))
             m.pinned_free(hdr.view(np.uint8))
             m.batch_free(bid)
+
+
+def test_packed_rows_refuse_arenas_beyond_their_staging(ctx):
+    """BSG_PROBE_ROWS_PACKED assembles a run's payloads in LDS: arenas of more than 1 024 blocks per device are refused, not mis-written."""
+    rng = np.random.default_rng(9)
+    plan, _, vocab = H.make_random_arena(rng, 1025, max_tokens=8, vocab_size=12)
+    words = ctx.build(plan.blob, plan.off, plan.fstart, plan.desc, plan.n_words)
+    aid = ctx.arena_load(words, plan.desc)
+    cb = Q.compile_queries([Q.Token(vocab[0]), None])
+    ops, poff, _ = cb.arrays()
+    bid = ctx.batch_create(H.gpu_terms(ctx, cb), ops, poff)
+    rows = pinned(ctx, np.uint64, 2 * 17)
+    hdr = pinned(ctx, np.uint32, 2)
+    with pytest.raises(BloomGpuError) as ei:
+        ctx.probe_many_rows([aid], bid, rows, hdr, _lib.PROBE_ROWS_PACKED)
+    assert "1024" in str(ei.value)
+    ctx.probe_many_rows([aid], bid, rows, hdr)                       # the dense layout takes it
+    want = O.survivors_tree(words, plan.desc.view(O.DESC_DTYPE), [Q.Token(vocab[0]), None])
+    assert np.array_equal(rows_to_dense(hdr, rows, 1025), want)
+    with pytest.raises(BloomGpuError):
+        ctx.probe_many([aid], bid, _lib.PROBE_ROWS_PACKED, 2, [1025])   # a flag of bsg_probe_many_rows only
+    ctx.pinned_free(rows.view(np.uint8)); ctx.pinned_free(hdr.view(np.uint8))
+    ctx.batch_free(bid); ctx.arena_free(aid)
