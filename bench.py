@@ -452,10 +452,10 @@ def main():
         r_elapsed, _ = pr.measure(make, args.steps, min(args.warmup, 4), per_call, timed=False, out=Ring(sh.mine[:row_words]), words_per_step=wps,
                                   hdr=Ring(hdr_ring), hdr_per_step=NQ)
         if rank == 0:
-            h0 = sh.part(0)[row_words:].view(np.uint32)[:NQ]
+            h0 = sh.part(0)[row_words:].view(np.uint8)[:NQ] if C.ROWS_PACKED else sh.part(0)[row_words:].view(np.uint32)[:NQ]      # (packed: byte headers)
             if not args.no_check and not np.array_equal(rows_to_dense(h0, sh.part(0)[:wps], B, packed=C.ROWS_PACKED), got):
                 sys.exit("survivor rows delivered to the shared host segment do not expand to the direct probe's bitsets")
-            rows_tags = [int(x) for x in np.bincount(h0 >> 30, minlength=4)]
+            rows_tags = [int(x) for x in np.bincount(h0 >> (6 if C.ROWS_PACKED else 30), minlength=4)]
     sh.close()
 
     # ---- kernel sampling beyond the timed region: the driver's --steps may cover a single dispatch, the number of record

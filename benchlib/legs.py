@@ -757,10 +757,14 @@ def c4_leg(ctx, args, rank, world, workers, log, barrier=None, headline=False):
         hdr_ring = sh.mine[slot_words * n_slots:].view(np.uint32)[: hdr_per_step * per_call * n_slots]
         rr, hr = Ring(ring), Ring(hdr_ring)
         dt3, _ = pr.measure(make, steps, 2, per_call, timed=False, out=rr, words_per_step=words_per_step, hdr=hr, hdr_per_step=hdr_per_step)
-        h_all = sh.part(rank)[slot_words * n_slots:].view(np.uint32)[hr.last: hr.last + hdr_per_step]
-        tags = np.bincount(h_all >> 30, minlength=4)
-        cnt = h_all & np.uint32(0x3FFFFFFF)
-        payload = int(4 * cnt[(h_all >> 30) == 2].sum() + 8 * sum(G[f] * int(((h_all[f * NQ: (f + 1) * NQ] >> 30) == 3).sum()) for f in range(n_files)))
+        if C.ROWS_PACKED:       # byte headers (tag << 6 | a LIST row's count) at the front of the call's header region
+            h_all = sh.part(rank)[slot_words * n_slots:].view(np.uint8)[hr.last * 4: hr.last * 4 + hdr_per_step]
+            tag_all, cnt = h_all >> 6, (h_all & 63).astype(np.int64)
+        else:
+            h_all = sh.part(rank)[slot_words * n_slots:].view(np.uint32)[hr.last: hr.last + hdr_per_step]
+            tag_all, cnt = h_all >> 30, (h_all & np.uint32(0x3FFFFFFF)).astype(np.int64)
+        tags = np.bincount(tag_all, minlength=4)
+        payload = int(4 * cnt[tag_all == 2].sum() + 8 * sum(G[f] * int((tag_all[f * NQ: (f + 1) * NQ] == 3).sum()) for f in range(n_files)))
         o = 0
         for f in range(n_files):                                   # the rows of the last call's first step expand to the direct probe's bitsets
             if local_blocks[f] and not args.no_check:
@@ -768,8 +772,8 @@ def c4_leg(ctx, args, rank, world, workers, log, barrier=None, headline=False):
                 if not np.array_equal(back, got[f]):
                     sys.exit("c4: survivor rows of file %d do not expand to the direct probe's bitsets" % f)
             o += NQ * G[f]
-        res["host_gather"]["rows"] = {"api": "bsg_probe_many_rows", "ms_per_step": dt3 / steps * 1e3, "value": probes * steps / dt3,
-                                      "bytes_per_step_per_gpu": int(4 * hdr_per_step + payload),
+        res["host_gather"]["rows"] = {"api": "bsg_probe_many_rows" + (" (BSG_PROBE_ROWS_PACKED)" if C.ROWS_PACKED else ""), "ms_per_step": dt3 / steps * 1e3, "value": probes * steps / dt3,
+                                      "bytes_per_step_per_gpu": int((1 if C.ROWS_PACKED else 4) * hdr_per_step + payload),
                                       "rows_by_tag_none_all_list_dense": [int(x) for x in tags],
                                       "vs_device_resident": dt3 / dt,
                                       "note": "header + ids / words where needed, written by the device into the page-locked segment; "

@@ -1504,7 +1504,8 @@ __global__ __launch_bounds__(256) void k_survivor_rows(const RowsArgs a, const A
 // ids as ceil(count / 2) words, a DENSE row's G words — lie back to back, in query order, from the start of the run's slot area.
 // Why: a store into host memory that does not fill a line is one PCIe write of its own; the dense layout makes one per LIST row
 // (17 240 per 20 C2 arenas: 18.7 of the kernel's 27 us, profiles/r06_hostwrite_lab.txt), the packed run leaves as one contiguous
-// stretch written with coalesced 8-byte stores.  Rows of at most kRowsStageG words only (the host checks).
+// stretch written with coalesced 8-byte stores.  Rows of at most kRowsStageG words only (the host checks).  Headers: one byte per row,
+// at BYTE (hdr_off + q) of the header buffer (see below).
 // grid = (ceil(n_queries / 256), arenas of the group)
 __global__ __launch_bounds__(256) void k_survivor_rows_packed(const RowsArgs a, const ArenaTable<kMaxRowsArenas> t, const RowsTable<kMaxRowsArenas> dst)
 {
@@ -1543,7 +1544,10 @@ __global__ __launch_bounds__(256) void k_survivor_rows_packed(const RowsArgs a, 
         cnt += (uint32_t)__popcll(w[g]);
     }
     const uint32_t tag = cnt == 0u ? kRowNone : cnt == ar.n_blocks ? kRowAll : cnt <= 2u * G ? kRowList : kRowDense;
-    if (live) a.hdr[d.hdr_off + q] = (tag << 30) | cnt;
+    // the packed form's header is ONE BYTE per row, tag << 6 | (a LIST row's count: at most 2 kRowsStageG = 32); an ALL row's count is
+    // the arena's block count, a DENSE row's the population of its words — 4 096 rows x 4 bytes per arena were 3.3 of the C4 step's
+    // 3.7 us of host traffic
+    if (live) reinterpret_cast<uint8_t *>(a.hdr)[d.hdr_off + q] = (uint8_t)((tag << 6) | (tag == kRowList ? cnt : 0u));
     const uint32_t size = !live ? 0u : tag == kRowList ? (cnt + 1u) >> 1 : tag == kRowDense ? G : 0u;       // payload words
     // exclusive prefix of the sizes over the run: within the wave by shuffles, across the four waves through LDS
     uint32_t incl = size;

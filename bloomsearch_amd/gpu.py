@@ -58,7 +58,12 @@ def rows_to_dense(hdr: np.ndarray, rows: np.ndarray, n_blocks: int, packed: bool
     full = np.full(G, ~np.uint64(0), dtype=np.uint64)
     if n_blocks & 63:
         full[-1] = np.uint64((1 << (n_blocks & 63)) - 1)
-    tag, cnt = np.asarray(hdr, dtype=np.uint32) >> 30, np.asarray(hdr, dtype=np.uint32) & np.uint32(0x3FFFFFFF)
+    if packed:      # byte headers: tag << 6 | a LIST row's count (hdr: the first len(hdr) BYTES of what was passed, see packed_headers)
+        hdr = np.asarray(hdr)
+        hb = hdr if hdr.dtype == np.uint8 else hdr.view(np.uint8)[: len(hdr)]          # (a u32 view of the buffer: its first len(hdr) bytes)
+        tag, cnt = (hb >> 6).astype(np.uint32), (hb & 63).astype(np.uint32)
+    else:
+        tag, cnt = np.asarray(hdr, dtype=np.uint32) >> 30, np.asarray(hdr, dtype=np.uint32) & np.uint32(0x3FFFFFFF)
     out[tag == 1] = full
     size = np.where(tag == 2, (cnt.astype(np.int64) + 1) >> 1, np.where(tag == 3, G, 0))           # payload words per row
     if packed:
@@ -74,6 +79,11 @@ def rows_to_dense(hdr: np.ndarray, rows: np.ndarray, n_blocks: int, packed: bool
         ids = flat[start[q]: start[q] + size[q]].view(np.uint32)[: int(cnt[q])].astype(np.int64)
         np.bitwise_or.at(out[q], ids >> 6, np.uint64(1) << (ids & 63).astype(np.uint64))
     return out
+
+
+def packed_headers(hdr: np.ndarray, index: int, n_queries: int) -> np.ndarray:
+    """The n_queries byte headers of arena (or device x arena) number `index` out of the header buffer of a BSG_PROBE_ROWS_PACKED call."""
+    return hdr.view(np.uint8)[index * n_queries: (index + 1) * n_queries]
 
 
 def estimate_parameters(n: int, p: float):

@@ -292,8 +292,11 @@ BSG_API int32_t bsg_set_probe_group(bsg_ctx *ctx, uint32_t max_arenas_per_launch
  * layout makes one per LIST row.  With the flag the payloads of every run of 256 consecutive queries (q / 256) of an arena lie back
  * to back, in query order, from the start of the run's slot area out_rows[row offset of the run's first query]: a LIST row takes
  * ceil(count / 2) words (its ids, u32), a DENSE row ceil(n_blocks / 64) words, NONE / ALL rows nothing — a row's payload begins
- * where the payloads of the run's earlier rows end, which the run's headers tell.  Headers and buffer sizes as without the flag;
- * arenas of at most 1 024 blocks per device (BSG_E_UNSUPPORTED beyond).  bsg_survivor_rows_list_packed reads such rows. */
+ * where the payloads of the run's earlier rows end, which the run's headers tell.  The headers shrink too: ONE BYTE per row at byte
+ * (i * n_queries + q) of out_hdr (device d's slice: from byte d * n_arenas * n_queries), tag << 6 | count of a LIST row (at most
+ * 32); an ALL row counts the arena's blocks, a DENSE row the bits of its words.  Buffer sizes as without the flag (the packed form
+ * uses the front of both); arenas of at most 1 024 blocks per device (BSG_E_UNSUPPORTED beyond, before anything is launched).
+ * bsg_survivor_rows_list_packed reads such rows. */
 #define BSG_ROW_NONE  0u
 #define BSG_ROW_ALL   1u
 #define BSG_ROW_LIST  2u

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from bloomsearch_amd import _lib, query as Q
-from bloomsearch_amd.gpu import BloomGpuError, rows_to_dense, survivor_list, survivor_row_list
+from bloomsearch_amd.gpu import BloomGpuError, packed_headers, rows_to_dense, survivor_list, survivor_row_list
 from oracle import oracle as O
 from tests import helpers as H
 from tests.helpers import device_ids
@@ -56,7 +56,7 @@ def test_rows_expand_to_the_oracle_survivor_sets_for_every_tag(ctx, group):
             o = 0
             for j, i in enumerate(order):
                 G, nb = Gs[j], nbs[i]
-                h = hdr[j * NQ: (j + 1) * NQ]
+                h = packed_headers(hdr, j, NQ) if packed else hdr[j * NQ: (j + 1) * NQ]
                 r = rows[o: o + NQ * G].reshape(NQ, G) if G else np.zeros((NQ, 0), dtype=np.uint64)
                 o += NQ * G
                 if nb == 0:
@@ -65,9 +65,13 @@ def test_rows_expand_to_the_oracle_survivor_sets_for_every_tag(ctx, group):
                 p, w = plans[i]
                 want = O.survivors_tree(w, p.desc.view(O.DESC_DTYPE), exprs)
                 assert np.array_equal(rows_to_dense(h, r, nb, packed=packed), want), (group, flags, j)
-                tags_seen |= set(int(t) for t in (h >> 30))
-                cnt = h & np.uint32(0x3FFFFFFF)
-                assert np.array_equal(cnt, [bin(int(x)).count("1") for x in (int.from_bytes(want[q].tobytes(), "little") for q in range(NQ))])
+                tags_seen |= set(int(t) for t in (h >> (6 if packed else 30)))
+                pops = np.array([bin(int(x)).count("1") for x in (int.from_bytes(want[q].tobytes(), "little") for q in range(NQ))])
+                if packed:      # a byte header carries the count of a LIST row only
+                    lst = (h >> 6) == 2
+                    assert np.array_equal((h & 63)[lst], pops[lst]) and not (h & 63)[~lst].any()
+                else:
+                    assert np.array_equal(h & np.uint32(0x3FFFFFFF), pops)
                 for q in (0, 1, 3, 5, 44, 255, 256, 257, NQ - 1):          # the C helpers agree with bsg_survivor_list of the bitset
                     if not packed:
                         assert np.array_equal(survivor_row_list(int(h[q]), r[q], nb), survivor_list(want[q], nb))
@@ -129,7 +133,7 @@ def test_rows_on_a_context_of_several_devices_merge_to_the_global_block_order():
                 rows[:] = np.iinfo(np.uint64).max
                 hdr[:] = np.iinfo(np.uint32).max
                 m.probe_many_rows(ids, bid, rows, hdr, _lib.PROBE_ROWS_PACKED if packed else 0)
-                tags = np.bincount(hdr >> 30, minlength=4)
+                tags = np.bincount(hdr.view(np.uint8)[:hw] >> 6, minlength=4) if packed else np.bincount(hdr >> 30, minlength=4)
                 assert tags[0] > 0 and tags[1] > 0 and tags[2] + tags[3] > 0, tags        # every kind of row took part
                 for j, i in enumerate(order):
                     want = O.survivors_tree(words[i], plans[i].desc.view(O.DESC_DTYPE), exprs)
