@@ -71,11 +71,14 @@ def main():
                 hdr = ctx.pinned_array(NQ * len(order) * 4).view(np.uint32)
                 rows[:] = np.iinfo(np.uint64).max
                 hdr[:] = np.iinfo(np.uint32).max
-                ctx.probe_many_rows([arenas[i] for i in order], bid, rows, hdr, flags)
+                # (every other time in the packed form where the arenas allow it: a run's payloads back to back, byte headers)
+                packed = bool(rng.random() < 0.5) and max(Gs, default=0) <= 16
+                ctx.probe_many_rows([arenas[i] for i in order], bid, rows, hdr, flags | (_lib.PROBE_ROWS_PACKED if packed else 0))
                 o = 0
                 for j, i in enumerate(order):
-                    if not np.array_equal(rows_to_dense(hdr[j * NQ: (j + 1) * NQ], rows[o: o + NQ * Gs[j]], plans[i].n_blocks), wants[i]):
-                        sys.exit("seed %d: survivor rows differ (nq %d, %d terms, %d arenas, flags %d, arena %d)" % (seed, nq, len(terms), len(order), flags, i))
+                    h = hdr.view(np.uint8)[j * NQ: (j + 1) * NQ] if packed else hdr[j * NQ: (j + 1) * NQ]
+                    if not np.array_equal(rows_to_dense(h, rows[o: o + NQ * Gs[j]], plans[i].n_blocks, packed=packed), wants[i]):
+                        sys.exit("seed %d: survivor rows differ (nq %d, %d terms, %d arenas, flags %d, arena %d, packed %s)" % (seed, nq, len(terms), len(order), flags, i, packed))
                     o += NQ * Gs[j]
                     n_bits += NQ * Gs[j] * 64
                 ctx.pinned_free(rows.view(np.uint8))
